@@ -1,0 +1,186 @@
+/* include/ps_hip.h — C-ABI of the MI355X (gfx950) backend for PowerServe's ggml decode hot path.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++/torch types.  Each entry
+ * point names the reference interface it replaces (paths relative to the PowerServe tree).
+ *
+ *   reference                                             this library
+ *   ---------------------------------------------------   ---------------------------------------------
+ *   powerserve_compute_forward_mul_mat  (ggml.h:767)      ps_hip_mul_mat
+ *   powerserve_compute_forward_add      (ggml.h:774)      ps_hip_add
+ *   powerserve_compute_forward_rms_norm (ggml.h:787)      ps_hip_rms_norm
+ *   powerserve_compute_forward_rope     (ggml.h:795)      ps_hip_rope
+ *   powerserve_compute_forward_dup      (ggml.h:804)      ps_hip_dup
+ *   powerserve_compute_forward_softmax_ext (ggml.h:810)   ps_hip_softmax_ext
+ *   powerserve_get_vec_dot_type         (ggml.h:765)      ps_hip_vec_dot_type
+ *   GGMLBackend::silu_hadamard (backend/ggml/ggml.cpp:115)        ps_hip_silu_hadamard
+ *   GGMLBackend::get_embedding (backend/ggml/ggml_wrapper.cpp:181) ps_hip_get_embedding
+ *   Executor GET_MASK          (executor/executor.cpp:210-224)    ps_hip_get_mask
+ *   quantize_row_q8_0 / q8_K   (ggml-quants.c:887, :3849)         ps_hip_quantize_act
+ *   GGMLBackend::plan + fused decode (backend/ggml/ggml.cpp:30)   ps_hip_model_* (one call per forward)
+ *
+ * Conventions
+ *   - ps_tensor mirrors ggml_tensor's (type, ne[4], nb[4] in BYTES, data) as built by convert_to_ggml
+ *     (backend/ggml/ggml.hpp:87-96).  `data` is a DEVICE pointer, except for quantized weights where it is
+ *     the ps_weight handle returned by ps_hip_weight_upload (the device copy is repacked).
+ *   - every function returns 0 on success, non-zero on failure; ps_hip_last_error(ctx) gives the message.
+ *     Nothing throws across this boundary; the C++ façade converts failures into the reference's
+ *     abort/throw behaviour (core/logger.hpp:56-82).
+ *   - one HIP stream per ctx; ops are asynchronous in stream order; ps_hip_sync waits.  A ctx is not
+ *     thread-safe (same as one GGMLBackend).
+ */
+#ifndef PS_HIP_H
+#define PS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PS_HIP_ABI_VERSION 1
+
+/* ggml_type values (libs/ggml/include/ggml.h:361-398); Q4_K/Q6_K extend PowerServe's DataType enum
+ * (core/data_type.hpp:24-35) which stops at Q8_0. */
+enum ps_dtype {
+    PS_F32  = 0,
+    PS_F16  = 1,
+    PS_Q4_0 = 2,
+    PS_Q8_0 = 8,
+    PS_Q4_K = 12,
+    PS_Q6_K = 14,
+    PS_Q8_K = 15,
+    PS_I32  = 26,
+};
+
+typedef struct ps_hip_ctx ps_hip_ctx;
+typedef struct ps_weight ps_weight;   /* device-resident quantized weight matrix [K, N] */
+typedef struct ps_hip_model ps_hip_model;
+typedef struct ps_hip_graph ps_hip_graph;
+
+typedef struct {
+    int32_t dtype;
+    int32_t _pad;
+    int64_t ne[4];  /* elements per dim, dim0 fastest */
+    uint64_t nb[4]; /* strides in bytes */
+    void *data;
+} ps_tensor;
+
+/* rope_compute_params (ggml.h:651-661) */
+typedef struct {
+    int32_t n_dims, n_ctx_orig;
+    float freq_base, freq_scale, ext_factor, attn_factor, beta_fast, beta_slow;
+    int32_t mode; /* rope_type: 0 adjacent pairs, 2 NEOX */
+} ps_rope_params;
+
+/* ModelConfig::LLMConfig (core/config.hpp:86-109) */
+typedef struct {
+    uint32_t dim, hidden_dim, n_layers, n_heads, n_kv_heads, seq_len, vocab_size, kv_dim, head_size;
+    float norm_eps;
+    ps_rope_params rope;
+} ps_llm_config;
+
+/* ------------------------------------------------------------------ context, memory, timing */
+int ps_hip_abi_version(void);
+int ps_hip_device_count(void);
+int ps_hip_create(int device, ps_hip_ctx **out);
+void ps_hip_destroy(ps_hip_ctx *ctx);
+const char *ps_hip_last_error(const ps_hip_ctx *ctx);
+int ps_hip_device_name(const ps_hip_ctx *ctx, char *buf, size_t cap);
+int ps_hip_malloc(ps_hip_ctx *ctx, size_t bytes, void **dptr);
+int ps_hip_free(ps_hip_ctx *ctx, void *dptr);
+int ps_hip_memcpy_h2d(ps_hip_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
+int ps_hip_memcpy_d2h(ps_hip_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
+int ps_hip_memset(ps_hip_ctx *ctx, void *dst_dev, int value, size_t bytes);
+int ps_hip_sync(ps_hip_ctx *ctx);
+void *ps_hip_stream(ps_hip_ctx *ctx); /* hipStream_t */
+/* HIP events on the ctx stream (bench.py measures kernel time with these) */
+int ps_hip_event_create(ps_hip_ctx *ctx, void **ev);
+int ps_hip_event_record(ps_hip_ctx *ctx, void *ev);
+int ps_hip_event_elapsed_ms(ps_hip_ctx *ctx, void *ev_start, void *ev_stop, float *ms); /* syncs ev_stop */
+int ps_hip_event_destroy(ps_hip_ctx *ctx, void *ev);
+
+/* ------------------------------------------------------------------ weights */
+/* host_blocks: N rows of GGUF blocks of `dtype` (row stride = ggml_row_size(dtype, K)), or F32 rows.
+ * The device copy is repacked into a structure-of-arrays layout private to the backend. */
+int ps_hip_weight_upload(ps_hip_ctx *ctx, int dtype, const void *host_blocks, int64_t K, int64_t N, ps_weight **out);
+void ps_hip_weight_free(ps_hip_ctx *ctx, ps_weight *w);
+/* GGUF bytes of the matrix = N * ggml_row_size(dtype, K): the roofline's algorithmic byte count */
+uint64_t ps_hip_weight_gguf_bytes(const ps_weight *w);
+int ps_hip_weight_dtype(const ps_weight *w);
+
+/* ------------------------------------------------------------------ op level (reference-shaped) */
+int ps_hip_vec_dot_type(int dtype);
+size_t ps_hip_row_size(int dtype, int64_t k);
+/* x: [K, rows] F32 contiguous (device) -> out: rows x GGUF-layout block_q8_0 / block_q8_K (device).
+ * Bit-exact with quantize_row_q8_0 (AVX2 branch) / quantize_row_q8_K. */
+int ps_hip_quantize_act(ps_hip_ctx *ctx, int vdt, const float *x, int64_t K, int64_t rows, void *out_blocks);
+/* dst[ne01, ne11, ne12] = src0 x src1.  src0: quantized weight handle (2-D) or F32 tensor with arbitrary
+ * nb[1..3] (K/V-cache views, GQA broadcast over dim 2); src1: F32, nb[0]==4; dst: F32 contiguous rows. */
+int ps_hip_mul_mat(ps_hip_ctx *ctx, const ps_tensor *dst, const ps_tensor *src0, const ps_tensor *src1);
+int ps_hip_rms_norm(ps_hip_ctx *ctx, const ps_tensor *dst, const ps_tensor *src, const ps_tensor *weight, float eps);
+/* pos: HOST int32[n_pos] (the reference passes a std::vector<int>, executor.cpp:123-128) */
+int ps_hip_rope(ps_hip_ctx *ctx, const ps_tensor *dst, const ps_tensor *src, const int32_t *pos, int n_pos,
+                const ps_rope_params *rp);
+int ps_hip_softmax_ext(ps_hip_ctx *ctx, const ps_tensor *dst, const ps_tensor *src, const ps_tensor *mask,
+                       float scale, float max_bias);
+int ps_hip_add(ps_hip_ctx *ctx, const ps_tensor *dst, const ps_tensor *a, const ps_tensor *b);
+int ps_hip_dup(ps_hip_ctx *ctx, const ps_tensor *dst, const ps_tensor *src); /* COPY and CONT */
+int ps_hip_silu_hadamard(ps_hip_ctx *ctx, const ps_tensor *dst, const ps_tensor *gate, const ps_tensor *up);
+/* weight->data: ps_weight handle (quantized or F32 table [dim, vocab]); tokens: HOST int32[n] */
+int ps_hip_get_embedding(ps_hip_ctx *ctx, const ps_tensor *dst, const ps_tensor *weight, const int32_t *tokens,
+                         int n);
+/* dst [n_kv, bs] F32: (j <= pos[i]) ? 0 : -inf  — or, with tree != NULL (bs x bs bytes, row i = which batch
+ * tokens token i may attend to), the speculative-decode tree mask over the last bs cache slots. */
+int ps_hip_get_mask(ps_hip_ctx *ctx, const ps_tensor *dst, const int32_t *pos, int n_pos, const uint8_t *tree);
+/* rows of `src` ([n, rows] F32) -> int32 index of the first maximum per row, written to out_dev */
+int ps_hip_argmax(ps_hip_ctx *ctx, const float *src, int64_t n, int64_t rows, int32_t *out_dev);
+
+/* ------------------------------------------------------------------ whole-model fast path
+ * What HIPBackend::plan() lowers the reference's 28-op layer sequence to: fused kernels, a persistent
+ * arena, a device-resident FP32 KV cache (K [n_ctx][kv_dim], V [kv_dim][n_ctx] — the reference's layout,
+ * backend/ggml/ggml_kv_cache.cpp:48-57, model/module/norm_attention.cpp:82-104) and a captured hipGraph
+ * for the single-token step. */
+typedef struct {
+    ps_llm_config cfg;
+    int32_t is_qwen2; /* QKV bias (model/qwen2/qwen2_model.cpp:75) */
+    int32_t max_batch; /* largest forward batch (prefill chunk) */
+    const ps_weight *token_embd, *output; /* output == NULL -> tied lm_head (weights.hpp:67-68) */
+    const float *output_norm;             /* device F32 [dim] */
+    /* per layer arrays of n_layers entries */
+    const float *const *attn_norm, *const *ffn_norm;
+    const ps_weight *const *attn_q, *const *attn_k, *const *attn_v, *const *attn_output;
+    const ps_weight *const *ffn_gate, *const *ffn_up, *const *ffn_down;
+    const float *const *attn_q_bias, *const *attn_k_bias, *const *attn_v_bias; /* NULL unless is_qwen2 */
+} ps_model_desc;
+
+int ps_hip_model_create(ps_hip_ctx *ctx, const ps_model_desc *desc, ps_hip_model **out);
+void ps_hip_model_destroy(ps_hip_model *m);
+/* KVCacheInterface bookkeeping (core/kv_cache.hpp:97-163) */
+size_t ps_hip_model_kv_position(const ps_hip_model *m);
+int ps_hip_model_kv_truncate(ps_hip_model *m, size_t n_tokens);
+int ps_hip_model_kv_rollback(ps_hip_model *m, size_t n_tokens);
+int ps_hip_model_kv_move(ps_hip_model *m, size_t dst_index, size_t src_index);
+/* One Model::forward (model/llama/llama_model.cpp:52-117).  tokens/pos: HOST arrays of n entries,
+ * positions consecutive from pos[0].  tree (may be NULL): bs x bs attention mask among the batch tokens
+ * (speculative tree verify).  lm_head != 0: logits for all n tokens are left in the model's device buffer
+ * (ps_hip_model_logits) and their arg-max ids are written to argmax_host (may be NULL).  Advances the KV
+ * position by n (m_kv->advance, llama_model.cpp:109). */
+int ps_hip_model_forward(ps_hip_model *m, const int32_t *tokens, int n, const int32_t *pos, const uint8_t *tree,
+                         int lm_head, int32_t *argmax_host);
+/* Greedy single-token steps, the decode hot loop (model/model.hpp:170-183): feeds `token` at the current
+ * KV position, then its own arg-max, `steps` times, without host round trips (hipGraph replay).  out_ids
+ * HOST int32[steps]. */
+int ps_hip_model_decode_greedy(ps_hip_model *m, int32_t token, int steps, int32_t *out_ids);
+const float *ps_hip_model_logits(const ps_hip_model *m); /* device [max_batch][vocab] */
+const float *ps_hip_model_k_cache(const ps_hip_model *m, int layer);
+const float *ps_hip_model_v_cache(const ps_hip_model *m, int layer);
+/* per-forward accounting for the roofline: GGUF bytes of all mat-mul weights streamed by one token */
+uint64_t ps_hip_model_weight_bytes_per_token(const ps_hip_model *m);
+/* 0 = fused kernels + hipGraph (default); 1 = fused kernels, eager launches; used by tests/bench */
+int ps_hip_model_set_mode(ps_hip_model *m, int mode);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PS_HIP_H */

@@ -1,0 +1,54 @@
+"""Build the gfx950 HIP library in-tree: powerserve_amd/lib/libps_hip.so (hipcc cross-compiles without a GPU)."""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+OBJDIR = os.path.join(HERE, "build")
+SOURCES = ["api.hip", "model.hip", "k_quant.hip", "k_gemv.hip", "k_gemm.hip", "k_ops.hip", "k_attn.hip"]
+# -ffp-contract=off: the parity contract needs every fp32 op to round where the reference's C source rounds;
+# fused multiply-adds are written explicitly (__fmaf_rn) where the reference uses FMA intrinsics.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-result",
+         "-I" + os.path.join(HERE, "..", "include")]
+
+
+def _newer(src: str, obj: str) -> bool:
+    if not os.path.exists(obj):
+        return True
+    t = os.path.getmtime(obj)
+    deps = [src] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    deps.append(os.path.join(HERE, "..", "include", "ps_hip.h"))
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    os.makedirs(LIBDIR, exist_ok=True)
+    os.makedirs(OBJDIR, exist_ok=True)
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objs, jobs = [], []
+    for s in SOURCES:
+        src, obj = os.path.join(CSRC, s), os.path.join(OBJDIR, s.replace(".hip", ".o"))
+        objs.append(obj)
+        if force or _newer(src, obj):
+            jobs.append([hipcc, *FLAGS, "-c", src, "-o", obj])
+
+    def run(cmd):
+        if verbose:
+            print("[build]", os.path.basename(cmd[-3]), flush=True)
+        subprocess.run(cmd, check=True)
+
+    with ThreadPoolExecutor(max_workers=8) as ex:
+        list(ex.map(run, jobs))
+    so = os.path.join(LIBDIR, "libps_hip.so")
+    if jobs or not os.path.exists(so):
+        subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", so, *objs], check=True)
+    return so
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

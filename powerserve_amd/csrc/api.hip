@@ -1,0 +1,372 @@
+// C-ABI (include/ps_hip.h): context, memory, weights and the reference-shaped operator entry points.
+#include "ps_internal.h"
+#include "ps_ops.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+// ------------------------------------------------------------------ host restatement of the RoPE cache
+// ggml_rope_cache_init (libs/ggml/src/ggml.c:15344-15358) + rope_yarn (:15319-15336) + corr dims
+// (:15360-15366).  Computed on the host with the same libm calls and the same theta *= theta_scale
+// recurrence as the reference, then uploaded; freq_factors is always NULL in PowerServe
+// (backend/ggml/ggml_wrapper.cpp:104-106).
+static float rope_corr_dim(int n_dims, int n_ctx_orig, float n_rot, float base) {
+    return n_dims * logf(n_ctx_orig / (n_rot * 2 * (float)M_PI)) / (2 * logf(base));
+}
+void ps_rope_table_host(const ps_rope_params *rp, int64_t ne0, const int32_t *pos, int n_pos, float *table) {
+    const float theta_scale = powf(rp->freq_base, -2.0f / rp->n_dims);
+    float corr0 = fmaxf(0.f, floorf(rope_corr_dim(rp->n_dims, rp->n_ctx_orig, rp->beta_fast, rp->freq_base)));
+    float corr1 = fminf((float)rp->n_dims - 1, ceilf(rope_corr_dim(rp->n_dims, rp->n_ctx_orig, rp->beta_slow, rp->freq_base)));
+    for (int i = 0; i < n_pos; i++) {
+        float *cache = table + (int64_t)i * ne0;
+        volatile float theta = (float)(pos ? pos[i] : i);
+        for (int64_t i0 = 0; i0 < ne0; i0 += 2) {
+            const float theta_extrap = theta;
+            volatile float theta_interp = rp->freq_scale * theta_extrap;
+            float th = theta_interp, mscale = rp->attn_factor;
+            if (rp->ext_factor != 0.0f) {
+                const float y = ((int)i0 / 2 - corr0) / fmaxf(0.001f, corr1 - corr0);
+                const float ramp_mix = (1 - fminf(1, fmaxf(0, y))) * rp->ext_factor;
+                volatile float t1 = theta_interp * (1 - ramp_mix);
+                volatile float t2 = theta_extrap * ramp_mix;
+                th = t1 + t2;
+                mscale *= 1.0f + 0.1f * logf(1.0f / rp->freq_scale);
+            }
+            volatile float c = cosf(th), s = sinf(th);
+            cache[i0 + 0] = c * mscale;
+            cache[i0 + 1] = s * mscale;
+            theta = theta * theta_scale;
+        }
+    }
+}
+
+static inline bool is_quant(int t) { return t == PS_Q4_0 || t == PS_Q8_0 || t == PS_Q4_K || t == PS_Q6_K; }
+
+extern "C" {
+
+int ps_hip_abi_version(void) { return PS_HIP_ABI_VERSION; }
+
+int ps_hip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int ps_hip_create(int device, ps_hip_ctx **out) {
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device >= n) return 1;
+    if (hipSetDevice(device) != hipSuccess) return 1;
+    auto c    = new ps_hip_ctx();
+    c->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cu = prop.multiProcessorCount;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return 1; }
+    *out = c;
+    return 0;
+}
+
+void ps_hip_destroy(ps_hip_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    if (c->act_buf) (void)hipFree(c->act_buf);
+    if (c->i32_buf) (void)hipFree(c->i32_buf);
+    if (c->u8_buf) (void)hipFree(c->u8_buf);
+    if (c->rope_buf) (void)hipFree(c->rope_buf);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char *ps_hip_last_error(const ps_hip_ctx *c) { return c ? c->err.c_str() : "no context"; }
+
+int ps_hip_device_name(const ps_hip_ctx *c, char *buf, size_t cap) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, c->device) != hipSuccess) return 1;
+    snprintf(buf, cap, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    return 0;
+}
+
+int ps_hip_malloc(ps_hip_ctx *c, size_t bytes, void **dptr) {
+    PS_CHECK(c, hipSetDevice(c->device));
+    PS_CHECK(c, hipMalloc(dptr, bytes ? bytes : 16));
+    return 0;
+}
+int ps_hip_free(ps_hip_ctx *c, void *dptr) {
+    PS_CHECK(c, hipStreamSynchronize(c->stream));
+    PS_CHECK(c, hipFree(dptr));
+    return 0;
+}
+int ps_hip_memcpy_h2d(ps_hip_ctx *c, void *dst, const void *src, size_t bytes) {
+    PS_CHECK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    PS_CHECK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+int ps_hip_memcpy_d2h(ps_hip_ctx *c, void *dst, const void *src, size_t bytes) {
+    PS_CHECK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    PS_CHECK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+int ps_hip_memset(ps_hip_ctx *c, void *dst, int value, size_t bytes) {
+    PS_CHECK(c, hipMemsetAsync(dst, value, bytes, c->stream));
+    return 0;
+}
+int ps_hip_sync(ps_hip_ctx *c) {
+    PS_CHECK(c, hipStreamSynchronize(c->stream));
+    PS_CHECK(c, hipGetLastError());
+    return 0;
+}
+void *ps_hip_stream(ps_hip_ctx *c) { return (void *)c->stream; }
+
+int ps_hip_event_create(ps_hip_ctx *c, void **ev) {
+    hipEvent_t e;
+    PS_CHECK(c, hipEventCreate(&e));
+    *ev = (void *)e;
+    return 0;
+}
+int ps_hip_event_record(ps_hip_ctx *c, void *ev) {
+    PS_CHECK(c, hipEventRecord((hipEvent_t)ev, c->stream));
+    return 0;
+}
+int ps_hip_event_elapsed_ms(ps_hip_ctx *c, void *a, void *b, float *ms) {
+    PS_CHECK(c, hipEventSynchronize((hipEvent_t)b));
+    PS_CHECK(c, hipEventElapsedTime(ms, (hipEvent_t)a, (hipEvent_t)b));
+    return 0;
+}
+int ps_hip_event_destroy(ps_hip_ctx *c, void *ev) {
+    PS_CHECK(c, hipEventDestroy((hipEvent_t)ev));
+    return 0;
+}
+
+// ------------------------------------------------------------------ type helpers (ggml.c:681-1015)
+size_t ps_hip_row_size(int t, int64_t k) {
+    switch (t) {
+    case PS_F32: case PS_I32: return (size_t)k * 4;
+    case PS_F16: return (size_t)k * 2;
+    case PS_Q4_0: return (size_t)(k / 32) * 18;
+    case PS_Q8_0: return (size_t)(k / 32) * 34;
+    case PS_Q4_K: return (size_t)(k / 256) * 144;
+    case PS_Q6_K: return (size_t)(k / 256) * 210;
+    case PS_Q8_K: return (size_t)(k / 256) * 292;
+    }
+    return 0;
+}
+int ps_hip_vec_dot_type(int t) {
+    switch (t) {
+    case PS_Q4_0: case PS_Q8_0: return PS_Q8_0;
+    case PS_Q4_K: case PS_Q6_K: return PS_Q8_K;
+    }
+    return t;
+}
+
+// ------------------------------------------------------------------ weights
+int ps_hip_weight_upload(ps_hip_ctx *c, int dtype, const void *host, int64_t K, int64_t N, ps_weight **out) {
+    *out = nullptr;
+    if (!(is_quant(dtype) || dtype == PS_F32)) PS_FAIL(c, "weight_upload: unsupported dtype");
+    const int64_t blk = (dtype == PS_Q4_K || dtype == PS_Q6_K) ? 256 : (dtype == PS_F32 ? 1 : 32);
+    if (K % blk) PS_FAIL(c, "weight_upload: K is not a multiple of the block size");
+    PS_CHECK(c, hipSetDevice(c->device));
+    auto w        = new ps_weight();
+    w->dtype      = dtype;
+    w->K          = K;
+    w->N          = N;
+    w->gguf_bytes = (uint64_t)N * ps_hip_row_size(dtype, K);
+    const size_t raw = (size_t)w->gguf_bytes;
+    auto fail = [&](const char *m) { ps_hip_weight_free(c, w); c->err = m; return 1; };
+    if (dtype == PS_F32) {
+        if (hipMalloc((void **)&w->qs, raw) != hipSuccess) return fail("weight_upload: hipMalloc");
+        if (hipMemcpyAsync(w->qs, host, raw, hipMemcpyHostToDevice, c->stream) != hipSuccess) return fail("weight_upload: copy");
+        PS_CHECK(c, hipStreamSynchronize(c->stream));
+        *out = w;
+        return 0;
+    }
+    uint8_t *tmp = nullptr;
+    if (hipMalloc((void **)&tmp, raw + 64) != hipSuccess) return fail("weight_upload: hipMalloc(tmp)");
+    size_t qs_b = 0, aux_b = 0, qh_b = 0, sc_b = 0;
+    if (dtype == PS_Q4_0) { qs_b = (size_t)N * K / 2; aux_b = (size_t)N * (K / 32) * 2; }
+    if (dtype == PS_Q8_0) { qs_b = (size_t)N * K; aux_b = (size_t)N * (K / 32) * 2; }
+    if (dtype == PS_Q4_K) { qs_b = (size_t)N * K / 2; aux_b = (size_t)N * (K / 256) * 16; }
+    if (dtype == PS_Q6_K) { qs_b = (size_t)N * K / 2; qh_b = (size_t)N * K / 4; sc_b = (size_t)N * K / 16; aux_b = (size_t)N * (K / 256) * 2; }
+    bool ok = hipMalloc((void **)&w->qs, qs_b + 64) == hipSuccess && hipMalloc((void **)&w->aux, aux_b + 64) == hipSuccess;
+    if (ok && qh_b) ok = hipMalloc((void **)&w->qh, qh_b + 64) == hipSuccess && hipMalloc((void **)&w->sc, sc_b + 64) == hipSuccess;
+    if (!ok) { (void)hipFree(tmp); return fail("weight_upload: hipMalloc(planes)"); }
+    if (hipMemcpyAsync(tmp, host, raw, hipMemcpyHostToDevice, c->stream) != hipSuccess) { (void)hipFree(tmp); return fail("weight_upload: copy"); }
+    psk_repack_weight(c->stream, dtype, tmp, K, N, w);
+    hipError_t e = hipStreamSynchronize(c->stream);
+    (void)hipFree(tmp);
+    if (e != hipSuccess) return fail("weight_upload: repack");
+    *out = w;
+    return 0;
+}
+
+void ps_hip_weight_free(ps_hip_ctx *c, ps_weight *w) {
+    if (!w) return;
+    (void)c;
+    if (w->qs) (void)hipFree(w->qs);
+    if (w->aux) (void)hipFree(w->aux);
+    if (w->qh) (void)hipFree(w->qh);
+    if (w->sc) (void)hipFree(w->sc);
+    delete w;
+}
+uint64_t ps_hip_weight_gguf_bytes(const ps_weight *w) { return w->gguf_bytes; }
+int ps_hip_weight_dtype(const ps_weight *w) { return w->dtype; }
+
+// ------------------------------------------------------------------ scratch helpers
+static int ensure(ps_hip_ctx *c, void **buf, size_t *cap, size_t need) {
+    if (*cap >= need) return 0;
+    PS_CHECK(c, hipStreamSynchronize(c->stream));
+    if (*buf) PS_CHECK(c, hipFree(*buf));
+    *buf = nullptr;
+    *cap = 0;
+    PS_CHECK(c, hipMalloc(buf, need));
+    *cap = need;
+    return 0;
+}
+static int stage_i32(ps_hip_ctx *c, const int32_t *host, int n, int32_t **dev) {
+    if (ensure(c, (void **)&c->i32_buf, &c->i32_cap, (size_t)n * 4 + 16)) return 1;
+    PS_CHECK(c, hipMemcpyAsync(c->i32_buf, host, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    PS_CHECK(c, hipStreamSynchronize(c->stream)); // host buffer may be a temporary
+    *dev = c->i32_buf;
+    return 0;
+}
+
+// ------------------------------------------------------------------ ops
+int ps_hip_quantize_act(ps_hip_ctx *c, int vdt, const float *x, int64_t K, int64_t rows, void *out_blocks) {
+    if (vdt != PS_Q8_0 && vdt != PS_Q8_K) PS_FAIL(c, "quantize_act: vdt must be Q8_0 or Q8_K");
+    if (K % (vdt == PS_Q8_0 ? 32 : 256)) PS_FAIL(c, "quantize_act: K not a multiple of the block size");
+    if (ensure(c, &c->act_buf, &c->act_cap, ps_act_bytes(K, rows))) return 1;
+    ps_act a = ps_act_carve(c->act_buf, K, rows);
+    psk_quantize_act(c->stream, vdt, 0, x, nullptr, nullptr, 0.f, K, rows, a);
+    psk_pack_act_blocks(c->stream, vdt, a, K, rows, out_blocks);
+    PS_CHECK(c, hipGetLastError());
+    return 0;
+}
+
+int ps_hip_mul_mat(ps_hip_ctx *c, const ps_tensor *dst, const ps_tensor *src0, const ps_tensor *src1) {
+    // checks mirror powerserve_compute_forward_mul_mat's asserts (ggml.c:13457-13470) and Graph::mat_mul
+    if (src0->ne[0] != src1->ne[0]) PS_FAIL(c, "mul_mat: ne00 != ne10");
+    if (dst->ne[0] != src0->ne[1] || dst->ne[1] != src1->ne[1] || dst->ne[2] != src1->ne[2] || dst->ne[3] != src1->ne[3])
+        PS_FAIL(c, "mul_mat: bad dst shape");
+    if (src1->dtype != PS_F32 || dst->dtype != PS_F32) PS_FAIL(c, "mul_mat: src1/dst must be F32");
+    if (src1->nb[0] != 4 || dst->nb[0] != 4) PS_FAIL(c, "mul_mat: permuted src1/dst not supported");
+    if (is_quant(src0->dtype)) {
+        const ps_weight *w = (const ps_weight *)src0->data;
+        if (!w || w->dtype != src0->dtype || w->K != src0->ne[0] || w->N != src0->ne[1]) PS_FAIL(c, "mul_mat: weight handle mismatch");
+        if (w->dtype == PS_Q6_K) PS_FAIL(c, "mul_mat: Q6_K mat-mul not implemented yet");
+        const int64_t K = w->K, bs = src1->ne[1] * src1->ne[2] * src1->ne[3];
+        if (src1->nb[1] != (uint64_t)K * 4 || dst->nb[1] != (uint64_t)w->N * 4) PS_FAIL(c, "mul_mat: quantized path needs contiguous rows");
+        const int vdt = ps_hip_vec_dot_type(w->dtype);
+        if (ensure(c, &c->act_buf, &c->act_cap, ps_act_bytes(K, bs))) return 1;
+        ps_act a = ps_act_carve(c->act_buf, K, bs);
+        psk_quantize_act(c->stream, vdt, 0, (const float *)src1->data, nullptr, nullptr, 0.f, K, bs, a);
+        for (int64_t c0 = 0; c0 < bs; c0 += 4) { // <= 4 columns per GEMV launch
+            const int64_t nb = bs - c0 < 4 ? bs - c0 : 4;
+            psk_gemv_args g{};
+            g.n_w = 1; g.w[0] = w; g.out[0] = (float *)dst->data + c0 * w->N; g.ldo[0] = w->N;
+            ps_act ac = a; ac.qs += c0 * K; ac.d += c0 * (K / (vdt == PS_Q8_0 ? 32 : 256)); ac.bs16 += c0 * (K / 16);
+            if (int rc = psk_gemv(c->stream, c->n_cu, g, ac, vdt, K, nb)) { c->err = "mul_mat: gemv launch rc=" + std::to_string(rc); return 2; }
+        }
+    } else if (src0->dtype == PS_F32) {
+        if (src0->nb[0] != 4) PS_FAIL(c, "mul_mat: transposed src0 not supported");
+        if (src1->ne[2] % src0->ne[2] || src1->ne[3] % src0->ne[3]) PS_FAIL(c, "mul_mat: src0 not broadcastable");
+        psl_mul_mat_f32(c->stream, dst, src0, src1);
+    } else {
+        PS_FAIL(c, "mul_mat: unsupported src0 dtype");
+    }
+    PS_CHECK(c, hipGetLastError());
+    return 0;
+}
+
+int ps_hip_rms_norm(ps_hip_ctx *c, const ps_tensor *dst, const ps_tensor *src, const ps_tensor *weight, float eps) {
+    if (src->dtype != PS_F32 || src->nb[0] != 4 || dst->nb[0] != 4) PS_FAIL(c, "rms_norm: F32 rows required");
+    if (!(eps > 0.0f)) PS_FAIL(c, "rms_norm: eps must be > 0");
+    if (weight && weight->ne[0] != src->ne[0]) PS_FAIL(c, "rms_norm: weight length mismatch");
+    psl_rms_norm(c->stream, dst, src, weight ? (const float *)weight->data : nullptr, eps);
+    PS_CHECK(c, hipGetLastError());
+    return 0;
+}
+
+int ps_hip_rope(ps_hip_ctx *c, const ps_tensor *dst, const ps_tensor *src, const int32_t *pos, int n_pos, const ps_rope_params *rp) {
+    if (src->ne[2] != n_pos) PS_FAIL(c, "rope: ne2 != number of positions");
+    if (rp->n_dims > src->ne[0] || rp->n_dims % 2) PS_FAIL(c, "rope: bad n_dims");
+    const size_t bytes = (size_t)n_pos * src->ne[0] * 4;
+    std::vector<float> tab((size_t)n_pos * src->ne[0]);
+    ps_rope_table_host(rp, src->ne[0], pos, n_pos, tab.data());
+    if (ensure(c, (void **)&c->rope_buf, &c->rope_cap, bytes)) return 1;
+    PS_CHECK(c, hipMemcpyAsync(c->rope_buf, tab.data(), bytes, hipMemcpyHostToDevice, c->stream));
+    PS_CHECK(c, hipStreamSynchronize(c->stream));
+    psl_rope(c->stream, dst, src, c->rope_buf, rp->n_dims, (rp->mode & 2) ? 1 : 0);
+    PS_CHECK(c, hipGetLastError());
+    return 0;
+}
+
+int ps_hip_softmax_ext(ps_hip_ctx *c, const ps_tensor *dst, const ps_tensor *src, const ps_tensor *mask, float scale, float max_bias) {
+    if (max_bias != 0.0f) PS_FAIL(c, "softmax_ext: ALiBi (max_bias != 0) is not on PowerServe's path");
+    if (src->ne[0] * 4 > 150 * 1024) PS_FAIL(c, "softmax_ext: row too long for the LDS-resident kernel");
+    static bool attr = false;
+    (void)attr;
+    psl_softmax_ext(c->stream, dst, src, mask ? (const float *)mask->data : nullptr, scale);
+    PS_CHECK(c, hipGetLastError());
+    return 0;
+}
+
+int ps_hip_add(ps_hip_ctx *c, const ps_tensor *dst, const ps_tensor *a, const ps_tensor *b) {
+    for (int i = 0; i < 4; i++)
+        if (a->ne[i] % b->ne[i]) PS_FAIL(c, "add: b is not repeat-broadcastable into a");
+    psl_add(c->stream, dst, a, b);
+    PS_CHECK(c, hipGetLastError());
+    return 0;
+}
+
+int ps_hip_dup(ps_hip_ctx *c, const ps_tensor *dst, const ps_tensor *src) {
+    const int64_t nd = dst->ne[0] * dst->ne[1] * dst->ne[2] * dst->ne[3], ns = src->ne[0] * src->ne[1] * src->ne[2] * src->ne[3];
+    if (nd != ns) PS_FAIL(c, "dup: element counts differ");
+    if (dst->dtype != PS_F32 || src->dtype != PS_F32) PS_FAIL(c, "dup: F32 only");
+    psl_dup(c->stream, dst, src);
+    PS_CHECK(c, hipGetLastError());
+    return 0;
+}
+
+int ps_hip_silu_hadamard(ps_hip_ctx *c, const ps_tensor *dst, const ps_tensor *gate, const ps_tensor *up) {
+    const int64_t n = gate->ne[0] * gate->ne[1] * gate->ne[2] * gate->ne[3];
+    psl_silu_hadamard(c->stream, (float *)dst->data, (const float *)gate->data, (const float *)up->data, n);
+    PS_CHECK(c, hipGetLastError());
+    return 0;
+}
+
+int ps_hip_get_embedding(ps_hip_ctx *c, const ps_tensor *dst, const ps_tensor *weight, const int32_t *tokens, int n) {
+    const ps_weight *w = (const ps_weight *)weight->data;
+    if (!w || dst->ne[0] != w->K || dst->ne[1] != n) PS_FAIL(c, "get_embedding: shape mismatch");
+    for (int i = 0; i < n; i++)
+        if (tokens[i] < 0 || tokens[i] >= w->N) PS_FAIL(c, "get_embedding: token id out of range");
+    int32_t *td;
+    if (stage_i32(c, tokens, n, &td)) return 1;
+    psl_get_rows(c->stream, w, td, n, (float *)dst->data);
+    PS_CHECK(c, hipGetLastError());
+    return 0;
+}
+
+int ps_hip_get_mask(ps_hip_ctx *c, const ps_tensor *dst, const int32_t *pos, int n_pos, const uint8_t *tree) {
+    if (dst->ne[1] != n_pos) PS_FAIL(c, "get_mask: ne1 != batch");
+    int32_t *pd;
+    if (stage_i32(c, pos, n_pos, &pd)) return 1;
+    const uint8_t *td = nullptr;
+    if (tree) {
+        if (ensure(c, (void **)&c->u8_buf, &c->u8_cap, (size_t)n_pos * n_pos)) return 1;
+        PS_CHECK(c, hipMemcpyAsync(c->u8_buf, tree, (size_t)n_pos * n_pos, hipMemcpyHostToDevice, c->stream));
+        PS_CHECK(c, hipStreamSynchronize(c->stream));
+        td = c->u8_buf;
+    }
+    psl_get_mask(c->stream, (float *)dst->data, dst->ne[0], n_pos, pd, td);
+    PS_CHECK(c, hipGetLastError());
+    return 0;
+}
+
+int ps_hip_argmax(ps_hip_ctx *c, const float *src, int64_t n, int64_t rows, int32_t *out_dev) {
+    psl_argmax(c->stream, src, n, rows, out_dev);
+    PS_CHECK(c, hipGetLastError());
+    return 0;
+}
+
+} // extern "C"

@@ -1,0 +1,320 @@
+// Whole-model fast path: what HIPBackend::plan() lowers the reference's per-layer op sequence to
+// (LlamaModel::forward, src/model/llama/llama_model.cpp:52-117; NormAttention::build,
+// src/model/module/norm_attention.cpp:26-160; FFN::build, src/model/module/ffn.cpp:22-42).
+//
+// Launch plan per layer (decode, bs <= 4):
+//   quantize_act(rmsnorm) -> gemv[Wq|Wk|Wv](+bias) -> rope_append -> attn_scores -> attn_softmax_pv
+//   -> quantize_act -> gemv[Wo]+residual -> quantize_act(rmsnorm) -> gemv[Wgate|Wup] SiLU*up
+//   -> quantize_act -> gemv[Wdown]+residual
+// A persistent arena replaces the reference's malloc-per-intermediate (src/executor/executor.cpp:23-45);
+// the single-token step is captured once into a hipGraph and replayed (all position-dependent values are
+// read from a device-resident ps_step_state).
+#include "ps_internal.h"
+#include "ps_ops.h"
+
+#include <cstdio>
+#include <cstring>
+
+int psk_gemm(hipStream_t st, int n_cu, const psk_gemv_args &a, ps_act act, int vdt, int64_t K, int64_t bs); // k_gemm.hip
+
+namespace {
+__global__ void set_state_kernel(ps_step_state *s, int pos0, int bs, int n_out) {
+    s->pos0 = pos0; s->bs = bs; s->n_out = n_out;
+}
+// after the lm_head arg-max of a greedy step: feed the id back as the next token and advance the state
+__global__ void decode_advance_kernel(ps_step_state *s, const int32_t *argmax, int32_t *token, int32_t *ids) {
+    const int id = argmax[0];
+    token[0]     = id;
+    ids[s->n_out] = id;
+    s->n_out += 1;
+    s->pos0 += 1;
+}
+__global__ void kv_move_kernel(float *k, float *v, int kvd, int n_ctx, int dst, int src) {
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= kvd) return;
+    k[(int64_t)dst * kvd + d]   = k[(int64_t)src * kvd + d];
+    v[(int64_t)d * n_ctx + dst] = v[(int64_t)d * n_ctx + src];
+}
+} // namespace
+
+struct ps_hip_model {
+    ps_hip_ctx *ctx = nullptr;
+    ps_llm_config cfg{};
+    bool qwen2 = false;
+    int max_batch = 1;
+    const ps_weight *token_embd = nullptr, *output = nullptr;
+    const float *output_norm = nullptr;
+    std::vector<const float *> attn_norm, ffn_norm, bq, bk, bv;
+    std::vector<const ps_weight *> wq, wk, wv, wo, wg, wu, wd;
+    // arena
+    float *x = nullptr, *q = nullptr, *k = nullptr, *v = nullptr, *att = nullptr, *hb = nullptr, *g1 = nullptr, *u1 = nullptr;
+    float *scores = nullptr, *logits = nullptr, *rope_table = nullptr;
+    void *act_mem = nullptr;
+    std::vector<float *> k_cache, v_cache;
+    ps_step_state *state = nullptr;
+    int32_t *tokens_dev = nullptr, *argmax_dev = nullptr, *ids_dev = nullptr;
+    uint8_t *tree_dev = nullptr;
+    size_t position = 0;
+    int mode = 0;
+    hipGraphExec_t step_graph = nullptr;
+    uint64_t weight_bytes = 0;
+    std::vector<void *> owned;
+};
+
+static int dmalloc(ps_hip_model *m, void **p, size_t bytes) {
+    ps_hip_ctx *c = m->ctx;
+    PS_CHECK(c, hipMalloc(p, bytes ? bytes : 16));
+    m->owned.push_back(*p);
+    return 0;
+}
+
+static int mm(ps_hip_model *m, psk_gemv_args &g, ps_act act, int64_t K, int64_t bs) {
+    ps_hip_ctx *c = m->ctx;
+    const int vdt = ps_hip_vec_dot_type(g.w[0]->dtype);
+    const int64_t blk = vdt == PS_Q8_0 ? 32 : 256;
+    if (bs > 4) {
+        int rc = psk_gemm(c->stream, c->n_cu, g, act, vdt, K, bs);
+        if (rc == 0) return 0;
+        if (rc != -1) { c->err = "gemm launch rc=" + std::to_string(rc); return 2; }
+        // rc == -1: shape not covered by the MFMA kernel -> column groups through the GEMV
+    }
+    for (int64_t c0 = 0; c0 < bs; c0 += 4) {
+        const int64_t nb = bs - c0 < 4 ? bs - c0 : 4;
+        psk_gemv_args gg = g;
+        for (int i = 0; i < g.n_w; i++) gg.out[i] = g.out[i] + c0 * g.ldo[i];
+        if (g.residual) gg.residual = g.residual + c0 * g.ldo[0];
+        ps_act ac = act;
+        ac.qs += c0 * K; ac.d += c0 * (K / blk); ac.bs16 += c0 * (K / 16);
+        if (int rc = psk_gemv(c->stream, c->n_cu, gg, ac, vdt, K, nb)) { c->err = "gemv launch rc=" + std::to_string(rc); return 2; }
+    }
+    return 0;
+}
+
+// enqueue one forward over `bs` tokens whose ids are in tokens_dev and whose state is in m->state
+static int enqueue_forward(ps_hip_model *m, int bs, bool lm_head, bool use_tree) {
+    ps_hip_ctx *c = m->ctx;
+    hipStream_t st = c->stream;
+    const ps_llm_config &f = m->cfg;
+    const int64_t dim = f.dim, kvd = f.kv_dim, hid = f.hidden_dim;
+    const int64_t Kmax = dim > hid ? dim : hid;
+    ps_act act = ps_act_carve(m->act_mem, Kmax, m->max_batch);
+    // activation rows are laid out with the row strides of the *current* K, so carve per use:
+    auto act_for = [&](int64_t K) { return ps_act_carve(m->act_mem, K, m->max_batch); };
+    (void)act;
+
+    psl_get_rows(st, m->token_embd, m->tokens_dev, bs, m->x);
+    psl_attn_args aa{};
+    aa.n_heads = (int)f.n_heads; aa.n_kv_heads = (int)f.n_kv_heads; aa.head_size = (int)f.head_size; aa.n_ctx = (int)f.seq_len;
+    aa.neox = (f.rope.mode & 2) ? 1 : 0; aa.n_dims = f.rope.n_dims; aa.state = m->state; aa.rope_table = m->rope_table;
+    aa.q = m->q; aa.k = m->k; aa.v = m->v; aa.scores = m->scores; aa.att = m->att;
+    aa.tree = use_tree ? m->tree_dev : nullptr;
+    aa.scale = 1.0f / sqrtf((float)f.head_size);
+
+    for (uint32_t L = 0; L < f.n_layers; L++) {
+        const int vdt_a = ps_hip_vec_dot_type(m->wq[L]->dtype);
+        ps_act a1 = act_for(dim);
+        psk_quantize_act(st, vdt_a, 1, m->x, nullptr, m->attn_norm[L], f.norm_eps, dim, bs, a1);
+        psk_gemv_args g{};
+        g.n_w = 3;
+        g.w[0] = m->wq[L]; g.w[1] = m->wk[L]; g.w[2] = m->wv[L];
+        g.out[0] = m->q; g.out[1] = m->k; g.out[2] = m->v;
+        g.ldo[0] = dim; g.ldo[1] = kvd; g.ldo[2] = kvd;
+        if (m->qwen2) { g.bias[0] = m->bq[L]; g.bias[1] = m->bk[L]; g.bias[2] = m->bv[L]; }
+        if (mm(m, g, a1, dim, bs)) return 2;
+
+        aa.k_cache = m->k_cache[L]; aa.v_cache = m->v_cache[L];
+        psl_rope_append(st, aa, bs);
+        psl_attn_scores(st, aa, bs);
+        psl_attn_softmax_pv(st, aa, bs);
+
+        const int vdt_o = ps_hip_vec_dot_type(m->wo[L]->dtype);
+        psk_quantize_act(st, vdt_o, 0, m->att, nullptr, nullptr, 0.f, dim, bs, a1);
+        psk_gemv_args go{};
+        go.n_w = 1; go.w[0] = m->wo[L]; go.out[0] = m->x; go.ldo[0] = dim; go.residual = m->x;
+        if (mm(m, go, a1, dim, bs)) return 2;
+
+        const int vdt_f = ps_hip_vec_dot_type(m->wg[L]->dtype);
+        psk_quantize_act(st, vdt_f, 1, m->x, nullptr, m->ffn_norm[L], f.norm_eps, dim, bs, a1);
+        ps_act a2 = act_for(hid);
+        const int vdt_d = ps_hip_vec_dot_type(m->wd[L]->dtype);
+        if (bs <= 4) {
+            psk_gemv_args gf{};
+            gf.n_w = 2; gf.w[0] = m->wg[L]; gf.w[1] = m->wu[L]; gf.out[0] = m->hb; gf.out[1] = m->hb; gf.ldo[0] = hid; gf.ldo[1] = hid;
+            gf.silu_pair = 1;
+            if (mm(m, gf, a1, dim, bs)) return 2;
+            psk_quantize_act(st, vdt_d, 0, m->hb, nullptr, nullptr, 0.f, hid, bs, a2);
+        } else {
+            psk_gemv_args gf{};
+            gf.n_w = 2; gf.w[0] = m->wg[L]; gf.w[1] = m->wu[L]; gf.out[0] = m->g1; gf.out[1] = m->u1; gf.ldo[0] = hid; gf.ldo[1] = hid;
+            if (mm(m, gf, a1, dim, bs)) return 2;
+            psk_quantize_act(st, vdt_d, 2, m->g1, m->u1, nullptr, 0.f, hid, bs, a2);
+        }
+        psk_gemv_args gd{};
+        gd.n_w = 1; gd.w[0] = m->wd[L]; gd.out[0] = m->x; gd.ldo[0] = dim; gd.residual = m->x;
+        if (mm(m, gd, a2, hid, bs)) return 2;
+    }
+    if (lm_head) {
+        const ps_weight *ow = m->output ? m->output : m->token_embd; // tied lm_head (weights.hpp:67-68)
+        const int vdt = ps_hip_vec_dot_type(ow->dtype);
+        ps_act a1 = act_for(dim);
+        psk_quantize_act(st, vdt, 1, m->x, nullptr, m->output_norm, f.norm_eps, dim, bs, a1);
+        psk_gemv_args gl{};
+        gl.n_w = 1; gl.w[0] = ow; gl.out[0] = m->logits; gl.ldo[0] = f.vocab_size;
+        if (mm(m, gl, a1, dim, bs)) return 2;
+        psl_argmax(st, m->logits, f.vocab_size, bs, m->argmax_dev);
+    }
+    PS_CHECK(c, hipGetLastError());
+    return 0;
+}
+
+extern "C" {
+
+int ps_hip_model_create(ps_hip_ctx *c, const ps_model_desc *d, ps_hip_model **out) {
+    *out = nullptr;
+    const ps_llm_config &f = d->cfg;
+    if (f.n_heads % f.n_kv_heads || f.head_size * f.n_heads != f.dim || f.head_size * f.n_kv_heads != f.kv_dim)
+        PS_FAIL(c, "model_create: inconsistent head configuration");
+    if (f.head_size % 32 || f.head_size > 128) PS_FAIL(c, "model_create: head_size must be 32, 64, 96 or 128");
+    if (f.n_heads / f.n_kv_heads > 8) PS_FAIL(c, "model_create: GQA ratio > 8 not supported");
+    if ((int)f.rope.n_dims != (int)f.head_size) PS_FAIL(c, "model_create: rope n_dims != head_size (reference asserts the same, norm_attention.cpp:38)");
+    if (f.seq_len % 4) PS_FAIL(c, "model_create: n_ctx must be a multiple of 4");
+    if ((size_t)(f.n_heads / f.n_kv_heads) * f.seq_len * 4 > 150 * 1024) PS_FAIL(c, "model_create: n_ctx too large for the LDS-resident softmax (cap n_ctx)");
+    PS_CHECK(c, hipSetDevice(c->device));
+    auto m = new ps_hip_model();
+    m->ctx = c; m->cfg = f; m->qwen2 = d->is_qwen2 != 0; m->max_batch = d->max_batch > 0 ? d->max_batch : 1;
+    m->token_embd = d->token_embd; m->output = d->output; m->output_norm = d->output_norm;
+    const uint32_t L = f.n_layers;
+    auto cpf = [&](std::vector<const float *> &v, const float *const *src) { v.assign(L, nullptr); if (src) for (uint32_t i = 0; i < L; i++) v[i] = src[i]; };
+    auto cpw = [&](std::vector<const ps_weight *> &v, const ps_weight *const *src) { v.assign(L, nullptr); for (uint32_t i = 0; i < L; i++) v[i] = src[i]; };
+    cpf(m->attn_norm, d->attn_norm); cpf(m->ffn_norm, d->ffn_norm);
+    cpf(m->bq, d->attn_q_bias); cpf(m->bk, d->attn_k_bias); cpf(m->bv, d->attn_v_bias);
+    cpw(m->wq, d->attn_q); cpw(m->wk, d->attn_k); cpw(m->wv, d->attn_v); cpw(m->wo, d->attn_output);
+    cpw(m->wg, d->ffn_gate); cpw(m->wu, d->ffn_up); cpw(m->wd, d->ffn_down);
+    m->weight_bytes = (m->output ? m->output : m->token_embd)->gguf_bytes;
+    for (uint32_t i = 0; i < L; i++)
+        m->weight_bytes += m->wq[i]->gguf_bytes + m->wk[i]->gguf_bytes + m->wv[i]->gguf_bytes + m->wo[i]->gguf_bytes +
+                           m->wg[i]->gguf_bytes + m->wu[i]->gguf_bytes + m->wd[i]->gguf_bytes;
+
+    const size_t mb = (size_t)m->max_batch, dim = f.dim, kvd = f.kv_dim, hid = f.hidden_dim, nctx = f.seq_len;
+    auto fail = [&]() { ps_hip_model_destroy(m); return 1; };
+    if (dmalloc(m, (void **)&m->x, mb * dim * 4) || dmalloc(m, (void **)&m->q, mb * dim * 4) ||
+        dmalloc(m, (void **)&m->k, mb * kvd * 4) || dmalloc(m, (void **)&m->v, mb * kvd * 4) ||
+        dmalloc(m, (void **)&m->att, mb * dim * 4) || dmalloc(m, (void **)&m->hb, mb * hid * 4) ||
+        dmalloc(m, (void **)&m->g1, mb * hid * 4) || dmalloc(m, (void **)&m->u1, mb * hid * 4) ||
+        dmalloc(m, (void **)&m->scores, mb * f.n_heads * nctx * 4) || dmalloc(m, (void **)&m->logits, mb * f.vocab_size * 4) ||
+        dmalloc(m, (void **)&m->rope_table, nctx * f.head_size * 4) ||
+        dmalloc(m, &m->act_mem, ps_act_bytes(dim > hid ? dim : hid, mb)) ||
+        dmalloc(m, (void **)&m->state, sizeof(ps_step_state)) || dmalloc(m, (void **)&m->tokens_dev, mb * 4) ||
+        dmalloc(m, (void **)&m->argmax_dev, mb * 4) || dmalloc(m, (void **)&m->ids_dev, (nctx + 1) * 4) ||
+        dmalloc(m, (void **)&m->tree_dev, mb * mb))
+        return fail();
+    m->k_cache.assign(L, nullptr); m->v_cache.assign(L, nullptr);
+    for (uint32_t i = 0; i < L; i++) {
+        if (dmalloc(m, (void **)&m->k_cache[i], nctx * kvd * 4) || dmalloc(m, (void **)&m->v_cache[i], nctx * kvd * 4)) return fail();
+        (void)hipMemsetAsync(m->k_cache[i], 0, nctx * kvd * 4, c->stream);
+        (void)hipMemsetAsync(m->v_cache[i], 0, nctx * kvd * 4, c->stream);
+    }
+    // RoPE table for every cache position, host-built with the reference recurrence
+    std::vector<float> tab(nctx * f.head_size);
+    ps_rope_table_host(&f.rope, f.head_size, nullptr, (int)nctx, tab.data());
+    if (hipMemcpyAsync(m->rope_table, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, c->stream) != hipSuccess) return fail();
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return fail();
+    *out = m;
+    return 0;
+}
+
+void ps_hip_model_destroy(ps_hip_model *m) {
+    if (!m) return;
+    (void)hipStreamSynchronize(m->ctx->stream);
+    if (m->step_graph) (void)hipGraphExecDestroy(m->step_graph);
+    for (void *p : m->owned) (void)hipFree(p);
+    delete m;
+}
+
+size_t ps_hip_model_kv_position(const ps_hip_model *m) { return m->position; }
+int ps_hip_model_kv_truncate(ps_hip_model *m, size_t n) { if (n < m->position) m->position = n; return 0; }
+int ps_hip_model_kv_rollback(ps_hip_model *m, size_t n) {
+    if (n > m->position) { m->ctx->err = "kv_rollback: more tokens than cached"; return 2; }
+    m->position -= n;
+    return 0;
+}
+int ps_hip_model_kv_move(ps_hip_model *m, size_t dst, size_t src) {
+    if (dst == src) return 0;
+    if (dst >= m->cfg.seq_len || src >= m->cfg.seq_len) { m->ctx->err = "kv_move: index out of range"; return 2; }
+    for (uint32_t L = 0; L < m->cfg.n_layers; L++)
+        hipLaunchKernelGGL(kv_move_kernel, dim3((m->cfg.kv_dim + 255) / 256), dim3(256), 0, m->ctx->stream, m->k_cache[L],
+                           m->v_cache[L], (int)m->cfg.kv_dim, (int)m->cfg.seq_len, (int)dst, (int)src);
+    return 0;
+}
+
+int ps_hip_model_forward(ps_hip_model *m, const int32_t *tokens, int n, const int32_t *pos, const uint8_t *tree, int lm_head,
+                         int32_t *argmax_host) {
+    ps_hip_ctx *c = m->ctx;
+    if (n <= 0 || n > m->max_batch) PS_FAIL(c, "model_forward: batch size out of range");
+    for (int i = 1; i < n; i++)
+        if (pos[i] != pos[0] + i) PS_FAIL(c, "model_forward: positions must be consecutive (KV append is one contiguous copy, norm_attention.cpp:82-91)");
+    if (pos[0] < 0 || (size_t)pos[0] + (size_t)n > m->cfg.seq_len) PS_FAIL(c, "model_forward: KV cache is full (n_ctx)");
+    for (int i = 0; i < n; i++)
+        if (tokens[i] < 0 || (uint32_t)tokens[i] >= m->cfg.vocab_size) PS_FAIL(c, "model_forward: token id out of range");
+    PS_CHECK(c, hipSetDevice(c->device));
+    PS_CHECK(c, hipMemcpyAsync(m->tokens_dev, tokens, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    if (tree) PS_CHECK(c, hipMemcpyAsync(m->tree_dev, tree, (size_t)n * n, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(1), 0, c->stream, m->state, pos[0], n, 0);
+    PS_CHECK(c, hipStreamSynchronize(c->stream)); // tokens/tree may be host temporaries
+    if (int rc = enqueue_forward(m, n, lm_head != 0, tree != nullptr)) return rc;
+    if (lm_head && argmax_host) PS_CHECK(c, hipMemcpyAsync(argmax_host, m->argmax_dev, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    PS_CHECK(c, hipStreamSynchronize(c->stream));
+    m->position = (size_t)pos[0] + (size_t)n; // m_kv->advance (llama_model.cpp:109)
+    return 0;
+}
+
+int ps_hip_model_decode_greedy(ps_hip_model *m, int32_t token, int steps, int32_t *out_ids) {
+    ps_hip_ctx *c = m->ctx;
+    if (steps <= 0) return 0;
+    if (m->position + (size_t)steps > m->cfg.seq_len) PS_FAIL(c, "decode_greedy: KV cache would overflow n_ctx");
+    if (token < 0 || (uint32_t)token >= m->cfg.vocab_size) PS_FAIL(c, "decode_greedy: token id out of range");
+    PS_CHECK(c, hipSetDevice(c->device));
+    PS_CHECK(c, hipMemcpyAsync(m->tokens_dev, &token, 4, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(1), 0, c->stream, m->state, (int)m->position, 1, 0);
+    PS_CHECK(c, hipStreamSynchronize(c->stream));
+    int s = 0;
+    if (m->mode == 0 && !m->step_graph) {
+        // first step runs eagerly (also performs every one-time hipFuncSetAttribute), then the identical
+        // launch sequence is captured; capture itself executes nothing
+        if (int rc = enqueue_forward(m, 1, true, false)) return rc;
+        hipLaunchKernelGGL(decode_advance_kernel, dim3(1), dim3(1), 0, c->stream, m->state, m->argmax_dev, m->tokens_dev, m->ids_dev);
+        PS_CHECK(c, hipStreamSynchronize(c->stream));
+        s = 1;
+        hipGraph_t g = nullptr;
+        PS_CHECK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+        int rc = enqueue_forward(m, 1, true, false);
+        hipLaunchKernelGGL(decode_advance_kernel, dim3(1), dim3(1), 0, c->stream, m->state, m->argmax_dev, m->tokens_dev, m->ids_dev);
+        hipError_t e = hipStreamEndCapture(c->stream, &g);
+        if (rc || e != hipSuccess) { c->err = "decode_greedy: graph capture failed: " + c->err; if (g) (void)hipGraphDestroy(g); return 2; }
+        PS_CHECK(c, hipGraphInstantiate(&m->step_graph, g, nullptr, nullptr, 0));
+        (void)hipGraphDestroy(g);
+    }
+    for (; s < steps; s++) {
+        if (m->mode == 0) {
+            PS_CHECK(c, hipGraphLaunch(m->step_graph, c->stream));
+        } else {
+            if (int rc = enqueue_forward(m, 1, true, false)) return rc;
+            hipLaunchKernelGGL(decode_advance_kernel, dim3(1), dim3(1), 0, c->stream, m->state, m->argmax_dev, m->tokens_dev, m->ids_dev);
+        }
+    }
+    PS_CHECK(c, hipMemcpyAsync(out_ids, m->ids_dev, (size_t)steps * 4, hipMemcpyDeviceToHost, c->stream));
+    PS_CHECK(c, hipStreamSynchronize(c->stream));
+    m->position += (size_t)steps;
+    return 0;
+}
+
+const float *ps_hip_model_logits(const ps_hip_model *m) { return m->logits; }
+const float *ps_hip_model_k_cache(const ps_hip_model *m, int L) { return m->k_cache[L]; }
+const float *ps_hip_model_v_cache(const ps_hip_model *m, int L) { return m->v_cache[L]; }
+uint64_t ps_hip_model_weight_bytes_per_token(const ps_hip_model *m) { return m->weight_bytes; }
+int ps_hip_model_set_mode(ps_hip_model *m, int mode) {
+    m->mode = mode;
+    return 0;
+}
+
+} // extern "C"

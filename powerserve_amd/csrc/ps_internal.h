@@ -1,0 +1,101 @@
+// Host-side internal structures of libps_hip (not part of the C-ABI).
+#pragma once
+#include "../../include/ps_hip.h"
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+struct ps_hip_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int n_cu = 256;
+    std::string err;
+    // scratch for op-level mul_mat activation quantization
+    void *act_buf = nullptr;
+    size_t act_cap = 0;
+    // small device staging for host-provided pos/tokens
+    int32_t *i32_buf = nullptr;
+    size_t i32_cap = 0;
+    uint8_t *u8_buf = nullptr;
+    size_t u8_cap = 0;
+    float *rope_buf = nullptr;
+    size_t rope_cap = 0;
+};
+
+// Device layout of a quantized weight matrix [K, N] (structure of arrays, private to the backend):
+//   Q4_0 : qs  [N][K/32][16]  nibbles          d   [N][K/32] fp16
+//   Q8_0 : qs  [N][K]         int8             d   [N][K/32] fp16
+//   Q4_K : qs  [N][K/256][128] nibbles         hdr [N][K/256] x 16 B {d, dmin, scales[12]}
+//   Q6_K : qs  [N][K/256][128] (ql)  qh [N][K/256][64]  sc [N][K/16] int8   d [N][K/256] fp16
+//   F32  : qs  [N][K] float
+struct ps_weight {
+    int dtype;
+    int64_t K, N;
+    uint8_t *qs  = nullptr;
+    uint8_t *aux = nullptr; // d (fp16) / hdr
+    uint8_t *qh  = nullptr;
+    uint8_t *sc  = nullptr;
+    uint64_t gguf_bytes = 0;
+};
+
+// Activation quantized for the integer dot (structure of arrays):
+//   qs   [rows][K] int8
+//   d    [rows][K/blk] float   (Q8_0: the fp16-rounded scale widened back to fp32; Q8_K: fp32 scale)
+//   bs16 [rows][K/16] int16    sums of 16 consecutive quants (== block_q8_K.bsums; also kept for Q8_0)
+struct ps_act {
+    int8_t *qs;
+    float *d;
+    int16_t *bs16;
+};
+
+#define PS_CHECK(ctx, call)                                                                          \
+    do {                                                                                             \
+        hipError_t e_ = (call);                                                                      \
+        if (e_ != hipSuccess) {                                                                      \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                          \
+            return 1;                                                                                \
+        }                                                                                            \
+    } while (0)
+
+#define PS_FAIL(ctx, msg)                                                                            \
+    do {                                                                                             \
+        (ctx)->err = (msg);                                                                          \
+        return 2;                                                                                    \
+    } while (0)
+
+static inline size_t ps_act_bytes(int64_t K, int64_t rows) {
+    // qs + d (worst case blk 32) + bs16, each 256-B aligned
+    auto al = [](size_t x) { return (x + 255) / 256 * 256; };
+    return al((size_t)K * rows) + al((size_t)(K / 32) * rows * 4) + al((size_t)(K / 16) * rows * 2);
+}
+static inline ps_act ps_act_carve(void *base, int64_t K, int64_t rows) {
+    auto al = [](size_t x) { return (x + 255) / 256 * 256; };
+    ps_act a;
+    char *p = (char *)base;
+    a.qs    = (int8_t *)p;
+    p += al((size_t)K * rows);
+    a.d = (float *)p;
+    p += al((size_t)(K / 32) * rows * 4);
+    a.bs16 = (int16_t *)p;
+    return a;
+}
+
+// ---- kernel launchers (defined in k_*.hip); all enqueue on `st`
+// activation quantization.  mode: 0 plain, 1 rmsnorm(x, w, eps) first, 2 silu(x)*x2 first
+void psk_quantize_act(hipStream_t st, int vdt, int mode, const float *x, const float *x2, const float *w, float eps,
+                      int64_t K, int64_t rows, ps_act out);
+void psk_pack_act_blocks(hipStream_t st, int vdt, ps_act in, int64_t K, int64_t rows, void *out_blocks);
+void psk_repack_weight(hipStream_t st, int dtype, const uint8_t *raw, int64_t K, int64_t N, ps_weight *w);
+
+struct psk_gemv_args {
+    int n_w;                 // 1..3 matrices sharing the activation
+    const ps_weight *w[3];
+    float *out[3];           // [N_i][bs] row stride ldo[i] floats per batch column
+    const float *bias[3];    // optional per-row bias (Qwen2)
+    int64_t ldo[3];
+    const float *residual;   // optional: out[0] = residual + y   (same layout as out[0])
+    int silu_pair;           // 1: n_w==2, out[0][r] = silu(y0[r]) * y1[r]
+};
+int psk_gemv(hipStream_t st, int n_cu, const psk_gemv_args &a, ps_act act, int vdt, int64_t K, int64_t bs);

@@ -1,0 +1,43 @@
+// Launchers of the reference-shaped operator kernels (k_ops.hip) and the fused attention kernels
+// (k_attn.hip).  Everything enqueues on `st`; pointers are device pointers.
+#pragma once
+#include "ps_internal.h"
+
+void psl_mul_mat_f32(hipStream_t st, const ps_tensor *dst, const ps_tensor *a, const ps_tensor *b);
+void psl_rms_norm(hipStream_t st, const ps_tensor *dst, const ps_tensor *src, const float *w, float eps);
+void psl_rope(hipStream_t st, const ps_tensor *dst, const ps_tensor *src, const float *cache, int n_dims, int neox);
+void psl_softmax_ext(hipStream_t st, const ps_tensor *dst, const ps_tensor *src, const float *mask, float scale);
+void psl_add(hipStream_t st, const ps_tensor *dst, const ps_tensor *a, const ps_tensor *b);
+void psl_dup(hipStream_t st, const ps_tensor *dst, const ps_tensor *src);
+void psl_silu_hadamard(hipStream_t st, float *out, const float *g, const float *u, int64_t n);
+void psl_get_rows(hipStream_t st, const ps_weight *w, const int32_t *tokens_dev, int n, float *out);
+void psl_get_mask(hipStream_t st, float *out, int64_t n_kv, int bs, const int32_t *pos_dev, const uint8_t *tree_dev);
+void psl_argmax(hipStream_t st, const float *src, int64_t n, int64_t rows, int32_t *out);
+
+// device-resident per-step state of the fused model path (read by kernels so a captured graph replays)
+struct ps_step_state {
+    int32_t pos0;    // KV position of the first token of this forward
+    int32_t bs;      // tokens in this forward
+    int32_t n_out;   // decode: number of ids written so far
+    int32_t _pad;
+};
+
+struct psl_attn_args {
+    int n_heads, n_kv_heads, head_size, n_ctx, neox, n_dims;
+    const ps_step_state *state;
+    const float *rope_table; // [n_ctx][head_size] (cos, sin) pairs, host-built (ggml.c:15344-15358)
+    float *q;                // [bs][n_heads*hs]   in: raw q, out: rotated q
+    const float *k, *v;      // [bs][kv_dim]
+    float *k_cache;          // [n_ctx][kv_dim]
+    float *v_cache;          // [kv_dim][n_ctx]
+    float *scores;           // [bs][n_heads][n_ctx] scratch
+    float *att;              // [bs][n_heads*hs]
+    const uint8_t *tree;     // optional [bs][bs] tree mask
+    float scale;
+};
+void psl_rope_append(hipStream_t st, const psl_attn_args &a, int bs);
+void psl_attn_scores(hipStream_t st, const psl_attn_args &a, int bs);
+void psl_attn_softmax_pv(hipStream_t st, const psl_attn_args &a, int bs);
+
+// host restatement of ggml_rope_cache_init for positions [0, n_pos) -> table[n_pos][ne0]
+void ps_rope_table_host(const ps_rope_params *rp, int64_t ne0, const int32_t *pos, int n_pos, float *table);

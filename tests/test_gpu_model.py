@@ -1,0 +1,101 @@
+"""End-to-end parity of the fused model path (ps_hip_model_*) against the CPU oracle on identical GGUF weights.
+
+north_star bar: bit-exact greedy token ids, logits within 1e-3 relative.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def load_tensors(path):
+    from powerserve_amd import gguf
+    rd = gguf.GGUFReader(path)
+    out = {}
+    for name, ti in rd.tensors.items():
+        ne = list(ti.ne) + [1]
+        out[name] = (ti.type, np.array(rd.data(name)), ne[0], ne[1])
+    return out
+
+
+CASES = [("tiny-llama", 2), ("tiny-llama", 8), ("tiny-llama", 12), ("tiny-qwen2", 8), ("tiny-qwen2", 2),
+         ("small-llama", 2), ("small-llama-hs128", 12)]
+
+
+@pytest.mark.parametrize("preset,wt", CASES)
+def test_generate_matches_oracle(ctx, oracle, tmp_path, preset, wt):
+    from oracle import binding as B
+    from powerserve_amd import hip, synth
+    d = str(tmp_path / "m")
+    mj = synth.write_model_dir(d, preset, wt, n_ctx=128, seed=wt + len(preset))
+    cfg = B.make_config(mj["llm_config"])
+    om = oracle.model(cfg, mj["model_arch"], load_tensors(os.path.join(d, "ggml/weights.gguf")), n_threads=4)
+    gm = hip.Model(ctx, d, max_batch=16)
+    rng = np.random.default_rng(42)
+    prompt = rng.integers(0, cfg.vocab_size, 21)
+    steps = 24
+    want_ids, want_logits, *_ = om.generate(prompt, 8, steps, want_logits=True)
+    # prefill in chunks (bs 8, 8, 4) + greedy decode through the captured graph
+    got_ids = gm.generate(prompt, 8, steps)
+    assert np.array_equal(got_ids, want_ids), (got_ids, want_ids)
+    # eager mode must agree with graph replay
+    gm.set_mode(1)
+    assert np.array_equal(gm.generate(prompt, 8, steps), want_ids)
+    gm.set_mode(0)
+    # logits of every decode step: teacher-force the oracle's ids one token at a time
+    gm.reset()
+    gm.forward(prompt[:-1][:16], np.arange(16), lm_head=False)
+    gm.forward(prompt[:-1][16:], np.arange(16, 20), lm_head=False)
+    cur = int(prompt[-1])
+    worst = 0.0
+    for s in range(steps):
+        lg, am = gm.forward([cur], [gm.position], lm_head=True)
+        worst = max(worst, rel_err(lg[0], want_logits[s]))
+        assert int(am[0]) == int(want_ids[s])
+        cur = int(want_ids[s])
+    assert worst < 1e-3, worst
+    # KV cache contents (K rows, transposed V) match the reference layout
+    n = gm.position
+    assert rel_err(gm.k_cache(0)[:n], om.k_cache(0)[:n]) < 1e-4
+    assert rel_err(gm.v_cache(1)[:, :n], om.v_cache(1)[:, :n]) < 1e-4
+    gm.close()
+    om.close()
+
+
+def test_batched_forward_logits(ctx, oracle, tmp_path):
+    """lm_head over a whole batch (LlamaModel::forward returns vocab x bs logits) + batch-size invariance."""
+    from oracle import binding as B
+    from powerserve_amd import hip, synth
+    d = str(tmp_path / "m")
+    mj = synth.write_model_dir(d, "tiny-llama", 12, n_ctx=64)
+    cfg = B.make_config(mj["llm_config"])
+    om = oracle.model(cfg, "llama", load_tensors(os.path.join(d, "ggml/weights.gguf")), n_threads=4)
+    gm = hip.Model(ctx, d, max_batch=16)
+    toks = np.arange(3, 14) % cfg.vocab_size
+    want = om.forward(toks, np.arange(toks.size), True)
+    got, am = gm.forward(toks, np.arange(toks.size), True)
+    assert rel_err(got, want) < 1e-3
+    assert np.array_equal(am, want.argmax(1))
+    gm.reset()
+    got1 = np.concatenate([gm.forward([t], [i], True)[0] for i, t in enumerate(toks)])
+    assert rel_err(got1, want) < 1e-3
+    gm.close()
+    om.close()
+
+
+def test_kv_full_and_bad_tokens_fail_loudly(ctx, tmp_path):
+    from powerserve_amd import hip, synth
+    d = str(tmp_path / "m")
+    synth.write_model_dir(d, "tiny-llama", 8, n_ctx=16)
+    gm = hip.Model(ctx, d, max_batch=8)
+    with pytest.raises(hip.PSHipError):
+        gm.forward([1, 2, 3], [14, 15, 16], lm_head=False)      # runs past n_ctx
+    with pytest.raises(hip.PSHipError):
+        gm.forward([99999], [0], lm_head=False)                  # token id out of range
+    with pytest.raises(hip.PSHipError):
+        gm.forward([1, 2], [0, 2], lm_head=False)                # non-consecutive positions
+    gm.close()

@@ -1,0 +1,187 @@
+"""GPU parity of the reference-shaped operator entry points (include/ps_hip.h) against the CPU oracle.
+
+Bar (BASELINE.json north_star): integer/byte results bit-exact (activation quantization); fp32 results within
+1e-3 relative — the tests use 2e-5 (tensor-relative), the measured gap of a different fp32 summation order.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL = 2e-5
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from powerserve_amd import hip as h
+    return h
+
+
+@pytest.mark.parametrize("K", [32, 256, 896, 2048, 4096, 4864, 14336])
+@pytest.mark.parametrize("vdt", [8, 15])
+def test_quantize_act_bit_exact(ctx, oracle, hip, K, vdt):
+    if vdt == 15 and K % 256:
+        pytest.skip("Q8_K needs K % 256 == 0")
+    rng = np.random.default_rng(K + vdt)
+    rows = 5
+    x = rng.standard_normal((rows, K)).astype(np.float32)
+    x[0] *= 0.01
+    x[1] *= 30.0
+    x[2, : min(K, 256)] = 0.0                      # all-zero block
+    x[3, 3] = 7.5; x[3, 9] = -7.5; x[3, 40 % K] = 7.5  # +-max ties: first occurrence decides the sign
+    x[4, ::2] = 1e-40                              # denormals
+    dx = ctx.to_device(x)
+    rs = ctx.L.ps_hip_row_size(vdt, K)
+    out = ctx.empty((rows, rs), np.uint8)
+    ctx.check(ctx.L.ps_hip_quantize_act(ctx.h, vdt, dx.ptr, K, rows, out.ptr))
+    got = out.numpy()
+    for r in range(rows):
+        want = oracle.from_float(vdt, x[r])
+        assert np.array_equal(got[r], want), f"row {r}: {np.flatnonzero(got[r] != want)[:8]}"
+
+
+@pytest.mark.parametrize("wt", [2, 8, 12])
+@pytest.mark.parametrize("K,N", [(256, 64), (512, 96), (896, 130), (2048, 256), (4096, 128), (4864, 64), (14336, 32)])
+@pytest.mark.parametrize("bs", [1, 2, 5])
+def test_mul_mat_quant(ctx, oracle, hip, wt, K, N, bs):
+    from powerserve_amd import synth
+    if wt == 12 and K % 256:
+        pytest.skip("Q4_K needs K % 256 == 0")
+    rng = np.random.default_rng(wt * 1000 + K + N + bs)
+    w = synth.random_blocks(rng, wt, N, K)
+    x = rng.standard_normal((bs, K)).astype(np.float32)
+    want = oracle.mul_mat(wt, w, K, N, x)
+    W = ctx.upload_weight(wt, w, K, N)
+    dx, dy = ctx.to_device(x), ctx.empty((bs, N))
+    ctx.check(ctx.L.ps_hip_mul_mat(ctx.h, C.byref(dy.tensor()), C.byref(W.tensor()), C.byref(dx.tensor())))
+    got = dy.numpy()
+    assert rel_err(got, want) < TOL, rel_err(got, want)
+    W.free()
+
+
+def test_mul_mat_f32_gqa_views(ctx, oracle, hip):
+    """K-cache view x permuted q (norm_attention.cpp:115-129) and V-cache view x kq (:138-147)."""
+    rng = np.random.default_rng(7)
+    hs, n_kv_heads, r2, n_ctx, n_kv, bs = 64, 2, 3, 48, 33, 4
+    n_heads, kvd, dim = n_kv_heads * r2, n_kv_heads * hs, n_kv_heads * r2 * hs
+    Kc = rng.standard_normal((n_ctx, kvd)).astype(np.float32)
+    q = rng.standard_normal((bs, n_heads, hs)).astype(np.float32)
+    dK, dq = ctx.to_device(Kc), ctx.to_device(q)
+    kq = ctx.empty((n_heads, bs, n_kv))
+    k_view = dK.tensor(ne=[hs, n_kv, n_kv_heads, 1], nb=[4, kvd * 4, hs * 4, hs * 4 * n_kv_heads])
+    q_perm = dq.tensor(ne=[hs, bs, n_heads, 1], nb=[4, dim * 4, hs * 4, dim * 4 * bs])
+    ctx.check(ctx.L.ps_hip_mul_mat(ctx.h, C.byref(kq.tensor()), C.byref(k_view), C.byref(q_perm)))
+    want = np.einsum("jgd,bgrd->grbj", Kc[:n_kv].reshape(n_kv, n_kv_heads, hs), q.reshape(bs, n_kv_heads, r2, hs)).reshape(n_heads, bs, n_kv)
+    assert rel_err(kq.numpy(), want) < TOL
+    # V (transposed cache [kv_dim][n_ctx]) x p
+    Vc = rng.standard_normal((kvd, n_ctx)).astype(np.float32)
+    p = rng.random((n_heads, bs, n_kv)).astype(np.float32)
+    dV, dp = ctx.to_device(Vc), ctx.to_device(p)
+    out = ctx.empty((n_heads, bs, hs))
+    v_view = dV.tensor(ne=[n_kv, hs, n_kv_heads, 1], nb=[4, n_ctx * 4, n_ctx * 4 * hs, n_ctx * 4 * hs * n_kv_heads])
+    ctx.check(ctx.L.ps_hip_mul_mat(ctx.h, C.byref(out.tensor()), C.byref(v_view), C.byref(dp.tensor())))
+    want = np.einsum("gdj,grbj->grbd", Vc[:, :n_kv].reshape(n_kv_heads, hs, n_kv), p.reshape(n_kv_heads, r2, bs, n_kv)).reshape(n_heads, bs, hs)
+    assert rel_err(out.numpy(), want) < TOL
+
+
+@pytest.mark.parametrize("dim,eps", [(896, 1e-6), (2048, 1e-5), (4096, 1e-5)])
+def test_rms_norm(ctx, oracle, hip, dim, eps):
+    rng = np.random.default_rng(dim)
+    x = (rng.standard_normal((6, dim)) * 3).astype(np.float32)
+    w = (1 + 0.1 * rng.standard_normal(dim)).astype(np.float32)
+    dx, dw, dy = ctx.to_device(x), ctx.to_device(w), ctx.empty((6, dim))
+    ctx.check(ctx.L.ps_hip_rms_norm(ctx.h, C.byref(dy.tensor()), C.byref(dx.tensor()), C.byref(dw.tensor()), eps))
+    want = oracle.rms_norm(x, w, eps)
+    got = dy.numpy()
+    assert np.abs(got.view(np.int32).astype(np.int64) - want.view(np.int32).astype(np.int64)).max() <= 1  # <= 1 ulp
+
+
+@pytest.mark.parametrize("mode,hs,base", [(0, 64, 1e4), (2, 64, 1e6), (0, 128, 5e5)])
+def test_rope_bit_exact(ctx, oracle, hip, mode, hs, base):
+    from oracle import binding as B
+    rng = np.random.default_rng(hs + mode)
+    pos = np.array([0, 1, 17, 2047, 4095], dtype=np.int32)
+    x = rng.standard_normal((pos.size, 8, hs)).astype(np.float32)
+    rp = hip.RopeParams(hs, 4096, base, 1.0, 0.0, 1.0, 32.0, 0.0, mode)
+    dx, dy = ctx.to_device(x), ctx.empty(x.shape)
+    ctx.check(ctx.L.ps_hip_rope(ctx.h, C.byref(dy.tensor()), C.byref(dx.tensor()), pos.ctypes.data_as(C.c_void_p), pos.size, C.byref(rp)))
+    want = oracle.rope(x, pos, B.RopeParams(hs, 4096, base, 1.0, 0.0, 1.0, 32.0, 0.0, mode))
+    assert np.array_equal(dy.numpy(), want)
+
+
+@pytest.mark.parametrize("n_kv", [1, 7, 33, 200, 2304])
+def test_softmax_ext(ctx, oracle, hip, n_kv):
+    rng = np.random.default_rng(n_kv)
+    bs, nh = 3, 4
+    s = (rng.standard_normal((nh, bs, n_kv)) * 4).astype(np.float32)
+    pos = np.array([max(0, n_kv - 3), max(0, n_kv - 2), n_kv - 1], dtype=np.int32)
+    mask = np.where(np.arange(n_kv)[None, :] <= pos[:, None], 0.0, -np.inf).astype(np.float32)
+    ds, dm, do = ctx.to_device(s), ctx.empty((bs, n_kv)), ctx.empty(s.shape)
+    ctx.check(ctx.L.ps_hip_get_mask(ctx.h, C.byref(dm.tensor()), pos.ctypes.data_as(C.c_void_p), bs, None))
+    assert np.array_equal(dm.numpy(), mask)
+    ctx.check(ctx.L.ps_hip_softmax_ext(ctx.h, C.byref(do.tensor()), C.byref(ds.tensor()), C.byref(dm.tensor()), 0.125, 0.0))
+    want = oracle.softmax_ext(s, mask, 0.125)
+    got = do.numpy()
+    assert rel_err(got, want) < 1e-6
+    assert np.all(got[mask[None].repeat(nh, 0) < 0] == 0.0)
+
+
+def test_add_dup_silu(ctx, oracle, hip):
+    rng = np.random.default_rng(3)
+    a = rng.standard_normal((5, 96)).astype(np.float32)
+    b = rng.standard_normal((5, 96)).astype(np.float32)
+    bias = rng.standard_normal((96,)).astype(np.float32)
+    da, db, dbias, do = ctx.to_device(a), ctx.to_device(b), ctx.to_device(bias), ctx.empty(a.shape)
+    ctx.check(ctx.L.ps_hip_add(ctx.h, C.byref(do.tensor()), C.byref(da.tensor()), C.byref(db.tensor())))
+    assert np.array_equal(do.numpy(), oracle.add(a, b))
+    ctx.check(ctx.L.ps_hip_add(ctx.h, C.byref(do.tensor()), C.byref(da.tensor()), C.byref(dbias.tensor())))
+    assert np.array_equal(do.numpy(), oracle.add(a, bias))
+    g = (rng.standard_normal((3, 500)) * 4).astype(np.float32)
+    u = rng.standard_normal((3, 500)).astype(np.float32)
+    dg, du, dh = ctx.to_device(g), ctx.to_device(u), ctx.empty(g.shape)
+    ctx.check(ctx.L.ps_hip_silu_hadamard(ctx.h, C.byref(dh.tensor()), C.byref(dg.tensor()), C.byref(du.tensor())))
+    want = oracle.silu_hadamard(g, u)
+    assert np.abs(dh.numpy().view(np.int32).astype(np.int64) - want.view(np.int32).astype(np.int64)).max() <= 4  # expf ulp
+    # dup: permuted [hs, bs, heads] view -> contiguous (PERMUTE+CONT, norm_attention.cpp:149-151)
+    hs, bs, nh = 16, 3, 4
+    src = rng.standard_normal((nh, bs, hs)).astype(np.float32)  # kqv [hs, bs, n_heads]
+    dsrc, ddst = ctx.to_device(src), ctx.empty((bs, nh * hs))
+    perm = dsrc.tensor(ne=[hs, nh, bs, 1], nb=[4, hs * bs * 4, hs * 4, hs * bs * nh * 4])
+    ctx.check(ctx.L.ps_hip_dup(ctx.h, C.byref(ddst.tensor(ne=[hs * nh, bs, 1, 1])), C.byref(perm)))
+    assert np.array_equal(ddst.numpy(), src.transpose(1, 0, 2).reshape(bs, nh * hs))
+
+
+@pytest.mark.parametrize("wt", [0, 2, 8, 12, 14])
+def test_get_embedding(ctx, oracle, hip, wt):
+    from powerserve_amd import synth
+    rng = np.random.default_rng(wt)
+    dim, vocab = 512, 100
+    tab = synth.random_blocks(rng, wt, vocab, dim)
+    W = ctx.upload_weight(wt, tab, dim, vocab)
+    toks = np.array([0, 99, 5, 5, 42], dtype=np.int32)
+    out = ctx.empty((toks.size, dim))
+    ctx.check(ctx.L.ps_hip_get_embedding(ctx.h, C.byref(out.tensor()), C.byref(W.tensor()), toks.ctypes.data_as(C.c_void_p), toks.size))
+    want = oracle.get_embedding(wt, tab, dim, toks)
+    assert np.array_equal(out.numpy(), want)
+    W.free()
+
+
+def test_argmax_first_max(ctx, hip):
+    x = np.zeros((3, 1000), dtype=np.float32)
+    x[0, 17] = 2.0; x[0, 500] = 2.0
+    x[1, 999] = 1.0
+    dx, out = ctx.to_device(x), ctx.empty((3,), np.int32)
+    ctx.check(ctx.L.ps_hip_argmax(ctx.h, dx.ptr, 1000, 3, out.ptr))
+    assert out.numpy().tolist() == [17, 999, 0]
+
+
+def test_errors_are_reported_not_thrown(ctx, hip):
+    a = ctx.empty((2, 64))
+    t = a.tensor()
+    bad = a.tensor(ne=[32, 4, 1, 1])
+    rc = ctx.L.ps_hip_mul_mat(ctx.h, C.byref(t), C.byref(t), C.byref(bad))
+    assert rc != 0 and b"mul_mat" in ctx.L.ps_hip_last_error(ctx.h)

@@ -1,0 +1,82 @@
+"""CPU: the plain-C restatement (oracle/ps_oracle.c) against the committed golden vectors produced by the REAL
+reference (oracle/gen_golden.py).  Runs anywhere (no GPU, no /root/reference).  The restatement reproduces the
+reference's AVX2 lane structure, so everything here is BIT-EXACT."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+T = {"Q4_0": 2, "Q8_0": 8, "Q4_K": 12, "Q6_K": 14}
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def test_act_quant_bit_exact(oracle):
+    g = np.load(os.path.join(GOLD, "act_quant.npz"))
+    for K in (256, 896, 4096):
+        x = g[f"x_{K}"]
+        for i in range(x.shape[0]):
+            assert np.array_equal(oracle.from_float(8, x[i]), g[f"q8_0_{K}"][i])
+            if K % 256 == 0:
+                assert np.array_equal(oracle.from_float(15, x[i]), g[f"q8_K_{K}"][i])
+
+
+def test_mul_mat_bit_exact(oracle):
+    g = np.load(os.path.join(GOLD, "mul_mat.npz"))
+    n = 0
+    for key in g.files:
+        if not key.startswith("y_"):
+            continue
+        _, tn1, tn2, K, N, bs = key.split("_")
+        t = T[tn1 + "_" + tn2]
+        y = oracle.mul_mat(t, g["w_" + key[2:]], int(K), int(N), g["x_" + key[2:]])
+        assert np.array_equal(bits(y), bits(g[key])), key
+        n += 1
+    assert n == 12
+
+
+def test_ops_bit_exact(oracle):
+    from oracle import binding as B
+    g = np.load(os.path.join(GOLD, "ops.npz"))
+    assert np.array_equal(bits(oracle.rms_norm(g["rms_x"], g["rms_w"], 1e-6)), bits(g["rms_y"]))
+    for mode, hs, base in ((0, 64, 1e4), (2, 64, 1e6), (0, 128, 5e5)):
+        rp = B.RopeParams(hs, 4096, base, 1.0, 0.0, 1.0, 32.0, 0.0, mode)
+        y = oracle.rope(g[f"rope_x_{mode}_{hs}"], g[f"rope_pos_{mode}_{hs}"], rp)
+        assert np.array_equal(bits(y), bits(g[f"rope_y_{mode}_{hs}"]))
+    for n_kv in (1, 33, 300):
+        y = oracle.softmax_ext(g[f"sm_x_{n_kv}"], g[f"sm_mask_{n_kv}"], 0.125)
+        assert np.array_equal(bits(y), bits(g[f"sm_y_{n_kv}"]))
+    assert np.array_equal(bits(oracle.silu_hadamard(g["silu_g"], g["silu_u"])), bits(g["silu_y"]))
+
+
+def _sha(path):
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        for c in iter(lambda: f.read(1 << 20), b""):
+            h.update(c)
+    return h.hexdigest()
+
+
+@pytest.mark.parametrize("preset,tn", [("tiny-llama", "Q4_0"), ("tiny-llama", "Q8_0"), ("tiny-qwen2", "Q8_0"), ("tiny-qwen2", "Q4_0")])
+def test_e2e_bit_exact(oracle, tmp_path, preset, tn):
+    """whole-model forward of the restatement == real LlamaModel/Qwen2Model::forward, logits bit-for-bit"""
+    from oracle import binding as B
+    from powerserve_amd import gguf, synth
+    g = np.load(os.path.join(GOLD, f"e2e_{preset}_{tn}.npz"))
+    d = str(tmp_path / "m")
+    mj = synth.write_model_dir(d, preset, T[tn], n_ctx=int(g["n_ctx"]), seed=int(g["seed"]))
+    path = os.path.join(d, "ggml", "weights.gguf")
+    assert _sha(path) == str(g["gguf_sha256"]), "synthetic model generator drifted: regenerate tests/golden (oracle/gen_golden.py)"
+    rd = gguf.GGUFReader(path)
+    tensors = {n: (ti.type, np.array(rd.data(n)), ti.ne[0], (list(ti.ne) + [1])[1]) for n, ti in rd.tensors.items()}
+    m = oracle.model(B.make_config(mj["llm_config"]), mj["model_arch"], tensors, n_threads=4)
+    ids, logits, *_ = m.generate(g["prompt"], 8, 24, want_logits=True)
+    assert np.array_equal(ids, g["ids"])
+    assert np.array_equal(bits(logits), bits(g["logits"]))
+    m.reset()
+    assert np.array_equal(bits(m.forward(g["prompt"][:9], np.arange(9), True)), bits(g["batch_logits"]))
+    m.close()
