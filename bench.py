@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""bench.py — decode/prefill throughput of the MI355X backend on BASELINE.json's headline workload.
+
+    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+
+Workload (config.workload): Llama-3.1-8B shape, pure Q4_K synthetic weights (random-init in the quantized
+domain, powerserve_amd/synth.py), prompt of 2048 random token ids, greedy decode.  A "step" is one
+single-token decode step = one pass of the hot path (tokens/s defined as in
+app/run/run.cpp:138-154).  `value` = decode tokens/s aggregated over all N replicas (weak scaling: one full
+model + KV cache per GPU, no data-path collective; RCCL only broadcasts the prompt and gathers the ids).
+
+Extra objects on the JSON line:
+  roofline      HBM roofline of the dominant kernel family (quantized GEMV): algorithmic GGUF bytes per launch
+                / average launch duration measured here with HIP events on the backend's own stream.
+  cpu_baseline  the CPU restatement of the reference (oracle "port") timed on this host on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=256)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--preset", default="llama-3.1-8b")
+    ap.add_argument("--wtype", default="Q4_K")
+    ap.add_argument("--prompt-len", type=int, default=2048)
+    ap.add_argument("--n-ctx", type=int, default=4096)
+    ap.add_argument("--batch", type=int, default=128, help="prefill chunk (reference default batch_size=128)")
+    ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=4)
+    ap.add_argument("--model-dir", default=None)
+    ap.add_argument("--eager", action="store_true", help="eager launches instead of hipGraph replay (rocprofv3 runs)")
+    return ap.parse_args()
+
+
+def ensure_model(args, rank, barrier):
+    from powerserve_amd import gguf, synth
+    wt = gguf.NAME_TYPE[args.wtype]
+    d = args.model_dir or os.path.join(os.environ.get("TMPDIR", "/tmp"), f"ps_bench_{args.preset}_{args.wtype}_{args.seed}")
+    marker = os.path.join(d, ".done")
+    if rank == 0 and not os.path.exists(marker):
+        t0 = time.time()
+        synth.write_model_dir(d, args.preset, wt, n_ctx=args.n_ctx, seed=args.seed)
+        open(marker, "w").write("ok")
+        print(f"[bench] synthetic model written to {d} in {time.time() - t0:.1f}s", file=sys.stderr)
+    barrier()
+    return d
+
+
+def cpu_baseline(model_dir, n_ctx, prompt, steps):
+    """CPU port (oracle/ps_oracle.c, bit-exact vs the real reference) on this host: bounded sample."""
+    from oracle import binding as B  # checker/baseline only — never on the product path
+    from powerserve_amd import gguf, synth
+    mj = synth.load_model_json(model_dir)
+    llm = dict(mj["llm_config"])
+    llm["n_ctx"] = 64  # the sample never goes past a few positions; keeps the FP32 KV small on the host
+    cfg = B.make_config(llm)
+    rd = gguf.GGUFReader(os.path.join(model_dir, "ggml", "weights.gguf"))
+    tensors = {n: (ti.type, rd.data(n), ti.ne[0], (list(ti.ne) + [1])[1]) for n, ti in rd.tensors.items()}
+    cores = os.cpu_count() or 1
+    nth = max(1, min(cores - 1, 48))
+    m = B.Oracle().model(cfg, mj["model_arch"], tensors, n_threads=nth)
+    p = np.asarray(prompt[:4], dtype=np.int32)
+    ids, _, tp, td = m.generate(p, 4, steps)
+    m.close()
+    return {"value": steps / td, "unit": "tokens/s", "cores": nth, "kind": "port",
+            "sample": f"{steps} greedy decode steps after a {p.size - 1}-token prefill (n_kv<{p.size + steps}), same GGUF weights; "
+                      f"prefill {(p.size - 1) / max(tp, 1e-9):.2f} tok/s", "host_cores": cores, "ids": [int(i) for i in ids]}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        import torch
+        import torch.distributed as dist_
+        torch.cuda.set_device(local)
+        dist_.init_process_group("nccl", device_id=torch.device("cuda", local))  # RCCL over xGMI
+        dist = dist_
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    from powerserve_amd import hip
+    model_dir = ensure_model(args, rank, barrier)
+    ctx = hip.Ctx(local)
+    t0 = time.time()
+    model = hip.Model(ctx, model_dir, max_batch=max(args.batch, 1), n_ctx=args.n_ctx)
+    load_s = time.time() - t0
+    cfg = model.cfg
+    if args.eager:
+        model.set_mode(1)
+
+    # ---- prompt: rank 0 draws it, RCCL broadcast to every replica (the only inbound collective)
+    prompt = np.random.default_rng(42).integers(0, cfg.vocab_size, args.prompt_len).astype(np.int32)
+    if dist is not None:
+        import torch
+        t = torch.from_numpy(prompt if rank == 0 else np.zeros_like(prompt)).cuda()
+        dist.broadcast(t, src=0)
+        prompt = t.cpu().numpy()
+
+    # ---- prefill (all but the last prompt token, lm_head skipped: src/model/model.hpp:147-163)
+    barrier(); ctx.sync()
+    t0 = time.perf_counter()
+    model.reset()
+    done = 0
+    while done < prompt.size - 1:
+        bs = min(args.batch, prompt.size - 1 - done)
+        model.forward(prompt[done:done + bs], np.arange(done, done + bs), lm_head=False)
+        done += bs
+    ctx.sync(); barrier()
+    prefill_s = time.perf_counter() - t0
+
+    # ---- decode: W untimed warmup steps, then exactly K timed steps
+    cur = int(prompt[-1])
+    ids_w = model.decode_greedy(cur, args.warmup) if args.warmup > 0 else np.zeros(0, np.int32)
+    if ids_w.size:
+        cur = int(ids_w[-1])
+    barrier(); ctx.sync()
+    e0, e1 = ctx.event(), ctx.event()
+    t0 = time.perf_counter()
+    ctx.record(e0)
+    ids = model.decode_greedy(cur, args.steps)
+    ctx.record(e1)
+    ctx.sync(); barrier()
+    dt = time.perf_counter() - t0
+    dev_ms = ctx.elapsed_ms(e0, e1)
+    if dist is not None:
+        import torch
+        tt = torch.tensor([dt, prefill_s], dtype=torch.float64).cuda()
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt, prefill_s = float(tt[0]), float(tt[1])
+        # gather the sampled ids of every replica (the only outbound collective) and check they agree
+        mine = torch.from_numpy(ids.astype(np.int32)).cuda()
+        allv = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allv, mine)
+        replicas_agree = all(bool((a == allv[0]).all()) for a in allv)
+    else:
+        replicas_agree = True
+
+    out = None
+    if rank == 0:
+        wbytes = model.weight_bytes_per_token
+        n_kv_mid = args.prompt_len + args.warmup + args.steps // 2
+        kv_bytes = cfg.n_layers * 2 * n_kv_mid * cfg.kv_dim * 4
+        # ---- roofline of the GEMV family: GEMV-only pass over one token's weights, event-bracketed
+        rf = gemv_roofline(ctx, model, wbytes)
+        out = {
+            "metric": "decode tokens/s (greedy, Llama-3.1-8B Q4_K, 1 GPU per replica)" if args.preset == "llama-3.1-8b" and args.wtype == "Q4_K"
+            else f"decode tokens/s (greedy, {args.preset} {args.wtype})",
+            "value": world * args.steps / dt, "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "int8 x int4 block dot, fp32 accumulate (ggml Q4_K x Q8_K semantics)" if args.wtype == "Q4_K" else "int8 block dot, fp32 accumulate",
+            "data": "synthetic (random-init weights generated in the quantized domain; random prompt ids, seed 42)",
+            "config": {"workload": f"{args.preset} pure {args.wtype}, prefill {args.prompt_len} + decode {args.steps}, n_ctx {args.n_ctx}, FP32 KV",
+                       "prefill_chunk": args.batch, "replicas": world, "collectives": "RCCL broadcast(prompt) + all_gather(ids)" if world > 1 else "none"},
+            "prefill_tokens_per_s": world * (args.prompt_len - 1) / prefill_s, "prefill_s": prefill_s,
+            "decode_device_ms_per_step": dev_ms / args.steps, "model_load_s": load_s,
+            "weight_bytes_per_token": wbytes, "kv_bytes_per_token_mid": kv_bytes,
+            "decode_effective_GBps": (wbytes + kv_bytes) / (dt / args.steps) / 1e9,
+            "replicas_agree": replicas_agree, "first_ids": [int(i) for i in ids[:8]],
+            "roofline": rf,
+        }
+        if not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(model_dir, args.n_ctx, prompt, args.cpu_steps)
+            except Exception as e:  # the baseline must never take the GPU number down with it
+                out["cpu_baseline"] = {"value": None, "error": repr(e)}
+    model.close()
+    ctx.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+def gemv_roofline(ctx, model, wbytes):
+    """Average duration of the quantized-GEMV launches of one decode token, HIP events on the backend stream.
+
+    The library replays the exact GEMV launch sequence of a token (every layer's own weights, so the 4.2 GB
+    stream is HBM-cold like in the real step) with nothing else in between; boundary_us (same number of empty
+    launches) is reported so that kernel-only time can be compared with rocprofv3's per-kernel average."""
+    import ctypes as C
+    L = ctx.L
+    if not hasattr(L, "ps_hip_model_bench_gemv"):
+        return None
+    L.ps_hip_model_bench_gemv.restype = C.c_int
+    L.ps_hip_model_bench_gemv.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]
+    seq_ms, null_ms, n = C.c_double(), C.c_double(), C.c_int()
+    ctx.check(L.ps_hip_model_bench_gemv(model.h, 20, C.byref(seq_ms), C.byref(null_ms), C.byref(n)))
+    launches = n.value
+    avg_us = 1e3 * seq_ms.value / launches
+    boundary_us = 1e3 * null_ms.value / launches
+    kern_us = max(avg_us - boundary_us, 1e-3)
+    achieved = wbytes / launches / (kern_us * 1e-6) / 1e9
+    return {"bound": "hbm", "kernel": "gemv_kernel<Q4_K,...> (all quantized mat-vec launches of one token)",
+            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": None, "bytes_per_launch": wbytes / launches, "launches_per_token": launches,
+            "avg_launch_us_incl_boundary": avg_us, "launch_boundary_us": boundary_us, "avg_kernel_us": kern_us,
+            "achieved_incl_boundary": wbytes / launches / (avg_us * 1e-6) / 1e9,
+            "gemv_ms_per_token": seq_ms.value}
+
+
+if __name__ == "__main__":
+    main()

@@ -177,6 +177,10 @@ const float *ps_hip_model_k_cache(const ps_hip_model *m, int layer);
 const float *ps_hip_model_v_cache(const ps_hip_model *m, int layer);
 /* per-forward accounting for the roofline: GGUF bytes of all mat-mul weights streamed by one token */
 uint64_t ps_hip_model_weight_bytes_per_token(const ps_hip_model *m);
+/* Measurement helper (bench.py roofline): replays the quantized mat-vec launches of one single-token forward
+ * `reps` times between HIP events on the ctx stream -> seq_ms per token; null_ms = the same number of empty
+ * launches (launch-boundary cost); n_launches = mat-vec launches per token. */
+int ps_hip_model_bench_gemv(ps_hip_model *m, int reps, double *seq_ms, double *null_ms, int *n_launches);
 /* 0 = fused kernels + hipGraph (default); 1 = fused kernels, eager launches; used by tests/bench */
 int ps_hip_model_set_mode(ps_hip_model *m, int mode);
 

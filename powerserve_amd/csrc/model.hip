@@ -29,6 +29,7 @@ __global__ void decode_advance_kernel(ps_step_state *s, const int32_t *argmax, i
     s->n_out += 1;
     s->pos0 += 1;
 }
+__global__ void null_kernel(int *p) { if (p && threadIdx.x == 12345) *p = 0; }
 __global__ void kv_move_kernel(float *k, float *v, int kvd, int n_ctx, int dst, int src) {
     const int d = blockIdx.x * blockDim.x + threadIdx.x;
     if (d >= kvd) return;
@@ -312,6 +313,61 @@ const float *ps_hip_model_logits(const ps_hip_model *m) { return m->logits; }
 const float *ps_hip_model_k_cache(const ps_hip_model *m, int L) { return m->k_cache[L]; }
 const float *ps_hip_model_v_cache(const ps_hip_model *m, int L) { return m->v_cache[L]; }
 uint64_t ps_hip_model_weight_bytes_per_token(const ps_hip_model *m) { return m->weight_bytes; }
+// Roofline helper for bench.py: replay only the quantized mat-vec launches of one single-token forward
+// (every layer's own weights -> the stream is HBM-cold exactly like a real step), `reps` times, bracketed by
+// HIP events on the backend stream; then the same number of empty launches to expose the launch boundary.
+int ps_hip_model_bench_gemv(ps_hip_model *m, int reps, double *seq_ms, double *null_ms, int *n_launches) {
+    ps_hip_ctx *c = m->ctx;
+    const ps_llm_config &f = m->cfg;
+    const int64_t dim = f.dim, kvd = f.kv_dim, hid = f.hidden_dim;
+    hipEvent_t e0, e1;
+    PS_CHECK(c, hipEventCreate(&e0));
+    PS_CHECK(c, hipEventCreate(&e1));
+    int launches = 0;
+    auto pass = [&](bool count) -> int {
+        ps_act a1 = ps_act_carve(m->act_mem, dim, m->max_batch), a2 = ps_act_carve(m->act_mem, hid, m->max_batch);
+        for (uint32_t L = 0; L < f.n_layers; L++) {
+            psk_gemv_args g{};
+            g.n_w = 3; g.w[0] = m->wq[L]; g.w[1] = m->wk[L]; g.w[2] = m->wv[L];
+            g.out[0] = m->q; g.out[1] = m->k; g.out[2] = m->v; g.ldo[0] = dim; g.ldo[1] = kvd; g.ldo[2] = kvd;
+            if (mm(m, g, a1, dim, 1)) return 2;
+            psk_gemv_args go{};
+            go.n_w = 1; go.w[0] = m->wo[L]; go.out[0] = m->att; go.ldo[0] = dim;
+            if (mm(m, go, a1, dim, 1)) return 2;
+            psk_gemv_args gf{};
+            gf.n_w = 2; gf.w[0] = m->wg[L]; gf.w[1] = m->wu[L]; gf.out[0] = m->g1; gf.out[1] = m->g1; gf.ldo[0] = hid; gf.ldo[1] = hid; gf.silu_pair = 1;
+            if (mm(m, gf, a1, dim, 1)) return 2;
+            psk_gemv_args gd{};
+            gd.n_w = 1; gd.w[0] = m->wd[L]; gd.out[0] = m->att; gd.ldo[0] = dim;
+            if (mm(m, gd, a2, hid, 1)) return 2;
+            if (count) launches += 4;
+        }
+        psk_gemv_args gl{};
+        gl.n_w = 1; gl.w[0] = m->output ? m->output : m->token_embd; gl.out[0] = m->logits; gl.ldo[0] = f.vocab_size;
+        if (mm(m, gl, a1, dim, 1)) return 2;
+        if (count) launches += 1;
+        return 0;
+    };
+    if (pass(true)) return 2; // warm-up + launch count
+    PS_CHECK(c, hipStreamSynchronize(c->stream));
+    PS_CHECK(c, hipEventRecord(e0, c->stream));
+    for (int r = 0; r < reps; r++) if (pass(false)) return 2;
+    PS_CHECK(c, hipEventRecord(e1, c->stream));
+    PS_CHECK(c, hipEventSynchronize(e1));
+    float ms = 0.f;
+    PS_CHECK(c, hipEventElapsedTime(&ms, e0, e1));
+    *seq_ms = (double)ms / reps;
+    PS_CHECK(c, hipEventRecord(e0, c->stream));
+    for (int r = 0; r < reps * launches; r++) hipLaunchKernelGGL(null_kernel, dim3(256), dim3(256), 0, c->stream, (int *)nullptr);
+    PS_CHECK(c, hipEventRecord(e1, c->stream));
+    PS_CHECK(c, hipEventSynchronize(e1));
+    PS_CHECK(c, hipEventElapsedTime(&ms, e0, e1));
+    *null_ms = (double)ms / reps;
+    *n_launches = launches;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return 0;
+}
+
 int ps_hip_model_set_mode(ps_hip_model *m, int mode) {
     m->mode = mode;
     return 0;
