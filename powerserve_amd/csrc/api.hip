@@ -184,9 +184,11 @@ int ps_hip_weight_upload(ps_hip_ctx *c, int dtype, const void *host, int64_t K, 
     uint8_t *tmp = nullptr;
     if (hipMalloc((void **)&tmp, raw + 64) != hipSuccess) return fail("weight_upload: hipMalloc(tmp)");
     size_t qs_b = 0, aux_b = 0, qh_b = 0, sc_b = 0;
-    if (dtype == PS_Q4_0) { qs_b = (size_t)N * K / 2; aux_b = (size_t)N * (K / 32) * 2; }
-    if (dtype == PS_Q8_0) { qs_b = (size_t)N * K; aux_b = (size_t)N * (K / 32) * 2; }
-    if (dtype == PS_Q4_K) { qs_b = (size_t)N * K / 2; aux_b = (size_t)N * (K / 256) * 16; }
+    if (dtype == PS_Q4_0 || dtype == PS_Q8_0 || dtype == PS_Q4_K) { // lane-major repack: 1 KiB units per row group
+        const int64_t rg = ps_w_rg(dtype), ng = (N + rg - 1) / rg, nu = (K + ps_w_unit(dtype) - 1) / ps_w_unit(dtype);
+        qs_b  = (size_t)(ng * nu) * 1024;
+        aux_b = (size_t)(ng * nu) * (size_t)rg * (dtype == PS_Q4_K ? 16 : 8);
+    }
     if (dtype == PS_Q6_K) { qs_b = (size_t)N * K / 2; qh_b = (size_t)N * K / 4; sc_b = (size_t)N * K / 16; aux_b = (size_t)N * (K / 256) * 2; }
     bool ok = hipMalloc((void **)&w->qs, qs_b + 64) == hipSuccess && hipMalloc((void **)&w->aux, aux_b + 64) == hipSuccess;
     if (ok && qh_b) ok = hipMalloc((void **)&w->qh, qh_b + 64) == hipSuccess && hipMalloc((void **)&w->sc, sc_b + 64) == hipSuccess;
@@ -259,13 +261,12 @@ int ps_hip_mul_mat(ps_hip_ctx *c, const ps_tensor *dst, const ps_tensor *src0, c
         const int vdt = ps_hip_vec_dot_type(w->dtype);
         if (ensure(c, &c->act_buf, &c->act_cap, ps_act_bytes(K, bs))) return 1;
         ps_act a = ps_act_carve(c->act_buf, K, bs);
-        psk_quantize_act(c->stream, vdt, 0, (const float *)src1->data, nullptr, nullptr, 0.f, K, bs, a);
-        for (int64_t c0 = 0; c0 < bs; c0 += 4) { // <= 4 columns per GEMV launch
+        for (int64_t c0 = 0; c0 < bs; c0 += 4) { // <= 4 columns per GEMV launch; activation quantized in its prologue
             const int64_t nb = bs - c0 < 4 ? bs - c0 : 4;
             psk_gemv_args g{};
             g.n_w = 1; g.w[0] = w; g.out[0] = (float *)dst->data + c0 * w->N; g.ldo[0] = w->N;
-            ps_act ac = a; ac.qs += c0 * K; ac.d += c0 * (K / (vdt == PS_Q8_0 ? 32 : 256)); ac.bs16 += c0 * (K / 16);
-            if (int rc = psk_gemv(c->stream, c->n_cu, g, ac, vdt, K, nb)) { c->err = "mul_mat: gemv launch rc=" + std::to_string(rc); return 2; }
+            g.pro = 2; g.pro_x = (const float *)src1->data + c0 * K;
+            if (int rc = psk_gemv(c->stream, c->n_cu, g, a, vdt, K, nb)) { c->err = "mul_mat: gemv launch rc=" + std::to_string(rc); return 2; }
         }
     } else if (src0->dtype == PS_F32) {
         if (src0->nb[0] != 4) PS_FAIL(c, "mul_mat: transposed src0 not supported");

@@ -1,18 +1,35 @@
-// KV-cache attention for the fused model path (gfx950, HBM-bound on the FP32 K/V stream).
+// KV-cache attention for the fused model path (gfx950) — bit-exact with the reference's F32 path.
 //
 // Fuses what NormAttention::build emits after the QKV mat-muls
-// (src/model/module/norm_attention.cpp:72-151): ROPE x2, TRANSPOSE, VIEW+COPY x2 (KV append),
-// PERMUTE, K-view MAT_MUL, GET_MASK (src/executor/executor.cpp:210-224), SOFTMAX_EXT, V-view MAT_MUL,
-// PERMUTE+CONT — 13 graph ops — into three launches with no intermediate layout shuffles:
-//   rope_append      : rotate q in place, rotate k into its K-cache row, scatter v into the transposed V cache
-//   attn_scores      : raw q·K for a 64-position tile per workgroup (all q heads of one kv head share the K tile)
-//   attn_softmax_pv  : scale + mask + softmax (ggml_v_expf polynomial, double row sum) held in LDS, then V·p
+// (src/model/module/norm_attention.cpp:72-151): ROPE x2, TRANSPOSE, VIEW+COPY x2 (KV append), PERMUTE,
+// K-view MAT_MUL, GET_MASK (src/executor/executor.cpp:210-224), SOFTMAX_EXT, V-view MAT_MUL, PERMUTE+CONT —
+// 13 graph ops — into four launches with no intermediate layout shuffles:
+//   rope_append   rotate q in place, rotate k into its K-cache row, scatter v into the transposed V cache
+//   attn_scores   s = K·q          (ggml_vec_dot_f32, libs/ggml/src/ggml.c:2092-2133)
+//   attn_softmax  scale + mask + softmax rows (ggml.c:14889-14925, ggml_vec_soft_max_f32 :2814-2863)
+//   attn_pv       out = V·p        (ggml_vec_dot_f32 again, rows of the transposed V cache)
 // KV layout is the reference's: K [n_ctx][kv_dim], V [kv_dim][n_ctx] FP32 (backend/ggml/ggml_kv_cache.cpp:48-57).
+//
+// Exact order: ggml_vec_dot_f32's AVX build keeps 4 accumulators x 8 lanes = 32 fp32 chains over elements
+// e = 32*i + c (c = 0..31), reduces them as (acc0+acc2, acc1+acc3), (+), low/high 128-bit halves, two hadds
+// (GGML_F32x8_REDUCE, ggml.c:1354-1371), and adds the n % 32 leftovers one by one.  Here 32 GPU lanes own the
+// 32 chains of one dot product (coalesced 128-B reads) and the reduction is the xor-16, 8, 4, 1, 2 butterfly.
 // All position-dependent values come from a device-resident ps_step_state so a captured hipGraph replays.
 #include "ps_dev.h"
+#include "ps_expf.h"
 #include "ps_ops.h"
 
 namespace {
+
+// GGML_F32x8_REDUCE over the 32 chains held by 32 consecutive lanes (c = lane & 31 = acc*8 + l)
+__device__ __forceinline__ float reduce_f32x8x4(float v) {
+    v = __fadd_rn(v, __shfl_xor(v, 16, 64)); // acc0 += acc2, acc1 += acc3
+    v = __fadd_rn(v, __shfl_xor(v, 8, 64));  // acc0 += acc1
+    v = __fadd_rn(v, __shfl_xor(v, 4, 64));  // low 128 + high 128
+    v = __fadd_rn(v, __shfl_xor(v, 1, 64));  // hadd
+    v = __fadd_rn(v, __shfl_xor(v, 2, 64));  // hadd
+    return v;
+}
 
 // ---------------------------------------------------------------- rope + KV append
 __global__ void rope_append_kernel(psl_attn_args a, int bs) {
@@ -43,122 +60,154 @@ __global__ void rope_append_kernel(psl_attn_args a, int bs) {
     }
 }
 
-// ---------------------------------------------------------------- scores: s[i][h][j] = q[i][h] · K[j][kvh]
-// grid (n_ctx/64, n_kv_heads, bs); 4 waves; a wave takes 8 K rows at a time, 8 lanes per row, each lane
-// NV float4 of the row (coalesced 128 B per 8 lanes); the K fragment stays in registers while the q
-// fragments of the r2 heads sharing this kv head stream from L1.
-template <int NV>
+// ---------------------------------------------------------------- scores: s[i][h][j] = K[j][kvh] · q[i][h]
+// grid (n_ctx/32, n_kv_heads, bs); a half-wave (32 lanes) per position, 8 half-waves x 4 rounds = 32 positions.
+constexpr int R2MAX = 8;
+template <int NV> // head_size / 32
 __global__ __launch_bounds__(256) void attn_scores_kernel(psl_attn_args a) {
     const int hs = NV * 32, dim = a.n_heads * hs, kvd = a.n_kv_heads * hs, r2 = a.n_heads / a.n_kv_heads;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane & 7, rowl = lane >> 3;
+    const int c = threadIdx.x & 31, hw = threadIdx.x >> 5;
     const int kvh = blockIdx.y, i = blockIdx.z;
     const int n_kv = a.state->pos0 + a.state->bs;
-    const int j0 = blockIdx.x * 64;
+    const int j0 = blockIdx.x * 32;
     if (j0 >= n_kv) return;
     const float *qb = a.q + (int64_t)i * dim + (int64_t)kvh * r2 * hs;
     float *sb       = a.scores + ((int64_t)i * a.n_heads + (int64_t)kvh * r2) * a.n_ctx;
+    float qf[R2MAX][NV];
 #pragma unroll
-    for (int rb = 0; rb < 2; rb++) {
-        const int j = j0 + wave * 16 + rb * 8 + rowl;
+    for (int g = 0; g < R2MAX; g++)
+#pragma unroll
+        for (int m = 0; m < NV; m++) qf[g][m] = (g < r2) ? qb[g * hs + m * 32 + c] : 0.f;
+#pragma unroll
+    for (int rd = 0; rd < 4; rd++) {
+        const int j     = j0 + rd * 8 + hw;
         const bool live = j < n_kv;
-        float4 kf[NV];
         const float *kr = a.k_cache + (int64_t)(live ? j : 0) * kvd + kvh * hs;
+        float kf[NV];
 #pragma unroll
-        for (int m = 0; m < NV; m++) kf[m] = *(const float4 *)(kr + m * 32 + sub * 4);
-        for (int g = 0; g < r2; g++) {
-            float s = 0.f;
+        for (int m = 0; m < NV; m++) kf[m] = kr[m * 32 + c];
 #pragma unroll
-            for (int m = 0; m < NV; m++) {
-                const float4 qf = *(const float4 *)(qb + g * hs + m * 32 + sub * 4);
-                s = __fmaf_rn(kf[m].x, qf.x, s);
-                s = __fmaf_rn(kf[m].y, qf.y, s);
-                s = __fmaf_rn(kf[m].z, qf.z, s);
-                s = __fmaf_rn(kf[m].w, qf.w, s);
+        for (int g = 0; g < R2MAX; g++) {
+            if (g < r2) {
+                float s = 0.f;
+#pragma unroll
+                for (int m = 0; m < NV; m++) s = __fmaf_rn(kf[m], qf[g][m], s); // sum = x*y + sum, x = K row (src0)
+                s = reduce_f32x8x4(s);
+                if (live && c == 0) sb[(int64_t)g * a.n_ctx + j] = s;
             }
-            s = group_sum<8>(s);
-            if (live && sub == 0) sb[(int64_t)g * a.n_ctx + j] = s;
         }
     }
 }
 
-// ---------------------------------------------------------------- softmax + V·p
-// grid (hs/4, n_kv_heads, bs); each wave produces one output channel d for the r2 heads of the group.
-// LDS: p[r2][n_kv] floats.
-constexpr int R2MAX = 8;
-__global__ __launch_bounds__(256) void attn_softmax_pv_kernel(psl_attn_args a) {
-    extern __shared__ __attribute__((aligned(16))) float p[];
+// ---------------------------------------------------------------- softmax rows, in place: scores -> p
+// grid (n_heads, bs).  wp = s*scale (+mask); max; exp: ggml_v_expf on the groups of 8, libm expf on the
+// n_kv % 8 tail; per-group float sum tree then double accumulation; p = e * (float)(1.0/sum).
+__global__ __launch_bounds__(256) void attn_softmax_kernel(psl_attn_args a) {
     __shared__ float redf[4];
     __shared__ double redd[4];
-    const int hs = a.head_size, dim = a.n_heads * hs, r2 = a.n_heads / a.n_kv_heads;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int kvh = blockIdx.y, i = blockIdx.z, bs = a.state->bs, pos0 = a.state->pos0;
-    const int n_kv = pos0 + bs;
-    const int n_kv4 = (n_kv + 3) & ~3;
-    // ---- softmax rows of the r2 heads (ggml.c:14889-14925, ggml_vec_soft_max_f32 :2814-2863)
-    for (int g = 0; g < r2; g++) {
-        const float *sp = a.scores + ((int64_t)i * a.n_heads + (int64_t)kvh * r2 + g) * a.n_ctx;
-        float *pg = p + (int64_t)g * n_kv4;
-        float mx = -INFINITY;
-        for (int j = threadIdx.x; j < n_kv4; j += 256) {
-            float v = -INFINITY;
-            if (j < n_kv) {
-                bool ok = (j < pos0) ? true : (a.tree ? a.tree[i * bs + (j - pos0)] != 0 : (j - pos0) <= i);
-                v = __fmul_rn(sp[j], a.scale);
-                v = __fadd_rn(v, ok ? 0.f : -INFINITY);
-            }
-            pg[j] = v;
-            mx = fmaxf(mx, v);
-        }
-        mx = wave_max(mx);
-        __syncthreads(); // protects redf/redd reuse across g
-        if (lane == 0) redf[wave] = mx;
-        __syncthreads();
-        mx = fmaxf(fmaxf(redf[0], redf[1]), fmaxf(redf[2], redf[3]));
-        double sum = 0.0;
-        for (int j = threadIdx.x; j < n_kv4; j += 256) {
-            const float e = (j < n_kv) ? ps_v_expf(__fsub_rn(pg[j], mx)) : 0.f;
-            pg[j] = e;
-            sum += (double)e;
-        }
-        sum = wave_sum_d(sum);
-        if (lane == 0) redd[wave] = sum;
-        __syncthreads();
-        const double tot = (redd[0] + redd[1]) + (redd[2] + redd[3]);
-        const float inv = (float)(1.0 / tot);
-        for (int j = threadIdx.x; j < n_kv4; j += 256) pg[j] = __fmul_rn(pg[j], inv);
+    const int h = blockIdx.x, i = blockIdx.y, bs = a.state->bs, pos0 = a.state->pos0;
+    const int n_kv = pos0 + bs, n8 = n_kv & ~7;
+    float *row = a.scores + ((int64_t)i * a.n_heads + h) * a.n_ctx;
+    float mx = -INFINITY;
+    for (int j = threadIdx.x; j < n_kv; j += 256) {
+        const bool ok = (j < pos0) ? true : (a.tree ? a.tree[i * bs + (j - pos0)] != 0 : (j - pos0) <= i);
+        float v = __fmul_rn(row[j], a.scale);
+        v       = __fadd_rn(v, ok ? 0.f : -INFINITY);
+        row[j]  = v;
+        mx      = fmaxf(mx, v);
     }
+    mx = wave_max(mx);
+    if (lane == 0) redf[wave] = mx;
     __syncthreads();
-    // ---- V·p: channel d = blockIdx.x*4 + wave of kv head kvh; V row is contiguous along positions
-    const int d = blockIdx.x * 4 + wave;
+    mx = fmaxf(fmaxf(redf[0], redf[1]), fmaxf(redf[2], redf[3]));
+    // one lane per group of 8 keeps the reference's in-group association: ((v0+v4)+(v2+v6)) + ((v1+v5)+(v3+v7))
+    double sum = 0.0;
+    for (int g = threadIdx.x; g * 8 < n8; g += 256) {
+        float v[8];
+#pragma unroll
+        for (int l = 0; l < 8; l++) { v[l] = ps_v_expf(__fsub_rn(row[g * 8 + l], mx)); row[g * 8 + l] = v[l]; }
+        const float a0 = __fadd_rn(v[4], v[0]), a1 = __fadd_rn(v[5], v[1]), a2 = __fadd_rn(v[6], v[2]), a3 = __fadd_rn(v[7], v[3]);
+        sum += (double)__fadd_rn(__fadd_rn(a0, a2), __fadd_rn(a1, a3));
+    }
+    if (threadIdx.x == 0) {
+        for (int j = n8; j < n_kv; j++) { const float e = ps_expf_glibc(__fsub_rn(row[j], mx)); row[j] = e; sum += (double)e; }
+    }
+    sum = wave_sum_d(sum);
+    if (lane == 0) redd[wave] = sum;
+    __syncthreads();
+    const double tot = (redd[0] + redd[1]) + (redd[2] + redd[3]);
+    const float inv  = (float)(1.0 / tot);
+    for (int j = threadIdx.x; j < n_kv; j += 256) row[j] = __fmul_rn(row[j], inv);
+}
+
+// ---------------------------------------------------------------- out[i][h][d] = V^T[kvh*hs + d][0..n_kv) · p[i][h][0..n_kv)
+// grid (hs/4, n_kv_heads, bs), 128 threads: a half-wave per output channel d, all r2 heads of the kv group.
+__global__ __launch_bounds__(128) void attn_pv_kernel(psl_attn_args a) {
+    const int hs = a.head_size, dim = a.n_heads * hs, r2 = a.n_heads / a.n_kv_heads;
+    const int c = threadIdx.x & 31, hw = threadIdx.x >> 5;
+    const int kvh = blockIdx.y, i = blockIdx.z;
+    const int n_kv = a.state->pos0 + a.state->bs, np = n_kv & ~31;
+    const int d = blockIdx.x * 4 + hw;
     const float *vr = a.v_cache + ((int64_t)kvh * hs + d) * a.n_ctx;
+    const float *pb = a.scores + ((int64_t)i * a.n_heads + (int64_t)kvh * r2) * a.n_ctx;
     float acc[R2MAX];
 #pragma unroll
     for (int g = 0; g < R2MAX; g++) acc[g] = 0.f;
-    for (int j = lane * 4; j < n_kv4; j += 256) {
-        float4 v = *(const float4 *)(vr + j); // n_ctx is a multiple of 4; slots >= n_kv hold p == 0
-        if (j + 3 >= n_kv) { // never multiply stale cache contents (could be NaN) by 0
-            if (j + 0 >= n_kv) v.x = 0.f;
-            if (j + 1 >= n_kv) v.y = 0.f;
-            if (j + 2 >= n_kv) v.z = 0.f;
-            if (j + 3 >= n_kv) v.w = 0.f;
-        }
+    for (int j = c; j < np; j += 32) {
+        const float v = vr[j];
 #pragma unroll
-        for (int g = 0; g < R2MAX; g++) {
-            if (g < r2) {
-                const float4 pv = *(const float4 *)(p + (int64_t)g * n_kv4 + j);
-                acc[g] = __fmaf_rn(v.x, pv.x, acc[g]);
-                acc[g] = __fmaf_rn(v.y, pv.y, acc[g]);
-                acc[g] = __fmaf_rn(v.z, pv.z, acc[g]);
-                acc[g] = __fmaf_rn(v.w, pv.w, acc[g]);
-            }
-        }
+        for (int g = 0; g < R2MAX; g++)
+            if (g < r2) acc[g] = __fmaf_rn(v, pb[(int64_t)g * a.n_ctx + j], acc[g]); // x = V row (src0), y = p
     }
 #pragma unroll
     for (int g = 0; g < R2MAX; g++) {
         if (g < r2) {
-            const float s = wave_sum(acc[g]);
-            if (lane == 0) a.att[(int64_t)i * dim + ((int64_t)kvh * r2 + g) * hs + d] = s;
+            float s = reduce_f32x8x4(acc[g]);
+            for (int j = np; j < n_kv; j++) s = __fadd_rn(s, __fmul_rn(vr[j], pb[(int64_t)g * a.n_ctx + j])); // leftovers
+            if (c == 0) a.att[(int64_t)i * dim + ((int64_t)kvh * r2 + g) * hs + d] = s;
         }
+    }
+}
+
+// ---------------------------------------------------------------- arg-max, first maximum (prob_array.cpp:65-67)
+constexpr int AM_PARTS = 64;
+__global__ __launch_bounds__(256) void argmax_partial_kernel(const float *src, int64_t n, float *pv, int *pi) {
+    __shared__ float bv[4];
+    __shared__ int bi[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float *x = src + (int64_t)blockIdx.y * n;
+    const int64_t per = (n + AM_PARTS - 1) / AM_PARTS, lo = blockIdx.x * per, hi = (lo + per < n) ? lo + per : n;
+    float best = -INFINITY; int idx = 0x7fffffff;
+    for (int64_t j = lo + threadIdx.x; j < hi; j += 256) {
+        const float v = x[j];
+        if (v > best || (v == best && (int)j < idx)) { best = v; idx = (int)j; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64); const int oi = __shfl_xor(idx, o, 64);
+        if (ov > best || (ov == best && oi < idx)) { best = ov; idx = oi; }
+    }
+    if (lane == 0) { bv[wave] = best; bi[wave] = idx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; w++) if (bv[w] > best || (bv[w] == best && bi[w] < idx)) { best = bv[w]; idx = bi[w]; }
+        pv[blockIdx.y * AM_PARTS + blockIdx.x] = best; pi[blockIdx.y * AM_PARTS + blockIdx.x] = idx;
+    }
+}
+// one wave per row; optionally also performs the greedy-decode bookkeeping (feeds the id back as the next token)
+__global__ __launch_bounds__(64) void argmax_final_kernel(const float *pv, const int *pi, int32_t *out, ps_step_state *st,
+                                                          int32_t *token, int32_t *ids) {
+    const int lane = threadIdx.x;
+    float best = pv[blockIdx.x * AM_PARTS + lane]; int idx = pi[blockIdx.x * AM_PARTS + lane];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64); const int oi = __shfl_xor(idx, o, 64);
+        if (ov > best || (ov == best && oi < idx)) { best = ov; idx = oi; }
+    }
+    if (lane == 0) {
+        out[blockIdx.x] = idx;
+        if (st) { token[0] = idx; ids[st->n_out] = idx; st->n_out += 1; st->pos0 += 1; }
     }
 }
 
@@ -172,21 +221,24 @@ void psl_rope_append(hipStream_t st, const psl_attn_args &a, int bs) {
 }
 
 void psl_attn_scores(hipStream_t st, const psl_attn_args &a, int bs) {
-    dim3 g((unsigned)((a.n_ctx + 63) / 64), (unsigned)a.n_kv_heads, (unsigned)bs);
+    dim3 g((unsigned)((a.n_ctx + 31) / 32), (unsigned)a.n_kv_heads, (unsigned)bs);
     if (a.head_size == 128) hipLaunchKernelGGL(attn_scores_kernel<4>, g, dim3(256), 0, st, a);
     else if (a.head_size == 64) hipLaunchKernelGGL(attn_scores_kernel<2>, g, dim3(256), 0, st, a);
     else if (a.head_size == 32) hipLaunchKernelGGL(attn_scores_kernel<1>, g, dim3(256), 0, st, a);
     else hipLaunchKernelGGL(attn_scores_kernel<3>, g, dim3(256), 0, st, a); // head_size 96
 }
 
-void psl_attn_softmax_pv(hipStream_t st, const psl_attn_args &a, int bs) {
-    const int r2 = a.n_heads / a.n_kv_heads;
-    const size_t smem = (size_t)r2 * (size_t)((a.n_ctx + 3) & ~3) * 4;
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void *)attn_softmax_pv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
-        attr = true;
-    }
+void psl_attn_softmax(hipStream_t st, const psl_attn_args &a, int bs) {
+    hipLaunchKernelGGL(attn_softmax_kernel, dim3((unsigned)a.n_heads, (unsigned)bs), dim3(256), 0, st, a);
+}
+
+void psl_attn_pv(hipStream_t st, const psl_attn_args &a, int bs) {
     dim3 g((unsigned)(a.head_size / 4), (unsigned)a.n_kv_heads, (unsigned)bs);
-    hipLaunchKernelGGL(attn_softmax_pv_kernel, g, dim3(256), smem, st, a);
+    hipLaunchKernelGGL(attn_pv_kernel, g, dim3(128), 0, st, a);
+}
+
+void psl_argmax2(hipStream_t st, const float *src, int64_t n, int64_t rows, int32_t *out, float *part_v, int *part_i,
+                 ps_step_state *state, int32_t *token, int32_t *ids) {
+    hipLaunchKernelGGL(argmax_partial_kernel, dim3(AM_PARTS, (unsigned)rows), dim3(256), 0, st, src, n, part_v, part_i);
+    hipLaunchKernelGGL(argmax_final_kernel, dim3((unsigned)rows), dim3(64), 0, st, part_v, part_i, out, state, token, ids);
 }

@@ -1,22 +1,28 @@
-// Quantized weight x quantized activation mat-vec for decode (gfx950, HBM-bound).
+// Quantized weight x quantized activation mat-vec (gfx950) — HBM-bound, and BIT-EXACT with the reference.
 //
 // Replaces the per-(row, col) vec_dot loop of powerserve_compute_forward_mul_mat
-// (libs/ggml/src/ggml.c:13578-13647, one_chunk :13344-13432) with the integer block dots of
-//   ggml_vec_dot_q4_0_q8_0 (ggml-quants.c:3935), ggml_vec_dot_q8_0_q8_0 (:5532), ggml_vec_dot_q4_K_q8_K (:7727).
-// Integer parts are exact; the fp32 scale-accumulate uses the same products (dx*dy per block,
-// d*y.d / dmin*y.d per super-block) with a different summation order (<= ~1e-6 relative).
+// (libs/ggml/src/ggml.c:13578-13647, one_chunk :13344-13432).  The reference's x86 build runs the AVX2
+// kernels ggml_vec_dot_q4_0_q8_0 (ggml-quants.c:4205-4228), ggml_vec_dot_q8_0_q8_0 (:5761-5782) and
+// ggml_vec_dot_q4_K_q8_K (:7809-7873).  Each keeps EIGHT fp32 accumulator lanes: lane u sums, per 32-element
+// block, the integer partial over elements 4u..4u+3 ("quad u"), converts it to float and does
+//     acc[u] = fma(d_block, (float)partial[u], acc[u])            sequentially over the blocks of the row,
+// then reduces the 8 lanes with hsum_float_8 (ggml-quants.c:62-68).  A different fp32 summation order changes
+// the last bits of every mat-mul output, and because the next op re-quantizes activations to int8 a 1-ulp
+// difference can flip a quant and grow to 1e-2 in the logits.  So this kernel reproduces the order exactly:
 //
-// Design (memory-bound: every weight byte is read exactly once, nothing else touches HBM):
-//   * weights live in a structure-of-arrays repack (ps_internal.h): a wave reads a row's quant plane as
-//     fully coalesced 16 B/lane = 1 KiB "chunks" with non-temporal loads; TB chunks per row and R rows are
-//     put in flight before any arithmetic (no LDS round trip for weights — GEMV operands are used once).
-//   * the quantized activation (a few KB) is staged once per workgroup into LDS and re-read per chunk with
-//     ds_read_b128; it is shared by every row the workgroup streams.
-//   * one wave = one output row group; lanes hold 4x v_dot4_i32_i8 partial sums, the row result is a
-//     64-lane shuffle reduction.  Up to three matrices share one launch (QKV, gate/up) and the epilogue
-//     applies bias / residual add / SiLU*up so those never become separate kernels.
+//   * one GPU lane = one (weight row r, AVX lane u).  The weights are repacked at upload (ps_internal.h)
+//     so that the 16 bytes a lane needs for one "unit" (a Q4_K super-block / four Q4_0 or Q8_0 blocks) are
+//     contiguous and a wavefront's 64 x 16 B load is one fully coalesced 1 KiB piece of 8 (16) rows.
+//     Every weight byte is still read exactly once, with non-temporal loads, no LDS round trip.
+//   * the lane computes quad partials with v_dot4_i32_i8 (exact), the per-block scale product exactly as
+//     the reference (d = dx*dy), and runs its own fma chain in block order; hsum_float_8's association is a
+//     xor-4, xor-2, xor-1 butterfly over the 8 lanes of a row.  Result == reference, bit for bit.
+//   * the activation row is quantized ONCE PER WORKGROUP in the prologue (RMSNorm / plain / pre-quantized),
+//     bit-exactly (ps_quant_dev.h), into LDS; it is re-read per unit with ds_read_b32 broadcast across rows.
+//   * up to three matrices share a launch (QKV, gate+up) and the epilogue applies bias / residual / SiLU*up.
 #include "ps_dev.h"
 #include "ps_internal.h"
+#include "ps_quant_dev.h"
 
 namespace {
 
@@ -25,206 +31,227 @@ struct GemvW {
     const uint8_t *aux;
     float *out;
     const float *bias;
-    int64_t N, ldo;
+    int64_t N, ldo, n_groups;
 };
 
 struct GemvParams {
     GemvW w[3];
     int n_w;
-    int64_t rows_total, K, bs;
+    int64_t groups_total, K, bs;
     const float *residual;
     int64_t col_bytes; // LDS bytes per activation column (16-B multiple)
+    // prologue: 0 = activation already quantized (aq/ad/abs16), 1 = rmsnorm(x, nw, eps), 2 = quantize(x)
+    const float *x, *nw;
+    float eps;
     const int8_t *aq;
     const float *ad;
     const int16_t *abs16;
 };
 
 template <int WT> struct WTraits;
-template <> struct WTraits<PS_Q4_0> { static constexpr int EPC = 2048, BLK = 32;  };  // elements per 1 KiB chunk
-template <> struct WTraits<PS_Q4_K> { static constexpr int EPC = 2048, BLK = 256; };
-template <> struct WTraits<PS_Q8_0> { static constexpr int EPC = 1024, BLK = 32;  };
+template <> struct WTraits<PS_Q4_0> { static constexpr int RG = 16, UNIT = 128, BLK = 32,  VDT = PS_Q8_0; };
+template <> struct WTraits<PS_Q8_0> { static constexpr int RG = 8,  UNIT = 128, BLK = 32,  VDT = PS_Q8_0; };
+template <> struct WTraits<PS_Q4_K> { static constexpr int RG = 8,  UNIT = 256, BLK = 256, VDT = PS_Q8_K; };
 
-// LDS image of one activation column
-struct LAct {
-    const int8_t *qs;
-    const float *d;
-    const int *bs32;
+struct LAct { // LDS image of one activation column (natural element order)
+    const int *q32;   // int8 quants viewed as dwords
+    const float *d;   // per-block scale
+    const int *bs32;  // sums of 32 consecutive quants
 };
 
-__device__ __forceinline__ float silu_mul(float g, float u) { // backend/ggml/ggml.cpp:122-127
-    float val = g;
-    val       = __fmul_rn(val, __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-val))));
-    return __fmul_rn(val, u);
-}
+__device__ __forceinline__ int bfe8(uint32_t v, int byte) { return (int)((v >> (8 * byte)) & 0xff); }
 
-// one 16-byte piece of a row's quant plane against one activation column
+// one unit (1 KiB of 8/16 rows) against one activation column; acc0/acc1/accm are this lane's fma chains
 template <int WT>
-__device__ __forceinline__ void chunk_dot(const uint4 q, const uint4 h, const float dw, const int lane, const int t,
-                                          const LAct a, float &facc, float &macc) {
+__device__ __forceinline__ void unit_dot(const uint4 q, const uint4 h, const int unit, const int u, const LAct a,
+                                         float &acc0, float &acc1, float &accm) {
     constexpr uint32_t M = 0x0F0F0F0Fu;
     if (WT == PS_Q4_K) {
-        const int c = lane & 7, sb = t * 8 + (lane >> 3);
-        const int e0 = sb * 256 + (c >> 1) * 64 + (c & 1) * 16;
-        const int4 yl = *(const int4 *)(a.qs + e0);
-        const int4 yh = *(const int4 *)(a.qs + e0 + 32);
-        int dl = dot4((int)(q.x & M), yl.x, 0);
-        dl     = dot4((int)(q.y & M), yl.y, dl);
-        dl     = dot4((int)(q.z & M), yl.z, dl);
-        dl     = dot4((int)(q.w & M), yl.w, dl);
-        int dh = dot4((int)((q.x >> 4) & M), yh.x, 0);
-        dh     = dot4((int)((q.y >> 4) & M), yh.y, dh);
-        dh     = dot4((int)((q.z >> 4) & M), yh.z, dh);
-        dh     = dot4((int)((q.w >> 4) & M), yh.w, dh);
-        int sc0, sc1, mc, tmp;
-        ps_scale_min_k4(2 * (c >> 1), h.y, h.z, h.w, sc0, tmp);
-        ps_scale_min_k4(2 * (c >> 1) + 1, h.y, h.z, h.w, sc1, tmp);
-        ps_scale_min_k4(c, h.y, h.z, h.w, tmp, mc);
-        const float yd   = a.d[sb];
+        // h = {d|dmin, scales[0..3], scales[4..7], scales[8..11]}; 6-bit unpack as ggml-quants.c:7818-7823
+        const uint32_t sc03 = h.y & 0x3f3f3f3fu;
+        const uint32_t sc47 = (h.w & 0x0f0f0f0fu) | (((h.y >> 6) & 0x03030303u) << 4);
+        const uint32_t mn03 = h.z & 0x3f3f3f3fu;
+        const uint32_t mn47 = ((h.w >> 4) & 0x0f0f0f0fu) | (((h.z >> 6) & 0x03030303u) << 4);
+        const int base = unit * 64 + u; // dword index of element unit*256 + u*4
+        const uint32_t wq[4] = {q.x, q.y, q.z, q.w};
+        int s = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int yl = a.q32[base + j * 16], yh = a.q32[base + j * 16 + 8];
+            const uint32_t scp = (j < 2) ? sc03 : sc47;
+            const int sl = bfe8(scp, (2 * j) & 3), sh = bfe8(scp, (2 * j + 1) & 3);
+            s += sl * dot4((int)(wq[j] & M), yl, 0) + sh * dot4((int)((wq[j] >> 4) & M), yh, 0);
+        }
+        const float yd   = a.d[unit];
         const float d    = __fmul_rn(yd, ps_h2f((uint16_t)(h.x & 0xffff)));
         const float dmin = __fmul_rn(-yd, ps_h2f((uint16_t)(h.x >> 16)));
-        facc = __fmaf_rn(d, (float)(sc0 * dl + sc1 * dh), facc);
-        macc = __fmaf_rn(dmin, (float)(mc * a.bs32[sb * 8 + c]), macc);
-    } else if (WT == PS_Q4_0) {
-        const int bi = t * 64 + lane;
-        const int4 yl = *(const int4 *)(a.qs + bi * 32);
-        const int4 yh = *(const int4 *)(a.qs + bi * 32 + 16);
-        int s = dot4((int)(q.x & M), yl.x, 0);
-        s     = dot4((int)(q.y & M), yl.y, s);
-        s     = dot4((int)(q.z & M), yl.z, s);
-        s     = dot4((int)(q.w & M), yl.w, s);
-        s     = dot4((int)((q.x >> 4) & M), yh.x, s);
-        s     = dot4((int)((q.y >> 4) & M), yh.y, s);
-        s     = dot4((int)((q.z >> 4) & M), yh.z, s);
-        s     = dot4((int)((q.w >> 4) & M), yh.w, s);
-        s -= 8 * a.bs32[bi]; // sum (q-8)*y = sum q*y - 8*sum y
-        facc = __fmaf_rn(__fmul_rn(dw, a.d[bi]), (float)s, facc);
-    } else { // Q8_0
-        const int eo = t * 1024 + lane * 16;
-        const int4 y = *(const int4 *)(a.qs + eo);
-        int s = dot4((int)q.x, y.x, 0);
-        s     = dot4((int)q.y, y.y, s);
-        s     = dot4((int)q.z, y.z, s);
-        s     = dot4((int)q.w, y.w, s);
-        facc = __fmaf_rn(__fmul_rn(dw, a.d[eo >> 5]), (float)s, facc);
+        acc0 = __fmaf_rn(d, (float)s, acc0);
+        // acc_m lane v = u & 3: prod = mins[2v]*q8s[2v] + mins[2v+1]*q8s[2v+1]   (ggml-quants.c:7831-7834)
+        const int v = u & 3;
+        const uint32_t mp = (v < 2) ? mn03 : mn47;
+        const int prod = bfe8(mp, (2 * v) & 3) * a.bs32[unit * 8 + 2 * v] + bfe8(mp, (2 * v + 1) & 3) * a.bs32[unit * 8 + 2 * v + 1];
+        accm = __fmaf_rn(dmin, (float)prod, accm);
+    } else if (WT == PS_Q8_0) {
+        // q = quad u of blocks 4*unit .. 4*unit+3; h.x,h.y = their four fp16 scales
+        const uint32_t wq[4] = {q.x, q.y, q.z, q.w};
+        const uint16_t dh[4] = {(uint16_t)(h.x & 0xffff), (uint16_t)(h.x >> 16), (uint16_t)(h.y & 0xffff), (uint16_t)(h.y >> 16)};
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const int blk = unit * 4 + b;
+            const int s = dot4((int)wq[b], a.q32[blk * 8 + u], 0);
+            acc0 = __fmaf_rn(__fmul_rn(ps_h2f(dh[b]), a.d[blk]), (float)s, acc0);
+        }
+    } else { // Q4_0: lane u' (0..3) holds bytes 4u'..4u'+3 of each block: low nibbles = quad u', high = quad u'+4
+        const uint32_t wq[4] = {q.x, q.y, q.z, q.w};
+        const uint16_t dh[4] = {(uint16_t)(h.x & 0xffff), (uint16_t)(h.x >> 16), (uint16_t)(h.y & 0xffff), (uint16_t)(h.y >> 16)};
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const int blk = unit * 4 + b;
+            const int yl = a.q32[blk * 8 + u], yh = a.q32[blk * 8 + 4 + u];
+            const int sl = dot4((int)(wq[b] & M), yl, 0) - 8 * dot4(0x01010101, yl, 0);        // sum (q-8)*y
+            const int sh = dot4((int)((wq[b] >> 4) & M), yh, 0) - 8 * dot4(0x01010101, yh, 0);
+            const float d = __fmul_rn(ps_h2f(dh[b]), a.d[blk]);
+            acc0 = __fmaf_rn(d, (float)sl, acc0);
+            acc1 = __fmaf_rn(d, (float)sh, acc1);
+        }
     }
 }
 
-// MODE 0: out = y (+bias) (+residual);  MODE 1: out[0] = silu(y_w0) * y_w1 (R == 2, rows paired)
-template <int WT, int TB, int R, int BS, int MODE>
+// hsum_float_8 association (+ acc_m for Q4_K): valid in the lane with u == 0
+template <int WT>
+__device__ __forceinline__ float row_reduce(float acc0, float acc1, float accm) {
+    if (WT == PS_Q4_0) {
+        float r = __fadd_rn(acc1, acc0); // a[k+4] + a[k]
+        r = __fadd_rn(r, __shfl_xor(r, 2, 64));
+        r = __fadd_rn(r, __shfl_xor(r, 1, 64));
+        return r;
+    }
+    float r = __fadd_rn(acc0, __shfl_xor(acc0, 4, 64));
+    r = __fadd_rn(r, __shfl_xor(r, 2, 64));
+    r = __fadd_rn(r, __shfl_xor(r, 1, 64));
+    if (WT == PS_Q4_K) {
+        float m = __fadd_rn(accm, __shfl_xor(accm, 2, 64)); // (m0+m2), (m1+m3)
+        m = __fadd_rn(m, __shfl_xor(m, 1, 64));
+        r = __fadd_rn(r, m);
+    }
+    return r;
+}
+
+// EPI 0: out = y (+bias) (+residual).   EPI 1: out[0] = silu(y_w0) * y_w1 (same row of w[0] and w[1]).
+template <int WT, int BS, int EPI, int PRO>
 __global__ __launch_bounds__(256) void gemv_kernel(const GemvParams p) {
     using TR = WTraits<WT>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ double red[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t K = p.K;
-    const int nblk  = (int)(K / TR::BLK);            // scale blocks per row
-    const int nb32  = (int)(K / 32);
-    const size_t col_bytes = (size_t)p.col_bytes;
+    const int Kp   = (int)((K + TR::UNIT - 1) / TR::UNIT * TR::UNIT); // padded to whole units; pad region is zero
+    const int nblk = Kp / TR::BLK, nb32 = Kp / 32, nb16 = Kp / 16;
+    const int nblk_k = (int)(K / TR::BLK), nb16_k = (int)(K / 16);
 
-    // ---- stage the quantized activation column(s) into LDS
+    // ---- activation column(s) -> LDS: [int8 q[Kp]] [float d[nblk]] [int bs32[nb32]] [int16 bs16[nb16] scratch]
     for (int col = 0; col < BS; col++) {
-        char *base = smem + col * col_bytes;
-        int8_t *lq = (int8_t *)base;
-        float *ld  = (float *)(base + (K + 15) / 16 * 16);
-        int *lb    = (int *)(ld + nblk);
-        const bool on = col < p.bs;
-        for (int64_t i = threadIdx.x * 16; i < K; i += 256 * 16)
-            *(int4 *)(lq + i) = on ? *(const int4 *)(p.aq + col * K + i) : make_int4(0, 0, 0, 0);
-        for (int i = threadIdx.x; i < nblk; i += 256) ld[i] = on ? p.ad[col * nblk + i] : 0.f;
-        for (int i = threadIdx.x; i < nb32; i += 256) {
-            const int16_t *b = p.abs16 + col * (K / 16) + 2 * i;
-            lb[i]            = on ? (int)b[0] + (int)b[1] : 0;
+        char *base   = smem + col * p.col_bytes;
+        int8_t *lq   = (int8_t *)base;
+        float *ld    = (float *)(base + Kp);
+        int *lb      = (int *)(ld + nblk);
+        int16_t *l16 = (int16_t *)(lb + nb32);
+        if (col < p.bs) {
+            if (Kp != K) { // zero the padding blocks (their weights are zero too: fma(0, s, acc) leaves acc unchanged)
+                for (int i = (int)K + threadIdx.x * 4; i < Kp; i += 256 * 4) *(int *)(lq + i) = 0;
+                for (int i = nblk_k + threadIdx.x; i < nblk; i += 256) ld[i] = 0.f;
+                for (int i = nb16_k + threadIdx.x; i < nb16; i += 256) l16[i] = 0;
+            }
+            if (PRO == 0) {
+                for (int64_t i = threadIdx.x * 16; i < K; i += 256 * 16) *(int4 *)(lq + i) = *(const int4 *)(p.aq + col * K + i);
+                for (int i = threadIdx.x; i < nblk_k; i += 256) ld[i] = p.ad[col * nblk_k + i];
+                for (int i = threadIdx.x; i < nb16_k; i += 256) l16[i] = p.abs16[col * nb16_k + i];
+                __syncthreads();
+            } else {
+                ps_quantize_row_wg<TR::VDT, PRO == 1 ? 1 : 0>(p.x + col * K, nullptr, p.nw, p.eps, K, lq, ld, l16, red);
+            }
+            for (int i = threadIdx.x; i < nb32; i += 256) lb[i] = (int)l16[2 * i] + (int)l16[2 * i + 1];
+        } else {
+            for (int i = threadIdx.x * 4; i < Kp; i += 256 * 4) *(int *)(lq + i) = 0;
+            for (int i = threadIdx.x; i < nblk; i += 256) ld[i] = 0.f;
+            for (int i = threadIdx.x; i < nb32; i += 256) lb[i] = 0;
         }
     }
     __syncthreads();
 
-    const int Tn          = (int)((K + TR::EPC - 1) / TR::EPC); // 1 KiB chunks per row
-    const int64_t row_qb  = (WT == PS_Q8_0) ? K : K / 2;         // quant-plane bytes per row
-    const int64_t n_groups = (MODE == 1) ? p.w[0].N : (p.rows_total + R - 1) / R;
+    const int r = (WT == PS_Q4_0) ? (lane >> 2) : (lane >> 3);
+    const int u = (WT == PS_Q4_0) ? (lane & 3) : (lane & 7);
+    const int n_units        = (int)((K + TR::UNIT - 1) / TR::UNIT);
+    const int64_t unit_bytes = 1024;                                   // quant-plane bytes per unit per row group
+    const int64_t aux_unit   = (int64_t)TR::RG * (WT == PS_Q4_K ? 16 : 8);
+    const int64_t n_tasks    = (EPI == 1) ? p.w[0].n_groups : p.groups_total;
+    constexpr int UNR = 4;
 
-    for (int64_t g = (int64_t)blockIdx.x * 4 + wave; g < n_groups; g += (int64_t)gridDim.x * 4) {
-        const uint8_t *qrow[R];
-        const uint8_t *arow[R];
-        int wi[R];
-        int64_t lr[R];
-        bool rv[R];
+    for (int64_t task = (int64_t)blockIdx.x * 4 + wave; task < n_tasks; task += (int64_t)gridDim.x * 4) {
+        float yres[BS][EPI == 1 ? 2 : 1];
+        int wi = 0;
+        int64_t grp = task;
 #pragma unroll
-        for (int r = 0; r < R; r++) {
-            int64_t row = (MODE == 1) ? g : g * R + r;
-            int i       = (MODE == 1) ? r : 0;
-            rv[r]       = (MODE == 1) ? true : row < p.rows_total;
-            if (MODE == 0) {
-                if (!rv[r]) row = 0;
-                if (p.n_w > 1 && row >= p.w[0].N) { row -= p.w[0].N; i = 1; }
-                if (p.n_w > 2 && i == 1 && row >= p.w[1].N) { row -= p.w[1].N; i = 2; }
+        for (int pass = 0; pass < (EPI == 1 ? 2 : 1); pass++) {
+            if (EPI == 1) {
+                wi = pass;
+            } else {
+                if (p.n_w > 1 && grp >= p.w[0].n_groups) { grp -= p.w[0].n_groups; wi = 1; }
+                if (p.n_w > 2 && wi == 1 && grp >= p.w[1].n_groups) { grp -= p.w[1].n_groups; wi = 2; }
             }
-            wi[r]   = i;
-            lr[r]   = row;
-            qrow[r] = p.w[i].qs + row * row_qb;
-            arow[r] = p.w[i].aux + row * (int64_t)nblk * ((WT == PS_Q4_K) ? 16 : 2);
-        }
-        float facc[R][BS], macc[R][BS];
+            const GemvW &W    = p.w[wi];
+            const uint8_t *qg = W.qs + grp * n_units * unit_bytes + (int64_t)lane * 16;
+            const uint8_t *ag = W.aux + grp * n_units * aux_unit + (int64_t)r * (WT == PS_Q4_K ? 16 : 8);
+            float acc0[BS], acc1[BS], accm[BS];
 #pragma unroll
-        for (int r = 0; r < R; r++)
+            for (int c = 0; c < BS; c++) { acc0[c] = 0.f; acc1[c] = 0.f; accm[c] = 0.f; }
+            for (int u0 = 0; u0 < n_units; u0 += UNR) {
+                uint4 q[UNR], h[UNR];
 #pragma unroll
-            for (int c = 0; c < BS; c++) { facc[r][c] = 0.f; macc[r][c] = 0.f; }
-
-        for (int t0 = 0; t0 < Tn; t0 += TB) {
-            uint4 q[R][TB], h[R][TB];
-            float dw[R][TB];
-            bool ok[TB];
-            // ---- put every load of this batch in flight first
+                for (int i = 0; i < UNR; i++) { // all loads of the batch in flight first
+                    const int un = u0 + i;
+                    q[i] = make_uint4(0, 0, 0, 0);
+                    h[i] = make_uint4(0, 0, 0, 0);
+                    if (un < n_units) {
+                        q[i] = ld_stream16(qg + (int64_t)un * unit_bytes);
+                        if (WT == PS_Q4_K) h[i] = *(const uint4 *)(ag + (int64_t)un * aux_unit);
+                        else { const uint2 t = *(const uint2 *)(ag + (int64_t)un * aux_unit); h[i].x = t.x; h[i].y = t.y; }
+                    }
+                }
 #pragma unroll
-            for (int tt = 0; tt < TB; tt++) {
-                const int t        = t0 + tt;
-                const int64_t boff = (int64_t)t * 1024 + lane * 16;
-                ok[tt]             = (t < Tn) && (boff < row_qb);
+                for (int i = 0; i < UNR; i++) {
+                    if (u0 + i < n_units) {
 #pragma unroll
-                for (int r = 0; r < R; r++) {
-                    q[r][tt] = make_uint4(0, 0, 0, 0);
-                    h[r][tt] = make_uint4(0, 0, 0, 0);
-                    dw[r][tt] = 0.f;
-                    if (ok[tt]) {
-                        q[r][tt] = ld_stream16(qrow[r] + boff);
-                        if (WT == PS_Q4_K) h[r][tt] = *(const uint4 *)(arow[r] + (size_t)(t * 8 + (lane >> 3)) * 16);
-                        else if (WT == PS_Q4_0) dw[r][tt] = ps_h2f(*(const uint16_t *)(arow[r] + (size_t)(t * 64 + lane) * 2));
-                        else dw[r][tt] = ps_h2f(*(const uint16_t *)(arow[r] + (size_t)(t * 32 + (lane >> 1)) * 2));
+                        for (int c = 0; c < BS; c++) {
+                            const char *base = smem + c * p.col_bytes;
+                            LAct a;
+                            a.q32  = (const int *)base;
+                            a.d    = (const float *)(base + Kp);
+                            a.bs32 = (const int *)(a.d + nblk);
+                            unit_dot<WT>(q[i], h[i], u0 + i, u, a, acc0[c], acc1[c], accm[c]);
+                        }
                     }
                 }
             }
-            // ---- integer dots against the LDS-resident activation
 #pragma unroll
-            for (int tt = 0; tt < TB; tt++) {
-                if (!ok[tt]) continue;
-#pragma unroll
-                for (int c = 0; c < BS; c++) {
-                    const char *base = smem + c * col_bytes;
-                    LAct a;
-                    a.qs   = (const int8_t *)base;
-                    a.d    = (const float *)(base + (K + 15) / 16 * 16);
-                    a.bs32 = (const int *)(a.d + nblk);
-#pragma unroll
-                    for (int r = 0; r < R; r++) chunk_dot<WT>(q[r][tt], h[r][tt], dw[r][tt], lane, t0 + tt, a, facc[r][c], macc[r][c]);
-                }
-            }
+            for (int c = 0; c < BS; c++) yres[c][pass] = row_reduce<WT>(acc0[c], acc1[c], accm[c]);
         }
-        // ---- row results + epilogue
+        // ---- epilogue: lane with u == 0 owns row grp*RG + r
+        const GemvW &W    = p.w[wi];
+        const int64_t row = grp * TR::RG + r;
+        if (u == 0 && row < W.N) {
 #pragma unroll
-        for (int c = 0; c < BS; c++) {
-            float y[R];
-#pragma unroll
-            for (int r = 0; r < R; r++) y[r] = wave_sum(facc[r][c]) + wave_sum(macc[r][c]);
-            if (lane == 0 && c < p.bs) {
-                if (MODE == 1) {
-                    p.w[0].out[c * p.w[0].ldo + g] = silu_mul(y[0], y[R - 1]);
-                } else {
-#pragma unroll
-                    for (int r = 0; r < R; r++) {
-                        if (!rv[r]) continue;
-                        const GemvW &W = p.w[wi[r]];
-                        float v        = y[r];
-                        if (W.bias) v = __fadd_rn(v, W.bias[lr[r]]);
-                        if (p.residual && wi[r] == 0) v = __fadd_rn(p.residual[c * W.ldo + lr[r]], v);
-                        W.out[c * W.ldo + lr[r]] = v;
+            for (int c = 0; c < BS; c++) {
+                if (c < p.bs) {
+                    float v;
+                    if (EPI == 1) {
+                        v = ps_silu_mul(yres[c][0], yres[c][EPI == 1 ? 1 : 0]);
+                        p.w[0].out[c * p.w[0].ldo + row] = v;
+                    } else {
+                        v = yres[c][0];
+                        if (W.bias) v = __fadd_rn(v, W.bias[row]);
+                        if (p.residual && wi == 0) v = __fadd_rn(p.residual[c * W.ldo + row], v);
+                        W.out[c * W.ldo + row] = v;
                     }
                 }
             }
@@ -232,84 +259,83 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvParams p) {
     }
 }
 
-template <int WT, int TB, int R, int BS, int MODE>
-void launch_one(hipStream_t st, int n_cu, const GemvParams &p, size_t smem) {
-    const int64_t n_groups = (MODE == 1) ? p.w[0].N : (p.rows_total + R - 1) / R;
-    int64_t grid           = (n_groups + 3) / 4;
-    const int64_t cap      = (int64_t)n_cu * (smem > 36 * 1024 ? 2 : 4);
+template <int WT, int BS, int EPI, int PRO>
+void launch_one(hipStream_t st, int n_cu, const GemvParams &p) {
+    const int64_t n_tasks = (EPI == 1) ? p.w[0].n_groups : p.groups_total;
+    const size_t smem     = (size_t)p.col_bytes * BS;
+    int64_t grid          = (n_tasks + 3) / 4;
+    const int64_t cap     = (int64_t)n_cu * (smem > 40 * 1024 ? 2 : 4);
     if (grid > cap) grid = cap;
     if (grid < 1) grid = 1;
     static bool attr_set = false;
     if (!attr_set && smem > 48 * 1024) {
-        (void)hipFuncSetAttribute((const void *)gemv_kernel<WT, TB, R, BS, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024);
+        (void)hipFuncSetAttribute((const void *)gemv_kernel<WT, BS, EPI, PRO>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemv_kernel<WT, TB, R, BS, MODE>), dim3((unsigned)grid), dim3(256), smem, st, p);
+    hipLaunchKernelGGL((gemv_kernel<WT, BS, EPI, PRO>), dim3((unsigned)grid), dim3(256), smem, st, p);
 }
 
-template <int WT, int BS, int MODE>
-void launch_tb(hipStream_t st, int n_cu, const GemvParams &p, size_t smem, int Tn, bool pair_rows) {
-    // R = 2 when rows are short (few chunks) or paired; TB = chunks kept in flight per row
-    if (MODE == 1 || pair_rows) {
-        if (Tn <= 1) launch_one<WT, 1, 2, BS, MODE>(st, n_cu, p, smem);
-        else if (Tn == 2) launch_one<WT, 2, 2, BS, MODE>(st, n_cu, p, smem);
-        else launch_one<WT, 4, 2, BS, MODE>(st, n_cu, p, smem);
+template <int WT, int BS>
+int launch_epi(hipStream_t st, int n_cu, const GemvParams &p, int epi, int pro) {
+    if (epi == 1) {
+        if (pro == 0) launch_one<WT, BS, 1, 0>(st, n_cu, p);
+        else if (pro == 1) launch_one<WT, BS, 1, 1>(st, n_cu, p);
+        else launch_one<WT, BS, 1, 2>(st, n_cu, p);
     } else {
-        if (Tn <= 1) launch_one<WT, 1, 1, BS, MODE>(st, n_cu, p, smem);
-        else if (Tn == 2) launch_one<WT, 2, 1, BS, MODE>(st, n_cu, p, smem);
-        else if (Tn == 7) launch_one<WT, 7, 1, BS, MODE>(st, n_cu, p, smem);
-        else launch_one<WT, 4, 1, BS, MODE>(st, n_cu, p, smem);
-    }
-}
-
-template <int WT>
-int launch_wt(hipStream_t st, int n_cu, const GemvParams &p, size_t col_bytes, int mode) {
-    const int Tn = (int)((p.K + WTraits<WT>::EPC - 1) / WTraits<WT>::EPC);
-    bool even    = true;
-    for (int i = 0; i < p.n_w; i++) even = even && (p.w[i].N % 2 == 0);
-    const bool pair_rows = even && Tn <= 2;
-    if (p.bs == 1) {
-        if (mode == 1) launch_tb<WT, 1, 1>(st, n_cu, p, col_bytes, Tn, true);
-        else launch_tb<WT, 1, 0>(st, n_cu, p, col_bytes, Tn, pair_rows);
-    } else if (p.bs <= 4) {
-        if (mode == 1) launch_tb<WT, 4, 1>(st, n_cu, p, col_bytes * 4, Tn, true);
-        else launch_tb<WT, 4, 0>(st, n_cu, p, col_bytes * 4, Tn, false);
-    } else {
-        return 3;
+        if (pro == 0) launch_one<WT, BS, 0, 0>(st, n_cu, p);
+        else if (pro == 1) launch_one<WT, BS, 0, 1>(st, n_cu, p);
+        else launch_one<WT, BS, 0, 2>(st, n_cu, p);
     }
     return 0;
 }
 
+template <int WT>
+int launch_wt(hipStream_t st, int n_cu, const GemvParams &p, int epi, int pro) {
+    if (p.bs == 1) return launch_epi<WT, 1>(st, n_cu, p, epi, pro);
+    if (p.bs <= 4) return launch_epi<WT, 4>(st, n_cu, p, epi, pro);
+    return 3;
+}
+
 } // namespace
 
-// bs <= 4 columns per launch; larger batches go through the MFMA GEMM (k_gemm.hip) or are split by the caller.
+size_t psk_gemv_lds_col_bytes(int wt, int64_t K) {
+    const int64_t blk = (wt == PS_Q4_K) ? 256 : 32, unit = (wt == PS_Q4_K) ? 256 : 128;
+    const int64_t Kp = (K + unit - 1) / unit * unit;
+    const size_t b = (size_t)Kp + (size_t)(Kp / blk) * 4 + (size_t)(Kp / 32) * 4 + (size_t)(Kp / 16) * 2;
+    return (b + 15) / 16 * 16;
+}
+
+// bs <= 4 columns per launch; larger batches are split by the caller.
 int psk_gemv(hipStream_t st, int n_cu, const psk_gemv_args &a, ps_act act, int vdt, int64_t K, int64_t bs) {
     GemvParams p{};
-    p.n_w        = a.n_w;
-    p.rows_total = 0;
-    p.K          = K;
-    p.bs         = bs;
-    p.residual   = a.residual;
-    p.aq         = act.qs;
-    p.ad         = act.d;
-    p.abs16      = act.bs16;
-    const int wt = a.w[0]->dtype;
+    p.n_w          = a.n_w;
+    p.groups_total = 0;
+    p.K            = K;
+    p.bs           = bs;
+    p.residual     = a.residual;
+    p.x            = a.pro_x;
+    p.nw           = a.pro_norm_w;
+    p.eps          = a.pro_eps;
+    p.aq           = act.qs;
+    p.ad           = act.d;
+    p.abs16        = act.bs16;
+    const int wt   = a.w[0]->dtype;
+    const int rg   = (wt == PS_Q4_0) ? 16 : 8;
     for (int i = 0; i < a.n_w; i++) {
         if (a.w[i]->dtype != wt || a.w[i]->K != K) return 4;
-        p.w[i] = GemvW{a.w[i]->qs, a.w[i]->aux, a.out[i], a.bias[i], a.w[i]->N, a.ldo[i]};
-        p.rows_total += a.w[i]->N;
+        const int64_t ng = (a.w[i]->N + rg - 1) / rg;
+        p.w[i] = GemvW{a.w[i]->qs, a.w[i]->aux, a.out[i], a.bias[i], a.w[i]->N, a.ldo[i], ng};
+        p.groups_total += ng;
     }
     (void)vdt;
-    const int64_t blk      = (wt == PS_Q4_K) ? 256 : 32;
-    const size_t col_bytes = ((size_t)((K + 15) / 16 * 16) + (size_t)(K / blk) * 4 + (size_t)(K / 32) * 4 + 15) / 16 * 16;
-    p.col_bytes            = (int64_t)col_bytes;
-    const int mode         = a.silu_pair ? 1 : 0;
-    if (mode == 1 && (a.n_w != 2 || a.w[0]->N != a.w[1]->N)) return 5;
+    p.col_bytes = (int64_t)psk_gemv_lds_col_bytes(wt, K);
+    if ((size_t)p.col_bytes * (bs == 1 ? 1 : 4) > 150 * 1024) return 7;
+    const int epi = a.silu_pair ? 1 : 0;
+    if (epi == 1 && (a.n_w != 2 || a.w[0]->N != a.w[1]->N)) return 5;
     switch (wt) {
-    case PS_Q4_0: return launch_wt<PS_Q4_0>(st, n_cu, p, col_bytes, mode);
-    case PS_Q8_0: return launch_wt<PS_Q8_0>(st, n_cu, p, col_bytes, mode);
-    case PS_Q4_K: return launch_wt<PS_Q4_K>(st, n_cu, p, col_bytes, mode);
+    case PS_Q4_0: return launch_wt<PS_Q4_0>(st, n_cu, p, epi, a.pro);
+    case PS_Q8_0: return launch_wt<PS_Q8_0>(st, n_cu, p, epi, a.pro);
+    case PS_Q4_K: return launch_wt<PS_Q4_K>(st, n_cu, p, epi, a.pro);
     }
     return 6;
 }

@@ -174,18 +174,26 @@ __global__ void get_rows_kernel(WView w, const int32_t *tokens, int n, float *ou
         if (w.dtype == PS_F32) {
             v = ((const float *)w.qs)[row * K + e];
         } else if (w.dtype == PS_Q4_0) {
-            const int64_t b = e / 32; const int j = (int)(e % 32);
-            const uint8_t byte = w.qs[row * (K / 2) + b * 16 + (j & 15)];
-            const int q = (j < 16 ? (byte & 0xF) : (byte >> 4)) - 8;
-            v = __fmul_rn((float)q, ps_h2f(((const uint16_t *)w.aux)[row * (K / 32) + b]));
+            const int64_t nu = (K + 127) / 128, g = row / 16, blk = e / 32;
+            const int r = (int)(row % 16), j = (int)(e % 32), byte = j & 15, bl = (int)(blk & 3);
+            const int64_t gs = g * nu + blk / 4;
+            const uint8_t bv = w.qs[((gs * 16 + r) * 4 + (byte >> 2)) * 16 + bl * 4 + (byte & 3)];
+            const int q = (j < 16 ? (bv & 0xF) : (bv >> 4)) - 8;
+            v = __fmul_rn((float)q, ps_h2f(((const uint16_t *)w.aux)[(gs * 16 + r) * 4 + bl]));
         } else if (w.dtype == PS_Q8_0) {
-            v = __fmul_rn((float)((const int8_t *)w.qs)[row * K + e], ps_h2f(((const uint16_t *)w.aux)[row * (K / 32) + e / 32]));
+            const int64_t nu = (K + 127) / 128, g = row / 8, blk = e / 32;
+            const int r = (int)(row % 8), j = (int)(e % 32), bl = (int)(blk & 3);
+            const int64_t gs = g * nu + blk / 4;
+            const int8_t qv = ((const int8_t *)w.qs)[((gs * 8 + r) * 8 + (j >> 2)) * 16 + bl * 4 + (j & 3)];
+            v = __fmul_rn((float)qv, ps_h2f(((const uint16_t *)w.aux)[(gs * 8 + r) * 4 + bl]));
         } else if (w.dtype == PS_Q4_K) {
-            const int64_t sb = e / 256; const int r = (int)(e % 256), j = r / 64, l = r % 64;
-            const uint4 h = ((const uint4 *)w.aux)[row * (K / 256) + sb];
+            const int64_t nsb = K / 256, sb = e / 256, g = row / 8;
+            const int r = (int)(row % 8), rr = (int)(e % 256), j = rr / 64, l = rr % 64, byte = l & 31;
+            const int64_t gs = g * nsb + sb;
+            const uint4 h = ((const uint4 *)w.aux)[gs * 8 + r];
             int sc, m; ps_scale_min_k4(2 * j + (l >= 32), h.y, h.z, h.w, sc, m);
-            const uint8_t byte = w.qs[row * (K / 2) + sb * 128 + j * 32 + (l & 31)];
-            const int q = (l < 32) ? (byte & 0xF) : (byte >> 4);
+            const uint8_t bv = w.qs[((gs * 8 + r) * 8 + (byte >> 2)) * 16 + j * 4 + (byte & 3)];
+            const int q = (l < 32) ? (bv & 0xF) : (bv >> 4);
             const float d = ps_h2f((uint16_t)(h.x & 0xffff)), mn = ps_h2f((uint16_t)(h.x >> 16));
             v = __fsub_rn(__fmul_rn(__fmul_rn(d, (float)sc), (float)q), __fmul_rn(mn, (float)m));
         } else { // Q6_K

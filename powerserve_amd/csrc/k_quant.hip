@@ -14,6 +14,7 @@
 // reference rounds.
 #include "ps_dev.h"
 #include "ps_internal.h"
+#include "ps_quant_dev.h"
 
 namespace {
 
@@ -26,103 +27,13 @@ struct QuantArgs {
     int16_t *bs16;
 };
 
-__device__ __forceinline__ float produce(int mode, float xv, float x2v, float wv, float scale) {
-    if (mode == 1) return __fmul_rn(xv, __fmul_rn(wv, scale)); // y = x * (w * scale)   (ggml.c:2466)
-    if (mode == 2) {                                            // silu_hadamard        (ggml.cpp:122-127)
-        float val = xv;
-        val       = __fmul_rn(val, __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-val))));
-        return __fmul_rn(val, x2v);
-    }
-    return xv;
-}
-
 template <int VDT, int MODE>
 __global__ __launch_bounds__(256) void quantize_act_kernel(QuantArgs a) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ double red[4];
     const int64_t row = blockIdx.x, K = a.K;
-    const float *x  = a.x + row * K;
-    const float *x2 = a.x2 ? a.x2 + row * K : nullptr;
-    const int64_t n_tiles = (K + 255) / 256;
-
-    float scale = 1.0f;
-    if (MODE == 1) {
-        // sum += (double)(x*x); mean = sum/ne00; scale = 1/sqrtf(mean + eps)   (ggml.c:12698-12707)
-        __shared__ double red[4];
-        double s = 0.0;
-        for (int64_t t = wave; t < n_tiles; t += 4) {
-            const int64_t e = t * 256 + lane * 4;
-            if (e < K) {
-                const float4 v = *(const float4 *)(x + e);
-                s += (double)__fmul_rn(v.x, v.x);
-                s += (double)__fmul_rn(v.y, v.y);
-                s += (double)__fmul_rn(v.z, v.z);
-                s += (double)__fmul_rn(v.w, v.w);
-            }
-        }
-        s = wave_sum_d(s);
-        if (lane == 0) red[wave] = s;
-        __syncthreads();
-        const double tot = (red[0] + red[1]) + (red[2] + red[3]);
-        const float mean = (float)(tot / (double)K);
-        scale            = __fdiv_rn(1.0f, sqrtf(__fadd_rn(mean, a.eps)));
-    }
-
-    for (int64_t t = wave; t < n_tiles; t += 4) {
-        const int64_t e  = t * 256 + lane * 4;
-        const bool live  = e < K;
-        float v[4]       = {0.f, 0.f, 0.f, 0.f};
-        if (live) {
-            const float4 xv = *(const float4 *)(x + e);
-            float4 x2v      = make_float4(0, 0, 0, 0), wv = make_float4(0, 0, 0, 0);
-            if (MODE == 2) x2v = *(const float4 *)(x2 + e);
-            if (MODE == 1) wv = *(const float4 *)(a.w + e);
-            v[0] = produce(MODE, xv.x, x2v.x, wv.x, scale);
-            v[1] = produce(MODE, xv.y, x2v.y, wv.y, scale);
-            v[2] = produce(MODE, xv.z, x2v.z, wv.z, scale);
-            v[3] = produce(MODE, xv.w, x2v.w, wv.w, scale);
-        }
-        int q[4];
-        if (VDT == PS_Q8_0) {
-            float amax = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
-            amax       = group_max<8>(amax);
-            const float d  = __fdiv_rn(amax, 127.f);
-            const float id = (amax != 0.0f) ? __fdiv_rn(127.f, amax) : 0.0f;
-#pragma unroll
-            for (int i = 0; i < 4; i++) q[i] = __float2int_rn(__fmul_rn(v[i], id)); // round-half-even
-            if (live && (lane & 7) == 0) a.d[row * (K / 32) + e / 32] = ps_h2f(ps_f2h(d));
-        } else { // Q8_K
-            // first element (in index order) with the strictly largest |x| decides the sign of iscale
-            float amax = 0.f, mx = 0.f;
-            int idx    = 0;
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const float ax = fabsf(v[i]);
-                if (ax > amax) { amax = ax; mx = v[i]; idx = lane * 4 + i; }
-            }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const float oa = __shfl_xor(amax, o, 64), om = __shfl_xor(mx, o, 64);
-                const int oi   = __shfl_xor(idx, o, 64);
-                if (oa > amax || (oa == amax && oi < idx)) { amax = oa; mx = om; idx = oi; }
-            }
-            if (amax == 0.f) {
-                q[0] = q[1] = q[2] = q[3] = 0;
-                if (live && lane == 0) a.d[row * (K / 256) + t] = 0.f;
-            } else {
-                const float iscale = __fdiv_rn(-127.f, mx);
-#pragma unroll
-                for (int i = 0; i < 4; i++) q[i] = min(127, __float2int_rn(__fmul_rn(iscale, v[i])));
-                if (live && lane == 0) a.d[row * (K / 256) + t] = __fdiv_rn(1.0f, iscale);
-            }
-        }
-        const int s16 = group_sum_i<4>(q[0] + q[1] + q[2] + q[3]);
-        if (live) {
-            const uint32_t packed = (uint32_t)(q[0] & 0xff) | ((uint32_t)(q[1] & 0xff) << 8) |
-                                    ((uint32_t)(q[2] & 0xff) << 16) | ((uint32_t)(q[3] & 0xff) << 24);
-            *(uint32_t *)(a.qs + row * K + e) = packed;
-            if ((lane & 3) == 0) a.bs16[row * (K / 16) + e / 16] = (int16_t)s16;
-        }
-    }
+    const int64_t nblk = K / (VDT == PS_Q8_0 ? 32 : 256);
+    ps_quantize_row_wg<VDT, MODE>(a.x + row * K, a.x2 ? a.x2 + row * K : nullptr, a.w, a.eps, K, a.qs + row * K,
+                                  a.d + row * nblk, a.bs16 + row * (K / 16), red);
 }
 
 // SoA activation -> GGUF block layout (block_q8_0 34 B / block_q8_K 292 B), for parity tests of the
@@ -151,32 +62,56 @@ __global__ void pack_act_blocks_kernel(int vdt, const int8_t *qs, const float *d
     }
 }
 
-// GGUF blocks -> backend SoA (see ps_internal.h).  One thread per 16-byte piece / per block.
-__global__ void repack_q4_0_kernel(const uint8_t *raw, int64_t nblk, uint8_t *qs, uint8_t *d) {
-    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= nblk) return;
-    const uint16_t *s = (const uint16_t *)(raw + b * 18);
-    ((uint16_t *)d)[b] = s[0];
-    uint16_t *o        = (uint16_t *)(qs + b * 16);
-#pragma unroll
-    for (int i = 0; i < 8; i++) o[i] = s[1 + i];
+// GGUF blocks -> lane-major repack (ps_internal.h).  One thread per output dword.
+__global__ void repack_q4_K_kernel(const uint8_t *raw, int64_t N, int64_t nsb, uint32_t *qs, uint4 *hdr) {
+    const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; // dword index in qs
+    const int64_t ng = (N + 7) / 8;
+    if (o >= ng * nsb * 256) return;
+    const int j = (int)(o & 3), u = (int)((o >> 2) & 7), r = (int)((o >> 5) & 7);
+    const int64_t gs = o >> 8, sb = gs % nsb, g = gs / nsb, row = g * 8 + r;
+    uint32_t v = 0;
+    if (row < N) {
+        const uint8_t *blk = raw + (row * nsb + sb) * 144;
+        v = *(const uint32_t *)(blk + 16 + j * 32 + u * 4);
+        if (j == 0 && u == 0) hdr[gs * 8 + r] = *(const uint4 *)blk;
+    } else if (j == 0 && u == 0) {
+        hdr[gs * 8 + r] = make_uint4(0, 0, 0, 0);
+    }
+    qs[o] = v;
 }
-__global__ void repack_q8_0_kernel(const uint8_t *raw, int64_t nblk, uint8_t *qs, uint8_t *d) {
-    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= nblk) return;
-    const uint16_t *s = (const uint16_t *)(raw + b * 34);
-    ((uint16_t *)d)[b] = s[0];
-    uint16_t *o        = (uint16_t *)(qs + b * 32);
-#pragma unroll
-    for (int i = 0; i < 16; i++) o[i] = s[1 + i];
+__global__ void repack_q8_0_kernel(const uint8_t *raw, int64_t N, int64_t nb, int64_t nu, uint32_t *qs, uint16_t *d) {
+    const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t ng = (N + 7) / 8;
+    if (o >= ng * nu * 256) return;
+    const int bl = (int)(o & 3), u = (int)((o >> 2) & 7), r = (int)((o >> 5) & 7);
+    const int64_t gs = o >> 8, b4 = gs % nu, g = gs / nu, row = g * 8 + r, blk = b4 * 4 + bl;
+    uint32_t v = 0;
+    uint16_t dv = 0;
+    if (row < N && blk < nb) {
+        const uint8_t *b = raw + (row * nb + blk) * 34;
+        const uint16_t *s = (const uint16_t *)(b + 2 + u * 4);
+        v  = (uint32_t)s[0] | ((uint32_t)s[1] << 16);
+        dv = *(const uint16_t *)b;
+    }
+    qs[o] = v;
+    if (u == 0) d[(gs * 8 + r) * 4 + bl] = dv;
 }
-__global__ void repack_q4_K_kernel(const uint4 *raw, int64_t nblk, uint4 *qs, uint4 *hdr) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; // 16-byte piece index
-    if (i >= nblk * 9) return;
-    const int64_t b = i / 9;
-    const int c     = (int)(i % 9);
-    const uint4 v   = raw[i];
-    if (c == 0) hdr[b] = v; else qs[b * 8 + (c - 1)] = v;
+__global__ void repack_q4_0_kernel(const uint8_t *raw, int64_t N, int64_t nb, int64_t nu, uint32_t *qs, uint16_t *d) {
+    const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t ng = (N + 15) / 16;
+    if (o >= ng * nu * 256) return;
+    const int bl = (int)(o & 3), u = (int)((o >> 2) & 3), r = (int)((o >> 4) & 15);
+    const int64_t gs = o >> 8, b4 = gs % nu, g = gs / nu, row = g * 16 + r, blk = b4 * 4 + bl;
+    uint32_t v = 0;
+    uint16_t dv = 0;
+    if (row < N && blk < nb) {
+        const uint8_t *b = raw + (row * nb + blk) * 18;
+        const uint16_t *s = (const uint16_t *)(b + 2 + u * 4);
+        v  = (uint32_t)s[0] | ((uint32_t)s[1] << 16);
+        dv = *(const uint16_t *)b;
+    }
+    qs[o] = v;
+    if (u == 0) d[(gs * 16 + r) * 4 + bl] = dv;
 }
 __global__ void repack_q6_K_kernel(const uint8_t *raw, int64_t nblk, uint8_t *ql, uint8_t *qh, uint8_t *sc,
                                    uint8_t *d) {
@@ -214,16 +149,16 @@ void psk_pack_act_blocks(hipStream_t st, int vdt, ps_act in, int64_t K, int64_t 
 
 void psk_repack_weight(hipStream_t st, int dtype, const uint8_t *raw, int64_t K, int64_t N, ps_weight *w) {
     const int T = 256;
-    if (dtype == PS_Q4_0) {
-        const int64_t nb = N * (K / 32);
-        hipLaunchKernelGGL(repack_q4_0_kernel, dim3((unsigned)((nb + T - 1) / T)), dim3(T), 0, st, raw, nb, w->qs, w->aux);
-    } else if (dtype == PS_Q8_0) {
-        const int64_t nb = N * (K / 32);
-        hipLaunchKernelGGL(repack_q8_0_kernel, dim3((unsigned)((nb + T - 1) / T)), dim3(T), 0, st, raw, nb, w->qs, w->aux);
+    if (dtype == PS_Q4_0 || dtype == PS_Q8_0) {
+        const int64_t nb = K / 32, nu = (K + 127) / 128, rg = dtype == PS_Q4_0 ? 16 : 8, ng = (N + rg - 1) / rg;
+        const int64_t n = ng * nu * 256;
+        if (dtype == PS_Q4_0)
+            hipLaunchKernelGGL(repack_q4_0_kernel, dim3((unsigned)((n + T - 1) / T)), dim3(T), 0, st, raw, N, nb, nu, (uint32_t *)w->qs, (uint16_t *)w->aux);
+        else
+            hipLaunchKernelGGL(repack_q8_0_kernel, dim3((unsigned)((n + T - 1) / T)), dim3(T), 0, st, raw, N, nb, nu, (uint32_t *)w->qs, (uint16_t *)w->aux);
     } else if (dtype == PS_Q4_K) {
-        const int64_t nb = N * (K / 256);
-        hipLaunchKernelGGL(repack_q4_K_kernel, dim3((unsigned)((nb * 9 + T - 1) / T)), dim3(T), 0, st, (const uint4 *)raw,
-                           nb, (uint4 *)w->qs, (uint4 *)w->aux);
+        const int64_t nsb = K / 256, ng = (N + 7) / 8, n = ng * nsb * 256;
+        hipLaunchKernelGGL(repack_q4_K_kernel, dim3((unsigned)((n + T - 1) / T)), dim3(T), 0, st, raw, N, nsb, (uint32_t *)w->qs, (uint4 *)w->aux);
     } else if (dtype == PS_Q6_K) {
         const int64_t nb = N * (K / 256);
         hipLaunchKernelGGL(repack_q6_K_kernel, dim3((unsigned)((nb * 105 + T - 1) / T)), dim3(T), 0, st, raw, nb, w->qs,

@@ -21,14 +21,6 @@ namespace {
 __global__ void set_state_kernel(ps_step_state *s, int pos0, int bs, int n_out) {
     s->pos0 = pos0; s->bs = bs; s->n_out = n_out;
 }
-// after the lm_head arg-max of a greedy step: feed the id back as the next token and advance the state
-__global__ void decode_advance_kernel(ps_step_state *s, const int32_t *argmax, int32_t *token, int32_t *ids) {
-    const int id = argmax[0];
-    token[0]     = id;
-    ids[s->n_out] = id;
-    s->n_out += 1;
-    s->pos0 += 1;
-}
 __global__ void null_kernel(int *p) { if (p && threadIdx.x == 12345) *p = 0; }
 __global__ void kv_move_kernel(float *k, float *v, int kvd, int n_ctx, int dst, int src) {
     const int d = blockIdx.x * blockDim.x + threadIdx.x;
@@ -54,6 +46,8 @@ struct ps_hip_model {
     std::vector<float *> k_cache, v_cache;
     ps_step_state *state = nullptr;
     int32_t *tokens_dev = nullptr, *argmax_dev = nullptr, *ids_dev = nullptr;
+    float *am_v = nullptr;
+    int *am_i = nullptr;
     uint8_t *tree_dev = nullptr;
     size_t position = 0;
     int mode = 0;
@@ -84,6 +78,7 @@ static int mm(ps_hip_model *m, psk_gemv_args &g, ps_act act, int64_t K, int64_t 
         psk_gemv_args gg = g;
         for (int i = 0; i < g.n_w; i++) gg.out[i] = g.out[i] + c0 * g.ldo[i];
         if (g.residual) gg.residual = g.residual + c0 * g.ldo[0];
+        if (g.pro) gg.pro_x = g.pro_x + c0 * K;
         ps_act ac = act;
         ac.qs += c0 * K; ac.d += c0 * (K / blk); ac.bs16 += c0 * (K / 16);
         if (int rc = psk_gemv(c->stream, c->n_cu, gg, ac, vdt, K, nb)) { c->err = "gemv launch rc=" + std::to_string(rc); return 2; }
@@ -92,7 +87,7 @@ static int mm(ps_hip_model *m, psk_gemv_args &g, ps_act act, int64_t K, int64_t 
 }
 
 // enqueue one forward over `bs` tokens whose ids are in tokens_dev and whose state is in m->state
-static int enqueue_forward(ps_hip_model *m, int bs, bool lm_head, bool use_tree) {
+static int enqueue_forward(ps_hip_model *m, int bs, bool lm_head, bool use_tree, bool advance = false) {
     ps_hip_ctx *c = m->ctx;
     hipStream_t st = c->stream;
     const ps_llm_config &f = m->cfg;
@@ -112,57 +107,53 @@ static int enqueue_forward(ps_hip_model *m, int bs, bool lm_head, bool use_tree)
     aa.scale = 1.0f / sqrtf((float)f.head_size);
 
     for (uint32_t L = 0; L < f.n_layers; L++) {
-        const int vdt_a = ps_hip_vec_dot_type(m->wq[L]->dtype);
         ps_act a1 = act_for(dim);
-        psk_quantize_act(st, vdt_a, 1, m->x, nullptr, m->attn_norm[L], f.norm_eps, dim, bs, a1);
         psk_gemv_args g{};
         g.n_w = 3;
         g.w[0] = m->wq[L]; g.w[1] = m->wk[L]; g.w[2] = m->wv[L];
         g.out[0] = m->q; g.out[1] = m->k; g.out[2] = m->v;
         g.ldo[0] = dim; g.ldo[1] = kvd; g.ldo[2] = kvd;
         if (m->qwen2) { g.bias[0] = m->bq[L]; g.bias[1] = m->bk[L]; g.bias[2] = m->bv[L]; }
+        g.pro = 1; g.pro_x = m->x; g.pro_norm_w = m->attn_norm[L]; g.pro_eps = f.norm_eps; // RMSNorm + quantize in the prologue
         if (mm(m, g, a1, dim, bs)) return 2;
 
         aa.k_cache = m->k_cache[L]; aa.v_cache = m->v_cache[L];
         psl_rope_append(st, aa, bs);
         psl_attn_scores(st, aa, bs);
-        psl_attn_softmax_pv(st, aa, bs);
+        psl_attn_softmax(st, aa, bs);
+        psl_attn_pv(st, aa, bs);
 
-        const int vdt_o = ps_hip_vec_dot_type(m->wo[L]->dtype);
-        psk_quantize_act(st, vdt_o, 0, m->att, nullptr, nullptr, 0.f, dim, bs, a1);
         psk_gemv_args go{};
         go.n_w = 1; go.w[0] = m->wo[L]; go.out[0] = m->x; go.ldo[0] = dim; go.residual = m->x;
+        go.pro = 2; go.pro_x = m->att;
         if (mm(m, go, a1, dim, bs)) return 2;
 
-        const int vdt_f = ps_hip_vec_dot_type(m->wg[L]->dtype);
-        psk_quantize_act(st, vdt_f, 1, m->x, nullptr, m->ffn_norm[L], f.norm_eps, dim, bs, a1);
         ps_act a2 = act_for(hid);
         const int vdt_d = ps_hip_vec_dot_type(m->wd[L]->dtype);
-        if (bs <= 4) {
-            psk_gemv_args gf{};
-            gf.n_w = 2; gf.w[0] = m->wg[L]; gf.w[1] = m->wu[L]; gf.out[0] = m->hb; gf.out[1] = m->hb; gf.ldo[0] = hid; gf.ldo[1] = hid;
-            gf.silu_pair = 1;
-            if (mm(m, gf, a1, dim, bs)) return 2;
-            psk_quantize_act(st, vdt_d, 0, m->hb, nullptr, nullptr, 0.f, hid, bs, a2);
-        } else {
-            psk_gemv_args gf{};
-            gf.n_w = 2; gf.w[0] = m->wg[L]; gf.w[1] = m->wu[L]; gf.out[0] = m->g1; gf.out[1] = m->u1; gf.ldo[0] = hid; gf.ldo[1] = hid;
-            if (mm(m, gf, a1, dim, bs)) return 2;
-            psk_quantize_act(st, vdt_d, 2, m->g1, m->u1, nullptr, 0.f, hid, bs, a2);
-        }
+        psk_gemv_args gf{};
+        gf.n_w = 2; gf.w[0] = m->wg[L]; gf.w[1] = m->wu[L]; gf.out[0] = m->hb; gf.out[1] = m->hb; gf.ldo[0] = hid; gf.ldo[1] = hid;
+        gf.silu_pair = 1;
+        gf.pro = 1; gf.pro_x = m->x; gf.pro_norm_w = m->ffn_norm[L]; gf.pro_eps = f.norm_eps;
+        if (mm(m, gf, a1, dim, bs)) return 2;
         psk_gemv_args gd{};
         gd.n_w = 1; gd.w[0] = m->wd[L]; gd.out[0] = m->x; gd.ldo[0] = dim; gd.residual = m->x;
+        if (psk_gemv_lds_col_bytes(m->wd[L]->dtype, hid) * (bs == 1 ? 1 : 4) <= 64 * 1024 && hid <= 8192) {
+            gd.pro = 2; gd.pro_x = m->hb; // short rows: quantize in the prologue
+        } else {
+            psk_quantize_act(st, vdt_d, 0, m->hb, nullptr, nullptr, 0.f, hid, bs, a2);
+        }
         if (mm(m, gd, a2, hid, bs)) return 2;
     }
     if (lm_head) {
         const ps_weight *ow = m->output ? m->output : m->token_embd; // tied lm_head (weights.hpp:67-68)
         const int vdt = ps_hip_vec_dot_type(ow->dtype);
         ps_act a1 = act_for(dim);
-        psk_quantize_act(st, vdt, 1, m->x, nullptr, m->output_norm, f.norm_eps, dim, bs, a1);
+        (void)vdt;
         psk_gemv_args gl{};
         gl.n_w = 1; gl.w[0] = ow; gl.out[0] = m->logits; gl.ldo[0] = f.vocab_size;
+        gl.pro = 1; gl.pro_x = m->x; gl.pro_norm_w = m->output_norm; gl.pro_eps = f.norm_eps;
         if (mm(m, gl, a1, dim, bs)) return 2;
-        psl_argmax(st, m->logits, f.vocab_size, bs, m->argmax_dev);
+        psl_argmax2(st, m->logits, f.vocab_size, bs, m->argmax_dev, m->am_v, m->am_i, advance ? m->state : nullptr, m->tokens_dev, m->ids_dev);
     }
     PS_CHECK(c, hipGetLastError());
     return 0;
@@ -179,7 +170,6 @@ int ps_hip_model_create(ps_hip_ctx *c, const ps_model_desc *d, ps_hip_model **ou
     if (f.n_heads / f.n_kv_heads > 8) PS_FAIL(c, "model_create: GQA ratio > 8 not supported");
     if ((int)f.rope.n_dims != (int)f.head_size) PS_FAIL(c, "model_create: rope n_dims != head_size (reference asserts the same, norm_attention.cpp:38)");
     if (f.seq_len % 4) PS_FAIL(c, "model_create: n_ctx must be a multiple of 4");
-    if ((size_t)(f.n_heads / f.n_kv_heads) * f.seq_len * 4 > 150 * 1024) PS_FAIL(c, "model_create: n_ctx too large for the LDS-resident softmax (cap n_ctx)");
     PS_CHECK(c, hipSetDevice(c->device));
     auto m = new ps_hip_model();
     m->ctx = c; m->cfg = f; m->qwen2 = d->is_qwen2 != 0; m->max_batch = d->max_batch > 0 ? d->max_batch : 1;
@@ -207,7 +197,7 @@ int ps_hip_model_create(ps_hip_ctx *c, const ps_model_desc *d, ps_hip_model **ou
         dmalloc(m, &m->act_mem, ps_act_bytes(dim > hid ? dim : hid, mb)) ||
         dmalloc(m, (void **)&m->state, sizeof(ps_step_state)) || dmalloc(m, (void **)&m->tokens_dev, mb * 4) ||
         dmalloc(m, (void **)&m->argmax_dev, mb * 4) || dmalloc(m, (void **)&m->ids_dev, (nctx + 1) * 4) ||
-        dmalloc(m, (void **)&m->tree_dev, mb * mb))
+        dmalloc(m, (void **)&m->tree_dev, mb * mb) || dmalloc(m, (void **)&m->am_v, mb * 64 * 4) || dmalloc(m, (void **)&m->am_i, mb * 64 * 4))
         return fail();
     m->k_cache.assign(L, nullptr); m->v_cache.assign(L, nullptr);
     for (uint32_t i = 0; i < L; i++) {
@@ -282,14 +272,12 @@ int ps_hip_model_decode_greedy(ps_hip_model *m, int32_t token, int steps, int32_
     if (m->mode == 0 && !m->step_graph) {
         // first step runs eagerly (also performs every one-time hipFuncSetAttribute), then the identical
         // launch sequence is captured; capture itself executes nothing
-        if (int rc = enqueue_forward(m, 1, true, false)) return rc;
-        hipLaunchKernelGGL(decode_advance_kernel, dim3(1), dim3(1), 0, c->stream, m->state, m->argmax_dev, m->tokens_dev, m->ids_dev);
+        if (int rc = enqueue_forward(m, 1, true, false, true)) return rc;
         PS_CHECK(c, hipStreamSynchronize(c->stream));
         s = 1;
         hipGraph_t g = nullptr;
         PS_CHECK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-        int rc = enqueue_forward(m, 1, true, false);
-        hipLaunchKernelGGL(decode_advance_kernel, dim3(1), dim3(1), 0, c->stream, m->state, m->argmax_dev, m->tokens_dev, m->ids_dev);
+        int rc = enqueue_forward(m, 1, true, false, true);
         hipError_t e = hipStreamEndCapture(c->stream, &g);
         if (rc || e != hipSuccess) { c->err = "decode_greedy: graph capture failed: " + c->err; if (g) (void)hipGraphDestroy(g); return 2; }
         PS_CHECK(c, hipGraphInstantiate(&m->step_graph, g, nullptr, nullptr, 0));
@@ -299,8 +287,7 @@ int ps_hip_model_decode_greedy(ps_hip_model *m, int32_t token, int steps, int32_
         if (m->mode == 0) {
             PS_CHECK(c, hipGraphLaunch(m->step_graph, c->stream));
         } else {
-            if (int rc = enqueue_forward(m, 1, true, false)) return rc;
-            hipLaunchKernelGGL(decode_advance_kernel, dim3(1), dim3(1), 0, c->stream, m->state, m->argmax_dev, m->tokens_dev, m->ids_dev);
+            if (int rc = enqueue_forward(m, 1, true, false, true)) return rc;
         }
     }
     PS_CHECK(c, hipMemcpyAsync(out_ids, m->ids_dev, (size_t)steps * 4, hipMemcpyDeviceToHost, c->stream));

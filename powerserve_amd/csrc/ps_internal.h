@@ -24,12 +24,19 @@ struct ps_hip_ctx {
     size_t rope_cap = 0;
 };
 
-// Device layout of a quantized weight matrix [K, N] (structure of arrays, private to the backend):
-//   Q4_0 : qs  [N][K/32][16]  nibbles          d   [N][K/32] fp16
-//   Q8_0 : qs  [N][K]         int8             d   [N][K/32] fp16
-//   Q4_K : qs  [N][K/256][128] nibbles         hdr [N][K/256] x 16 B {d, dmin, scales[12]}
-//   Q6_K : qs  [N][K/256][128] (ql)  qh [N][K/256][64]  sc [N][K/16] int8   d [N][K/256] fp16
-//   F32  : qs  [N][K] float
+// Device layout of a quantized weight matrix [K, N]: a LANE-MAJOR repack of the GGUF blocks, private to the
+// backend (every GGUF byte appears exactly once; zero padding only in a partial last row group / unit).
+// Rows are taken in groups of RG; a "unit" is 1 KiB of quant data of one row group, laid out so that the
+// 16 bytes at  lane*16  are what GPU lane (row r, AVX accumulator lane u) of k_gemv.hip consumes:
+//   Q4_K (RG 8, unit = 1 super-block):  qs [group][sb][r][u][j=0..3][4 B] = bytes 32j+4u..32j+4u+3 of the
+//                                       super-block (low nibbles: quad u of sub-block 2j, high: of 2j+1)
+//                                       aux[group][sb][r] 16 B = {d, dmin, scales[12]}
+//   Q8_0 (RG 8, unit = 4 blocks):       qs [group][b4][r][u][blk=0..3][4 B] = quants 4u..4u+3 of block 4*b4+blk
+//                                       aux[group][b4][r][4] fp16 d
+//   Q4_0 (RG 16, unit = 4 blocks):      qs [group][b4][r][u'=0..3][blk][4 B] = bytes 4u'..4u'+3 of the block
+//                                       (low nibbles: quad u', high nibbles: quad u'+4);  aux as Q8_0
+//   Q6_K : plane layout  qs [N][K/256][128] (ql)  qh [N][K/256][64]  sc [N][K/16] int8  aux [N][K/256] fp16
+//   F32  : qs [N][K] float
 struct ps_weight {
     int dtype;
     int64_t K, N;
@@ -97,5 +104,13 @@ struct psk_gemv_args {
     int64_t ldo[3];
     const float *residual;   // optional: out[0] = residual + y   (same layout as out[0])
     int silu_pair;           // 1: n_w==2, out[0][r] = silu(y0[r]) * y1[r]
+    // activation source: pro 0 = `act` (already quantized), 1 = rmsnorm(pro_x, pro_norm_w, pro_eps) then
+    // quantize, 2 = quantize(pro_x); pro_x is [bs][K] F32.  Done once per workgroup in the kernel prologue.
+    int pro;
+    const float *pro_x, *pro_norm_w;
+    float pro_eps;
 };
+size_t psk_gemv_lds_col_bytes(int wt, int64_t K);
+static inline int64_t ps_w_rg(int dtype) { return dtype == PS_Q4_0 ? 16 : 8; }
+static inline int64_t ps_w_unit(int dtype) { return dtype == PS_Q4_K ? 256 : 128; }
 int psk_gemv(hipStream_t st, int n_cu, const psk_gemv_args &a, ps_act act, int vdt, int64_t K, int64_t bs);

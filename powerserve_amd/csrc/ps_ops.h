@@ -37,7 +37,12 @@ struct psl_attn_args {
 };
 void psl_rope_append(hipStream_t st, const psl_attn_args &a, int bs);
 void psl_attn_scores(hipStream_t st, const psl_attn_args &a, int bs);
-void psl_attn_softmax_pv(hipStream_t st, const psl_attn_args &a, int bs);
+void psl_attn_softmax(hipStream_t st, const psl_attn_args &a, int bs);
+void psl_attn_pv(hipStream_t st, const psl_attn_args &a, int bs);
+// two-stage arg-max (64 partials per row).  With state != NULL the final stage also does the greedy-decode
+// bookkeeping: token[0] = id, ids[state->n_out++] = id, state->pos0++.
+void psl_argmax2(hipStream_t st, const float *src, int64_t n, int64_t rows, int32_t *out, float *part_v, int *part_i,
+                 ps_step_state *state, int32_t *token, int32_t *ids);
 
 // host restatement of ggml_rope_cache_init for positions [0, n_pos) -> table[n_pos][ne0]
 void ps_rope_table_host(const ps_rope_params *rp, int64_t ne0, const int32_t *pos, int n_pos, float *table);

@@ -57,11 +57,12 @@ def test_generate_matches_oracle(ctx, oracle, tmp_path, preset, wt):
         worst = max(worst, rel_err(lg[0], want_logits[s]))
         assert int(am[0]) == int(want_ids[s])
         cur = int(want_ids[s])
-    assert worst < 1e-3, worst
+    # every kernel reproduces the reference's accumulation order: logits are bit-exact, not merely < 1e-3
+    assert worst == 0.0, worst
     # KV cache contents (K rows, transposed V) match the reference layout
     n = gm.position
-    assert rel_err(gm.k_cache(0)[:n], om.k_cache(0)[:n]) < 1e-4
-    assert rel_err(gm.v_cache(1)[:, :n], om.v_cache(1)[:, :n]) < 1e-4
+    assert np.array_equal(gm.k_cache(0)[:n], om.k_cache(0)[:n])
+    assert np.array_equal(gm.v_cache(1)[:, :n], om.v_cache(1)[:, :n])
     gm.close()
     om.close()
 
@@ -78,11 +79,11 @@ def test_batched_forward_logits(ctx, oracle, tmp_path):
     toks = np.arange(3, 14) % cfg.vocab_size
     want = om.forward(toks, np.arange(toks.size), True)
     got, am = gm.forward(toks, np.arange(toks.size), True)
-    assert rel_err(got, want) < 1e-3
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), rel_err(got, want)
     assert np.array_equal(am, want.argmax(1))
     gm.reset()
     got1 = np.concatenate([gm.forward([t], [i], True)[0] for i, t in enumerate(toks)])
-    assert rel_err(got1, want) < 1e-3
+    assert rel_err(got1, want) < 1e-3  # one-token-at-a-time changes n_kv per row (different vector/tail split in softmax): close, not identical
     gm.close()
     om.close()
 

@@ -59,7 +59,8 @@ def test_mul_mat_quant(ctx, oracle, hip, wt, K, N, bs):
     dx, dy = ctx.to_device(x), ctx.empty((bs, N))
     ctx.check(ctx.L.ps_hip_mul_mat(ctx.h, C.byref(dy.tensor()), C.byref(W.tensor()), C.byref(dx.tensor())))
     got = dy.numpy()
-    assert rel_err(got, want) < TOL, rel_err(got, want)
+    # the GEMV reproduces the reference's AVX2 accumulation order: bit-exact, not just close
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (rel_err(got, want), np.flatnonzero(got != want)[:8])
     W.free()
 
 
