@@ -78,20 +78,24 @@ __global__ __launch_bounds__(256) void attn_scores_kernel(psl_attn_args a) {
     for (int g = 0; g < R2MAX; g++)
 #pragma unroll
         for (int m = 0; m < NV; m++) qf[g][m] = (g < r2) ? qb[g * hs + m * 32 + c] : 0.f;
+    float kf[4][NV];
+#pragma unroll
+    for (int rd = 0; rd < 4; rd++) {
+        const int j     = j0 + rd * 8 + hw;
+        const float *kr = a.k_cache + (int64_t)(j < n_kv ? j : 0) * kvd + kvh * hs;
+#pragma unroll
+        for (int m = 0; m < NV; m++) kf[rd][m] = kr[m * 32 + c];
+    }
 #pragma unroll
     for (int rd = 0; rd < 4; rd++) {
         const int j     = j0 + rd * 8 + hw;
         const bool live = j < n_kv;
-        const float *kr = a.k_cache + (int64_t)(live ? j : 0) * kvd + kvh * hs;
-        float kf[NV];
-#pragma unroll
-        for (int m = 0; m < NV; m++) kf[m] = kr[m * 32 + c];
 #pragma unroll
         for (int g = 0; g < R2MAX; g++) {
             if (g < r2) {
                 float s = 0.f;
 #pragma unroll
-                for (int m = 0; m < NV; m++) s = __fmaf_rn(kf[m], qf[g][m], s); // sum = x*y + sum, x = K row (src0)
+                for (int m = 0; m < NV; m++) s = __fmaf_rn(kf[rd][m], qf[g][m], s); // sum = x*y + sum, x = K row (src0)
                 s = reduce_f32x8x4(s);
                 if (live && c == 0) sb[(int64_t)g * a.n_ctx + j] = s;
             }
@@ -143,6 +147,7 @@ __global__ __launch_bounds__(256) void attn_softmax_kernel(psl_attn_args a) {
 
 // ---------------------------------------------------------------- out[i][h][d] = V^T[kvh*hs + d][0..n_kv) · p[i][h][0..n_kv)
 // grid (hs/4, n_kv_heads, bs), 128 threads: a half-wave per output channel d, all r2 heads of the kv group.
+// Loads are issued U steps ahead (V from HBM, p from L2); the fma chains stay in position order.
 __global__ __launch_bounds__(128) void attn_pv_kernel(psl_attn_args a) {
     const int hs = a.head_size, dim = a.n_heads * hs, r2 = a.n_heads / a.n_kv_heads;
     const int c = threadIdx.x & 31, hw = threadIdx.x >> 5;
@@ -154,11 +159,25 @@ __global__ __launch_bounds__(128) void attn_pv_kernel(psl_attn_args a) {
     float acc[R2MAX];
 #pragma unroll
     for (int g = 0; g < R2MAX; g++) acc[g] = 0.f;
-    for (int j = c; j < np; j += 32) {
-        const float v = vr[j];
+    constexpr int U = 8;
+    for (int j0 = c; j0 < np; j0 += 32 * U) {
+        float v[U], pv[U][R2MAX];
 #pragma unroll
-        for (int g = 0; g < R2MAX; g++)
-            if (g < r2) acc[g] = __fmaf_rn(v, pb[(int64_t)g * a.n_ctx + j], acc[g]); // x = V row (src0), y = p
+        for (int t = 0; t < U; t++) {
+            const int j = j0 + 32 * t;
+            const bool ok = j < np;
+            v[t] = ok ? vr[j] : 0.f;
+#pragma unroll
+            for (int g = 0; g < R2MAX; g++) pv[t][g] = (ok && g < r2) ? pb[(int64_t)g * a.n_ctx + j] : 0.f;
+        }
+#pragma unroll
+        for (int t = 0; t < U; t++) {
+            if (j0 + 32 * t < np) {
+#pragma unroll
+                for (int g = 0; g < R2MAX; g++)
+                    if (g < r2) acc[g] = __fmaf_rn(v[t], pv[t][g], acc[g]); // x = V row (src0), y = p
+            }
+        }
     }
 #pragma unroll
     for (int g = 0; g < R2MAX; g++) {

@@ -27,13 +27,33 @@ struct QuantArgs {
     int16_t *bs16;
 };
 
-template <int VDT, int MODE>
-__global__ __launch_bounds__(256) void quantize_act_kernel(QuantArgs a) {
-    __shared__ double red[4];
+// MODE 1 (RMSNorm needs the whole row): one workgroup per row.
+template <int VDT, int TPW>
+__global__ __launch_bounds__(256) void quantize_norm_kernel(QuantArgs a) {
+    __shared__ double red[8];
     const int64_t row = blockIdx.x, K = a.K;
     const int64_t nblk = K / (VDT == PS_Q8_0 ? 32 : 256);
-    ps_quantize_row_wg<VDT, MODE>(a.x + row * K, a.x2 ? a.x2 + row * K : nullptr, a.w, a.eps, K, a.qs + row * K,
-                                  a.d + row * nblk, a.bs16 + row * (K / 16), red);
+    ps_quantize_row_wg<VDT, 1, TPW>(a.x + row * K, a.w, a.eps, K, a.qs + row * K, a.d + row * nblk, a.bs16 + row * (K / 16), red);
+}
+// MODE 0 / 2: blocks are independent -> one wave per 256-element tile, grid (tiles/4, rows)
+template <int VDT, int MODE>
+__global__ __launch_bounds__(256) void quantize_tiles_kernel(QuantArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t row = blockIdx.y, K = a.K, t = (int64_t)blockIdx.x * 4 + wave, e = t * 256 + lane * 4;
+    if (t * 256 >= K) return;
+    const int64_t nblk = K / (VDT == PS_Q8_0 ? 32 : 256);
+    const bool live = e < K;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (live) {
+        const float4 xv = *(const float4 *)(a.x + row * K + e);
+        v[0] = xv.x; v[1] = xv.y; v[2] = xv.z; v[3] = xv.w;
+        if (MODE == 2) {
+            const float4 uv = *(const float4 *)(a.x2 + row * K + e);
+            v[0] = ps_silu_mul(xv.x, uv.x); v[1] = ps_silu_mul(xv.y, uv.y);
+            v[2] = ps_silu_mul(xv.z, uv.z); v[3] = ps_silu_mul(xv.w, uv.w);
+        }
+    }
+    ps_quantize_tile<VDT>(v, live, e, t, a.qs + row * K, a.d + row * nblk, a.bs16 + row * (K / 16));
 }
 
 // SoA activation -> GGUF block layout (block_q8_0 34 B / block_q8_K 292 B), for parity tests of the
@@ -131,14 +151,24 @@ __global__ void repack_q6_K_kernel(const uint8_t *raw, int64_t nblk, uint8_t *ql
 void psk_quantize_act(hipStream_t st, int vdt, int mode, const float *x, const float *x2, const float *w, float eps,
                       int64_t K, int64_t rows, ps_act out) {
     QuantArgs a{x, x2, w, eps, K, out.qs, out.d, out.bs16};
-    dim3 g((unsigned)rows), b(256);
-#define LAUNCH(V, M) hipLaunchKernelGGL((quantize_act_kernel<V, M>), g, b, 0, st, a)
-    if (vdt == PS_Q8_0) {
-        if (mode == 0) LAUNCH(PS_Q8_0, 0); else if (mode == 1) LAUNCH(PS_Q8_0, 1); else LAUNCH(PS_Q8_0, 2);
-    } else {
-        if (mode == 0) LAUNCH(PS_Q8_K, 0); else if (mode == 1) LAUNCH(PS_Q8_K, 1); else LAUNCH(PS_Q8_K, 2);
+    if (mode == 1) {
+        dim3 g((unsigned)rows), b(256);
+        const int64_t tpw = ((K + 255) / 256 + 3) / 4;
+#define LN(V) do { if (tpw <= 4) hipLaunchKernelGGL((quantize_norm_kernel<V, 4>), g, b, 0, st, a); \
+                   else if (tpw <= 8) hipLaunchKernelGGL((quantize_norm_kernel<V, 8>), g, b, 0, st, a); \
+                   else hipLaunchKernelGGL((quantize_norm_kernel<V, 16>), g, b, 0, st, a); } while (0)
+        if (vdt == PS_Q8_0) LN(PS_Q8_0); else LN(PS_Q8_K);
+#undef LN
+        return;
     }
-#undef LAUNCH
+    dim3 g((unsigned)(((K + 255) / 256 + 3) / 4), (unsigned)rows), b(256);
+    if (vdt == PS_Q8_0) {
+        if (mode == 0) hipLaunchKernelGGL((quantize_tiles_kernel<PS_Q8_0, 0>), g, b, 0, st, a);
+        else hipLaunchKernelGGL((quantize_tiles_kernel<PS_Q8_0, 2>), g, b, 0, st, a);
+    } else {
+        if (mode == 0) hipLaunchKernelGGL((quantize_tiles_kernel<PS_Q8_K, 0>), g, b, 0, st, a);
+        else hipLaunchKernelGGL((quantize_tiles_kernel<PS_Q8_K, 2>), g, b, 0, st, a);
+    }
 }
 
 void psk_pack_act_blocks(hipStream_t st, int vdt, ps_act in, int64_t K, int64_t rows, void *out_blocks) {

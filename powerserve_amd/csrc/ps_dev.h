@@ -55,6 +55,59 @@ __device__ __forceinline__ int group_sum_i(int v) {
     return v;
 }
 
+// ---- DPP (data-parallel primitive) lane exchange: VALU-speed cross-lane moves inside a row of 16 lanes,
+//      no LDS-pipe round trip (ds_bpermute ~100 cycles each).  ctrl: 0xB1 quad_perm[1,0,3,2] (xor 1),
+//      0x4E quad_perm[2,3,0,1] (xor 2), 0x141 row_half_mirror (lane 7-i), 0x140 row_mirror (lane 15-i),
+//      0x101..0x10F row_shl:n (lane i reads lane i+n, 0 beyond the row).
+template <int CTRL> __device__ __forceinline__ int dpp_i(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true);
+}
+template <int CTRL> __device__ __forceinline__ float dpp_f(float v) { return __int_as_float(dpp_i<CTRL>(__float_as_int(v))); }
+template <int CTRL> __device__ __forceinline__ double dpp_d(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = dpp_i<CTRL>((int)(b & 0xffffffffll)), hi = dpp_i<CTRL>((int)(b >> 32));
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+// order-insensitive reductions (max / min / integer sums / double sums that are not order-critical)
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, dpp_f<0xB1>(v)); v = fmaxf(v, dpp_f<0x4E>(v)); v = fmaxf(v, dpp_f<0x141>(v)); v = fmaxf(v, dpp_f<0x140>(v));
+    return v;
+}
+__device__ __forceinline__ float wave_max_dpp(float v) {
+    v = row16_max(v);
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+}
+__device__ __forceinline__ int wave_min_i_dpp(int v) {
+    v = min(v, dpp_i<0xB1>(v)); v = min(v, dpp_i<0x4E>(v)); v = min(v, dpp_i<0x141>(v)); v = min(v, dpp_i<0x140>(v));
+    const int r0 = __builtin_amdgcn_readlane(v, 0), r1 = __builtin_amdgcn_readlane(v, 16);
+    const int r2 = __builtin_amdgcn_readlane(v, 32), r3 = __builtin_amdgcn_readlane(v, 48);
+    return min(min(r0, r1), min(r2, r3));
+}
+__device__ __forceinline__ double wave_sum_d_dpp(double v) {
+    v += dpp_d<0xB1>(v); v += dpp_d<0x4E>(v); v += dpp_d<0x141>(v); v += dpp_d<0x140>(v);
+    const long long b = __double_as_longlong(v);
+    const int lo = (int)(b & 0xffffffffll), hi = (int)(b >> 32);
+    double r[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int l = __builtin_amdgcn_readlane(lo, 16 * k), h = __builtin_amdgcn_readlane(hi, 16 * k);
+        r[k] = __longlong_as_double(((long long)h << 32) | (unsigned int)l);
+    }
+    return (r[0] + r[1]) + (r[2] + r[3]);
+}
+__device__ __forceinline__ float group8_max_dpp(float v) { // aligned groups of 8 lanes
+    v = fmaxf(v, dpp_f<0xB1>(v)); v = fmaxf(v, dpp_f<0x4E>(v)); v = fmaxf(v, dpp_f<0x141>(v));
+    return v;
+}
+__device__ __forceinline__ int group4_sum_i_dpp(int v) { // aligned groups of 4 lanes
+    v += dpp_i<0xB1>(v); v += dpp_i<0x4E>(v);
+    return v;
+}
+
 // ---- int8 dot: 4 signed bytes x 4 signed bytes + acc  (v_dot4_i32_i8)
 __device__ __forceinline__ int dot4(int a, int b, int acc) {
     return __builtin_amdgcn_sdot4(a, b, acc, false);
