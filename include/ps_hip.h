@@ -159,6 +159,7 @@ void ps_hip_model_destroy(ps_hip_model *m);
 /* KVCacheInterface bookkeeping (core/kv_cache.hpp:97-163) */
 size_t ps_hip_model_kv_position(const ps_hip_model *m);
 int ps_hip_model_kv_truncate(ps_hip_model *m, size_t n_tokens);
+int ps_hip_model_kv_advance(ps_hip_model *m, size_t n_tokens); /* after an op-by-op forward through the ps_hip_* operators */
 int ps_hip_model_kv_rollback(ps_hip_model *m, size_t n_tokens);
 int ps_hip_model_kv_move(ps_hip_model *m, size_t dst_index, size_t src_index);
 /* One Model::forward (model/llama/llama_model.cpp:52-117).  tokens/pos: HOST arrays of n entries,

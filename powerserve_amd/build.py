@@ -47,6 +47,27 @@ def build(force: bool = False, verbose: bool = True) -> str:
     so = os.path.join(LIBDIR, "libps_hip.so")
     if jobs or not os.path.exists(so):
         subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", so, *objs], check=True)
+    build_host(force or bool(jobs), verbose)
+    return so
+
+
+HOST_SOURCES = ["json_gguf.cpp", "graph.cpp", "hip_backend.cpp", "model.cpp"]
+
+
+def build_host(force: bool = False, verbose: bool = True) -> str:
+    """C++20 host facade (Graph / Executor / HIPBackend / Model mirrors) -> lib/libps_host.so on top of the C-ABI.
+    POWERSERVE_EXCEPTION_ABORT: failures throw (reference option, src/core/exception.hpp:275-278) so that the
+    ctypes driver can report them instead of aborting the interpreter."""
+    hdir = os.path.join(CSRC, "host")
+    so = os.path.join(LIBDIR, "libps_host.so")
+    srcs = [os.path.join(hdir, f) for f in HOST_SOURCES]
+    deps = srcs + [os.path.join(hdir, f) for f in os.listdir(hdir) if f.endswith(".hpp")] + [os.path.join(HERE, "..", "include", "ps_hip.h")]
+    if not force and os.path.exists(so) and all(os.path.getmtime(d) <= os.path.getmtime(so) for d in deps):
+        return so
+    if verbose:
+        print("[build] host facade", flush=True)
+    subprocess.run(["g++", "-std=c++20", "-O2", "-fPIC", "-shared", "-DPOWERSERVE_EXCEPTION_ABORT", "-Wall", "-Wno-unused-function",
+                    "-o", so, *srcs, "-L" + LIBDIR, "-lps_hip", "-Wl,-rpath,$ORIGIN"], check=True)
     return so
 
 

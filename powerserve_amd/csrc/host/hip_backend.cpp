@@ -1,0 +1,228 @@
+#include "hip_backend.hpp"
+
+#include <cmath>
+#include <cstring>
+
+namespace powerserve {
+namespace hip {
+
+// ---------------------------------------------------------------- KV
+HIPKV::HIPKV(const ModelConfig::LLMConfig &c, ps_hip_model *model) :
+    m_kv_dim(c.kv_dim), m_n_kv_heads(c.n_kv_heads), m_n_ctx(c.seq_len), m_n_layers(c.n_layers), m_head_size(c.head_size), m_model(model) {
+    Stride stride = {sizeof(float), sizeof(float) * m_n_ctx, sizeof(float) * m_kv_dim * m_n_ctx, sizeof(float) * m_kv_dim * m_n_ctx};
+    for (size_t L = 0; L < m_n_layers; L++) {
+        key_tensors.emplace_back(Tensor(DataType::FP32, {m_n_ctx, m_kv_dim, 1, 1}));
+        value_tensors.emplace_back(Tensor(DataType::FP32, {m_n_ctx, m_kv_dim, 1, 1}));
+        key_tensors[L].m_data   = std::make_shared<HIPBuffer>(stride, (void *)ps_hip_model_k_cache(model, (int)L));
+        value_tensors[L].m_data = std::make_shared<HIPBuffer>(stride, (void *)ps_hip_model_v_cache(model, (int)L));
+    }
+}
+void HIPKV::advance(int n) {
+    POWERSERVE_ASSERT(position() + (size_t)n <= m_n_ctx, "the length of kvcache is up to the preset threshold");
+    ps_hip_model_kv_advance(m_model, (size_t)n);
+}
+void HIPKV::rollback(size_t n) {
+    POWERSERVE_ASSERT(position() >= n);
+    ps_hip_model_kv_rollback(m_model, n);
+}
+
+// ---------------------------------------------------------------- backend
+HIPBackend::HIPBackend(const ModelConfig::LLMConfig &config, const HyperParams &, int device) : m_config(config), m_device(device) {
+    if (ps_hip_create(device, &m_ctx) != 0) POWERSERVE_ABORT("ps_hip_create failed: no usable HIP device (there is no CPU fallback)");
+}
+HIPBackend::~HIPBackend() {
+    if (m_arena) ps_hip_free(m_ctx, m_arena);
+    m_kv.reset();
+    if (m_model) ps_hip_model_destroy(m_model);
+    if (m_ctx) ps_hip_destroy(m_ctx);
+}
+void HIPBackend::attach_model(ps_hip_model *m) {
+    m_model = m;
+    m_kv    = std::make_unique<HIPKV>(m_config, m);
+}
+void HIPBackend::check(int rc, const char *what) const {
+    if (rc != 0) POWERSERVE_ABORT(std::string(what) + ": " + ps_hip_last_error(m_ctx)); // C-ABI error -> reference abort/throw
+}
+void HIPBackend::sync() const { check(ps_hip_sync(m_ctx), "sync"); }
+void HIPBackend::reset_threadpool() { sync(); }
+
+void HIPBackend::arena_reserve(size_t bytes) {
+    if (bytes <= m_arena_cap) return;
+    sync();
+    if (m_arena) check(ps_hip_free(m_ctx, m_arena), "arena free");
+    size_t cap = std::max(bytes, m_arena_cap * 2);
+    void *p = nullptr;
+    check(ps_hip_malloc(m_ctx, cap, &p), "arena malloc");
+    m_arena = (char *)p; m_arena_cap = cap; m_arena_off = 0;
+}
+void *HIPBackend::arena_alloc(size_t bytes) {
+    bytes = (bytes + 255) / 256 * 256;
+    if (m_arena_off + bytes > m_arena_cap) POWERSERVE_ABORT("arena exhausted: Executor::allocate_buffers must reserve first");
+    void *p = m_arena + m_arena_off;
+    m_arena_off += bytes;
+    return p;
+}
+
+ps_tensor HIPBackend::to_ps(const Tensor *t) const { // convert_to_ggml (src/backend/ggml/ggml.hpp:87-96)
+    ps_tensor p{};
+    p.dtype = to_ggml_type(t->m_dtype);
+    auto &b = t->get<HIPBuffer>();
+    p.data  = b.m_data;
+    for (size_t i = 0; i < max_n_dims; i++) { p.ne[i] = (int64_t)t->m_shape[i]; p.nb[i] = b.m_stride[i]; }
+    return p;
+}
+
+void HIPBackend::matmul(const Tensor *dst, const Tensor *src0, const Tensor *src1) const {
+    auto d = to_ps(dst), a = to_ps(src0), b = to_ps(src1);
+    check(ps_hip_mul_mat(m_ctx, &d, &a, &b), "matmul");
+}
+void HIPBackend::rmsnorm(const Tensor *out, const Tensor *x, const Tensor *weight, float eps) const {
+    auto d = to_ps(out), a = to_ps(x), w = to_ps(weight);
+    check(ps_hip_rms_norm(m_ctx, &d, &a, &w, eps), "rmsnorm");
+}
+void HIPBackend::softmax(const Tensor *out, const Tensor *x) const {
+    auto d = to_ps(out), a = to_ps(x);
+    check(ps_hip_softmax_ext(m_ctx, &d, &a, nullptr, 1.0f, 0.0f), "softmax");
+}
+void HIPBackend::rope(Tensor *out, const Tensor *src, const std::vector<int> &pos, const ModelConfig::LLMConfig::RopeConfig &c) const {
+    auto d = to_ps(out), a = to_ps(src);
+    ps_rope_params rp{c.n_dims, c.n_ctx_orig, c.freq_base, c.freq_scale, c.ext_factor, c.attn_factor, c.beta_fast, c.beta_slow, c.rope_type};
+    std::vector<int32_t> p(pos.begin(), pos.end());
+    check(ps_hip_rope(m_ctx, &d, &a, p.data(), (int)p.size(), &rp), "rope");
+}
+void HIPBackend::add(const Tensor *dst, const Tensor *src0, const Tensor *src1) const {
+    auto d = to_ps(dst), a = to_ps(src0), b = to_ps(src1);
+    check(ps_hip_add(m_ctx, &d, &a, &b), "add");
+}
+void HIPBackend::permute(const Tensor *out, const Tensor *x, Shape axes) const { // metadata only (ggml_wrapper.cpp:125-133)
+    Stride stride{};
+    for (int i = 0; i < 4; i++) stride[axes[i]] = x->get<HIPBuffer>().m_stride[i];
+    out->get<HIPBuffer>().m_stride = stride;
+}
+void HIPBackend::transpose(const Tensor *out, const Tensor *x) const { // metadata only (ggml.cpp:170-177)
+    Stride stride{x->get<HIPBuffer>().m_stride};
+    std::swap(stride[0], stride[1]);
+    out->get<HIPBuffer>().m_data   = x->get<HIPBuffer>().m_data;
+    out->get<HIPBuffer>().m_stride = stride;
+}
+void HIPBackend::cont(const Tensor *out, const Tensor *x) const {
+    auto d = to_ps(out), a = to_ps(x);
+    check(ps_hip_dup(m_ctx, &d, &a), "cont");
+}
+void HIPBackend::copy(const Tensor *dst, const Tensor *src) const {
+    auto d = to_ps(dst), a = to_ps(src);
+    check(ps_hip_dup(m_ctx, &d, &a), "copy");
+}
+void HIPBackend::softmax_ext(const Tensor *out, const Tensor *x, const Tensor *mask, float scale, float max_bias) const {
+    auto d = to_ps(out), a = to_ps(x), m = to_ps(mask);
+    check(ps_hip_softmax_ext(m_ctx, &d, &a, &m, scale, max_bias), "softmax_ext");
+}
+void HIPBackend::silu_hadamard(const Tensor *out, const Tensor *hb, const Tensor *hb2) const {
+    POWERSERVE_ASSERT(is_contiguous(out, 0) && is_contiguous(hb, 0) && is_contiguous(hb2, 0));
+    auto d = to_ps(out), a = to_ps(hb), b = to_ps(hb2);
+    check(ps_hip_silu_hadamard(m_ctx, &d, &a, &b), "silu_hadamard");
+}
+void HIPBackend::get_embedding(const Tensor *dst, const Tensor *weight, const std::vector<int> &tokens) const {
+    POWERSERVE_ASSERT(tokens.size() == dst->m_shape[1]);
+    auto d = to_ps(dst), w = to_ps(weight);
+    std::vector<int32_t> t(tokens.begin(), tokens.end());
+    check(ps_hip_get_embedding(m_ctx, &d, &w, t.data(), (int)t.size()), "get_embedding");
+}
+void HIPBackend::get_mask(const Tensor *out, const std::vector<int> &pos, const CausalAttentionMask &mask) const {
+    auto d = to_ps(out);
+    std::vector<int32_t> p(pos.begin(), pos.end());
+    std::vector<uint8_t> tree;
+    if (!mask.mask.empty()) {
+        tree.resize(pos.size() * pos.size());
+        for (size_t i = 0; i < pos.size(); i++) for (size_t j = 0; j < pos.size(); j++) tree[i * pos.size() + j] = mask.mask[i][j] ? 1 : 0;
+    }
+    check(ps_hip_get_mask(m_ctx, &d, p.data(), (int)p.size(), tree.empty() ? nullptr : tree.data()), "get_mask");
+}
+bool HIPBackend::is_contiguous(const Tensor *t, int n) const { // ggml_is_contiguous_n
+    auto &s = t->get<HIPBuffer>().m_stride;
+    size_t next = get_type_size(t->m_dtype);
+    if (t->m_shape[0] != get_block_size(t->m_dtype) && s[0] != next) return false;
+    next *= t->m_shape[0] / get_block_size(t->m_dtype);
+    for (int i = 1; i < 4; i++) {
+        if (t->m_shape[i] != 1) { if (i > n) { if (s[i] != next) return false; next *= t->m_shape[i]; } else next = t->m_shape[i] * s[i]; }
+    }
+    return true;
+}
+int HIPBackend::get_vec_dot_type(const Tensor *t) const { return ps_hip_vec_dot_type(to_ggml_type(t->m_dtype)); }
+void HIPBackend::print(const Tensor *x, size_t) const {
+    POWERSERVE_ASSERT(x->m_dtype == DataType::FP32);
+    std::vector<float> h(x->n_elements());
+    sync();
+    check(ps_hip_memcpy_d2h(m_ctx, h.data(), x->get<HIPBuffer>().m_data, h.size() * 4), "print");
+    for (float v : h) std::printf("%.6f\n", (double)v);
+}
+void HIPBackend::plan(std::vector<std::shared_ptr<OpNode>> &) {
+    // The reference sizes its CPU work buffer here (src/backend/ggml/ggml.cpp:30-109).  On the device the
+    // activation-quantization scratch lives inside the kernels' LDS; the fused lowering of the whole layer
+    // sequence is selected by the model (Model::forward) and runs through ps_hip_model_forward.
+}
+
+} // namespace hip
+
+void Platform::init_hip_backend(const std::shared_ptr<ModelConfig> &config, const HyperParams &hparams, int device) {
+    hip_backends.insert({config->model_id, std::make_unique<hip::HIPBackend>(config->llm, hparams, device)});
+}
+
+// ---------------------------------------------------------------- executor (src/executor/executor.cpp:23-235)
+void Executor::allocate_buffers() {
+    auto &be = *m_platform.hip_backends[m_graph.m_model_id];
+    auto cstride = [](const Tensor &t, size_t es) { Stride s; s[0] = es; for (size_t i = 1; i < 4; i++) s[i] = s[i - 1] * t.m_shape[i - 1]; return s; };
+    size_t need = 0;
+    for (auto &t : m_graph.tensors)
+        if (!t->m_data && t->type != NodeType::TENSOR_VIEW) need += (t->n_elements() * (t->m_dtype == DataType::INT64 ? 8 : 4) + 255) / 256 * 256;
+    be.arena_reset();
+    be.arena_reserve(need + 4096); // one device allocation at most (grown geometrically), not one malloc per intermediate
+    for (auto &t : m_graph.tensors) {
+        if (t->m_data) continue;
+        size_t es;
+        switch (t->m_dtype) {
+        case DataType::FP32: case DataType::INT32: es = 4; break;
+        case DataType::INT64: es = 8; break;
+        default: POWERSERVE_ABORT("could not allocate buffer for data type");
+        }
+        if (t->type == NodeType::TENSOR_VIEW) {
+            auto *v = static_cast<TensorViewNode *>(t.get());
+            POWERSERVE_ASSERT(v->parent->m_data != nullptr, "parent buffer is nullptr");
+            t->m_data = std::make_shared<HIPBuffer>(cstride(*t, es), v->parent->get<HIPBuffer>().m_data);
+        } else {
+            t->m_data = std::make_shared<HIPBuffer>(cstride(*t, es), be.arena_alloc(t->n_elements() * es));
+        }
+    }
+}
+void Executor::plan() { m_platform.hip_backends[m_graph.m_model_id]->plan(m_graph.ops); }
+
+void Executor::run() {
+    auto &be = *m_platform.hip_backends[m_graph.m_model_id];
+    plan();
+    for (auto &op : m_graph.ops) {
+        switch (op->op) {
+        case OpType::GET_EMBEDDING: be.get_embedding(op->output(), op->prev[0]->tensor(), op->get_params<GetEmbeddingParams>().tokens); break;
+        case OpType::ADD: be.add(op->output(), op->prev[0]->tensor(), op->prev[1]->tensor()); break;
+        case OpType::MAT_MUL: be.matmul(op->output(), op->prev[0]->tensor(), op->prev[1]->tensor()); break;
+        case OpType::RMS_NORM: be.rmsnorm(op->output(), op->prev[0]->tensor(), op->prev[1]->tensor(), op->get_params<RMSNormParams>().eps); break;
+        case OpType::SILU_HADAMARD: be.silu_hadamard(op->output(), op->prev[0]->tensor(), op->prev[1]->tensor()); break;
+        case OpType::ROPE: { auto &p = op->get_params<RopeParams>(); be.rope(op->next[0]->tensor(), op->prev[0]->tensor(), p.pos, p.rope_cfg); } break;
+        case OpType::SOFTMAX: be.softmax(op->output(), op->prev[0]->tensor()); break;
+        case OpType::COPY: be.copy(op->prev[0]->tensor(), op->prev[1]->tensor()); break;
+        case OpType::PRINT: be.print(op->prev[0]->tensor(), op->get_params<PrintParams>().size); break;
+        case OpType::PERMUTE: be.permute(op->output(), op->prev[0]->tensor(), op->get_params<PermuteParams>().axes); break;
+        case OpType::CONT: be.cont(op->output(), op->prev[0]->tensor()); break;
+        case OpType::VIEW: { // executed in the executor, like the reference (executor.cpp:194-199)
+            auto out = op->output(); auto &p = op->get_params<ViewParams>();
+            out->get<HIPBuffer>().m_stride = p.stride;
+            out->get<HIPBuffer>().m_data   = (char *)out->get<HIPBuffer>().m_data + p.offset;
+        } break;
+        case OpType::SOFTMAX_EXT: { auto &p = op->get_params<SoftmaxExtParams>(); be.softmax_ext(op->output(), op->prev[0]->tensor(), op->prev[1]->tensor(), p.scale, p.max_bias); } break;
+        case OpType::GET_MASK: { auto &p = op->get_params<GetMaskParams>(); be.get_mask(op->output(), p.pos, p.mask); } break;
+        case OpType::TRANSPOSE: be.transpose(op->output(), op->prev[0]->tensor()); break;
+        default: POWERSERVE_ABORT("Unknown OpType: " + std::to_string((int)op->op));
+        }
+    }
+}
+
+} // namespace powerserve

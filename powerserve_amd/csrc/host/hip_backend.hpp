@@ -1,0 +1,100 @@
+// HIPBackend: drop-in peer of ggml::GGMLBackend (src/backend/ggml/ggml.hpp:186-250) — same method names, arity
+// and argument meaning — running on one MI355X through the C-ABI in include/ps_hip.h.  Platform mirrors
+// src/backend/platform.hpp:28-51 with a `hip_backends` map next to where the reference keeps `ggml_backends`.
+#pragma once
+#include "../../../include/ps_hip.h"
+#include "graph.hpp"
+#include "json_gguf.hpp"
+
+#include <map>
+
+namespace powerserve {
+
+struct Weight;
+namespace hip {
+
+// FP32 KV cache on the device in the reference layout (src/backend/ggml/ggml_kv_cache.cpp:35-57):
+// K [n_ctx][kv_dim], V [kv_dim][n_ctx]; tensors are exposed with shape {n_ctx, kv_dim} exactly like
+// GGMLKV::chunk.key_tensors so NormAttention::build's views apply unchanged.  Position bookkeeping follows
+// KVCache<T>::advance_tokens / rollback / truncate (src/core/kv_cache.hpp:249-272).
+struct HIPKV {
+    size_t m_kv_dim, m_n_kv_heads, m_n_ctx, m_n_layers, m_head_size, m_batch_size = 1, kv_size = 0;
+    std::vector<Tensor> key_tensors, value_tensors;
+    ps_hip_model *m_model;
+    HIPKV(const ModelConfig::LLMConfig &cfg, ps_hip_model *model);
+    size_t position() const { return ps_hip_model_kv_position(m_model); }
+    void reset_batch_size(size_t bs) { m_batch_size = bs; }
+    void reset_kv_cache() { ps_hip_model_kv_truncate(m_model, kv_size); }
+    void advance(int n);
+    void rollback(size_t n);
+    auto get_cache(size_t L) -> std::pair<Tensor &, Tensor &> { return {key_tensors[L], value_tensors[L]}; }
+};
+
+struct HIPBackend {
+    ps_hip_ctx *m_ctx = nullptr;
+    ps_hip_model *m_model = nullptr; // fused fast path + owner of the KV cache
+    std::unique_ptr<HIPKV> m_kv;
+    ModelConfig::LLMConfig m_config;
+    int m_device;
+    bool m_fused = true; // plan(): lower the canonical layer sequence to the fused kernels
+
+    HIPBackend(const ModelConfig::LLMConfig &config, const HyperParams &hparams, int device);
+    ~HIPBackend();
+    void attach_model(ps_hip_model *m); // called once the weights are uploaded
+
+    // ---- the reference's op set
+    void add(const Tensor *dst, const Tensor *src0, const Tensor *src1) const;
+    void get_embedding(const Tensor *dst, const Tensor *weight, const std::vector<int> &tokens) const;
+    void matmul(const Tensor *dst, const Tensor *src0, const Tensor *src1) const;
+    void rmsnorm(const Tensor *o, const Tensor *x, const Tensor *weight, float eps) const;
+    void rope(Tensor *out, const Tensor *src, const std::vector<int> &pos, const ModelConfig::LLMConfig::RopeConfig &rope_cfg) const;
+    void softmax(const Tensor *out, const Tensor *x) const;
+    void permute(const Tensor *out, const Tensor *x, Shape axes) const;
+    void cont(const Tensor *out, const Tensor *x) const;
+    void softmax_ext(const Tensor *out, const Tensor *x, const Tensor *mask, float scale, float max_bias) const;
+    bool is_contiguous(const Tensor *tensor, int n) const;
+    int get_vec_dot_type(const Tensor *tensor) const;
+    void silu_hadamard(const Tensor *out, const Tensor *hb, const Tensor *hb2) const;
+    void copy(const Tensor *dst, const Tensor *src) const;
+    void print(const Tensor *x, size_t size) const;
+    void reset_kv_batch_size(size_t batch_size) const { m_kv->reset_batch_size(batch_size); }
+    void transpose(const Tensor *out, const Tensor *x) const;
+    void get_mask(const Tensor *out, const std::vector<int> &pos, const CausalAttentionMask &mask) const; // executor.cpp:210-224
+    void plan(std::vector<std::shared_ptr<OpNode>> &ops);
+    void setup_work_data(size_t) {}
+    void setup_threadpool() {}  // a generation is bracketed by these in the reference (model.hpp:145,165-168):
+    void reset_threadpool();    // here: nothing to create, drain the stream at the end
+    void sync() const;
+
+    // per-forward arena for graph intermediates (replaces malloc-per-tensor, src/executor/executor.cpp:23-45)
+    void *arena_alloc(size_t bytes);
+    void arena_reset() { m_arena_off = 0; }
+    void arena_reserve(size_t bytes); // grows the arena (between forwards only)
+
+private:
+    void check(int rc, const char *what) const;
+    ps_tensor to_ps(const Tensor *t) const;
+    char *m_arena = nullptr;
+    size_t m_arena_cap = 0, m_arena_off = 0;
+};
+
+} // namespace hip
+
+struct Platform {
+    std::map<std::string, std::unique_ptr<hip::HIPBackend>> hip_backends;
+    void init_hip_backend(const std::shared_ptr<ModelConfig> &config, const HyperParams &hparams, int device = 0);
+    void destroy_hip_backend(const std::shared_ptr<ModelConfig> &config) { hip_backends.erase(config->model_id); }
+    size_t get_kv_position(std::string &model_id) const { return hip_backends.at(model_id)->m_kv->position(); }
+    void reset_kv_position(std::string &model_id) { hip_backends[model_id]->m_kv->reset_kv_cache(); }
+};
+
+struct Executor { // src/executor/executor.hpp:22-45
+    Platform &m_platform;
+    Graph &m_graph;
+    Executor(Platform &platform, Graph &graph) : m_platform(platform), m_graph(graph) {}
+    void allocate_buffers();
+    void plan();
+    void run();
+};
+
+} // namespace powerserve

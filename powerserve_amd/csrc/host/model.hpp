@@ -1,0 +1,86 @@
+// Model layer: weights, graph builders and the token loop, mirroring
+//   Weight / LayerWeights        src/model/common/weights.hpp:24-74, llama_weight.hpp:24-34, qwen2_weight.hpp:24-37
+//   NormAttention::build          src/model/module/norm_attention.cpp:26-160
+//   FFN::build                    src/model/module/ffn.cpp:22-42
+//   LlamaModel / Qwen2Model       src/model/llama/llama_model.cpp:52-132, src/model/qwen2/qwen2_model.cpp:75
+//   ModelTokenIterator            src/model/model.hpp:117-184
+//   load_model                    src/model/model_loader.cpp:23-41
+#pragma once
+#include "hip_backend.hpp"
+
+#include <deque>
+#include <span>
+
+namespace powerserve {
+
+struct LayerWeights {
+    Tensor attn_norm, ffn_norm, attn_q, attn_k, attn_v, attn_output, ffn_gate, ffn_up, ffn_down, attn_q_bias, attn_k_bias, attn_v_bias;
+};
+struct Weight {
+    Tensor token_embedding_table, output_weight, rms_final_weight;
+    std::vector<LayerWeights> lw;
+    bool tied = false;
+};
+
+struct LogitsVector { // src/model/model.hpp:27-39
+    BufferPtr buffer;
+    std::vector<std::span<const float>> logits_vector;
+    LogitsVector() = default;
+    LogitsVector(BufferPtr buf, size_t vocab_size, size_t batch_size) : buffer(buf) {
+        const float *l = static_cast<const float *>(dynamic_cast<CPUBuffer &>(*buffer).m_data);
+        for (size_t i = 0; i < batch_size; i++, l += vocab_size) logits_vector.emplace_back(l, l + vocab_size);
+    }
+};
+
+struct NormAttention {
+    const ModelConfig::LLMConfig &m_config;
+    std::shared_ptr<Weight> m_weights;
+    NormAttention(const ModelConfig::LLMConfig &c, std::shared_ptr<Weight> w) : m_config(c), m_weights(std::move(w)) {}
+    TensorNode *build(Graph &g, TensorNode *x, int64_t L, const TensorNode *k_cache, const TensorNode *v_cache, const std::vector<int> &pos,
+                      const CausalAttentionMask &mask, bool is_need_bias = false);
+};
+struct FFN {
+    const ModelConfig::LLMConfig &m_config;
+    std::shared_ptr<Weight> m_weights;
+    FFN(const ModelConfig::LLMConfig &c, std::shared_ptr<Weight> w) : m_config(c), m_weights(std::move(w)) {}
+    TensorNode *build(Graph &g, TensorNode *attn_o, int64_t L);
+};
+
+struct Model {
+    std::string m_filename;
+    std::shared_ptr<ModelConfig> m_config;
+    std::shared_ptr<Weight> m_weights;
+    std::shared_ptr<NormAttention> m_attn;
+    std::shared_ptr<FFN> m_ffn;
+    std::shared_ptr<Platform> m_platform;
+    bool m_is_need_bias = false; // Qwen2
+    bool m_use_fused    = true;  // fused kernels + hipGraph (HIPBackend::plan lowering); false: op-by-op graph
+
+    Model(const std::string &model_dir, const std::shared_ptr<ModelConfig> &config, const std::shared_ptr<Platform> &platform, int device,
+          size_t max_batch);
+    virtual ~Model();
+
+    // one forward over `tokens` at consecutive positions `pos`; lm_head: logits for every token
+    auto forward(const std::vector<int> &tokens, const std::vector<int> &pos, const CausalAttentionMask &mask, bool lm_head = true) -> LogitsVector;
+    // greedy (top_k = 1 == arg-max, src/sampler/prob_array.cpp:65-67)
+    auto decode(const std::vector<Token> &tokens, const std::vector<int> &pos, bool lm_head) -> std::vector<Token>;
+    // ModelTokenIterator: prefill all but the last prompt token in chunks of batch_size (no lm_head), then `steps`
+    // single-token greedy steps
+    auto generate(const std::vector<Token> &prompt, int steps, size_t batch_size) -> std::vector<Token>;
+
+    hip::HIPBackend &backend() { return *m_platform->hip_backends[m_config->model_id]; }
+
+private:
+    std::unique_ptr<GGUFFile> m_gguf;
+    std::vector<ps_weight *> m_dev_weights;
+    std::vector<void *> m_dev_f32;
+    auto forward_graph(const std::vector<int> &tokens, const std::vector<int> &pos, const CausalAttentionMask &mask, bool lm_head) -> LogitsVector;
+    auto forward_fused(const std::vector<int> &tokens, const std::vector<int> &pos, const CausalAttentionMask &mask, bool lm_head) -> LogitsVector;
+};
+using LlamaModel = Model;
+using Qwen2Model = Model;
+
+auto load_model(const std::string &model_dir, const std::shared_ptr<Platform> &platform, int device = 0, size_t max_batch = 128, int n_ctx_cap = 0)
+    -> std::shared_ptr<Model>;
+
+} // namespace powerserve

@@ -21,16 +21,6 @@
 
 namespace {
 
-// GGML_F32x8_REDUCE over the 32 chains held by 32 consecutive lanes (c = lane & 31 = acc*8 + l)
-__device__ __forceinline__ float reduce_f32x8x4(float v) {
-    v = __fadd_rn(v, __shfl_xor(v, 16, 64)); // acc0 += acc2, acc1 += acc3
-    v = __fadd_rn(v, __shfl_xor(v, 8, 64));  // acc0 += acc1
-    v = __fadd_rn(v, __shfl_xor(v, 4, 64));  // low 128 + high 128
-    v = __fadd_rn(v, __shfl_xor(v, 1, 64));  // hadd
-    v = __fadd_rn(v, __shfl_xor(v, 2, 64));  // hadd
-    return v;
-}
-
 // ---------------------------------------------------------------- rope + KV append
 __global__ void rope_append_kernel(psl_attn_args a, int bs) {
     const int hs = a.head_size, dim = a.n_heads * hs, kvd = a.n_kv_heads * hs, half = a.n_dims / 2;

@@ -2,6 +2,7 @@
 // graph the fused planner does not recognise, and the parity anchor for each fused kernel.
 // Built with -ffp-contract=off; every op rounds where the reference's C source rounds.
 #include "ps_dev.h"
+#include "ps_expf.h"
 #include "ps_internal.h"
 
 struct TDesc { // device view of a ps_tensor
@@ -20,22 +21,29 @@ static inline TDesc tdesc(const ps_tensor *t) {
 namespace {
 
 // ---------------------------------------------------------------- F32 x F32 mat-mul with ggml broadcast
-// ggml_vec_dot_f32 (ggml.c:2092) under powerserve_compute_forward_mul_mat with F32 traits: used for
-// K·q and V·softmax (model/module/norm_attention.cpp:115-147).  One wave per output element.
+// ggml_vec_dot_f32 (ggml.c:2092-2133) under powerserve_compute_forward_mul_mat with F32 traits: used for K·q and
+// V·softmax (model/module/norm_attention.cpp:115-147).  A half-wave (32 lanes) per output element owns the 32
+// fp32 chains of the reference's AVX build (elements 32*i + c), reduces them in GGML_F32x8_REDUCE order and adds
+// the n % 32 leftovers one by one: bit-exact.
 __global__ __launch_bounds__(256) void mul_mat_f32_kernel(TDesc dst, TDesc a, TDesc b) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = threadIdx.x & 31, hw = threadIdx.x >> 5;
     const int64_t n_out = dst.ne[0] * dst.ne[1] * dst.ne[2] * dst.ne[3];
     const int64_t r2 = b.ne[2] / a.ne[2], r3 = b.ne[3] / a.ne[3];
-    for (int64_t o = (int64_t)blockIdx.x * 4 + wave; o < n_out; o += (int64_t)gridDim.x * 4) {
-        int64_t i0 = o % dst.ne[0], rest = o / dst.ne[0];
+    const int64_t n = a.ne[0], np = n & ~(int64_t)31;
+    for (int64_t o0 = (int64_t)blockIdx.x * 8; o0 < n_out; o0 += (int64_t)gridDim.x * 8) {
+        const int64_t o = o0 + hw;
+        const bool live = o < n_out;
+        const int64_t oo = live ? o : 0;
+        int64_t i0 = oo % dst.ne[0], rest = oo / dst.ne[0];
         const int64_t i1 = rest % dst.ne[1]; rest /= dst.ne[1];
         const int64_t i2 = rest % dst.ne[2], i3 = rest / dst.ne[2];
         const float *x = (const float *)(a.data + i0 * a.nb[1] + (i2 / r2) * a.nb[2] + (i3 / r3) * a.nb[3]);
         const float *y = (const float *)(b.data + i1 * b.nb[1] + i2 * b.nb[2] + i3 * b.nb[3]);
         float s = 0.f;
-        for (int64_t k = lane; k < a.ne[0]; k += 64) s = __fmaf_rn(x[k], y[k], s);
-        s = wave_sum(s);
-        if (lane == 0) *(float *)(dst.data + i0 * dst.nb[0] + i1 * dst.nb[1] + i2 * dst.nb[2] + i3 * dst.nb[3]) = s;
+        for (int64_t k = c; k < np; k += 32) s = __fmaf_rn(x[k], y[k], s);
+        s = reduce_f32x8x4(s);
+        for (int64_t k = np; k < n; k++) s = __fadd_rn(s, __fmul_rn(x[k], y[k]));
+        if (live && c == 0) *(float *)(dst.data + i0 * dst.nb[0] + i1 * dst.nb[1] + i2 * dst.nb[2] + i3 * dst.nb[3]) = s;
     }
 }
 
@@ -86,13 +94,14 @@ __global__ void rope_kernel(TDesc dst, TDesc src, const float *cache, int n_dims
 }
 
 // ---------------------------------------------------------------- softmax_ext (ggml.c:14846-14940), max_bias == 0
-// one workgroup per row; the row (n_kv floats) is held in LDS.
+// one workgroup per row, row held in LDS.  Exactly ggml_vec_soft_max_f32 (ggml.c:2814-2863): ggml_v_expf on the
+// groups of 8 with the in-group sum tree, libm expf on the n % 8 tail, double row sum, p = e * (float)(1/sum).
 __global__ __launch_bounds__(256) void softmax_ext_kernel(TDesc dst, TDesc src, const float *mask, float scale) {
     extern __shared__ float wp[];
     __shared__ float redf[4];
     __shared__ double redd[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t row = blockIdx.x, nc = src.ne[0];
+    const int64_t row = blockIdx.x, nc = src.ne[0], n8 = nc & ~(int64_t)7;
     const float *sp = (const float *)(src.data + row * src.nb[1]);
     float *dp       = (float *)(dst.data + row * dst.nb[1]);
     const float *mp = mask ? mask + (row % src.ne[1]) * nc : nullptr;
@@ -108,11 +117,15 @@ __global__ __launch_bounds__(256) void softmax_ext_kernel(TDesc dst, TDesc src, 
     __syncthreads();
     mx = fmaxf(fmaxf(redf[0], redf[1]), fmaxf(redf[2], redf[3]));
     double sum = 0.0;
-    for (int64_t i = threadIdx.x; i < nc; i += 256) {
-        const float e = ps_v_expf(__fsub_rn(wp[i], mx));
-        wp[i] = e;
-        sum += (double)e;
+    for (int64_t g = threadIdx.x; g * 8 < n8; g += 256) {
+        float v[8];
+#pragma unroll
+        for (int l = 0; l < 8; l++) { v[l] = ps_v_expf(__fsub_rn(wp[g * 8 + l], mx)); wp[g * 8 + l] = v[l]; }
+        const float a0 = __fadd_rn(v[4], v[0]), a1 = __fadd_rn(v[5], v[1]), a2 = __fadd_rn(v[6], v[2]), a3 = __fadd_rn(v[7], v[3]);
+        sum += (double)__fadd_rn(__fadd_rn(a0, a2), __fadd_rn(a1, a3));
     }
+    if (threadIdx.x == 0)
+        for (int64_t i = n8; i < nc; i++) { const float e = ps_expf_glibc(__fsub_rn(wp[i], mx)); wp[i] = e; sum += (double)e; }
     sum = wave_sum_d(sum);
     if (lane == 0) redd[wave] = sum;
     __syncthreads();
@@ -157,7 +170,7 @@ __global__ void dup_kernel(TDesc dst, TDesc src) {
 __global__ void silu_hadamard_kernel(float *out, const float *g, const float *u, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         float val = g[i];
-        val       = __fmul_rn(val, __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-val))));
+        val       = __fmul_rn(val, __fdiv_rn(1.0f, __fadd_rn(1.0f, ps_expf_glibc(-val))));
         out[i]    = __fmul_rn(val, u[i]);
     }
 }
@@ -263,7 +276,7 @@ inline unsigned grid1d(int64_t n, int bs = 256, int64_t cap = 4096) {
 
 void psl_mul_mat_f32(hipStream_t st, const ps_tensor *dst, const ps_tensor *a, const ps_tensor *b) {
     const int64_t n_out = dst->ne[0] * dst->ne[1] * dst->ne[2] * dst->ne[3];
-    hipLaunchKernelGGL(mul_mat_f32_kernel, dim3(grid1d(n_out, 4, 8192)), dim3(256), 0, st, tdesc(dst), tdesc(a), tdesc(b));
+    hipLaunchKernelGGL(mul_mat_f32_kernel, dim3(grid1d(n_out, 8, 8192)), dim3(256), 0, st, tdesc(dst), tdesc(a), tdesc(b));
 }
 void psl_rms_norm(hipStream_t st, const ps_tensor *dst, const ps_tensor *src, const float *w, float eps) {
     const int64_t rows = src->ne[1] * src->ne[2] * src->ne[3];

@@ -224,6 +224,11 @@ void ps_hip_model_destroy(ps_hip_model *m) {
 
 size_t ps_hip_model_kv_position(const ps_hip_model *m) { return m->position; }
 int ps_hip_model_kv_truncate(ps_hip_model *m, size_t n) { if (n < m->position) m->position = n; return 0; }
+int ps_hip_model_kv_advance(ps_hip_model *m, size_t n) {
+    if (m->position + n > m->cfg.seq_len) { m->ctx->err = "kv_advance: KV cache is full (n_ctx)"; return 2; }
+    m->position += n;
+    return 0;
+}
 int ps_hip_model_kv_rollback(ps_hip_model *m, size_t n) {
     if (n > m->position) { m->ctx->err = "kv_rollback: more tokens than cached"; return 2; }
     m->position -= n;

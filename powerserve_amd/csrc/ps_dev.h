@@ -108,6 +108,18 @@ __device__ __forceinline__ int group4_sum_i_dpp(int v) { // aligned groups of 4 
     return v;
 }
 
+// ---- GGML_F32x8_REDUCE (libs/ggml/src/ggml.c:1354-1371) over the 32 fp32 chains of ggml_vec_dot_f32's AVX build,
+//      held by 32 consecutive lanes (c = lane & 31 = accumulator*8 + simd lane): acc0+=acc2, acc1+=acc3 (xor 16),
+//      acc0+=acc1 (xor 8), low+high 128 bits (xor 4), two hadds (xor 1, xor 2).  Valid in the lane with c == 0.
+__device__ __forceinline__ float reduce_f32x8x4(float v) {
+    v = __fadd_rn(v, __shfl_xor(v, 16, 64));
+    v = __fadd_rn(v, __shfl_xor(v, 8, 64));
+    v = __fadd_rn(v, __shfl_xor(v, 4, 64));
+    v = __fadd_rn(v, __shfl_xor(v, 1, 64));
+    v = __fadd_rn(v, __shfl_xor(v, 2, 64));
+    return v;
+}
+
 // ---- int8 dot: 4 signed bytes x 4 signed bytes + acc  (v_dot4_i32_i8)
 __device__ __forceinline__ int dot4(int a, int b, int acc) {
     return __builtin_amdgcn_sdot4(a, b, acc, false);

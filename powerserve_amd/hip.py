@@ -28,7 +28,7 @@ EXPORTS = [
     "ps_hip_weight_dtype", "ps_hip_vec_dot_type", "ps_hip_row_size", "ps_hip_quantize_act", "ps_hip_mul_mat",
     "ps_hip_rms_norm", "ps_hip_rope", "ps_hip_softmax_ext", "ps_hip_add", "ps_hip_dup", "ps_hip_silu_hadamard",
     "ps_hip_get_embedding", "ps_hip_get_mask", "ps_hip_argmax", "ps_hip_model_create", "ps_hip_model_destroy",
-    "ps_hip_model_kv_position", "ps_hip_model_kv_truncate", "ps_hip_model_kv_rollback", "ps_hip_model_kv_move",
+    "ps_hip_model_kv_position", "ps_hip_model_kv_truncate", "ps_hip_model_kv_advance", "ps_hip_model_kv_rollback", "ps_hip_model_kv_move",
     "ps_hip_model_forward", "ps_hip_model_decode_greedy", "ps_hip_model_logits", "ps_hip_model_k_cache",
     "ps_hip_model_v_cache", "ps_hip_model_weight_bytes_per_token", "ps_hip_model_set_mode", "ps_hip_model_bench_gemv",
 ]
@@ -107,7 +107,7 @@ def lib() -> C.CDLL:
         "ps_hip_get_embedding": (i32, [vp, T, T, vp, i32]), "ps_hip_get_mask": (i32, [vp, T, vp, i32, vp]),
         "ps_hip_argmax": (i32, [vp, vp, i64, i64, vp]),
         "ps_hip_model_create": (i32, [vp, C.POINTER(ModelDesc), C.POINTER(vp)]), "ps_hip_model_destroy": (None, [vp]),
-        "ps_hip_model_kv_position": (sz, [vp]), "ps_hip_model_kv_truncate": (i32, [vp, sz]),
+        "ps_hip_model_kv_position": (sz, [vp]), "ps_hip_model_kv_truncate": (i32, [vp, sz]), "ps_hip_model_kv_advance": (i32, [vp, sz]),
         "ps_hip_model_kv_rollback": (i32, [vp, sz]), "ps_hip_model_kv_move": (i32, [vp, sz, sz]),
         "ps_hip_model_forward": (i32, [vp, vp, i32, vp, vp, i32, vp]),
         "ps_hip_model_decode_greedy": (i32, [vp, i32, i32, vp]), "ps_hip_model_logits": (vp, [vp]),

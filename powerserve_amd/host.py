@@ -1,0 +1,83 @@
+"""ctypes driver for the C++ host facade (powerserve_amd/lib/libps_host.so): the Graph -> Executor -> HIPBackend
+mirror of the reference's host side, sitting on the C-ABI of include/ps_hip.h."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libps_host.so")
+EXPORTS = ["psh_last_error", "psh_model_load", "psh_model_free", "psh_model_set_fused", "psh_model_kv_position", "psh_model_reset",
+           "psh_model_vocab", "psh_model_forward", "psh_model_generate"]
+_LIB = None
+
+
+def lib() -> C.CDLL:
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: run __graft_entry__.build()")
+        L = C.CDLL(LIB_PATH)
+        L.psh_last_error.restype = C.c_char_p
+        L.psh_model_load.restype = C.c_void_p
+        L.psh_model_load.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int]
+        L.psh_model_free.argtypes = [C.c_void_p]
+        L.psh_model_set_fused.argtypes = [C.c_void_p, C.c_int]
+        L.psh_model_kv_position.restype = C.c_size_t
+        L.psh_model_kv_position.argtypes = [C.c_void_p]
+        L.psh_model_reset.argtypes = [C.c_void_p]
+        L.psh_model_vocab.restype = C.c_uint32
+        L.psh_model_vocab.argtypes = [C.c_void_p]
+        L.psh_model_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        L.psh_model_generate.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        _LIB = L
+    return _LIB
+
+
+class HostError(RuntimeError):
+    pass
+
+
+class HostModel:
+    """load_model(dir) + Model::forward / generate through the C++ facade."""
+
+    def __init__(self, model_dir: str, device: int = 0, max_batch: int = 128, n_ctx: int = 0):
+        self.L = lib()
+        self.h = self.L.psh_model_load(model_dir.encode(), device, max_batch, n_ctx)
+        if not self.h:
+            raise HostError(self.L.psh_last_error().decode())
+        self.vocab = self.L.psh_model_vocab(self.h)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.psh_model_free(self.h)
+            self.h = None
+
+    def set_fused(self, fused: bool):
+        """True: fused kernels + hipGraph (default).  False: op-by-op Graph/Executor path."""
+        self.L.psh_model_set_fused(self.h, int(fused))
+
+    @property
+    def position(self) -> int:
+        return self.L.psh_model_kv_position(self.h)
+
+    def reset(self):
+        self.L.psh_model_reset(self.h)
+
+    def forward(self, tokens, pos, lm_head=True):
+        t = np.ascontiguousarray(tokens, dtype=np.int32)
+        p = np.ascontiguousarray(pos, dtype=np.int32)
+        out = np.empty((t.size, self.vocab), dtype=np.float32) if lm_head else None
+        rc = self.L.psh_model_forward(self.h, t.ctypes.data, t.size, p.ctypes.data, int(lm_head), out.ctypes.data if lm_head else None)
+        if rc:
+            raise HostError(self.L.psh_last_error().decode())
+        return out
+
+    def generate(self, prompt, batch_size: int, steps: int):
+        p = np.ascontiguousarray(prompt, dtype=np.int32)
+        out = np.empty(steps, dtype=np.int32)
+        if self.L.psh_model_generate(self.h, p.ctypes.data, p.size, batch_size, steps, out.ctypes.data):
+            raise HostError(self.L.psh_last_error().decode())
+        return out

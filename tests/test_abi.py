@@ -52,3 +52,10 @@ def test_product_never_touches_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp", ".hpp")):
                 txt = open(os.path.join(dp, f), errors="ignore").read()
                 assert "ps_oracle" not in txt and "libps_ref" not in txt and "from oracle" not in txt and "import oracle" not in txt, os.path.join(dp, f)
+
+
+def test_host_facade_exports():
+    """the C++ host facade builds and exports its driver API (no GPU needed to load it)"""
+    from powerserve_amd import host
+    L = host.lib()
+    assert not [n for n in host.EXPORTS if not hasattr(L, n)]
