@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=4)
     ap.add_argument("--model-dir", default=None)
+    ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed/RCCL even for one rank (tests the N>1 code path)")
     ap.add_argument("--eager", action="store_true", help="eager launches instead of hipGraph replay (rocprofv3 runs)")
     return ap.parse_args()
 
@@ -83,17 +84,43 @@ def cpu_baseline(model_dir, n_ctx, prompt, steps):
                       f"prefill {(p.size - 1) / max(tp, 1e-9):.2f} tok/s", "host_cores": cores, "ids": [int(i) for i in ids]}
 
 
+def broadcast_prompt(dist, prompt, rank, device="cuda"):
+    """rank 0's prompt ids -> every replica (the only inbound collective; RCCL over xGMI on GPUs)"""
+    import torch
+    t = torch.from_numpy(np.ascontiguousarray(prompt, dtype=np.int32)).to(device)
+    dist.broadcast(t, src=0)
+    return t.cpu().numpy()
+
+
+def gather_ids(dist, ids, world, device="cuda"):
+    """all-gather the sampled ids of every replica (the only outbound collective) and check they agree"""
+    import torch
+    mine = torch.from_numpy(np.ascontiguousarray(ids, dtype=np.int32)).to(device)
+    allv = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(allv, mine)
+    return all(bool((a == allv[0]).all()) for a in allv), [a.cpu().numpy() for a in allv]
+
+
+def max_over_ranks(dist, values, device="cuda"):
+    import torch
+    tt = torch.tensor(list(values), dtype=torch.float64).to(device)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    return [float(v) for v in tt]
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         import torch
         import torch.distributed as dist_
         torch.cuda.set_device(local)
+        if "MASTER_ADDR" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
         dist_.init_process_group("nccl", device_id=torch.device("cuda", local))  # RCCL over xGMI
         dist = dist_
 
@@ -114,10 +141,7 @@ def main():
     # ---- prompt: rank 0 draws it, RCCL broadcast to every replica (the only inbound collective)
     prompt = np.random.default_rng(42).integers(0, cfg.vocab_size, args.prompt_len).astype(np.int32)
     if dist is not None:
-        import torch
-        t = torch.from_numpy(prompt if rank == 0 else np.zeros_like(prompt)).cuda()
-        dist.broadcast(t, src=0)
-        prompt = t.cpu().numpy()
+        prompt = broadcast_prompt(dist, prompt if rank == 0 else np.zeros_like(prompt), rank)
 
     # ---- prefill (all but the last prompt token, lm_head skipped: src/model/model.hpp:147-163)
     barrier(); ctx.sync()
@@ -146,15 +170,8 @@ def main():
     dt = time.perf_counter() - t0
     dev_ms = ctx.elapsed_ms(e0, e1)
     if dist is not None:
-        import torch
-        tt = torch.tensor([dt, prefill_s], dtype=torch.float64).cuda()
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt, prefill_s = float(tt[0]), float(tt[1])
-        # gather the sampled ids of every replica (the only outbound collective) and check they agree
-        mine = torch.from_numpy(ids.astype(np.int32)).cuda()
-        allv = [torch.empty_like(mine) for _ in range(world)]
-        dist.all_gather(allv, mine)
-        replicas_agree = all(bool((a == allv[0]).all()) for a in allv)
+        dt, prefill_s = max_over_ranks(dist, [dt, prefill_s])
+        replicas_agree, _ = gather_ids(dist, ids, world)
     else:
         replicas_agree = True
 

@@ -1,0 +1,78 @@
+"""GPU: the HIP path against the committed golden vectors that the REAL reference produced (tests/golden/,
+generator oracle/gen_golden.py).  No oracle library involved here: data only.  Everything is bit-exact."""
+import ctypes as C
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+T = {"Q4_0": 2, "Q8_0": 8, "Q4_K": 12}
+
+
+def test_act_quant_golden(ctx):
+    g = np.load(os.path.join(GOLD, "act_quant.npz"))
+    for K in (256, 896, 4096):
+        x = g[f"x_{K}"]
+        for vdt, key in ((8, "q8_0"), (15, "q8_K")):
+            if f"{key}_{K}" not in g.files:
+                continue
+            rs = ctx.L.ps_hip_row_size(vdt, K)
+            out = ctx.empty((x.shape[0], rs), np.uint8)
+            ctx.check(ctx.L.ps_hip_quantize_act(ctx.h, vdt, ctx.to_device(x).ptr, K, x.shape[0], out.ptr))
+            assert np.array_equal(out.numpy(), g[f"{key}_{K}"])
+
+
+def test_mul_mat_golden(ctx):
+    g = np.load(os.path.join(GOLD, "mul_mat.npz"))
+    n = 0
+    for key in g.files:
+        if not key.startswith("y_") or "Q6_K" in key:
+            continue
+        _, a, b, K, N, bs = key.split("_")
+        t, K, N = T[a + "_" + b], int(K), int(N)
+        W = ctx.upload_weight(t, g["w_" + key[2:]], K, N)
+        x = g["x_" + key[2:]]
+        dx, dy = ctx.to_device(x), ctx.empty((x.shape[0], N))
+        ctx.check(ctx.L.ps_hip_mul_mat(ctx.h, C.byref(dy.tensor()), C.byref(W.tensor()), C.byref(dx.tensor())))
+        assert np.array_equal(dy.numpy().view(np.uint32), g[key].view(np.uint32)), key
+        W.free()
+        n += 1
+    assert n == 9
+
+
+def _sha(path):
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        for c in iter(lambda: f.read(1 << 20), b""):
+            h.update(c)
+    return h.hexdigest()
+
+
+@pytest.mark.parametrize("preset,tn", [("tiny-llama", "Q4_0"), ("tiny-llama", "Q8_0"), ("tiny-qwen2", "Q8_0"), ("tiny-qwen2", "Q4_0")])
+def test_e2e_golden(ctx, tmp_path, preset, tn):
+    """logits and ids of the real LlamaModel/Qwen2Model::forward (reference binary), reproduced bit for bit"""
+    from powerserve_amd import hip, synth
+    g = np.load(os.path.join(GOLD, f"e2e_{preset}_{tn}.npz"))
+    d = str(tmp_path / "m")
+    synth.write_model_dir(d, preset, T[tn], n_ctx=int(g["n_ctx"]), seed=int(g["seed"]))
+    assert _sha(os.path.join(d, "ggml", "weights.gguf")) == str(g["gguf_sha256"])
+    m = hip.Model(ctx, d, max_batch=16)
+    prompt = g["prompt"]
+    assert np.array_equal(m.generate(prompt, 8, 24), g["ids"])
+    # per-step logits with the reference's own prefill chunking (8, 8, 4)
+    m.reset()
+    for lo in range(0, 20, 8):
+        hi = min(lo + 8, 20)
+        m.forward(prompt[lo:hi], np.arange(lo, hi), lm_head=False)
+    cur = int(prompt[-1])
+    for s in range(24):
+        lg, am = m.forward([cur], [m.position], lm_head=True)
+        assert np.array_equal(lg[0].view(np.uint32), g["logits"][s].view(np.uint32)), s
+        cur = int(g["ids"][s])
+    m.reset()
+    lg, _ = m.forward(prompt[:9], np.arange(9), lm_head=True)
+    assert np.array_equal(lg.view(np.uint32), g["batch_logits"].view(np.uint32))
+    m.close()

@@ -1,0 +1,66 @@
+"""CPU, world_size 2 over gloo: the replica protocol bench.py uses across GPUs — rank 0 broadcasts
+the prompt, every replica decodes independently (no data-path collective), sampled ids are all-gathered and must
+agree, timing is the MAX over ranks.  The GPU decode is replaced by a deterministic stand-in here; the collective
+logic is the same code path (bench.replica_exchange)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bench
+    prompt = np.arange(100, 140, dtype=np.int32) if rank == 0 else np.zeros(40, dtype=np.int32)
+    prompt = bench.broadcast_prompt(dist, prompt, rank, device="cpu")
+    ids = (prompt[:16] * 7 + 3) % 1000          # stand-in for the replica's greedy decode (deterministic in the prompt)
+    if rank == 1 and os.environ.get("PS_TEST_DIVERGE"):
+        ids = ids.copy(); ids[5] += 1
+    agree, all_ids = bench.gather_ids(dist, ids.astype(np.int32), world, device="cpu")
+    tmax = bench.max_over_ranks(dist, [0.5 + rank, 2.0 - rank], device="cpu")
+    q.put((rank, prompt.tolist(), agree, [a.tolist() for a in all_ids], tmax))
+    dist.destroy_process_group()
+
+
+def _run(diverge=False):
+    if diverge:
+        os.environ["PS_TEST_DIVERGE"] = "1"
+    else:
+        os.environ.pop("PS_TEST_DIVERGE", None)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in ps]
+    out = sorted(q.get(timeout=120) for _ in range(2))
+    [p.join(60) for p in ps]
+    return out
+
+
+def test_broadcast_gather_max():
+    out = _run()
+    for rank, prompt, agree, all_ids, tmax in out:
+        assert prompt == list(range(100, 140))           # rank 0's prompt reached every replica
+        assert agree and all_ids[0] == all_ids[1]
+        assert tmax == [1.5, 2.0]                        # MAX over ranks of each timing
+
+
+def test_divergent_replica_is_detected():
+    out = _run(diverge=True)
+    assert all(not agree for _, _, agree, _, _ in out)
