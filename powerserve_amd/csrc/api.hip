@@ -370,4 +370,10 @@ int ps_hip_argmax(ps_hip_ctx *c, const float *src, int64_t n, int64_t rows, int3
     return 0;
 }
 
+int ps_hip_debug_timeline(ps_hip_ctx *ctx, int key, uint64_t *host_out, int n_words) {
+    if (!ctx) return 1;
+    if (host_out) PS_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return psk_gemv_debug(key, host_out, n_words);
+}
+
 } // extern "C"

@@ -3,11 +3,11 @@
 // Fuses what NormAttention::build emits after the QKV mat-muls
 // (src/model/module/norm_attention.cpp:72-151): ROPE x2, TRANSPOSE, VIEW+COPY x2 (KV append), PERMUTE,
 // K-view MAT_MUL, GET_MASK (src/executor/executor.cpp:210-224), SOFTMAX_EXT, V-view MAT_MUL, PERMUTE+CONT —
-// 13 graph ops — into four launches with no intermediate layout shuffles:
+// 13 graph ops — into three launches with no intermediate layout shuffles:
 //   rope_append   rotate q in place, rotate k into its K-cache row, scatter v into the transposed V cache
-//   attn_scores   s = K·q          (ggml_vec_dot_f32, libs/ggml/src/ggml.c:2092-2133)
-//   attn_softmax  scale + mask + softmax rows (ggml.c:14889-14925, ggml_vec_soft_max_f32 :2814-2863)
-//   attn_pv       out = V·p        (ggml_vec_dot_f32 again, rows of the transposed V cache)
+//   attn_scores      s = K·q       (ggml_vec_dot_f32, libs/ggml/src/ggml.c:2092-2133)
+//   attn_softmax_pv  scale + mask + softmax (ggml.c:14889-14925, ggml_vec_soft_max_f32 :2814-2863) held in LDS,
+//                    then out = V·p (ggml_vec_dot_f32 again, rows of the transposed V cache)
 // KV layout is the reference's: K [n_ctx][kv_dim], V [kv_dim][n_ctx] FP32 (backend/ggml/ggml_kv_cache.cpp:48-57).
 //
 // Exact order: ggml_vec_dot_f32's AVX build keeps 4 accumulators x 8 lanes = 32 fp32 chains over elements
@@ -93,87 +93,136 @@ __global__ __launch_bounds__(256) void attn_scores_kernel(psl_attn_args a) {
     }
 }
 
-// ---------------------------------------------------------------- softmax rows, in place: scores -> p
-// grid (n_heads, bs).  wp = s*scale (+mask); max; exp: ggml_v_expf on the groups of 8, libm expf on the
-// n_kv % 8 tail; per-group float sum tree then double accumulation; p = e * (float)(1.0/sum).
-__global__ __launch_bounds__(256) void attn_softmax_kernel(psl_attn_args a) {
-    __shared__ float redf[4];
-    __shared__ double redd[4];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int h = blockIdx.x, i = blockIdx.y, bs = a.state->bs, pos0 = a.state->pos0;
-    const int n_kv = pos0 + bs, n8 = n_kv & ~7;
-    float *row = a.scores + ((int64_t)i * a.n_heads + h) * a.n_ctx;
-    float mx = -INFINITY;
-    for (int j = threadIdx.x; j < n_kv; j += 256) {
-        const bool ok = (j < pos0) ? true : (a.tree ? a.tree[i * bs + (j - pos0)] != 0 : (j - pos0) <= i);
-        float v = __fmul_rn(row[j], a.scale);
-        v       = __fadd_rn(v, ok ? 0.f : -INFINITY);
-        row[j]  = v;
-        mx      = fmaxf(mx, v);
-    }
-    mx = wave_max(mx);
-    if (lane == 0) redf[wave] = mx;
-    __syncthreads();
-    mx = fmaxf(fmaxf(redf[0], redf[1]), fmaxf(redf[2], redf[3]));
-    // one lane per group of 8 keeps the reference's in-group association: ((v0+v4)+(v2+v6)) + ((v1+v5)+(v3+v7))
-    double sum = 0.0;
-    for (int g = threadIdx.x; g * 8 < n8; g += 256) {
-        float v[8];
-#pragma unroll
-        for (int l = 0; l < 8; l++) { v[l] = ps_v_expf(__fsub_rn(row[g * 8 + l], mx)); row[g * 8 + l] = v[l]; }
-        const float a0 = __fadd_rn(v[4], v[0]), a1 = __fadd_rn(v[5], v[1]), a2 = __fadd_rn(v[6], v[2]), a3 = __fadd_rn(v[7], v[3]);
-        sum += (double)__fadd_rn(__fadd_rn(a0, a2), __fadd_rn(a1, a3));
-    }
-    if (threadIdx.x == 0) {
-        for (int j = n8; j < n_kv; j++) { const float e = ps_expf_glibc(__fsub_rn(row[j], mx)); row[j] = e; sum += (double)e; }
-    }
-    sum = wave_sum_d(sum);
-    if (lane == 0) redd[wave] = sum;
-    __syncthreads();
-    const double tot = (redd[0] + redd[1]) + (redd[2] + redd[3]);
-    const float inv  = (float)(1.0 / tot);
-    for (int j = threadIdx.x; j < n_kv; j += 256) row[j] = __fmul_rn(row[j], inv);
-}
-
-// ---------------------------------------------------------------- out[i][h][d] = V^T[kvh*hs + d][0..n_kv) · p[i][h][0..n_kv)
-// grid (hs/4, n_kv_heads, bs), 128 threads: a half-wave per output channel d, all r2 heads of the kv group.
-// Loads are issued U steps ahead (V from HBM, p from L2); the fma chains stay in position order.
-__global__ __launch_bounds__(128) void attn_pv_kernel(psl_attn_args a) {
+// ---------------------------------------------------------------- softmax + V·p in one launch
+// out[i][h][d] = V^T[kvh*hs + d][0..n_kv) · softmax(scale·s[i][h][:] + mask)
+// grid (hs/4, n_kv_heads, bs), 256 threads.  Phase 1: one wave per q head of the kv group turns its raw score row
+// into probabilities held in LDS (scale + mask, max, ggml_v_expf on groups of 8 with the in-group sum tree, libm
+// expf on the n_kv % 8 tail, double row sum, p = e * (float)(1/sum) — ggml.c:14889-14925, :2814-2863).  Phase 2: the
+// four V rows of this workgroup are streamed through LDS in tiles with every thread's loads in flight at once, and
+// 8 half-waves run the 32-lane fp32 chains of ggml_vec_dot_f32 in position order (chain state stays in registers
+// across tiles), then GGML_F32x8_REDUCE and the n_kv % 32 leftovers.
+constexpr int PV_TILE = 1024;
+__global__ __launch_bounds__(256) void attn_softmax_pv_kernel(psl_attn_args a) {
+    extern __shared__ __attribute__((aligned(16))) float pl[]; // [r2][n_kv4] probabilities, then [4][PV_TILE] V tile
     const int hs = a.head_size, dim = a.n_heads * hs, r2 = a.n_heads / a.n_kv_heads;
-    const int c = threadIdx.x & 31, hw = threadIdx.x >> 5;
-    const int kvh = blockIdx.y, i = blockIdx.z;
-    const int n_kv = a.state->pos0 + a.state->bs, np = n_kv & ~31;
-    const int d = blockIdx.x * 4 + hw;
-    const float *vr = a.v_cache + ((int64_t)kvh * hs + d) * a.n_ctx;
-    const float *pb = a.scores + ((int64_t)i * a.n_heads + (int64_t)kvh * r2) * a.n_ctx;
-    float acc[R2MAX];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int kvh = blockIdx.y, i = blockIdx.z, bs = a.state->bs, pos0 = a.state->pos0;
+    const int n_kv = pos0 + bs, n8 = n_kv & ~7, np = n_kv & ~31, n_kv4 = (n_kv + 3) & ~3;
+    float *vt = pl + (size_t)r2 * (((size_t)a.n_ctx + 3) & ~(size_t)3);
+    __shared__ float redf[R2MAX][4];
+    __shared__ double redd[R2MAX][4];
+    // ---- phase 1: softmax of the r2 rows, all 256 threads, every row's loads in flight together
+    constexpr int EPT = 4; // elements per thread per row per trip
+    float rmax[R2MAX];
 #pragma unroll
-    for (int g = 0; g < R2MAX; g++) acc[g] = 0.f;
-    constexpr int U = 8;
-    for (int j0 = c; j0 < np; j0 += 32 * U) {
-        float v[U], pv[U][R2MAX];
+    for (int g = 0; g < R2MAX; g++) rmax[g] = -INFINITY;
+    for (int j0 = threadIdx.x; j0 < n_kv; j0 += 256 * EPT) {
+        float sv[R2MAX][EPT];
 #pragma unroll
-        for (int t = 0; t < U; t++) {
-            const int j = j0 + 32 * t;
-            const bool ok = j < np;
-            v[t] = ok ? vr[j] : 0.f;
+        for (int g = 0; g < R2MAX; g++)
 #pragma unroll
-            for (int g = 0; g < R2MAX; g++) pv[t][g] = (ok && g < r2) ? pb[(int64_t)g * a.n_ctx + j] : 0.f;
-        }
+            for (int t = 0; t < EPT; t++) {
+                const int j = j0 + 256 * t;
+                sv[g][t] = (g < r2 && j < n_kv) ? a.scores[((int64_t)i * a.n_heads + (int64_t)kvh * r2 + g) * a.n_ctx + j] : 0.f;
+            }
 #pragma unroll
-        for (int t = 0; t < U; t++) {
-            if (j0 + 32 * t < np) {
+        for (int t = 0; t < EPT; t++) {
+            const int j = j0 + 256 * t;
+            if (j < n_kv) {
+                const bool ok = (j < pos0) ? true : (a.tree ? a.tree[i * bs + (j - pos0)] != 0 : (j - pos0) <= i);
 #pragma unroll
-                for (int g = 0; g < R2MAX; g++)
-                    if (g < r2) acc[g] = __fmaf_rn(v[t], pv[t][g], acc[g]); // x = V row (src0), y = p
+                for (int g = 0; g < R2MAX; g++) {
+                    if (g < r2) {
+                        float v = __fmul_rn(sv[g][t], a.scale);
+                        v       = __fadd_rn(v, ok ? 0.f : -INFINITY);
+                        pl[(size_t)g * n_kv4 + j] = v;
+                        rmax[g] = fmaxf(rmax[g], v);
+                    }
+                }
             }
         }
     }
 #pragma unroll
     for (int g = 0; g < R2MAX; g++) {
+        if (g < r2) { const float m = wave_max_dpp(rmax[g]); if (lane == 0) redf[g][wave] = m; }
+    }
+    __syncthreads();
+    double rsum[R2MAX];
+#pragma unroll
+    for (int g = 0; g < R2MAX; g++) {
+        rsum[g] = 0.0;
         if (g < r2) {
-            float s = reduce_f32x8x4(acc[g]);
-            for (int j = np; j < n_kv; j++) s = __fadd_rn(s, __fmul_rn(vr[j], pb[(int64_t)g * a.n_ctx + j])); // leftovers
+            const float mx = fmaxf(fmaxf(redf[g][0], redf[g][1]), fmaxf(redf[g][2], redf[g][3]));
+            float *pg = pl + (size_t)g * n_kv4;
+            for (int gi = threadIdx.x; gi * 8 < n8; gi += 256) { // one lane per group of 8: the reference's in-group association
+                const float4 lo = *(const float4 *)(pg + gi * 8), hi = *(const float4 *)(pg + gi * 8 + 4);
+                float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+                for (int l = 0; l < 8; l++) v[l] = ps_v_expf(__fsub_rn(v[l], mx));
+                *(float4 *)(pg + gi * 8)     = make_float4(v[0], v[1], v[2], v[3]);
+                *(float4 *)(pg + gi * 8 + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                const float a0 = __fadd_rn(v[4], v[0]), a1 = __fadd_rn(v[5], v[1]), a2 = __fadd_rn(v[6], v[2]), a3 = __fadd_rn(v[7], v[3]);
+                rsum[g] += (double)__fadd_rn(__fadd_rn(a0, a2), __fadd_rn(a1, a3));
+            }
+            if (threadIdx.x == 255)
+                for (int j = n8; j < n_kv; j++) { const float e = ps_expf_glibc(__fsub_rn(pg[j], mx)); pg[j] = e; rsum[g] += (double)e; }
+            const double sw = wave_sum_d_dpp(rsum[g]);
+            if (lane == 0) redd[g][wave] = sw;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < R2MAX; g++) {
+        if (g < r2) {
+            const float inv = (float)(1.0 / ((redd[g][0] + redd[g][1]) + (redd[g][2] + redd[g][3])));
+            float *pg = pl + (size_t)g * n_kv4;
+            for (int j = threadIdx.x; j < n_kv; j += 256) pg[j] = __fmul_rn(pg[j], inv);
+        }
+    }
+    // ---- phase 2: V·p.  half-wave hw: channel d = blockIdx.x*4 + (hw & 3), heads (hw >> 2), (hw >> 2) + 2, ...
+    const int c = threadIdx.x & 31, hw = threadIdx.x >> 5, dl = hw & 3, g0 = hw >> 2;
+    const int d = blockIdx.x * 4 + dl;
+    const float *vbase = a.v_cache + ((int64_t)kvh * hs + blockIdx.x * 4) * a.n_ctx;
+    float acc[R2MAX / 2];
+#pragma unroll
+    for (int k = 0; k < R2MAX / 2; k++) acc[k] = 0.f;
+    float4 ld[4];
+    auto load_tile = [&](int t0) { // 4 rows x PV_TILE floats = 1024 float4 = 4 per thread, all in flight
+        const int tn = min(PV_TILE, np - t0);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int f = threadIdx.x + 256 * k, row = f >> 8, col = (f & 255) * 4;
+            ld[k] = (col < tn) ? *(const float4 *)(vbase + (int64_t)row * a.n_ctx + t0 + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    if (np > 0) load_tile(0);
+    for (int t0 = 0; t0 < np; t0 += PV_TILE) {
+        const int tn = min(PV_TILE, np - t0); // multiple of 32
+        __syncthreads(); // probabilities complete (first trip) / previous tile fully consumed
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int f = threadIdx.x + 256 * k, row = f >> 8, col = (f & 255) * 4;
+            *(float4 *)(vt + row * PV_TILE + col) = ld[k];
+        }
+        __syncthreads();
+        if (t0 + PV_TILE < np) load_tile(t0 + PV_TILE); // next tile streams in while this one is consumed
+        for (int j = c; j < tn; j += 32) {
+            const float v = vt[dl * PV_TILE + j];
+#pragma unroll
+            for (int k = 0; k < R2MAX / 2; k++) {
+                const int g = g0 + 2 * k;
+                if (g < r2) acc[k] = __fmaf_rn(v, pl[(size_t)g * n_kv4 + t0 + j], acc[k]); // x = V row (src0), y = p
+            }
+        }
+    }
+    if (np == 0) __syncthreads();
+    const float *vr = a.v_cache + ((int64_t)kvh * hs + d) * a.n_ctx;
+#pragma unroll
+    for (int k = 0; k < R2MAX / 2; k++) {
+        const int g = g0 + 2 * k;
+        if (g < r2) {
+            float s = reduce_f32x8x4(acc[k]);
+            for (int j = np; j < n_kv; j++) s = __fadd_rn(s, __fmul_rn(vr[j], pl[(size_t)g * n_kv4 + j])); // leftovers
             if (c == 0) a.att[(int64_t)i * dim + ((int64_t)kvh * r2 + g) * hs + d] = s;
         }
     }
@@ -237,13 +286,15 @@ void psl_attn_scores(hipStream_t st, const psl_attn_args &a, int bs) {
     else hipLaunchKernelGGL(attn_scores_kernel<3>, g, dim3(256), 0, st, a); // head_size 96
 }
 
-void psl_attn_softmax(hipStream_t st, const psl_attn_args &a, int bs) {
-    hipLaunchKernelGGL(attn_softmax_kernel, dim3((unsigned)a.n_heads, (unsigned)bs), dim3(256), 0, st, a);
+size_t psl_attn_softmax_pv_lds(const psl_attn_args &a) {
+    const int r2 = a.n_heads / a.n_kv_heads;
+    return ((size_t)r2 * (((size_t)a.n_ctx + 3) & ~(size_t)3) + 4 * PV_TILE) * 4;
 }
-
-void psl_attn_pv(hipStream_t st, const psl_attn_args &a, int bs) {
+void psl_attn_softmax_pv(hipStream_t st, const psl_attn_args &a, int bs) {
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void *)attn_softmax_pv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512); attr = true; }
     dim3 g((unsigned)(a.head_size / 4), (unsigned)a.n_kv_heads, (unsigned)bs);
-    hipLaunchKernelGGL(attn_pv_kernel, g, dim3(128), 0, st, a);
+    hipLaunchKernelGGL(attn_softmax_pv_kernel, g, dim3(256), psl_attn_softmax_pv_lds(a), st, a);
 }
 
 void psl_argmax2(hipStream_t st, const float *src, int64_t n, int64_t rows, int32_t *out, float *part_v, int *part_i,

@@ -20,6 +20,7 @@
 //   * the activation row is quantized ONCE PER WORKGROUP in the prologue (RMSNorm / plain / pre-quantized),
 //     bit-exactly (ps_quant_dev.h), into LDS; it is re-read per unit with ds_read_b32 broadcast across rows.
 //   * up to three matrices share a launch (QKV, gate+up) and the epilogue applies bias / residual / SiLU*up.
+#include <type_traits>
 #include "ps_dev.h"
 #include "ps_internal.h"
 #include "ps_quant_dev.h"
@@ -46,6 +47,8 @@ struct GemvParams {
     const int8_t *aq;
     const float *ad;
     const int16_t *abs16;
+    unsigned long long *dbg; // timeline buffer or null (ps_hip_debug_timeline)
+    int split_q, split_r;    // gemv3: row groups per workgroup = split_q (+1 for the first split_r workgroups)
 };
 
 template <int WT> struct WTraits;
@@ -503,6 +506,412 @@ void launch_g1_ep(hipStream_t st, int n_cu, const GemvParams &p, int epi, int pr
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Decode kernel, producer/consumer form.  NW producer waves turn 1 KiB units into exact INTEGER partials and
+// drop them in LDS (8-16 B per lane and unit); one consumer wave runs the reference's fp32 fma chains over them
+// in unit order, one chunk (NW*UPW units) behind the producers, and writes the rows.  One barrier per chunk,
+// nobody waits for the chain.  A workgroup owns a contiguous range of row groups and treats their units as one
+// stream, so chunks may straddle row groups (K = 14336: 56 units, chunks of 28).  Producers keep two chunks of
+// weight loads in flight (register double buffer).
+// out of line on purpose: inlined, the double-precision expf inflates the register allocation of the whole kernel
+__device__ __attribute__((noinline)) float silu_mul_call(float g, float u) { return ps_silu_mul(g, u); }
+
+constexpr int G3_DBG_WGS = 1024; // workgroups with a timeline slot
+unsigned long long *g_dbg_buf = nullptr;
+int g_dbg_key = -1;
+struct G3Mats {
+    const uint8_t *qs0, *qs1, *qs2, *ax0, *ax1, *ax2;
+    int ng0, ng1, n_w, n_units;
+};
+// (row-group task, unit) -> quant plane / header plane of the owning matrix; everything wave-uniform (SALU)
+template <int EPI, int AUXU>
+__device__ __forceinline__ void g3_locate(const G3Mats m, int task, int un, const uint8_t *&qg, const uint8_t *&ag, int &ul) {
+    int grp = task;
+    const uint8_t *qb = m.qs0, *ab = m.ax0;
+    ul = un;
+    if (EPI == 0) {
+        if (m.n_w > 1 && grp >= m.ng0) {
+            grp -= m.ng0; qb = m.qs1; ab = m.ax1;
+            if (m.n_w > 2 && grp >= m.ng1) { grp -= m.ng1; qb = m.qs2; ab = m.ax2; }
+        }
+    } else if (un >= m.n_units) {
+        ul = un - m.n_units; qb = m.qs1; ab = m.ax1;
+    }
+    const uint32_t idx = (uint32_t)(grp * m.n_units + ul); // unit index inside the matrix: N*K/2048 < 2^31
+    qg = qb + ((uint64_t)idx << 10);
+    ag = ab + (uint64_t)idx * AUXU;
+}
+
+template <int WT> struct RecOf { using T = int4; };
+template <> struct RecOf<PS_Q4_K> { using T = int2; };
+
+// Q4_K record: {s, u < 4 ? prod : d|dmin}: the four acc_m lanes need prod, the other four carry the fp16 pair
+template <int WT>
+__device__ __forceinline__ typename RecOf<WT>::T unit_rec(const uint4 q, const uint4 h, const int unit, const int u, const LAct a) {
+    constexpr uint32_t M = 0x0F0F0F0Fu;
+    const uint32_t wq[4] = {q.x, q.y, q.z, q.w};
+    if constexpr (WT == PS_Q4_K) {
+        const uint32_t sc03 = h.y & 0x3f3f3f3fu;
+        const uint32_t sc47 = (h.w & 0x0f0f0f0fu) | (((h.y >> 6) & 0x03030303u) << 4);
+        const uint32_t mn03 = h.z & 0x3f3f3f3fu;
+        const uint32_t mn47 = ((h.w >> 4) & 0x0f0f0f0fu) | (((h.z >> 6) & 0x03030303u) << 4);
+        const int base = unit * 64 + u;
+        int s = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) { // |dot4| <= 4*15*127 and scale <= 63: 24-bit multiplies are exact
+            const int yl = a.q32[base + j * 16], yh = a.q32[base + j * 16 + 8];
+            const uint32_t scp = (j < 2) ? sc03 : sc47;
+            s += __mul24(bfe8(scp, (2 * j) & 3), dot4((int)(wq[j] & M), yl, 0)) + __mul24(bfe8(scp, (2 * j + 1) & 3), dot4((int)((wq[j] >> 4) & M), yh, 0));
+        }
+        const int v = u & 3;
+        const uint32_t mp = (v < 2) ? mn03 : mn47;
+        const int pr = __mul24(bfe8(mp, (2 * v) & 3), a.bs32[unit * 8 + 2 * v]) + __mul24(bfe8(mp, (2 * v + 1) & 3), a.bs32[unit * 8 + 2 * v + 1]);
+        return make_int2(s, u < 4 ? pr : (int)h.x);
+    } else if constexpr (WT == PS_Q8_0) {
+        int s[4];
+#pragma unroll
+        for (int b = 0; b < 4; b++) s[b] = dot4((int)wq[b], a.q32[(unit * 4 + b) * 8 + u], 0);
+        return make_int4(s[0], s[1], s[2], s[3]);
+    } else { // |sum (q-8)*y| over a quad <= 4*8*127: the low/high partials travel as an int16 pair
+        int s[4];
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const int blk = unit * 4 + b;
+            const int yl = a.q32[blk * 8 + u], yh = a.q32[blk * 8 + 4 + u];
+            const int sl = dot4((int)(wq[b] & M), yl, 0) - 8 * dot4(0x01010101, yl, 0);
+            const int sh = dot4((int)((wq[b] >> 4) & M), yh, 0) - 8 * dot4(0x01010101, yh, 0);
+            s[b] = (sl & 0xffff) | (sh << 16);
+        }
+        return make_int4(s[0], s[1], s[2], s[3]);
+    }
+}
+
+// hd: Q4_K d|dmin, Q8_0 / Q4_0 the four fp16 block scales of the unit
+template <int WT>
+__device__ __forceinline__ void rec_chain(const typename RecOf<WT>::T rc, const uint2 hd, const int unit, const LAct a,
+                                          float &acc0, float &acc1, float &accm) {
+    if constexpr (WT == PS_Q4_K) {
+        const float yd   = a.d[unit];
+        const float d    = __fmul_rn(yd, ps_h2f((uint16_t)(hd.x & 0xffff)));
+        const float dmin = __fmul_rn(-yd, ps_h2f((uint16_t)(hd.x >> 16)));
+        acc0 = __fmaf_rn(d, (float)rc.x, acc0);
+        accm = __fmaf_rn(dmin, (float)rc.y, accm); // lanes u >= 4: not an acc_m lane, never read
+    } else {
+        const int sv[4] = {rc.x, rc.y, rc.z, rc.w};
+        const uint16_t dh[4] = {(uint16_t)(hd.x & 0xffff), (uint16_t)(hd.x >> 16), (uint16_t)(hd.y & 0xffff), (uint16_t)(hd.y >> 16)};
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const float d = __fmul_rn(ps_h2f(dh[b]), a.d[unit * 4 + b]);
+            if constexpr (WT == PS_Q8_0) {
+                acc0 = __fmaf_rn(d, (float)sv[b], acc0);
+            } else {
+                acc0 = __fmaf_rn(d, (float)(int)(int16_t)(sv[b] & 0xffff), acc0);
+                acc1 = __fmaf_rn(d, (float)(sv[b] >> 16), acc1);
+            }
+        }
+    }
+}
+
+template <int WT, int UPW, int NW, int TPW, int EPI, int PRO>
+__global__ __launch_bounds__((NW + 1) * 64, 4) void gemv3_kernel(const GemvParams p) {
+    using TR  = WTraits<WT>;
+    using Rec = typename RecOf<WT>::T;
+    constexpr int UPB = NW * UPW; // units per chunk
+    // TPW: prologue tiles per wave, K <= (NW+1)*TPW*256
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ double red[16];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t K = p.K;
+    const int Kp   = (int)((K + TR::UNIT - 1) / TR::UNIT * TR::UNIT);
+    const int nblk = Kp / TR::BLK, nb32 = Kp / 32, nb16 = Kp / 16;
+    const int nblk_k = (int)(K / TR::BLK), nb16_k = (int)(K / 16);
+    int8_t *lq   = (int8_t *)smem;
+    float *ld    = (float *)(smem + Kp);
+    int *lb      = (int *)(ld + nblk);
+    int16_t *l16 = (int16_t *)(lb + nb32);
+    Rec *recs    = (Rec *)(smem + p.col_bytes); // [2][UPB][64]
+    uint2 *hdl   = (uint2 *)(recs + 2 * UPB * 64); // Q8_0 / Q4_0: the units' fp16 block scales, [2][UPB][RG]
+    LAct A;
+    A.q32 = (const int *)lq; A.d = ld; A.bs32 = lb;
+
+    const int r = (WT == PS_Q4_0) ? (lane >> 2) : (lane >> 3);
+    const int u = (WT == PS_Q4_0) ? (lane & 3) : (lane & 7);
+    const int n_units = Kp / TR::UNIT;
+    const int tot     = (EPI == 1) ? 2 * n_units : n_units; // EPI 1: gate units then up units of the same row group
+    constexpr int AUXR = (WT == PS_Q4_K) ? 16 : 8;          // header bytes per row and unit
+    constexpr int AUXU = TR::RG * AUXR;                     // header bytes per unit
+    const int n_tasks  = (int)((EPI == 1) ? p.w[0].n_groups : p.groups_total);
+    // contiguous range of row groups of this workgroup: the first split_r workgroups take split_q + 1 groups
+    const int g0 = (int)blockIdx.x * p.split_q + min((int)blockIdx.x, p.split_r);
+    const int g1 = g0 + p.split_q + ((int)blockIdx.x < p.split_r ? 1 : 0);
+    const int n_chunks = (int)(((int64_t)(g1 - g0) * tot + UPB - 1) / UPB);
+    const int n_rounds = (n_chunks + 1) / 2;
+    int step_g = 0, step_u = 2 * UPB; // a slot moves 2*UPB stream units per round (a few subtractions beat a division)
+    while (step_u >= tot) { step_u -= tot; step_g++; }
+    const uint32_t lane16 = (uint32_t)lane * 16u, raux = (uint32_t)r * AUXR;
+    unsigned long long *const dbg = (p.dbg && blockIdx.x < G3_DBG_WGS && lane == 0 && (wave == 0 || wave == NW)) ? p.dbg + ((size_t)blockIdx.x * 2 + (wave == NW)) * 32 : nullptr;
+    int dbg_n = 0;
+    auto mark = [&]() { if (dbg && dbg_n < 32) dbg[dbg_n++] = __builtin_amdgcn_s_memtime(); };
+    mark(); // 0: entry
+    if (dbg) dbg[29] = __builtin_amdgcn_s_memrealtime(); // 29/30: 100 MHz reference at entry / exit
+
+    // matrices of the launch, in scalar registers
+    const G3Mats mats{p.w[0].qs, p.w[1].qs, p.w[2].qs, p.w[0].aux, p.w[1].aux, p.w[2].aux,
+                      (int)p.w[0].n_groups, (int)p.w[1].n_groups, p.n_w, n_units};
+    const int ng0 = mats.ng0, ng1 = mats.ng1, n_w = mats.n_w;
+    auto locate = [&](int task, int un, const uint8_t *&qg, const uint8_t *&ag, int &ul) { g3_locate<EPI, AUXU>(mats, task, un, qg, ag, ul); };
+
+    static_assert(UPW == 4, "ps_vmwait4");
+    using HT = typename std::conditional<WT == PS_Q4_K, ps_u32x4, ps_u32x2>::type;
+    constexpr int LPC = 2 * UPW; // loads per chunk and lane
+    ps_u32x4 qA[UPW], qB[UPW];
+    HT hA[UPW], hB[UPW];
+    int tA[UPW], tB[UPW], uA[UPW], uB[UPW];
+    // Loads and partials are UNCONDITIONAL (slots past the end of the range are clamped to its last row group and
+    // their records are never read) and the loads are explicitly scheduled (ps_dev.h): a chunk is consumed while
+    // the next one is still in flight.
+    // `live` (wave-uniform): the chunk lies inside this workgroup's range.  Chunks past it are still "loaded", from
+    // the first KiB of the first matrix (L2-resident after the first touch), so that the loop stays free of
+    // conditional loads and the compiler can count vmcnt exactly.
+    auto issue = [&](ps_u32x4 (&q)[UPW], HT (&h)[UPW], const int (&t)[UPW], const int (&un)[UPW], bool live) {
+#pragma unroll
+        for (int i = 0; i < UPW; i++) {
+            const uint8_t *qg, *ag;
+            int ul;
+            locate(min(t[i], g1 - 1), un[i], qg, ag, ul);
+            if (!live) { qg = mats.qs0; ag = mats.ax0; }
+            const ps_u32x4 *qp = (const ps_u32x4 *)(qg + lane16);
+            q[i] = __builtin_nontemporal_load(qp);
+            h[i] = *(const HT *)(ag + raux);
+        }
+    };
+    // unit i of a chunk is waited for on its own: the partials start when the first KiB lands, and the compiler
+    // cannot hoist the unpacking of all four units above one wait (register pressure)
+    auto produce = [&](const ps_u32x4 (&q)[UPW], const HT (&h)[UPW], const int (&un)[UPW], int buf) {
+#pragma unroll
+        for (int i = 0; i < UPW; i++) {
+            const int ul = (EPI == 1 && un[i] >= n_units) ? un[i] - n_units : un[i];
+            uint4 hv;
+            if constexpr (WT == PS_Q4_K) hv = make_uint4(h[i].x, h[i].y, h[i].z, h[i].w); else hv = make_uint4(h[i].x, h[i].y, 0, 0);
+            recs[(buf * UPB + wave * UPW + i) * 64 + lane] = unit_rec<WT>(make_uint4(q[i].x, q[i].y, q[i].z, q[i].w), hv, ul, u, A);
+            if constexpr (WT != PS_Q4_K) { if (u == 0) hdl[(buf * UPB + wave * UPW + i) * TR::RG + r] = make_uint2(h[i].x, h[i].y); }
+            __builtin_amdgcn_sched_barrier(0); // one unit at a time: interleaving four of them costs more registers than it hides
+        }
+    };
+    auto advance = [&](int (&t)[UPW], int (&un)[UPW]) {
+#pragma unroll
+        for (int i = 0; i < UPW; i++) {
+            t[i] += step_g;
+            un[i] += step_u;
+            if (un[i] >= tot) { un[i] -= tot; t[i]++; }
+        }
+    };
+
+    float4 xv[TPW], wv[TPW];
+    // activation row first, the first chunks of weights right behind it (vmcnt retires in order: the prologue
+    // only waits for the L2-resident activation while the weights stream in)
+    if (PRO != 0) ps_qrow_load<(PRO == 1 ? 1 : 0), TPW>(p.x, p.nw, K, xv, wv);
+#pragma unroll
+    for (int i = 0; i < UPW; i++) {
+        int sa = min(wave, NW - 1) * UPW + i, ta = g0;
+        while (sa >= tot) { sa -= tot; ta++; }
+        int sb = sa + UPB, tb = ta;
+        while (sb >= tot) { sb -= tot; tb++; }
+        tA[i] = ta; uA[i] = sa;
+        tB[i] = tb; uB[i] = sb;
+    }
+    issue(qA, hA, tA, uA, true); // (g1 == g0 cannot happen: the grid never exceeds the number of row groups)
+    constexpr bool B_EARLY = (PRO == 0) || (TPW <= 2); // otherwise the prologue needs the registers
+    if (B_EARLY) issue(qB, hB, tB, uB, n_chunks > 1);
+    mark(); // 1: loads issued
+    { // activation -> LDS once per workgroup
+        if (Kp != K) {
+            for (int i = (int)K + threadIdx.x * 4; i < Kp; i += (NW + 1) * 64 * 4) *(int *)(lq + i) = 0;
+            for (int i = nblk_k + threadIdx.x; i < nblk; i += (NW + 1) * 64) ld[i] = 0.f;
+            for (int i = nb16_k + threadIdx.x; i < nb16; i += (NW + 1) * 64) l16[i] = 0;
+        }
+        if (PRO == 0) {
+            for (int64_t i = threadIdx.x * 16; i < K; i += (NW + 1) * 64 * 16) *(int4 *)(lq + i) = *(const int4 *)(p.aq + i);
+            for (int i = threadIdx.x; i < nblk_k; i += (NW + 1) * 64) ld[i] = p.ad[i];
+            for (int i = threadIdx.x; i < nb16_k; i += (NW + 1) * 64) l16[i] = p.abs16[i];
+            __syncthreads();
+        } else {
+            ps_qrow_compute<TR::VDT, (PRO == 1 ? 1 : 0), TPW>(xv, wv, p.eps, K, lq, ld, l16, red);
+        }
+        for (int i = threadIdx.x; i < nb32; i += (NW + 1) * 64) lb[i] = (int)l16[2 * i] + (int)l16[2 * i + 1];
+        __syncthreads();
+    }
+    mark(); // 2: activation in LDS
+    if (wave < NW) { // ---------------- producers
+        if (!B_EARLY) issue(qB, hB, tB, uB, n_chunks > 1);
+        for (int rd = 0; rd < n_rounds; rd++) { // chunk 2rd from A, 2rd+1 from B
+            produce(qA, hA, uA, 0);
+            mark(); // producers: 3, 5, ...: chunk A done
+            advance(tA, uA);
+            issue(qA, hA, tA, uA, 2 * rd + 2 < n_chunks);
+            __syncthreads();
+            if (2 * rd + 1 < n_chunks) produce(qB, hB, uB, 1); // (the loads stay unconditional, the arithmetic need not)
+            mark(); // 4, 6, ...: chunk B done
+            advance(tB, uB);
+            issue(qB, hB, tB, uB, 2 * rd + 3 < n_chunks);
+            __syncthreads();
+        }
+    } else { // ---------------- consumer: fp32 chains in unit order, one chunk behind the producers
+        __builtin_amdgcn_s_setprio(3); // one wave serves NW producers: it gets the issue slots first
+        float acc0 = 0.f, acc1 = 0.f, accm = 0.f, ygate = 0.f;
+        int task = g0, un = 0;
+        auto gate_done = [&]() { // gate row finished: reduce it, restart the chains for the up row
+            ygate = row_reduce<WT>(acc0, acc1, accm);
+            acc0 = 0.f; acc1 = 0.f; accm = 0.f;
+        };
+        auto row_done = [&]() {
+            const float y = row_reduce<WT>(acc0, acc1, accm);
+            int wi = 0, grp = task;
+            if (EPI == 0) {
+                if (n_w > 1 && grp >= ng0) { grp -= ng0; wi = 1; }
+                if (n_w > 2 && wi == 1 && grp >= ng1) { grp -= ng1; wi = 2; }
+            }
+            int64_t Nw = p.w[0].N;
+            float *o = p.w[0].out;
+            const float *b = p.w[0].bias;
+            if (wi == 1) { Nw = p.w[1].N; o = p.w[1].out; b = p.w[1].bias; }
+            if (wi == 2) { Nw = p.w[2].N; o = p.w[2].out; b = p.w[2].bias; }
+            const int64_t row = (int64_t)grp * TR::RG + r;
+            if (u == 0 && row < Nw) {
+                if (EPI == 1) {
+                    o[row] = ps_silu_mul(ygate, y);
+                } else {
+                    float v = y;
+                    if (b) v = __fadd_rn(v, b[row]);
+                    if (p.residual && wi == 0) v = __fadd_rn(p.residual[row], v);
+                    o[row] = v;
+                }
+            }
+            acc0 = 0.f; acc1 = 0.f; accm = 0.f;
+            un = 0;
+            task++;
+        };
+        // whole chunks inside one row (and inside one half of a gate/up pair): the common shapes
+        const bool chunk_in_row = (WT == PS_Q4_K) && (tot % UPB == 0) && (EPI == 0 || n_units % UPB == 0);
+        for (int c = 0; c < 2 * n_rounds; c++) {
+            mark(); // chain wave: 3, 5, ...: waiting for chunk c
+            __syncthreads();
+            mark(); // 4, 6, ...: chunk c handed over
+            const Rec *rb = recs + (size_t)(c & 1) * UPB * 64 + lane;
+            if constexpr (WT == PS_Q4_K) {
+                if (chunk_in_row) { // every record and activation scale of the chunk in one LDS round trip, then a branch-free chain
+                    if (task < g1) {
+                        if (EPI == 1 && un == n_units) gate_done();
+                        const int ul = (EPI == 1 && un >= n_units) ? un - n_units : un;
+                        constexpr int KB = UPB <= 16 ? UPB : UPB / 2; // records per LDS round trip (register budget)
+#pragma unroll
+                        for (int kb = 0; kb < UPB; kb += KB) {
+                            Rec rc[KB];
+                            float yd[KB];
+#pragma unroll
+                            for (int k = 0; k < KB; k++) rc[k] = rb[(kb + k) * 64];
+#pragma unroll
+                            for (int k = 0; k < KB; k++) yd[k] = A.d[ul + kb + k];
+#pragma unroll
+                            for (int k = 0; k < KB; k++) { // d|dmin sits in the record of lane u + 4 (row_shl:4 within the row of 16)
+                                const int up       = __builtin_amdgcn_update_dpp(0, rc[k].y, 0x104, 0xf, 0xf, false);
+                                const uint32_t hdx = (uint32_t)(u < 4 ? up : rc[k].y);
+                                const float d      = __fmul_rn(yd[k], ps_h2f((uint16_t)(hdx & 0xffff)));
+                                const float dmin   = __fmul_rn(-yd[k], ps_h2f((uint16_t)(hdx >> 16)));
+                                acc0 = __fmaf_rn(d, (float)rc[k].x, acc0);
+                                accm = __fmaf_rn(dmin, (float)rc[k].y, accm); // lanes u >= 4: not an acc_m lane, never read
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                        un += UPB;
+                        if (un == tot) row_done();
+                    }
+                    continue;
+                }
+            }
+            // generic: rows (and the gate half of a gate/up pair) end on multiples of four units (host-checked), so
+            // the boundary work is tested once per four chain steps
+            auto step = [&](const Rec rc, const uint2 hd_k, const int ul) {
+                uint2 hk = hd_k;
+                if constexpr (WT == PS_Q4_K) {
+                    const int up = __builtin_amdgcn_update_dpp(0, rc.y, 0x104, 0xf, 0xf, false);
+                    hk = make_uint2((uint32_t)(u < 4 ? up : rc.y), 0);
+                }
+                rec_chain<WT>(rc, hk, ul, A, acc0, acc1, accm);
+            };
+#pragma unroll 1
+            for (int k0 = 0; k0 < UPB; k0 += 4) { // four records in flight per LDS round trip
+                if (task >= g1) break;
+                const Rec r0 = rb[(k0 + 0) * 64], r1 = rb[(k0 + 1) * 64], r2 = rb[(k0 + 2) * 64], r3 = rb[(k0 + 3) * 64];
+                uint2 h0 = make_uint2(0, 0), h1 = h0, h2 = h0, h3 = h0;
+                if constexpr (WT != PS_Q4_K) {
+                    const uint2 *hb = hdl + ((c & 1) * UPB + k0) * TR::RG + r;
+                    h0 = hb[0]; h1 = hb[TR::RG]; h2 = hb[2 * TR::RG]; h3 = hb[3 * TR::RG];
+                }
+                if (EPI == 1 && un == n_units) gate_done();
+                const int ul = (EPI == 1 && un >= n_units) ? un - n_units : un;
+                step(r0, h0, ul); step(r1, h1, ul + 1); step(r2, h2, ul + 2); step(r3, h3, ul + 3);
+                un += 4;
+                if (un == tot) row_done();
+            }
+        }
+    }
+    if (dbg) { dbg[31] = __builtin_amdgcn_s_memtime(); dbg[30] = __builtin_amdgcn_s_memrealtime(); } // 31: done
+}
+
+template <int WT, int UPW, int NW, int TPW, int EPI, int PRO>
+void launch_g3(hipStream_t st, int n_cu, const GemvParams &p) {
+    const int64_t n_tasks = (EPI == 1) ? p.w[0].n_groups : p.groups_total;
+    const size_t smem     = (size_t)p.col_bytes + (size_t)2 * NW * UPW * (64 * sizeof(typename RecOf<WT>::T) + (WT == PS_Q4_K ? 0 : WTraits<WT>::RG * 8));
+    static int occ = 0;
+    if (occ == 0) { // resident workgroups per CU for this instantiation (registers / LDS), queried once
+        (void)hipFuncSetAttribute((const void *)gemv3_kernel<WT, UPW, NW, TPW, EPI, PRO>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)gemv3_kernel<WT, UPW, NW, TPW, EPI, PRO>, (NW + 1) * 64, smem) != hipSuccess || nb < 1) nb = 1;
+        // a workgroup's waves are dealt to the four SIMDs starting from the same one: only whole multiples of
+        // four waves pack to the register-file limit (measured: 5-wave groups at 108 VGPRs ran 2 per CU, not 3)
+        const int by_waves = 16 / (((NW + 1 + 3) / 4) * 4);
+        occ = nb > by_waves ? by_waves : nb;
+        if (occ < 1) occ = 1;
+    }
+    int64_t grid      = n_tasks;
+    const int64_t cap = (int64_t)n_cu * occ;
+    if (grid > cap) grid = cap;
+    if (grid < 1) grid = 1;
+    GemvParams pd = p;
+    pd.split_q = (int)(n_tasks / grid);
+    pd.split_r = (int)(n_tasks % grid);
+    pd.dbg = (g_dbg_buf && g_dbg_key == EPI * 4 + PRO) ? g_dbg_buf : nullptr;
+    if (pd.dbg) (void)hipMemsetAsync(g_dbg_buf, 0, (size_t)G3_DBG_WGS * 64 * 8, st);
+    hipLaunchKernelGGL((gemv3_kernel<WT, UPW, NW, TPW, EPI, PRO>), dim3((unsigned)grid), dim3((NW + 1) * 64), smem, st, pd);
+}
+
+template <int WT, int UPW, int NW, int TPW>
+void launch_g3_ep(hipStream_t st, int n_cu, const GemvParams &p, int epi, int pro) {
+    if (epi == 1) {
+        if (pro == 1) launch_g3<WT, UPW, NW, TPW, 1, 1>(st, n_cu, p); else launch_g3<WT, UPW, NW, TPW, 1, 0>(st, n_cu, p);
+    } else {
+        if (pro == 0) launch_g3<WT, UPW, NW, TPW, 0, 0>(st, n_cu, p);
+        else if (pro == 1) launch_g3<WT, UPW, NW, TPW, 0, 1>(st, n_cu, p);
+        else launch_g3<WT, UPW, NW, TPW, 0, 2>(st, n_cu, p);
+    }
+}
+
+// Eight-wave workgroups (seven producers + the chain wave), two per CU.  Returns false when the activation row
+// does not fit the prologue's register tiles or the row length is not a multiple of four units (falls back).
+template <int WT>
+bool launch_g3_wt(hipStream_t st, int n_cu, const GemvParams &p, int epi, int pro) {
+    if (epi == 1 && pro == 2) return false;
+    const int n_units = (int)((p.K + WTraits<WT>::UNIT - 1) / WTraits<WT>::UNIT);
+    if (n_units % 4 != 0) return false; // the consumer tests row boundaries once per four units
+    const size_t rec = sizeof(typename RecOf<WT>::T) + 2; // (+ the Q8_0 / Q4_0 scale plane)
+    if ((size_t)p.col_bytes + 2 * 28 * 64 * rec > 150 * 1024) return false;
+    if (p.K <= 8 * 2 * 256) { launch_g3_ep<WT, 4, 7, 2>(st, n_cu, p, epi, pro); return true; }
+    if (p.K <= 8 * 7 * 256) { launch_g3_ep<WT, 4, 7, 7>(st, n_cu, p, epi, pro); return true; }
+    return false;
+}
+
 // returns false when the row is too long for the register-resident kernel (falls back to gemv_kernel)
 template <int WT>
 bool launch_g1_wt(hipStream_t st, int n_cu, const GemvParams &p, int epi, int pro) {
@@ -549,6 +958,7 @@ int launch_epi(hipStream_t st, int n_cu, const GemvParams &p, int epi, int pro) 
 
 template <int WT>
 int launch_wt(hipStream_t st, int n_cu, const GemvParams &p, int epi, int pro) {
+    if (p.bs == 1 && launch_g3_wt<WT>(st, n_cu, p, epi, pro)) return 0;
     if (p.bs == 1 && launch_g1_wt<WT>(st, n_cu, p, epi, pro)) return 0;
     if (p.bs == 1) return launch_epi<WT, 1>(st, n_cu, p, epi, pro);
     if (p.bs <= 4) return launch_epi<WT, 4>(st, n_cu, p, epi, pro);
@@ -556,6 +966,16 @@ int launch_wt(hipStream_t st, int n_cu, const GemvParams &p, int epi, int pro) {
 }
 
 } // namespace
+
+int psk_gemv_debug(int key, uint64_t *host_out, int n_words) {
+    if (!host_out) {
+        if (key >= 0 && !g_dbg_buf && hipMalloc((void **)&g_dbg_buf, (size_t)G3_DBG_WGS * 64 * 8) != hipSuccess) return 2;
+        g_dbg_key = key;
+        return 0;
+    }
+    if (!g_dbg_buf || n_words > G3_DBG_WGS * 64) return 1;
+    return hipMemcpy(host_out, g_dbg_buf, (size_t)n_words * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : 2;
+}
 
 size_t psk_gemv_lds_col_bytes(int wt, int64_t K) {
     const int64_t blk = (wt == PS_Q4_K) ? 256 : 32, unit = (wt == PS_Q4_K) ? 256 : 128;

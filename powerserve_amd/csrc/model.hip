@@ -120,8 +120,7 @@ static int enqueue_forward(ps_hip_model *m, int bs, bool lm_head, bool use_tree,
         aa.k_cache = m->k_cache[L]; aa.v_cache = m->v_cache[L];
         psl_rope_append(st, aa, bs);
         psl_attn_scores(st, aa, bs);
-        psl_attn_softmax(st, aa, bs);
-        psl_attn_pv(st, aa, bs);
+        psl_attn_softmax_pv(st, aa, bs);
 
         psk_gemv_args go{};
         go.n_w = 1; go.w[0] = m->wo[L]; go.out[0] = m->x; go.ldo[0] = dim; go.residual = m->x;
@@ -137,7 +136,7 @@ static int enqueue_forward(ps_hip_model *m, int bs, bool lm_head, bool use_tree,
         if (mm(m, gf, a1, dim, bs)) return 2;
         psk_gemv_args gd{};
         gd.n_w = 1; gd.w[0] = m->wd[L]; gd.out[0] = m->x; gd.ldo[0] = dim; gd.residual = m->x;
-        if (psk_gemv_lds_col_bytes(m->wd[L]->dtype, hid) * (bs == 1 ? 1 : 4) <= 64 * 1024 && hid <= 8192) {
+        if (psk_gemv_lds_col_bytes(m->wd[L]->dtype, hid) * (bs == 1 ? 1 : 4) <= 64 * 1024 && (hid <= 8192 || bs == 1)) {
             gd.pro = 2; gd.pro_x = m->hb; // short rows: quantize in the prologue
         } else {
             psk_quantize_act(st, vdt_d, 0, m->hb, nullptr, nullptr, 0.f, hid, bs, a2);
@@ -170,6 +169,7 @@ int ps_hip_model_create(ps_hip_ctx *c, const ps_model_desc *d, ps_hip_model **ou
     if (f.n_heads / f.n_kv_heads > 8) PS_FAIL(c, "model_create: GQA ratio > 8 not supported");
     if ((int)f.rope.n_dims != (int)f.head_size) PS_FAIL(c, "model_create: rope n_dims != head_size (reference asserts the same, norm_attention.cpp:38)");
     if (f.seq_len % 4) PS_FAIL(c, "model_create: n_ctx must be a multiple of 4");
+    if ((size_t)(f.n_heads / f.n_kv_heads) * f.seq_len * 4 + 16 * 1024 > 158 * 1024) PS_FAIL(c, "model_create: n_ctx too large for the LDS-resident softmax rows (cap n_ctx)");
     PS_CHECK(c, hipSetDevice(c->device));
     auto m = new ps_hip_model();
     m->ctx = c; m->cfg = f; m->qwen2 = d->is_qwen2 != 0; m->max_batch = d->max_batch > 0 ? d->max_batch : 1;

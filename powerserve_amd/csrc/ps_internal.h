@@ -113,4 +113,5 @@ struct psk_gemv_args {
 size_t psk_gemv_lds_col_bytes(int wt, int64_t K);
 static inline int64_t ps_w_rg(int dtype) { return dtype == PS_Q4_0 ? 16 : 8; }
 static inline int64_t ps_w_unit(int dtype) { return dtype == PS_Q4_K ? 256 : 128; }
+int psk_gemv_debug(int key, uint64_t *host_out, int n_words); // timeline buffer: arm / read back
 int psk_gemv(hipStream_t st, int n_cu, const psk_gemv_args &a, ps_act act, int vdt, int64_t K, int64_t bs);

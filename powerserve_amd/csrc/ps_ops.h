@@ -37,8 +37,8 @@ struct psl_attn_args {
 };
 void psl_rope_append(hipStream_t st, const psl_attn_args &a, int bs);
 void psl_attn_scores(hipStream_t st, const psl_attn_args &a, int bs);
-void psl_attn_softmax(hipStream_t st, const psl_attn_args &a, int bs);
-void psl_attn_pv(hipStream_t st, const psl_attn_args &a, int bs);
+void psl_attn_softmax_pv(hipStream_t st, const psl_attn_args &a, int bs);
+size_t psl_attn_softmax_pv_lds(const psl_attn_args &a); // dynamic LDS bytes (grows with n_ctx)
 // two-stage arg-max (64 partials per row).  With state != NULL the final stage also does the greedy-decode
 // bookkeeping: token[0] = id, ids[state->n_out++] = id, state->pos0++.
 void psl_argmax2(hipStream_t st, const float *src, int64_t n, int64_t rows, int32_t *out, float *part_v, int *part_i,

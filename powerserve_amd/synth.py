@@ -24,6 +24,7 @@ PRESETS = {
     "qwen2-0.5b": ("qwen2", 896, 4864, 24, 14, 2, 64, 151936, 1e6, 2, True, 1e-6),
     "llama-3.2-1b": ("llama", 2048, 8192, 16, 32, 8, 64, 128256, 5e5, 0, True, 1e-5),
     "llama-3.1-8b": ("llama", 4096, 14336, 32, 32, 8, 128, 128256, 5e5, 0, False, 1e-5),
+    "llama-8b-dims-4l": ("llama", 4096, 14336, 4, 32, 8, 128, 4096, 5e5, 0, False, 1e-5),  # kernel diagnostics
     # small shapes for parity tests (finish in seconds on the CPU oracle)
     "tiny-llama": ("llama", 256, 512, 2, 4, 2, 64, 512, 1e4, 0, False, 1e-5),
     "tiny-qwen2": ("qwen2", 256, 512, 2, 4, 2, 64, 512, 1e6, 2, True, 1e-6),

@@ -64,6 +64,25 @@ def test_mul_mat_quant(ctx, oracle, hip, wt, K, N, bs):
     W.free()
 
 
+@pytest.mark.parametrize("wt", [2, 8, 12])
+@pytest.mark.parametrize("K,N", [(4096, 14001), (2048, 9000), (14336, 7001)])
+def test_mul_mat_quant_many_row_groups(ctx, oracle, hip, wt, K, N):
+    """More row groups than resident workgroups: every workgroup streams several groups (uneven split, partial
+    last group), chunks straddle rows, and the chain consumer runs behind the producers for many rounds."""
+    from powerserve_amd import synth
+    rng = np.random.default_rng(wt * 77 + K + N)
+    w = synth.random_blocks(rng, wt, N, K)
+    x = rng.standard_normal((1, K)).astype(np.float32)
+    want = oracle.mul_mat(wt, w, K, N, x)
+    W = ctx.upload_weight(wt, w, K, N)
+    dx, dy = ctx.to_device(x), ctx.empty((1, N))
+    for _ in range(3):  # repeated launches: no state may leak between them
+        ctx.check(ctx.L.ps_hip_mul_mat(ctx.h, C.byref(dy.tensor()), C.byref(W.tensor()), C.byref(dx.tensor())))
+        got = dy.numpy()
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (rel_err(got, want), np.flatnonzero(got != want)[:8])
+    W.free()
+
+
 def test_mul_mat_f32_gqa_views(ctx, oracle, hip):
     """K-cache view x permuted q (norm_attention.cpp:115-129) and V-cache view x kq (:138-147)."""
     rng = np.random.default_rng(7)

@@ -19,6 +19,14 @@ def main():
     cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
     namecol = "name" if "name" in cols else "kernel_name"
     rows = list(cur.execute(f"select {namecol}, start, end from kernels"))
+    if "--decode" in sys.argv:  # keep the greedy-decode window: from the first arg-max to the roofline replay's first empty launch
+        sys.argv.remove("--decode")
+        t0 = min((s for n, s, e in rows if "argmax_partial" in n), default=0)
+        t1 = min((s for n, s, e in rows if "null_kernel" in n), default=1 << 62)
+        rows = [r for r in rows if t0 <= r[1] < t1]
+        nsteps = sum(1 for n, s, e in rows if "argmax_final" in n)
+        span = (max(e for n, s, e in rows) - t0) / 1e6
+        print(f"decode window: {nsteps} steps, {span:.3f} ms wall -> {span / max(nsteps, 1):.3f} ms/step (eager)")
     agg = {}
     for n, s, e in rows:
         a = agg.setdefault(short(n), [0, 0, 1 << 62, 0])
