@@ -101,33 +101,67 @@ __global__ __launch_bounds__(256) void attn_scores_kernel(psl_attn_args a) {
 // four V rows of this workgroup are streamed through LDS in tiles with every thread's loads in flight at once, and
 // 8 half-waves run the 32-lane fp32 chains of ggml_vec_dot_f32 in position order (chain state stays in registers
 // across tiles), then GGML_F32x8_REDUCE and the n_kv % 32 leftovers.
-constexpr int PV_TILE = 1024;
-__global__ __launch_bounds__(256) void attn_softmax_pv_kernel(psl_attn_args a) {
-    extern __shared__ __attribute__((aligned(16))) float pl[]; // [r2][n_kv4] probabilities, then [4][PV_TILE] V tile
+constexpr int PV_TILE = 2560;          // V columns per LDS tile (4 channels x PV_TILE floats)
+constexpr int PV_VSTR = PV_TILE + 32;  // row stride: the two half-waves of a wave read different channels -> disjoint banks
+constexpr int PV_NT   = 1024;          // one workgroup per CU
+constexpr int PV_NW   = PV_NT / 64;
+constexpr int PV_LPT  = (4 * PV_TILE / 4 + PV_NT - 1) / PV_NT; // float4 V loads per thread and tile
+// Fused softmax + V·p for one (4-channel group, kv head, batch column): grid (hs/4, n_kv_heads, bs), 1024 threads.
+//   t = 0   the first V tile and every score of the r2 rows are requested together (independent streams)
+//   phase 1 exact softmax numerators e_j (ggml_vec_soft_max_f32, ggml.c:2831-2866: ggml_v_expf on groups of 8 with
+//           the in-group sum tree, libm expf on the n%8 tail, double sum), rows spread over the 16 waves
+//   phase 2 out[h][d] = ggml_vec_dot_f32(V[d], p[h]) (ggml.c:2126-2160): 32 fma chains over columns 32i+c, one lane
+//           each, p_j = e_j * (float)(1/sum) formed at the read (same rounding as the reference's scale pass),
+//           GGML_F32x8_REDUCE tree, n%32 leftovers (mul, add).  V comes through LDS tiles (prefetched one ahead).
+__global__ __launch_bounds__(PV_NT) void attn_softmax_pv_kernel(psl_attn_args a) {
+    extern __shared__ __attribute__((aligned(16))) float pl[]; // [r2][n_ctx4] e_j, then [4][PV_VSTR] V tile
     const int hs = a.head_size, dim = a.n_heads * hs, r2 = a.n_heads / a.n_kv_heads;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int kvh = blockIdx.y, i = blockIdx.z, bs = a.state->bs, pos0 = a.state->pos0;
     const int n_kv = pos0 + bs, n8 = n_kv & ~7, np = n_kv & ~31, n_kv4 = (n_kv + 3) & ~3;
     float *vt = pl + (size_t)r2 * (((size_t)a.n_ctx + 3) & ~(size_t)3);
-    __shared__ float redf[R2MAX][4];
-    __shared__ double redd[R2MAX][4];
-    // ---- phase 1: softmax of the r2 rows, all 256 threads, every row's loads in flight together
-    constexpr int EPT = 4; // elements per thread per row per trip
+    __shared__ float redf[R2MAX][PV_NW];
+    __shared__ double redd[R2MAX][PV_NW];
+    __shared__ float invs[R2MAX];
+
+    // ---- V tile loads (registers -> LDS), one tile ahead of the chains
+    const float *vbase = a.v_cache + ((int64_t)kvh * hs + blockIdx.x * 4) * a.n_ctx;
+    float4 ld[PV_LPT];
+    auto load_tile = [&](int t0) { // columns [t0, t0 + PV_TILE) of the 4 channel rows (zero past n_kv)
+#pragma unroll
+        for (int k = 0; k < PV_LPT; k++) {
+            const int f = threadIdx.x + PV_NT * k, row = f / (PV_TILE / 4), col = (f % (PV_TILE / 4)) * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < 4 && t0 + col < n_kv4) v = *(const float4 *)(vbase + (int64_t)row * a.n_ctx + t0 + col); // n_kv4 <= n_ctx4: in bounds
+            ld[k] = v;
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int k = 0; k < PV_LPT; k++) {
+            const int f = threadIdx.x + PV_NT * k, row = f / (PV_TILE / 4), col = (f % (PV_TILE / 4)) * 4;
+            if (row < 4) *(float4 *)(vt + row * PV_VSTR + col) = ld[k];
+        }
+    };
+    load_tile(0);
+
+    // ---- phase 1a: scores -> masked, scaled logits in LDS; row maxima
+    constexpr int EPT = 3; // elements per thread, row and trip: one trip covers n_kv <= 3072
     float rmax[R2MAX];
 #pragma unroll
     for (int g = 0; g < R2MAX; g++) rmax[g] = -INFINITY;
-    for (int j0 = threadIdx.x; j0 < n_kv; j0 += 256 * EPT) {
+    for (int j0 = threadIdx.x; j0 < n_kv; j0 += PV_NT * EPT) {
         float sv[R2MAX][EPT];
 #pragma unroll
         for (int g = 0; g < R2MAX; g++)
 #pragma unroll
             for (int t = 0; t < EPT; t++) {
-                const int j = j0 + 256 * t;
+                const int j = j0 + PV_NT * t;
                 sv[g][t] = (g < r2 && j < n_kv) ? a.scores[((int64_t)i * a.n_heads + (int64_t)kvh * r2 + g) * a.n_ctx + j] : 0.f;
             }
 #pragma unroll
         for (int t = 0; t < EPT; t++) {
-            const int j = j0 + 256 * t;
+            const int j = j0 + PV_NT * t;
             if (j < n_kv) {
                 const bool ok = (j < pos0) ? true : (a.tree ? a.tree[i * bs + (j - pos0)] != 0 : (j - pos0) <= i);
 #pragma unroll
@@ -147,14 +181,20 @@ __global__ __launch_bounds__(256) void attn_softmax_pv_kernel(psl_attn_args a) {
         if (g < r2) { const float m = wave_max_dpp(rmax[g]); if (lane == 0) redf[g][wave] = m; }
     }
     __syncthreads();
-    double rsum[R2MAX];
-#pragma unroll
-    for (int g = 0; g < R2MAX; g++) {
-        rsum[g] = 0.0;
+    // ---- phase 1b: e_j = exp(x_j - max), row sums.  r2 | 16: wave w works on row w % r2 with 16/r2 - 1 others,
+    //      else one wave per row
+    const bool split = (PV_NW % r2) == 0;
+    const int wpr    = split ? PV_NW / r2 : 1;
+    {
+        const int g = split ? wave % r2 : wave, sub = split ? wave / r2 : 0;
         if (g < r2) {
-            const float mx = fmaxf(fmaxf(redf[g][0], redf[g][1]), fmaxf(redf[g][2], redf[g][3]));
+            const int slot = sub * 64 + lane, nthr = wpr * 64;
+            float mx = redf[g][0];
+#pragma unroll
+            for (int w = 1; w < PV_NW; w++) mx = fmaxf(mx, redf[g][w]);
             float *pg = pl + (size_t)g * n_kv4;
-            for (int gi = threadIdx.x; gi * 8 < n8; gi += 256) { // one lane per group of 8: the reference's in-group association
+            double rs = 0.0;
+            for (int gi = slot; gi * 8 < n8; gi += nthr) { // one lane per group of 8: the reference's in-group association
                 const float4 lo = *(const float4 *)(pg + gi * 8), hi = *(const float4 *)(pg + gi * 8 + 4);
                 float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
 #pragma unroll
@@ -162,70 +202,56 @@ __global__ __launch_bounds__(256) void attn_softmax_pv_kernel(psl_attn_args a) {
                 *(float4 *)(pg + gi * 8)     = make_float4(v[0], v[1], v[2], v[3]);
                 *(float4 *)(pg + gi * 8 + 4) = make_float4(v[4], v[5], v[6], v[7]);
                 const float a0 = __fadd_rn(v[4], v[0]), a1 = __fadd_rn(v[5], v[1]), a2 = __fadd_rn(v[6], v[2]), a3 = __fadd_rn(v[7], v[3]);
-                rsum[g] += (double)__fadd_rn(__fadd_rn(a0, a2), __fadd_rn(a1, a3));
+                rs += (double)__fadd_rn(__fadd_rn(a0, a2), __fadd_rn(a1, a3));
             }
-            if (threadIdx.x == 255)
-                for (int j = n8; j < n_kv; j++) { const float e = ps_expf_glibc(__fsub_rn(pg[j], mx)); pg[j] = e; rsum[g] += (double)e; }
-            const double sw = wave_sum_d_dpp(rsum[g]);
-            if (lane == 0) redd[g][wave] = sw;
+            if (slot == 0)
+                for (int j = n8; j < n_kv; j++) { const float e = ps_expf_glibc(__fsub_rn(pg[j], mx)); pg[j] = e; rs += (double)e; }
+            const double sw = wave_sum_d_dpp(rs);
+            if (lane == 0) redd[g][sub] = sw;
         }
     }
     __syncthreads();
-#pragma unroll
-    for (int g = 0; g < R2MAX; g++) {
-        if (g < r2) {
-            const float inv = (float)(1.0 / ((redd[g][0] + redd[g][1]) + (redd[g][2] + redd[g][3])));
-            float *pg = pl + (size_t)g * n_kv4;
-            for (int j = threadIdx.x; j < n_kv; j += 256) pg[j] = __fmul_rn(pg[j], inv);
-        }
+    if (threadIdx.x < r2) {
+        double t = 0.0;
+        for (int w = 0; w < wpr; w++) t += redd[threadIdx.x][w];
+        invs[threadIdx.x] = (float)(1.0 / t);
     }
-    // ---- phase 2: V·p.  half-wave hw: channel d = blockIdx.x*4 + (hw & 3), heads (hw >> 2), (hw >> 2) + 2, ...
-    const int c = threadIdx.x & 31, hw = threadIdx.x >> 5, dl = hw & 3, g0 = hw >> 2;
-    const int d = blockIdx.x * 4 + dl;
-    const float *vbase = a.v_cache + ((int64_t)kvh * hs + blockIdx.x * 4) * a.n_ctx;
-    float acc[R2MAX / 2];
-#pragma unroll
-    for (int k = 0; k < R2MAX / 2; k++) acc[k] = 0.f;
-    float4 ld[4];
-    auto load_tile = [&](int t0) { // 4 rows x PV_TILE floats = 1024 float4 = 4 per thread, all in flight
-        const int tn = min(PV_TILE, np - t0);
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int f = threadIdx.x + 256 * k, row = f >> 8, col = (f & 255) * 4;
-            ld[k] = (col < tn) ? *(const float4 *)(vbase + (int64_t)row * a.n_ctx + t0 + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+    store_tile();
+    __syncthreads();
+
+    // ---- phase 2: V·p.  thread: chain c = tid & 31, channel dl = (tid >> 5) & 3, head g = tid >> 7
+    const int c = threadIdx.x & 31, dl = (threadIdx.x >> 5) & 3, g = threadIdx.x >> 7;
+    const bool live = g < r2;
+    const float inv = live ? invs[g] : 0.f;
+    const float *pg = pl + (size_t)(live ? g : 0) * n_kv4;
+    const float *vr = vt + dl * PV_VSTR;
+    float acc = 0.f, out = 0.f;
+    for (int t0 = 0; t0 < n_kv; t0 += PV_TILE) {
+        const int tn = min(PV_TILE, np - t0); // chain columns of this tile (multiple of 32, may be <= 0 on a leftover-only tile)
+        if (t0 > 0) {
+            __syncthreads(); // previous tile consumed
+            store_tile();
+            __syncthreads();
         }
-    };
-    if (np > 0) load_tile(0);
-    for (int t0 = 0; t0 < np; t0 += PV_TILE) {
-        const int tn = min(PV_TILE, np - t0); // multiple of 32
-        __syncthreads(); // probabilities complete (first trip) / previous tile fully consumed
+        if (t0 + PV_TILE < n_kv) load_tile(t0 + PV_TILE); // next tile streams in while this one is consumed
+        if (live) {
+            int j = c;
+            for (; j + 7 * 32 < tn; j += 8 * 32) { // eight LDS round trips in flight per chain step group
+                float v[8], e[8];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int f = threadIdx.x + 256 * k, row = f >> 8, col = (f & 255) * 4;
-            *(float4 *)(vt + row * PV_TILE + col) = ld[k];
-        }
-        __syncthreads();
-        if (t0 + PV_TILE < np) load_tile(t0 + PV_TILE); // next tile streams in while this one is consumed
-        for (int j = c; j < tn; j += 32) {
-            const float v = vt[dl * PV_TILE + j];
+                for (int k = 0; k < 8; k++) { v[k] = vr[j + 32 * k]; e[k] = pg[t0 + j + 32 * k]; }
 #pragma unroll
-            for (int k = 0; k < R2MAX / 2; k++) {
-                const int g = g0 + 2 * k;
-                if (g < r2) acc[k] = __fmaf_rn(v, pl[(size_t)g * n_kv4 + t0 + j], acc[k]); // x = V row (src0), y = p
+                for (int k = 0; k < 8; k++) acc = __fmaf_rn(v[k], __fmul_rn(e[k], inv), acc); // x = V row (src0), y = p
+            }
+            for (; j < tn; j += 32) acc = __fmaf_rn(vr[j], __fmul_rn(pg[t0 + j], inv), acc);
+            if (t0 + PV_TILE >= n_kv) { // last tile: reduce the 32 chains, then the n%32 leftovers in order
+                float sres = reduce_f32x8x4(acc);
+                for (int jj = np; jj < n_kv; jj++) sres = __fadd_rn(sres, __fmul_rn(vr[jj - t0], __fmul_rn(pg[jj], inv)));
+                out = sres;
             }
         }
     }
-    if (np == 0) __syncthreads();
-    const float *vr = a.v_cache + ((int64_t)kvh * hs + d) * a.n_ctx;
-#pragma unroll
-    for (int k = 0; k < R2MAX / 2; k++) {
-        const int g = g0 + 2 * k;
-        if (g < r2) {
-            float s = reduce_f32x8x4(acc[k]);
-            for (int j = np; j < n_kv; j++) s = __fadd_rn(s, __fmul_rn(vr[j], pl[(size_t)g * n_kv4 + j])); // leftovers
-            if (c == 0) a.att[(int64_t)i * dim + ((int64_t)kvh * r2 + g) * hs + d] = s;
-        }
-    }
+    if (live && c == 0) a.att[(int64_t)i * dim + ((int64_t)kvh * r2 + g) * hs + blockIdx.x * 4 + dl] = out;
 }
 
 // ---------------------------------------------------------------- arg-max, first maximum (prob_array.cpp:65-67)
@@ -288,13 +314,13 @@ void psl_attn_scores(hipStream_t st, const psl_attn_args &a, int bs) {
 
 size_t psl_attn_softmax_pv_lds(const psl_attn_args &a) {
     const int r2 = a.n_heads / a.n_kv_heads;
-    return ((size_t)r2 * (((size_t)a.n_ctx + 3) & ~(size_t)3) + 4 * PV_TILE) * 4;
+    return ((size_t)r2 * (((size_t)a.n_ctx + 3) & ~(size_t)3) + 4 * PV_VSTR) * 4;
 }
 void psl_attn_softmax_pv(hipStream_t st, const psl_attn_args &a, int bs) {
     static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void *)attn_softmax_pv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512); attr = true; }
+    if (!attr) { (void)hipFuncSetAttribute((const void *)attn_softmax_pv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024); attr = true; }
     dim3 g((unsigned)(a.head_size / 4), (unsigned)a.n_kv_heads, (unsigned)bs);
-    hipLaunchKernelGGL(attn_softmax_pv_kernel, g, dim3(256), psl_attn_softmax_pv_lds(a), st, a);
+    hipLaunchKernelGGL(attn_softmax_pv_kernel, g, dim3(PV_NT), psl_attn_softmax_pv_lds(a), st, a);
 }
 
 void psl_argmax2(hipStream_t st, const float *src, int64_t n, int64_t rows, int32_t *out, float *part_v, int *part_i,

@@ -652,9 +652,11 @@ __global__ __launch_bounds__((NW + 1) * 64, 4) void gemv3_kernel(const GemvParam
     const uint32_t lane16 = (uint32_t)lane * 16u, raux = (uint32_t)r * AUXR;
     unsigned long long *const dbg = (p.dbg && blockIdx.x < G3_DBG_WGS && lane == 0 && (wave == 0 || wave == NW)) ? p.dbg + ((size_t)blockIdx.x * 2 + (wave == NW)) * 32 : nullptr;
     int dbg_n = 0;
-    auto mark = [&]() { if (dbg && dbg_n < 32) dbg[dbg_n++] = __builtin_amdgcn_s_memtime(); };
+    auto mark = [&]() { if (dbg && dbg_n < 20) dbg[dbg_n++] = __builtin_amdgcn_s_memtime(); };
+    auto mark_at = [&](int i) { if (dbg) dbg[i] = __builtin_amdgcn_s_memtime(); }; // 20..28: start-up detail
     mark(); // 0: entry
     if (dbg) dbg[29] = __builtin_amdgcn_s_memrealtime(); // 29/30: 100 MHz reference at entry / exit
+    if (n_chunks > 0) mark_at(20); // kernel arguments have arrived
 
     // matrices of the launch, in scalar registers
     const G3Mats mats{p.w[0].qs, p.w[1].qs, p.w[2].qs, p.w[0].aux, p.w[1].aux, p.w[2].aux,
@@ -712,6 +714,7 @@ __global__ __launch_bounds__((NW + 1) * 64, 4) void gemv3_kernel(const GemvParam
     // activation row first, the first chunks of weights right behind it (vmcnt retires in order: the prologue
     // only waits for the L2-resident activation while the weights stream in)
     if (PRO != 0) ps_qrow_load<(PRO == 1 ? 1 : 0), TPW>(p.x, p.nw, K, xv, wv);
+    mark_at(21); // activation loads issued
 #pragma unroll
     for (int i = 0; i < UPW; i++) {
         int sa = min(wave, NW - 1) * UPW + i, ta = g0;
@@ -721,7 +724,9 @@ __global__ __launch_bounds__((NW + 1) * 64, 4) void gemv3_kernel(const GemvParam
         tA[i] = ta; uA[i] = sa;
         tB[i] = tb; uB[i] = sb;
     }
+    mark_at(22); // slots placed
     issue(qA, hA, tA, uA, true); // (g1 == g0 cannot happen: the grid never exceeds the number of row groups)
+    mark_at(23); // chunk A issued
     constexpr bool B_EARLY = (PRO == 0) || (TPW <= 2); // otherwise the prologue needs the registers
     if (B_EARLY) issue(qB, hB, tB, uB, n_chunks > 1);
     mark(); // 1: loads issued

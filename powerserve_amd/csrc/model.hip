@@ -169,7 +169,8 @@ int ps_hip_model_create(ps_hip_ctx *c, const ps_model_desc *d, ps_hip_model **ou
     if (f.n_heads / f.n_kv_heads > 8) PS_FAIL(c, "model_create: GQA ratio > 8 not supported");
     if ((int)f.rope.n_dims != (int)f.head_size) PS_FAIL(c, "model_create: rope n_dims != head_size (reference asserts the same, norm_attention.cpp:38)");
     if (f.seq_len % 4) PS_FAIL(c, "model_create: n_ctx must be a multiple of 4");
-    if ((size_t)(f.n_heads / f.n_kv_heads) * f.seq_len * 4 + 16 * 1024 > 158 * 1024) PS_FAIL(c, "model_create: n_ctx too large for the LDS-resident softmax rows (cap n_ctx)");
+    if ((size_t)(f.n_heads / f.n_kv_heads) * f.seq_len * 4 + 44 * 1024 > 158 * 1024) PS_FAIL(c, "model_create: n_ctx too large for the LDS-resident softmax rows (cap n_ctx)");
+    if (f.n_heads / f.n_kv_heads > 8) PS_FAIL(c, "model_create: more than 8 query heads per kv head");
     PS_CHECK(c, hipSetDevice(c->device));
     auto m = new ps_hip_model();
     m->ctx = c; m->cfg = f; m->qwen2 = d->is_qwen2 != 0; m->max_batch = d->max_batch > 0 ? d->max_batch : 1;
