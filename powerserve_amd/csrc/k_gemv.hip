@@ -23,6 +23,7 @@
 #include <type_traits>
 #include "ps_dev.h"
 #include "ps_internal.h"
+#include "ps_ops.h"
 #include "ps_quant_dev.h"
 
 namespace {
@@ -49,6 +50,7 @@ struct GemvParams {
     const int16_t *abs16;
     unsigned long long *dbg; // timeline buffer or null (ps_hip_debug_timeline)
     int split_q, split_r;    // gemv3: row groups per workgroup = split_q (+1 for the first split_r workgroups)
+    psk_rope_kv rope;        // EPI 2
 };
 
 template <int WT> struct WTraits;
@@ -529,7 +531,7 @@ __device__ __forceinline__ void g3_locate(const G3Mats m, int task, int un, cons
     int grp = task;
     const uint8_t *qb = m.qs0, *ab = m.ax0;
     ul = un;
-    if (EPI == 0) {
+    if (EPI != 1) {
         if (m.n_w > 1 && grp >= m.ng0) {
             grp -= m.ng0; qb = m.qs1; ab = m.ax1;
             if (m.n_w > 2 && grp >= m.ng1) { grp -= m.ng1; qb = m.qs2; ab = m.ax2; }
@@ -591,7 +593,7 @@ template <int WT>
 __device__ __forceinline__ void rec_chain(const typename RecOf<WT>::T rc, const uint2 hd, const int unit, const LAct a,
                                           float &acc0, float &acc1, float &accm) {
     if constexpr (WT == PS_Q4_K) {
-        const float yd   = a.d[unit];
+        const float yd   = __uint_as_float(hd.y); // == a.d[unit], read by the caller together with the records
         const float d    = __fmul_rn(yd, ps_h2f((uint16_t)(hd.x & 0xffff)));
         const float dmin = __fmul_rn(-yd, ps_h2f((uint16_t)(hd.x >> 16)));
         acc0 = __fmaf_rn(d, (float)rc.x, acc0);
@@ -612,12 +614,15 @@ __device__ __forceinline__ void rec_chain(const typename RecOf<WT>::T rc, const 
     }
 }
 
+constexpr int g3_waves(int nw) { return nw + (nw >= 12 ? 2 : 1); } // producers + chain waves
+
 template <int WT, int UPW, int NW, int TPW, int EPI, int PRO>
-__global__ __launch_bounds__((NW + 1) * 64, 4) void gemv3_kernel(const GemvParams p) {
+__global__ __launch_bounds__(g3_waves(NW) * 64, 4) void gemv3_kernel(const GemvParams p) {
+    constexpr int NC = g3_waves(NW) - NW; // chain waves: rows alternate between them
     using TR  = WTraits<WT>;
     using Rec = typename RecOf<WT>::T;
     constexpr int UPB = NW * UPW; // units per chunk
-    // TPW: prologue tiles per wave, K <= (NW+1)*TPW*256
+    // TPW: prologue tiles per wave, K <= g3_waves(NW)*TPW*256
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ double red[16];
     const int lane = threadIdx.x & 63;
@@ -653,7 +658,7 @@ __global__ __launch_bounds__((NW + 1) * 64, 4) void gemv3_kernel(const GemvParam
     unsigned long long *const dbg = (p.dbg && blockIdx.x < G3_DBG_WGS && lane == 0 && (wave == 0 || wave == NW)) ? p.dbg + ((size_t)blockIdx.x * 2 + (wave == NW)) * 32 : nullptr;
     int dbg_n = 0;
     auto mark = [&]() { if (dbg && dbg_n < 20) dbg[dbg_n++] = __builtin_amdgcn_s_memtime(); };
-    auto mark_at = [&](int i) { if (dbg) dbg[i] = __builtin_amdgcn_s_memtime(); }; // 20..28: start-up detail
+    auto mark_at = [&](int i) { if (dbg && wave == 0) dbg[i] = __builtin_amdgcn_s_memtime(); }; // 20..28: start-up detail
     mark(); // 0: entry
     if (dbg) dbg[29] = __builtin_amdgcn_s_memrealtime(); // 29/30: 100 MHz reference at entry / exit
     if (n_chunks > 0) mark_at(20); // kernel arguments have arrived
@@ -683,9 +688,9 @@ __global__ __launch_bounds__((NW + 1) * 64, 4) void gemv3_kernel(const GemvParam
             int ul;
             locate(min(t[i], g1 - 1), un[i], qg, ag, ul);
             if (!live) { qg = mats.qs0; ag = mats.ax0; }
-            const ps_u32x4 *qp = (const ps_u32x4 *)(qg + lane16);
+            const ps_u32x4 *qp = (const ps_u32x4 *)(qg + (live ? lane16 : 0u)); // not live: every lane the same 16 bytes
             q[i] = __builtin_nontemporal_load(qp);
-            h[i] = *(const HT *)(ag + raux);
+            h[i] = *(const HT *)(ag + (live ? raux : 0u));
         }
     };
     // unit i of a chunk is waited for on its own: the partials start when the first KiB lands, and the compiler
@@ -710,45 +715,44 @@ __global__ __launch_bounds__((NW + 1) * 64, 4) void gemv3_kernel(const GemvParam
         }
     };
 
-    float4 xv[TPW], wv[TPW];
-    // activation row first, the first chunks of weights right behind it (vmcnt retires in order: the prologue
-    // only waits for the L2-resident activation while the weights stream in)
-    if (PRO != 0) ps_qrow_load<(PRO == 1 ? 1 : 0), TPW>(p.x, p.nw, K, xv, wv);
-    mark_at(21); // activation loads issued
+    if (wave < NW) { // ---------------- producers (the chain waves never touch the vector-memory queue before their stores)
+        float4 xv[TPW], wv[TPW];
+        // activation row first, the first chunks of weights right behind it (vmcnt retires in order: the prologue
+        // only waits for the L2-resident activation while the weights stream in)
+        if (PRO != 0) ps_qrow_load<(PRO == 1 ? 1 : 0), TPW>(p.x, p.nw, K, xv, wv, NW);
+        mark_at(21); // activation loads issued
 #pragma unroll
-    for (int i = 0; i < UPW; i++) {
-        int sa = min(wave, NW - 1) * UPW + i, ta = g0;
-        while (sa >= tot) { sa -= tot; ta++; }
-        int sb = sa + UPB, tb = ta;
-        while (sb >= tot) { sb -= tot; tb++; }
-        tA[i] = ta; uA[i] = sa;
-        tB[i] = tb; uB[i] = sb;
-    }
-    mark_at(22); // slots placed
-    issue(qA, hA, tA, uA, true); // (g1 == g0 cannot happen: the grid never exceeds the number of row groups)
-    mark_at(23); // chunk A issued
-    constexpr bool B_EARLY = (PRO == 0) || (TPW <= 2); // otherwise the prologue needs the registers
-    if (B_EARLY) issue(qB, hB, tB, uB, n_chunks > 1);
-    mark(); // 1: loads issued
-    { // activation -> LDS once per workgroup
+        for (int i = 0; i < UPW; i++) {
+            int sa = wave * UPW + i, ta = g0;
+            while (sa >= tot) { sa -= tot; ta++; }
+            int sb = sa + UPB, tb = ta;
+            while (sb >= tot) { sb -= tot; tb++; }
+            tA[i] = ta; uA[i] = sa;
+            tB[i] = tb; uB[i] = sb;
+        }
+        mark_at(22); // slots placed
+        issue(qA, hA, tA, uA, true); // (g1 > g0 always: the grid never exceeds the number of row groups)
+        mark_at(23); // chunk A issued
+        constexpr bool B_EARLY = (PRO == 0) || (TPW <= 2); // otherwise the prologue needs the registers
+        if (B_EARLY) issue(qB, hB, tB, uB, n_chunks > 1);
+        mark(); // 1: loads issued
+        // activation -> LDS once per workgroup
         if (Kp != K) {
-            for (int i = (int)K + threadIdx.x * 4; i < Kp; i += (NW + 1) * 64 * 4) *(int *)(lq + i) = 0;
-            for (int i = nblk_k + threadIdx.x; i < nblk; i += (NW + 1) * 64) ld[i] = 0.f;
-            for (int i = nb16_k + threadIdx.x; i < nb16; i += (NW + 1) * 64) l16[i] = 0;
+            for (int i = (int)K + threadIdx.x * 4; i < Kp; i += NW * 64 * 4) *(int *)(lq + i) = 0;
+            for (int i = nblk_k + threadIdx.x; i < nblk; i += NW * 64) ld[i] = 0.f;
+            for (int i = nb16_k + threadIdx.x; i < nb16; i += NW * 64) l16[i] = 0;
         }
         if (PRO == 0) {
-            for (int64_t i = threadIdx.x * 16; i < K; i += (NW + 1) * 64 * 16) *(int4 *)(lq + i) = *(const int4 *)(p.aq + i);
-            for (int i = threadIdx.x; i < nblk_k; i += (NW + 1) * 64) ld[i] = p.ad[i];
-            for (int i = threadIdx.x; i < nb16_k; i += (NW + 1) * 64) l16[i] = p.abs16[i];
+            for (int64_t i = threadIdx.x * 16; i < K; i += NW * 64 * 16) *(int4 *)(lq + i) = *(const int4 *)(p.aq + i);
+            for (int i = threadIdx.x; i < nblk_k; i += NW * 64) ld[i] = p.ad[i];
+            for (int i = threadIdx.x; i < nb16_k; i += NW * 64) l16[i] = p.abs16[i];
             __syncthreads();
         } else {
-            ps_qrow_compute<TR::VDT, (PRO == 1 ? 1 : 0), TPW>(xv, wv, p.eps, K, lq, ld, l16, red);
+            ps_qrow_compute<TR::VDT, (PRO == 1 ? 1 : 0), TPW>(xv, wv, p.eps, K, lq, ld, l16, red, NW);
         }
-        for (int i = threadIdx.x; i < nb32; i += (NW + 1) * 64) lb[i] = (int)l16[2 * i] + (int)l16[2 * i + 1];
+        for (int i = threadIdx.x; i < nb32; i += NW * 64) lb[i] = (int)l16[2 * i] + (int)l16[2 * i + 1];
         __syncthreads();
-    }
-    mark(); // 2: activation in LDS
-    if (wave < NW) { // ---------------- producers
+        mark(); // 2: activation in LDS
         if (!B_EARLY) issue(qB, hB, tB, uB, n_chunks > 1);
         for (int rd = 0; rd < n_rounds; rd++) { // chunk 2rd from A, 2rd+1 from B
             produce(qA, hA, uA, 0);
@@ -762,10 +766,21 @@ __global__ __launch_bounds__((NW + 1) * 64, 4) void gemv3_kernel(const GemvParam
             issue(qB, hB, tB, uB, 2 * rd + 3 < n_chunks);
             __syncthreads();
         }
-    } else { // ---------------- consumer: fp32 chains in unit order, one chunk behind the producers
-        __builtin_amdgcn_s_setprio(3); // one wave serves NW producers: it gets the issue slots first
+    } else { // ---------------- chain waves: fp32 chains in unit order, one chunk behind the producers
+        // the prologue's barriers, nothing else (ps_qrow_compute: one after the sum of squares, one at its end)
+        if (PRO == 1) {
+            if (lane == 0) red[wave] = 0.0;
+            __syncthreads();
+        }
+        __syncthreads();
+        __syncthreads();
+        mark();
+        mark();
+        __builtin_amdgcn_s_setprio(3); // few waves serve NW producers: they get the issue slots first
+        const int cid = wave - NW;      // this chain wave owns the rows with (task - g0) % NC == cid
         float acc0 = 0.f, acc1 = 0.f, accm = 0.f, ygate = 0.f;
         int task = g0, un = 0;
+        auto mine = [&]() { return NC == 1 || ((task - g0) % NC) == cid; };
         auto gate_done = [&]() { // gate row finished: reduce it, restart the chains for the up row
             ygate = row_reduce<WT>(acc0, acc1, accm);
             acc0 = 0.f; acc1 = 0.f; accm = 0.f;
@@ -773,7 +788,7 @@ __global__ __launch_bounds__((NW + 1) * 64, 4) void gemv3_kernel(const GemvParam
         auto row_done = [&]() {
             const float y = row_reduce<WT>(acc0, acc1, accm);
             int wi = 0, grp = task;
-            if (EPI == 0) {
+            if (EPI != 1) {
                 if (n_w > 1 && grp >= ng0) { grp -= ng0; wi = 1; }
                 if (n_w > 2 && wi == 1 && grp >= ng1) { grp -= ng1; wi = 2; }
             }
@@ -783,7 +798,29 @@ __global__ __launch_bounds__((NW + 1) * 64, 4) void gemv3_kernel(const GemvParam
             if (wi == 1) { Nw = p.w[1].N; o = p.w[1].out; b = p.w[1].bias; }
             if (wi == 2) { Nw = p.w[2].N; o = p.w[2].out; b = p.w[2].bias; }
             const int64_t row = (int64_t)grp * TR::RG + r;
-            if (u == 0 && row < Nw) {
+            if constexpr (EPI == 2) { // q / k: rotate adjacent pairs (rows 2i, 2i+1 sit in neighbouring lane groups); v: transpose-append
+                float v = y;
+                if (b && row < Nw) v = __fadd_rn(v, b[row]);
+                constexpr int LPR = 64 / TR::RG; // lanes per row
+                const float vp = __shfl_xor(v, LPR, 64);
+                const psk_rope_kv &R = p.rope;
+                const int pos = R.state->pos0;
+                if (u == 0 && row < Nw) {
+                    if (wi == 2) {
+                        R.v_cache[row * R.n_ctx + pos] = v;
+                    } else {
+                        const int e = (int)(row % R.head_size);
+                        float res = v;
+                        if (e < R.n_dims) {
+                            const int i0 = e & ~1;
+                            const float c = R.rope_table[(int64_t)pos * R.head_size + i0], sn = R.rope_table[(int64_t)pos * R.head_size + i0 + 1];
+                            const float x0 = (e & 1) ? vp : v, x1 = (e & 1) ? v : vp;
+                            res = (e & 1) ? __fadd_rn(__fmul_rn(x0, sn), __fmul_rn(x1, c)) : __fsub_rn(__fmul_rn(x0, c), __fmul_rn(x1, sn));
+                        }
+                        if (wi == 0) o[row] = res; else R.k_cache[(int64_t)pos * R.kv_dim + row] = res;
+                    }
+                }
+            } else if (u == 0 && row < Nw) {
                 if (EPI == 1) {
                     o[row] = ps_silu_mul(ygate, y);
                 } else {
@@ -798,7 +835,7 @@ __global__ __launch_bounds__((NW + 1) * 64, 4) void gemv3_kernel(const GemvParam
             task++;
         };
         // whole chunks inside one row (and inside one half of a gate/up pair): the common shapes
-        const bool chunk_in_row = (WT == PS_Q4_K) && (tot % UPB == 0) && (EPI == 0 || n_units % UPB == 0);
+        const bool chunk_in_row = (WT == PS_Q4_K) && (tot % UPB == 0) && (EPI != 1 || n_units % UPB == 0);
         for (int c = 0; c < 2 * n_rounds; c++) {
             mark(); // chain wave: 3, 5, ...: waiting for chunk c
             __syncthreads();
@@ -806,10 +843,13 @@ __global__ __launch_bounds__((NW + 1) * 64, 4) void gemv3_kernel(const GemvParam
             const Rec *rb = recs + (size_t)(c & 1) * UPB * 64 + lane;
             if constexpr (WT == PS_Q4_K) {
                 if (chunk_in_row) { // every record and activation scale of the chunk in one LDS round trip, then a branch-free chain
-                    if (task < g1) {
+                    if (task < g1 && !mine()) { // the other chain wave's row
+                        un += UPB;
+                        if (un == tot) { un = 0; task++; }
+                    } else if (task < g1) {
                         if (EPI == 1 && un == n_units) gate_done();
                         const int ul = (EPI == 1 && un >= n_units) ? un - n_units : un;
-                        constexpr int KB = UPB <= 16 ? UPB : UPB / 2; // records per LDS round trip (register budget)
+                        constexpr int KB = UPB <= 16 ? UPB : (UPB % 16 == 0 ? 16 : (UPB % 14 == 0 ? 14 : 4)); // records per LDS round trip (register budget)
 #pragma unroll
                         for (int kb = 0; kb < UPB; kb += KB) {
                             Rec rc[KB];
@@ -835,30 +875,52 @@ __global__ __launch_bounds__((NW + 1) * 64, 4) void gemv3_kernel(const GemvParam
                     continue;
                 }
             }
-            // generic: rows (and the gate half of a gate/up pair) end on multiples of four units (host-checked), so
-            // the boundary work is tested once per four chain steps
-            auto step = [&](const Rec rc, const uint2 hd_k, const int ul) {
-                uint2 hk = hd_k;
-                if constexpr (WT == PS_Q4_K) {
-                    const int up = __builtin_amdgcn_update_dpp(0, rc.y, 0x104, 0xf, 0xf, false);
-                    hk = make_uint2((uint32_t)(u < 4 ? up : rc.y), 0);
+            // generic: rows (and the gate half of a gate/up pair) end on multiples of four units (host-checked).  The chunk
+            // is walked in runs (units of one row, one gate/up half); a run of the other chain wave is skipped whole,
+            // an own run is chained in batches of 8 / 4 records per LDS round trip (the producers keep the LDS queue
+            // long: round trips, not instructions, are what this wave waits for).
+            auto batch = [&](auto nconst, const int k0, const int ul) {
+                constexpr int N = decltype(nconst)::value;
+                Rec rc[N];
+                uint2 hh[N];
+#pragma unroll
+                for (int k = 0; k < N; k++) rc[k] = rb[(k0 + k) * 64];
+#pragma unroll
+                for (int k = 0; k < N; k++) {
+                    if constexpr (WT == PS_Q4_K) hh[k] = make_uint2(0u, __float_as_uint(A.d[ul + k]));
+                    else hh[k] = hdl[((c & 1) * UPB + k0 + k) * TR::RG + r];
                 }
-                rec_chain<WT>(rc, hk, ul, A, acc0, acc1, accm);
+#pragma unroll
+                for (int k = 0; k < N; k++) {
+                    uint2 hk = hh[k];
+                    if constexpr (WT == PS_Q4_K) { // d|dmin sits in the record of lane u + 4 (row_shl:4 within the row of 16)
+                        const int up = __builtin_amdgcn_update_dpp(0, rc[k].y, 0x104, 0xf, 0xf, false);
+                        hk.x = (uint32_t)(u < 4 ? up : rc[k].y);
+                    }
+                    rec_chain<WT>(rc[k], hk, ul + k, A, acc0, acc1, accm);
+                }
             };
-#pragma unroll 1
-            for (int k0 = 0; k0 < UPB; k0 += 4) { // four records in flight per LDS round trip
-                if (task >= g1) break;
-                const Rec r0 = rb[(k0 + 0) * 64], r1 = rb[(k0 + 1) * 64], r2 = rb[(k0 + 2) * 64], r3 = rb[(k0 + 3) * 64];
-                uint2 h0 = make_uint2(0, 0), h1 = h0, h2 = h0, h3 = h0;
-                if constexpr (WT != PS_Q4_K) {
-                    const uint2 *hb = hdl + ((c & 1) * UPB + k0) * TR::RG + r;
-                    h0 = hb[0]; h1 = hb[TR::RG]; h2 = hb[2 * TR::RG]; h3 = hb[3 * TR::RG];
+            for (int k0 = 0; k0 < UPB && task < g1;) {
+                const bool own = mine();
+                if (EPI == 1 && un == n_units && own) gate_done();
+                const int bound = (EPI == 1 && un < n_units) ? n_units : tot;
+                int len = min(bound - un, UPB - k0); // multiple of 4
+                if (own) {
+                    int ul = (EPI == 1 && un >= n_units) ? un - n_units : un, kk = k0;
+                    if constexpr (WT == PS_Q4_K) { // (16-byte records: four at a time is what the registers hold)
+                        int rem = len;
+                        for (; rem >= 16; rem -= 16, kk += 16, ul += 16) batch(std::integral_constant<int, 16>{}, kk, ul);
+                        if (rem >= 8) { batch(std::integral_constant<int, 8>{}, kk, ul); rem -= 8; kk += 8; ul += 8; }
+                        if (rem >= 4) batch(std::integral_constant<int, 4>{}, kk, ul);
+                    } else {
+                        for (int rem = len; rem >= 4; rem -= 4, kk += 4, ul += 4) batch(std::integral_constant<int, 4>{}, kk, ul);
+                    }
                 }
-                if (EPI == 1 && un == n_units) gate_done();
-                const int ul = (EPI == 1 && un >= n_units) ? un - n_units : un;
-                step(r0, h0, ul); step(r1, h1, ul + 1); step(r2, h2, ul + 2); step(r3, h3, ul + 3);
-                un += 4;
-                if (un == tot) row_done();
+                un += len;
+                k0 += len;
+                if (un == tot) {
+                    if (own) row_done(); else { un = 0; task++; }
+                }
             }
         }
     }
@@ -873,10 +935,10 @@ void launch_g3(hipStream_t st, int n_cu, const GemvParams &p) {
     if (occ == 0) { // resident workgroups per CU for this instantiation (registers / LDS), queried once
         (void)hipFuncSetAttribute((const void *)gemv3_kernel<WT, UPW, NW, TPW, EPI, PRO>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)gemv3_kernel<WT, UPW, NW, TPW, EPI, PRO>, (NW + 1) * 64, smem) != hipSuccess || nb < 1) nb = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)gemv3_kernel<WT, UPW, NW, TPW, EPI, PRO>, g3_waves(NW) * 64, smem) != hipSuccess || nb < 1) nb = 1;
         // a workgroup's waves are dealt to the four SIMDs starting from the same one: only whole multiples of
         // four waves pack to the register-file limit (measured: 5-wave groups at 108 VGPRs ran 2 per CU, not 3)
-        const int by_waves = 16 / (((NW + 1 + 3) / 4) * 4);
+        const int by_waves = 16 / (((g3_waves(NW) + 3) / 4) * 4);
         occ = nb > by_waves ? by_waves : nb;
         if (occ < 1) occ = 1;
     }
@@ -889,12 +951,14 @@ void launch_g3(hipStream_t st, int n_cu, const GemvParams &p) {
     pd.split_r = (int)(n_tasks % grid);
     pd.dbg = (g_dbg_buf && g_dbg_key == EPI * 4 + PRO) ? g_dbg_buf : nullptr;
     if (pd.dbg) (void)hipMemsetAsync(g_dbg_buf, 0, (size_t)G3_DBG_WGS * 64 * 8, st);
-    hipLaunchKernelGGL((gemv3_kernel<WT, UPW, NW, TPW, EPI, PRO>), dim3((unsigned)grid), dim3((NW + 1) * 64), smem, st, pd);
+    hipLaunchKernelGGL((gemv3_kernel<WT, UPW, NW, TPW, EPI, PRO>), dim3((unsigned)grid), dim3(g3_waves(NW) * 64), smem, st, pd);
 }
 
 template <int WT, int UPW, int NW, int TPW>
 void launch_g3_ep(hipStream_t st, int n_cu, const GemvParams &p, int epi, int pro) {
-    if (epi == 1) {
+    if (epi == 2) {
+        launch_g3<WT, UPW, NW, TPW, 2, 1>(st, n_cu, p);
+    } else if (epi == 1) {
         if (pro == 1) launch_g3<WT, UPW, NW, TPW, 1, 1>(st, n_cu, p); else launch_g3<WT, UPW, NW, TPW, 1, 0>(st, n_cu, p);
     } else {
         if (pro == 0) launch_g3<WT, UPW, NW, TPW, 0, 0>(st, n_cu, p);
@@ -903,17 +967,19 @@ void launch_g3_ep(hipStream_t st, int n_cu, const GemvParams &p, int epi, int pr
     }
 }
 
-// Eight-wave workgroups (seven producers + the chain wave), two per CU.  Returns false when the activation row
-// does not fit the prologue's register tiles or the row length is not a multiple of four units (falls back).
+// Sixteen-wave workgroups (fourteen producers + two chain waves), one per CU: the activation prologue runs once per
+// CU, and 256 workgroups split the usual row counts evenly.  Returns false when the activation row does not fit
+// the prologue's register tiles or the row length is not a multiple of four units (falls back).
 template <int WT>
 bool launch_g3_wt(hipStream_t st, int n_cu, const GemvParams &p, int epi, int pro) {
     if (epi == 1 && pro == 2) return false;
+    if (epi == 2 && pro != 1) return false;
     const int n_units = (int)((p.K + WTraits<WT>::UNIT - 1) / WTraits<WT>::UNIT);
     if (n_units % 4 != 0) return false; // the consumer tests row boundaries once per four units
     const size_t rec = sizeof(typename RecOf<WT>::T) + 2; // (+ the Q8_0 / Q4_0 scale plane)
-    if ((size_t)p.col_bytes + 2 * 28 * 64 * rec > 150 * 1024) return false;
-    if (p.K <= 8 * 2 * 256) { launch_g3_ep<WT, 4, 7, 2>(st, n_cu, p, epi, pro); return true; }
-    if (p.K <= 8 * 7 * 256) { launch_g3_ep<WT, 4, 7, 7>(st, n_cu, p, epi, pro); return true; }
+    if ((size_t)p.col_bytes + 2 * 56 * 64 * rec > 150 * 1024) return false;
+    if (p.K <= 14 * 2 * 256) { launch_g3_ep<WT, 4, 14, 2>(st, n_cu, p, epi, pro); return true; } // prologue tiles on the 14 producers
+    if (p.K <= 14 * 4 * 256) { launch_g3_ep<WT, 4, 14, 4>(st, n_cu, p, epi, pro); return true; }
     return false;
 }
 
@@ -964,6 +1030,7 @@ int launch_epi(hipStream_t st, int n_cu, const GemvParams &p, int epi, int pro) 
 template <int WT>
 int launch_wt(hipStream_t st, int n_cu, const GemvParams &p, int epi, int pro) {
     if (p.bs == 1 && launch_g3_wt<WT>(st, n_cu, p, epi, pro)) return 0;
+    if (epi == 2) return 8; // the fused RoPE epilogue exists in the producer/consumer kernel only (psk_gemv_rope_ok)
     if (p.bs == 1 && launch_g1_wt<WT>(st, n_cu, p, epi, pro)) return 0;
     if (p.bs == 1) return launch_epi<WT, 1>(st, n_cu, p, epi, pro);
     if (p.bs <= 4) return launch_epi<WT, 4>(st, n_cu, p, epi, pro);
@@ -980,6 +1047,13 @@ int psk_gemv_debug(int key, uint64_t *host_out, int n_words) {
     }
     if (!g_dbg_buf || n_words > G3_DBG_WGS * 64) return 1;
     return hipMemcpy(host_out, g_dbg_buf, (size_t)n_words * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : 2;
+}
+
+bool psk_gemv_rope_ok(int wt, int64_t K) { // mirrors launch_g3_wt
+    const int64_t unit = (wt == PS_Q4_K) ? 256 : 128, n_units = (K + unit - 1) / unit;
+    const size_t rec = (wt == PS_Q4_K ? 8 : 16) + 2;
+    return (wt == PS_Q4_K || wt == PS_Q8_0 || wt == PS_Q4_0) && n_units % 4 == 0 && K <= 14 * 4 * 256 &&
+           psk_gemv_lds_col_bytes(wt, K) + 2 * 56 * 64 * rec <= 150 * 1024;
 }
 
 size_t psk_gemv_lds_col_bytes(int wt, int64_t K) {
@@ -1014,7 +1088,11 @@ int psk_gemv(hipStream_t st, int n_cu, const psk_gemv_args &a, ps_act act, int v
     (void)vdt;
     p.col_bytes = (int64_t)psk_gemv_lds_col_bytes(wt, K);
     if ((size_t)p.col_bytes * (bs == 1 ? 1 : 4) > 150 * 1024) return 7;
-    const int epi = a.silu_pair ? 1 : 0;
+    const int epi = a.silu_pair ? 1 : (a.rope ? 2 : 0);
+    if (a.rope) {
+        if (a.n_w != 3 || bs != 1 || a.pro != 1) return 9;
+        p.rope = *a.rope;
+    }
     if (epi == 1 && (a.n_w != 2 || a.w[0]->N != a.w[1]->N)) return 5;
     switch (wt) {
     case PS_Q4_0: return launch_wt<PS_Q4_0>(st, n_cu, p, epi, a.pro);

@@ -115,10 +115,14 @@ static int enqueue_forward(ps_hip_model *m, int bs, bool lm_head, bool use_tree,
         g.ldo[0] = dim; g.ldo[1] = kvd; g.ldo[2] = kvd;
         if (m->qwen2) { g.bias[0] = m->bq[L]; g.bias[1] = m->bk[L]; g.bias[2] = m->bv[L]; }
         g.pro = 1; g.pro_x = m->x; g.pro_norm_w = m->attn_norm[L]; g.pro_eps = f.norm_eps; // RMSNorm + quantize in the prologue
+        aa.k_cache = m->k_cache[L]; aa.v_cache = m->v_cache[L];
+        // single token, adjacent-pair RoPE: rotation and the KV append ride in the mat-vec epilogue
+        const bool fuse_rope = bs == 1 && !aa.neox && psk_gemv_rope_ok(m->wq[L]->dtype, dim) && m->wk[L]->dtype == m->wq[L]->dtype && m->wv[L]->dtype == m->wq[L]->dtype;
+        psk_rope_kv rk{m->state, m->rope_table, aa.k_cache, aa.v_cache, (int)f.head_size, (int)f.rope.n_dims, (int)f.seq_len, (int)kvd};
+        if (fuse_rope) g.rope = &rk;
         if (mm(m, g, a1, dim, bs)) return 2;
 
-        aa.k_cache = m->k_cache[L]; aa.v_cache = m->v_cache[L];
-        psl_rope_append(st, aa, bs);
+        if (!fuse_rope) psl_rope_append(st, aa, bs);
         psl_attn_scores(st, aa, bs);
         psl_attn_softmax_pv(st, aa, bs);
 

@@ -96,6 +96,13 @@ void psk_quantize_act(hipStream_t st, int vdt, int mode, const float *x, const f
 void psk_pack_act_blocks(hipStream_t st, int vdt, ps_act in, int64_t K, int64_t rows, void *out_blocks);
 void psk_repack_weight(hipStream_t st, int dtype, const uint8_t *raw, int64_t K, int64_t N, ps_weight *w);
 
+// RoPE + KV-cache append fused into the QKV mat-vec epilogue (one activation column, adjacent-pair rotation)
+struct psk_rope_kv {
+    const struct ps_step_state *state; // pos0 = position of the token
+    const float *rope_table;           // [n_ctx][head_size] (cos, sin) pairs
+    float *k_cache, *v_cache;          // [n_ctx][kv_dim], [kv_dim][n_ctx]
+    int head_size, n_dims, n_ctx, kv_dim;
+};
 struct psk_gemv_args {
     int n_w;                 // 1..3 matrices sharing the activation
     const ps_weight *w[3];
@@ -109,7 +116,11 @@ struct psk_gemv_args {
     int pro;
     const float *pro_x, *pro_norm_w;
     float pro_eps;
+    // optional (n_w == 3, one column): out[0] receives the rotated q, k goes rotated to the K cache row pos0, v to the
+    // V cache column pos0 (norm_attention.cpp:76-113); out[1] / out[2] are not written
+    const psk_rope_kv *rope;
 };
+bool psk_gemv_rope_ok(int wt, int64_t K); // the fused epilogue exists for this weight type / row length
 size_t psk_gemv_lds_col_bytes(int wt, int64_t K);
 static inline int64_t ps_w_rg(int dtype) { return dtype == PS_Q4_0 ? 16 : 8; }
 static inline int64_t ps_w_unit(int dtype) { return dtype == PS_Q4_K ? 256 : 128; }

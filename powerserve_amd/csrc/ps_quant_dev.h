@@ -65,12 +65,12 @@ __device__ __forceinline__ void ps_quantize_tile(const float v[4], bool live, in
 //   ps_qrow_compute  RMSNorm (MODE 1) + quantization from those registers; ends with __syncthreads()
 // Requires K <= nw*TPW*256 (one tile slot per (wave, i)).  `red`: __shared__ double[16].
 template <int MODE, int TPW>
-__device__ __forceinline__ void ps_qrow_load(const float *x, const float *w, int64_t K, float4 (&xv)[TPW], float4 (&wv)[TPW]) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+__device__ __forceinline__ void ps_qrow_load(const float *x, const float *w, int64_t K, float4 (&xv)[TPW], float4 (&wv)[TPW], int nwl = 0) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = nwl ? nwl : (int)(blockDim.x >> 6); // nwl: only the first nwl waves take tiles
     const int64_t n_tiles = (K + 255) / 256;
 #pragma unroll
     for (int i = 0; i < TPW; i++) {
-        const int64_t t = wave + (int64_t)i * nw, e = t * 256 + lane * 4;
+        const int64_t t = wave < nw ? wave + (int64_t)i * nw : n_tiles, e = t * 256 + lane * 4;
         const bool in = t < n_tiles && e < K;
         xv[i] = in ? *(const float4 *)(x + e) : make_float4(0.f, 0.f, 0.f, 0.f);
         wv[i] = (MODE == 1 && in) ? *(const float4 *)(w + e) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -78,8 +78,8 @@ __device__ __forceinline__ void ps_qrow_load(const float *x, const float *w, int
 }
 template <int VDT, int MODE, int TPW>
 __device__ __forceinline__ void ps_qrow_compute(const float4 (&xv)[TPW], const float4 (&wv)[TPW], float eps, int64_t K, int8_t *qs,
-                                                float *d, int16_t *bs16, double *red) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+                                                float *d, int16_t *bs16, double *red, int nwl = 0) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6, nwt = nwl ? nwl : nw;
     const int64_t n_tiles = (K + 255) / 256;
     float scale = 1.0f;
     if (MODE == 1) {
@@ -102,7 +102,7 @@ __device__ __forceinline__ void ps_qrow_compute(const float4 (&xv)[TPW], const f
     }
 #pragma unroll
     for (int i = 0; i < TPW; i++) {
-        const int64_t t = wave + (int64_t)i * nw, e = t * 256 + lane * 4;
+        const int64_t t = wave < nwt ? wave + (int64_t)i * nwt : n_tiles, e = t * 256 + lane * 4;
         if (t >= n_tiles) continue; // wave-uniform
         const bool live = e < K;
         float v[4] = {xv[i].x, xv[i].y, xv[i].z, xv[i].w};
