@@ -559,15 +559,24 @@ __device__ __forceinline__ typename RecOf<WT>::T unit_rec(const uint4 q, const u
         const uint32_t mn47 = ((h.w >> 4) & 0x0f0f0f0fu) | (((h.z >> 6) & 0x03030303u) << 4);
         const int base = unit * 64 + u;
         int s = 0;
+        int ylv[4], yhv[4]; // every LDS read of the unit first: one wait instead of one per 64-element group
 #pragma unroll
-        for (int j = 0; j < 4; j++) { // |dot4| <= 4*15*127 and scale <= 63: 24-bit multiplies are exact
-            const int yl = a.q32[base + j * 16], yh = a.q32[base + j * 16 + 8];
-            const uint32_t scp = (j < 2) ? sc03 : sc47;
-            s += __mul24(bfe8(scp, (2 * j) & 3), dot4((int)(wq[j] & M), yl, 0)) + __mul24(bfe8(scp, (2 * j + 1) & 3), dot4((int)((wq[j] >> 4) & M), yh, 0));
-        }
+        for (int j = 0; j < 4; j++) { ylv[j] = a.q32[base + j * 16]; yhv[j] = a.q32[base + j * 16 + 8]; }
         const int v = u & 3;
+        const int bsa = a.bs32[unit * 8 + 2 * v], bsb = a.bs32[unit * 8 + 2 * v + 1];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            // |dot4| <= 4*15*127 fits int16, the 6-bit scales too: the two quad dots of a 64-element group are packed into
+            // one dword and meet their scale pair in a single v_dot2_i32_i16 (exact integer arithmetic, 32-bit accumulate)
+            const int yl = ylv[j], yh = yhv[j];
+            const uint32_t scp  = (j < 2) ? sc03 : sc47;
+            const uint32_t sc16 = __builtin_amdgcn_perm(0u, scp, (j & 1) ? 0x0c030c02u : 0x0c010c00u); // {scale[2j], scale[2j+1]} as int16
+            const int dl = dot4((int)(wq[j] & M), yl, 0), dh = dot4((int)((wq[j] >> 4) & M), yh, 0);
+            const uint32_t d16 = __builtin_amdgcn_perm((uint32_t)dh, (uint32_t)dl, 0x05040100u);       // {dl, dh} as int16
+            s = dot2_i16(d16, sc16, s);
+        }
         const uint32_t mp = (v < 2) ? mn03 : mn47;
-        const int pr = __mul24(bfe8(mp, (2 * v) & 3), a.bs32[unit * 8 + 2 * v]) + __mul24(bfe8(mp, (2 * v + 1) & 3), a.bs32[unit * 8 + 2 * v + 1]);
+        const int pr = __mul24(bfe8(mp, (2 * v) & 3), bsa) + __mul24(bfe8(mp, (2 * v + 1) & 3), bsb);
         return make_int2(s, u < 4 ? pr : (int)h.x);
     } else if constexpr (WT == PS_Q8_0) {
         int s[4];
@@ -719,7 +728,10 @@ __global__ __launch_bounds__(g3_waves(NW) * 64, 4) void gemv3_kernel(const GemvP
         float4 xv[TPW], wv[TPW];
         // activation row first, the first chunks of weights right behind it (vmcnt retires in order: the prologue
         // only waits for the L2-resident activation while the weights stream in)
-        if (PRO != 0) ps_qrow_load<(PRO == 1 ? 1 : 0), TPW>(p.x, p.nw, K, xv, wv, NW);
+        // the tiles go to as few (= the earliest started) waves as TPW allows: a late wave's activation load would sit
+        // behind the weight requests of all the earlier waves in the CU's vector-memory queue
+        const int nwl = min(NW, (int)((K + 255) / 256 + TPW - 1) / TPW);
+        if (PRO != 0) ps_qrow_load<(PRO == 1 ? 1 : 0), TPW>(p.x, p.nw, K, xv, wv, nwl);
         mark_at(21); // activation loads issued
 #pragma unroll
         for (int i = 0; i < UPW; i++) {
@@ -748,7 +760,7 @@ __global__ __launch_bounds__(g3_waves(NW) * 64, 4) void gemv3_kernel(const GemvP
             for (int i = threadIdx.x; i < nb16_k; i += NW * 64) l16[i] = p.abs16[i];
             __syncthreads();
         } else {
-            ps_qrow_compute<TR::VDT, (PRO == 1 ? 1 : 0), TPW>(xv, wv, p.eps, K, lq, ld, l16, red, NW);
+            ps_qrow_compute<TR::VDT, (PRO == 1 ? 1 : 0), TPW>(xv, wv, p.eps, K, lq, ld, l16, red, nwl);
         }
         for (int i = threadIdx.x; i < nb32; i += NW * 64) lb[i] = (int)l16[2 * i] + (int)l16[2 * i + 1];
         __syncthreads();
