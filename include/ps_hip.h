@@ -185,7 +185,8 @@ int ps_hip_model_bench_gemv(ps_hip_model *m, int reps, double *seq_ms, double *n
 /* Diagnostic: in-kernel timeline of the decode mat-vec (tools/gpu_timeline.py).  With host_out == NULL, arm
  * (key >= 0: record launches with epilogue*4 + prologue == key; key < 0: disarm).  With host_out != NULL, copy
  * the last recorded launch: n_words uint64 = [workgroup][role 0 producer wave 0 / 1 chain wave][32 events],
- * shader-clock ticks (s_memtime). */
+ * shader-clock ticks (s_memtime).  key = k1 + 100 * (k2 + 1) records a second launch family into a second block of
+ * the same size (kernel-boundary gaps). */
 int ps_hip_debug_timeline(ps_hip_ctx *ctx, int key, uint64_t *host_out, int n_words);
 /* 0 = fused kernels + hipGraph (default); 1 = fused kernels, eager launches; used by tests/bench */
 int ps_hip_model_set_mode(ps_hip_model *m, int mode);

@@ -961,8 +961,12 @@ void launch_g3(hipStream_t st, int n_cu, const GemvParams &p) {
     GemvParams pd = p;
     pd.split_q = (int)(n_tasks / grid);
     pd.split_r = (int)(n_tasks % grid);
-    pd.dbg = (g_dbg_buf && g_dbg_key == EPI * 4 + PRO) ? g_dbg_buf : nullptr;
-    if (pd.dbg) (void)hipMemsetAsync(g_dbg_buf, 0, (size_t)G3_DBG_WGS * 64 * 8, st);
+    pd.dbg = nullptr; // key = k1 + 100 * (k2 + 1): launches matching k1 record into the first half, k2 into the second
+    if (g_dbg_buf && g_dbg_key >= 0) {
+        const int k1 = g_dbg_key % 100, k2 = g_dbg_key / 100 - 1;
+        if (k1 == EPI * 4 + PRO) pd.dbg = g_dbg_buf;
+        else if (k2 == EPI * 4 + PRO) pd.dbg = g_dbg_buf + (size_t)G3_DBG_WGS * 64;
+    }
     hipLaunchKernelGGL((gemv3_kernel<WT, UPW, NW, TPW, EPI, PRO>), dim3((unsigned)grid), dim3(g3_waves(NW) * 64), smem, st, pd);
 }
 
@@ -1053,11 +1057,12 @@ int launch_wt(hipStream_t st, int n_cu, const GemvParams &p, int epi, int pro) {
 
 int psk_gemv_debug(int key, uint64_t *host_out, int n_words) {
     if (!host_out) {
-        if (key >= 0 && !g_dbg_buf && hipMalloc((void **)&g_dbg_buf, (size_t)G3_DBG_WGS * 64 * 8) != hipSuccess) return 2;
+        if (key >= 0 && !g_dbg_buf && hipMalloc((void **)&g_dbg_buf, (size_t)2 * G3_DBG_WGS * 64 * 8) != hipSuccess) return 2;
+        if (key >= 0 && hipMemset(g_dbg_buf, 0, (size_t)2 * G3_DBG_WGS * 64 * 8) != hipSuccess) return 2;
         g_dbg_key = key;
         return 0;
     }
-    if (!g_dbg_buf || n_words > G3_DBG_WGS * 64) return 1;
+    if (!g_dbg_buf || n_words > 2 * G3_DBG_WGS * 64) return 1;
     return hipMemcpy(host_out, g_dbg_buf, (size_t)n_words * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : 2;
 }
 

@@ -11,7 +11,10 @@ d = tempfile.mkdtemp(prefix="ps_tl_")
 synth.write_model_dir(d, "llama-8b-dims-4l", 12, n_ctx=512, seed=1)
 ctx = hip.Ctx(0)
 m = hip.Model(ctx, d, max_batch=8, n_ctx=512)
-m.set_mode(1)
+mode = int(os.environ.get('TL_MODE', '1'))  # 1 eager launches, 0 hipGraph replay
+m.set_mode(mode)
+if mode == 0:
+    keys = []
 m.forward(np.arange(8, dtype=np.int32) + 5, np.arange(8), lm_head=False)
 NW = 1024
 for key in keys:
@@ -32,6 +35,7 @@ for key in keys:
     print(f"key {key}: {n} workgroups; s_memtime runs at {mhz:.0f} ticks/us; workgroup lifetime median {np.median(dt_ref):.2f} us")
     t_in = (ev[:, 0, 29] - ev[:, 0, 29].min()) / 100.0
     t_out = (ev[:, 0, 30] - ev[:, 0, 29].min()) / 100.0
+    print(f"  100 MHz reference: first entry {ev[:, 0, 29].min() / 100.0:.2f} us, last exit {ev[:, 0, 30].max() / 100.0:.2f} us (absolute)")
     print("  entry time (us, 100 MHz reference) percentiles 0/25/50/75/100:", np.percentile(t_in, [0, 25, 50, 75, 100]).round(2),
           " exit:", np.percentile(t_out, [0, 25, 50, 75, 100]).round(2))
     hist, edges = np.histogram(t_in, bins=12)
@@ -50,3 +54,16 @@ for key in keys:
             v = (e[ok, i] - base[ok]) / mhz
             own = (e[ok, i] - ev[ok, 0, 0]) / mhz
             print(f"    {i:2d}: {v.mean():7.2f} {v.min():7.2f} {v.max():7.2f} | {own.mean():7.2f}   n={ok.sum()}")
+
+# boundary between two consecutive kernels: gate/up (5) then down (2) of the same layer
+ctx.check(ctx.L.ps_hip_debug_timeline(ctx.h, 5 + 100 * (2 + 1), None, 0))
+for _ in range(3):
+    m.decode_greedy(7, 4)
+buf = np.zeros(2 * NW * 64, dtype=np.uint64)
+ctx.check(ctx.L.ps_hip_debug_timeline(ctx.h, 0, buf.ctypes.data_as(C.c_void_p), buf.size))
+ev = buf.reshape(2, NW, 2, 32).astype(np.int64)
+a, b = ev[0][ev[0][:, 0, 0] > 0], ev[1][ev[1][:, 0, 0] > 0]
+# the buffers hold the LAST launch of each key: gate/up of the last layer, then down of the last layer
+print(f"gate/up: first entry {a[:, 0, 29].min() / 100.0:.2f}  last exit {a[:, 0, 30].max() / 100.0:.2f} us")
+print(f"down   : first entry {b[:, 0, 29].min() / 100.0:.2f}  last exit {b[:, 0, 30].max() / 100.0:.2f} us")
+print(f"boundary (last exit of gate/up -> first entry of down): {(b[:, 0, 29].min() - a[:, 0, 30].max()) / 100.0:.2f} us")
