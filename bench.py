@@ -180,8 +180,10 @@ def main():
         wbytes = model.weight_bytes_per_token
         n_kv_mid = args.prompt_len + args.warmup + args.steps // 2
         kv_bytes = cfg.n_layers * 2 * n_kv_mid * cfg.kv_dim * 4
-        # ---- roofline of the GEMV family: GEMV-only pass over one token's weights, event-bracketed
-        rf = gemv_roofline(ctx, model, wbytes)
+        # ---- roofline of the dominant kernel (gate/up mat-vec), event-bracketed replay
+        from powerserve_amd import gguf as _gguf
+        gate_up_bytes = 2 * cfg.hidden_dim * _gguf.row_size(_gguf.NAME_TYPE[args.wtype], cfg.dim)
+        rf = gemv_roofline(ctx, model, wbytes, gate_up_bytes, args.preset == "llama-3.1-8b" and args.wtype == "Q4_K")
         out = {
             "metric": "decode tokens/s (greedy, Llama-3.1-8B Q4_K, 1 GPU per replica)" if args.preset == "llama-3.1-8b" and args.wtype == "Q4_K"
             else f"decode tokens/s (greedy, {args.preset} {args.wtype})",
@@ -212,31 +214,49 @@ def main():
         print(json.dumps(out))
 
 
-def gemv_roofline(ctx, model, wbytes):
-    """Average duration of the quantized-GEMV launches of one decode token, HIP events on the backend stream.
+def _pmc_traffic(kernel_key):
+    """HBM bytes per launch of the dominant kernel from the committed PMC pass (profiles/r01_pmc_traffic.json, produced
+    by tools/pmc_summary.py from a separate `rocprofv3 --pmc FETCH_SIZE` run of this same command; FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for gfx950).  A live bench run cannot collect counters; null when absent."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get(kernel_key, {}).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
 
-    The library replays the exact GEMV launch sequence of a token (every layer's own weights, so the 4.2 GB
-    stream is HBM-cold like in the real step) with nothing else in between; boundary_us (same number of empty
-    launches) is reported so that kernel-only time can be compared with rocprofv3's per-kernel average."""
+
+def gemv_roofline(ctx, model, wbytes, gate_up_bytes, is_headline):
+    """Roofline of the dominant kernel: the gate/up mat-vec (two [K=dim, N=hidden] matrices in one launch).
+
+    The library replays that launch for every layer (each layer's own weights, so every launch streams HBM-cold bytes
+    exactly like in the real step; same kernel and fused RMSNorm prologue as the decode step) between HIP events on the
+    backend stream: achieved = GGUF bytes of the two matrices / average launch duration.  rocprofv3's per-kernel
+    average for gemv3_kernel<..., EPI 1, PRO 1> (profiles/) is the cross-check.  The same measurement over ALL mat-vec
+    launches of a token and the cost of an empty launch are reported next to it."""
     import ctypes as C
     L = ctx.L
     if not hasattr(L, "ps_hip_model_bench_gemv"):
         return None
     L.ps_hip_model_bench_gemv.restype = C.c_int
-    L.ps_hip_model_bench_gemv.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]
-    seq_ms, null_ms, n = C.c_double(), C.c_double(), C.c_int()
-    ctx.check(L.ps_hip_model_bench_gemv(model.h, 20, C.byref(seq_ms), C.byref(null_ms), C.byref(n)))
-    launches = n.value
-    avg_us = 1e3 * seq_ms.value / launches
-    boundary_us = 1e3 * null_ms.value / launches
-    kern_us = max(avg_us - boundary_us, 1e-3)
-    achieved = wbytes / launches / (kern_us * 1e-6) / 1e9
-    return {"bound": "hbm", "kernel": "gemv_kernel<Q4_K,...> (all quantized mat-vec launches of one token)",
+    L.ps_hip_model_bench_gemv.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]
+
+    def run(which):
+        seq_ms, null_ms, n = C.c_double(), C.c_double(), C.c_int()
+        ctx.check(L.ps_hip_model_bench_gemv(model.h, 20, which, C.byref(seq_ms), C.byref(null_ms), C.byref(n)))
+        return seq_ms.value, null_ms.value, n.value
+
+    g_ms, g_null, g_n = run(1)
+    a_ms, a_null, a_n = run(0)
+    avg_us = 1e3 * g_ms / g_n
+    achieved = gate_up_bytes / (avg_us * 1e-6) / 1e9
+    return {"bound": "hbm", "kernel": "gemv3_kernel<Q4_K, EPI 1 (SiLU(gate)*up), PRO 1 (RMSNorm+Q8_K)>: gate/up mat-vec, one launch per layer",
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": None, "bytes_per_launch": wbytes / launches, "launches_per_token": launches,
-            "avg_launch_us_incl_boundary": avg_us, "launch_boundary_us": boundary_us, "avg_kernel_us": kern_us,
-            "achieved_incl_boundary": wbytes / launches / (avg_us * 1e-6) / 1e9,
-            "gemv_ms_per_token": seq_ms.value}
+            "traffic": _pmc_traffic("gate_up") if is_headline else None,
+            "bytes_per_launch": gate_up_bytes, "avg_launch_us": avg_us, "launches_timed": 20 * g_n,
+            "empty_launch_us": 1e3 * g_null / g_n,
+            "all_matvec": {"launches_per_token": a_n, "ms_per_token": a_ms, "bytes_per_token": wbytes,
+                           "achieved": wbytes / (a_ms * 1e-3) / 1e9, "frac": wbytes / (a_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}}
 
 
 if __name__ == "__main__":

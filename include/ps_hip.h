@@ -178,10 +178,11 @@ const float *ps_hip_model_k_cache(const ps_hip_model *m, int layer);
 const float *ps_hip_model_v_cache(const ps_hip_model *m, int layer);
 /* per-forward accounting for the roofline: GGUF bytes of all mat-mul weights streamed by one token */
 uint64_t ps_hip_model_weight_bytes_per_token(const ps_hip_model *m);
-/* Measurement helper (bench.py roofline): replays the quantized mat-vec launches of one single-token forward
- * `reps` times between HIP events on the ctx stream -> seq_ms per token; null_ms = the same number of empty
- * launches (launch-boundary cost); n_launches = mat-vec launches per token. */
-int ps_hip_model_bench_gemv(ps_hip_model *m, int reps, double *seq_ms, double *null_ms, int *n_launches);
+/* Measurement helper (bench.py roofline): replays mat-vec launches of one single-token forward exactly as the decode
+ * step issues them (same kernels and fused prologues, every layer's own weights) `reps` times between HIP events on
+ * the ctx stream -> seq_ms per token.  which = 0: all quantized mat-vecs; 1: the gate/up launch of every layer only.
+ * null_ms = the same number of empty launches (launch-boundary cost); n_launches = launches per token. */
+int ps_hip_model_bench_gemv(ps_hip_model *m, int reps, int which, double *seq_ms, double *null_ms, int *n_launches);
 /* Diagnostic: in-kernel timeline of the decode mat-vec (tools/gpu_timeline.py).  With host_out == NULL, arm
  * (key >= 0: record launches with epilogue*4 + prologue == key; key < 0: disarm).  With host_out != NULL, copy
  * the last recorded launch: n_words uint64 = [workgroup][role 0 producer wave 0 / 1 chain wave][32 events],
