@@ -143,11 +143,15 @@ __device__ __forceinline__ float row_reduce(float acc0, float acc1, float accm) 
 }
 
 // EPI 0: out = y (+bias) (+residual).   EPI 1: out[0] = silu(y_w0) * y_w1 (same row of w[0] and w[1]).
-template <int WT, int BS, int EPI, int PRO>
-__global__ __launch_bounds__(256) void gemv_kernel(const GemvParams p) {
+// NWV waves per workgroup share one LDS copy of the BS activation columns; a wave owns a row group at a time and
+// keeps the fma chains of all BS columns in its own registers (no exchange).  BS 1/4 with 4 waves: small batches;
+// BS 8/16 with 16 waves: prefill / tree-verify column groups from pre-quantized activations (PRO 0).
+template <int WT, int BS, int EPI, int PRO, int NWV>
+__global__ __launch_bounds__(NWV * 64) void gemv_kernel(const GemvParams p) {
+    constexpr int NT = NWV * 64;
     using TR = WTraits<WT>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    __shared__ double red[8];
+    __shared__ double red[16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t K = p.K;
     const int Kp   = (int)((K + TR::UNIT - 1) / TR::UNIT * TR::UNIT); // padded to whole units; pad region is zero
@@ -163,23 +167,23 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvParams p) {
         int16_t *l16 = (int16_t *)(lb + nb32);
         if (col < p.bs) {
             if (Kp != K) { // zero the padding blocks (their weights are zero too: fma(0, s, acc) leaves acc unchanged)
-                for (int i = (int)K + threadIdx.x * 4; i < Kp; i += 256 * 4) *(int *)(lq + i) = 0;
-                for (int i = nblk_k + threadIdx.x; i < nblk; i += 256) ld[i] = 0.f;
-                for (int i = nb16_k + threadIdx.x; i < nb16; i += 256) l16[i] = 0;
+                for (int i = (int)K + threadIdx.x * 4; i < Kp; i += NT * 4) *(int *)(lq + i) = 0;
+                for (int i = nblk_k + threadIdx.x; i < nblk; i += NT) ld[i] = 0.f;
+                for (int i = nb16_k + threadIdx.x; i < nb16; i += NT) l16[i] = 0;
             }
             if (PRO == 0) {
-                for (int64_t i = threadIdx.x * 16; i < K; i += 256 * 16) *(int4 *)(lq + i) = *(const int4 *)(p.aq + col * K + i);
-                for (int i = threadIdx.x; i < nblk_k; i += 256) ld[i] = p.ad[col * nblk_k + i];
-                for (int i = threadIdx.x; i < nb16_k; i += 256) l16[i] = p.abs16[col * nb16_k + i];
+                for (int64_t i = threadIdx.x * 16; i < K; i += NT * 16) *(int4 *)(lq + i) = *(const int4 *)(p.aq + col * K + i);
+                for (int i = threadIdx.x; i < nblk_k; i += NT) ld[i] = p.ad[col * nblk_k + i];
+                for (int i = threadIdx.x; i < nb16_k; i += NT) l16[i] = p.abs16[col * nb16_k + i];
                 __syncthreads();
             } else {
-                ps_quantize_row_wg<TR::VDT, PRO == 1 ? 1 : 0, 16>(p.x + col * K, p.nw, p.eps, K, lq, ld, l16, red);
+                ps_quantize_row_wg<TR::VDT, PRO == 1 ? 1 : 0, 64 / NWV>(p.x + col * K, p.nw, p.eps, K, lq, ld, l16, red);
             }
-            for (int i = threadIdx.x; i < nb32; i += 256) lb[i] = (int)l16[2 * i] + (int)l16[2 * i + 1];
+            for (int i = threadIdx.x; i < nb32; i += NT) lb[i] = (int)l16[2 * i] + (int)l16[2 * i + 1];
         } else {
-            for (int i = threadIdx.x * 4; i < Kp; i += 256 * 4) *(int *)(lq + i) = 0;
-            for (int i = threadIdx.x; i < nblk; i += 256) ld[i] = 0.f;
-            for (int i = threadIdx.x; i < nb32; i += 256) lb[i] = 0;
+            for (int i = threadIdx.x * 4; i < Kp; i += NT * 4) *(int *)(lq + i) = 0;
+            for (int i = threadIdx.x; i < nblk; i += NT) ld[i] = 0.f;
+            for (int i = threadIdx.x; i < nb32; i += NT) lb[i] = 0;
         }
     }
     __syncthreads();
@@ -190,9 +194,9 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvParams p) {
     const int64_t unit_bytes = 1024;                                   // quant-plane bytes per unit per row group
     const int64_t aux_unit   = (int64_t)TR::RG * (WT == PS_Q4_K ? 16 : 8);
     const int64_t n_tasks    = (EPI == 1) ? p.w[0].n_groups : p.groups_total;
-    constexpr int UNR = 4;
+    constexpr int UNR = BS >= 8 ? 2 : 4; // weight units in flight per wave (the column accumulators need the registers)
 
-    for (int64_t task = (int64_t)blockIdx.x * 4 + wave; task < n_tasks; task += (int64_t)gridDim.x * 4) {
+    for (int64_t task = (int64_t)blockIdx.x * NWV + wave; task < n_tasks; task += (int64_t)gridDim.x * NWV) {
         float yres[BS][EPI == 1 ? 2 : 1];
         int wi = 0;
         int64_t grp = task;
@@ -1013,32 +1017,32 @@ bool launch_g1_wt(hipStream_t st, int n_cu, const GemvParams &p, int epi, int pr
     return true;
 }
 
-template <int WT, int BS, int EPI, int PRO>
+template <int WT, int BS, int EPI, int PRO, int NWV>
 void launch_one(hipStream_t st, int n_cu, const GemvParams &p) {
     const int64_t n_tasks = (EPI == 1) ? p.w[0].n_groups : p.groups_total;
     const size_t smem     = (size_t)p.col_bytes * BS;
-    int64_t grid          = (n_tasks + 3) / 4;
-    const int64_t cap     = (int64_t)n_cu * (smem > 40 * 1024 ? 2 : 4);
+    int64_t grid          = (n_tasks + NWV - 1) / NWV;
+    const int64_t cap     = (int64_t)n_cu * (NWV == 16 ? 1 : (smem > 40 * 1024 ? 2 : 4));
     if (grid > cap) grid = cap;
     if (grid < 1) grid = 1;
     static bool attr_set = false;
     if (!attr_set && smem > 48 * 1024) {
-        (void)hipFuncSetAttribute((const void *)gemv_kernel<WT, BS, EPI, PRO>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+        (void)hipFuncSetAttribute((const void *)gemv_kernel<WT, BS, EPI, PRO, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemv_kernel<WT, BS, EPI, PRO>), dim3((unsigned)grid), dim3(256), smem, st, p);
+    hipLaunchKernelGGL((gemv_kernel<WT, BS, EPI, PRO, NWV>), dim3((unsigned)grid), dim3(NWV * 64), smem, st, p);
 }
 
 template <int WT, int BS>
 int launch_epi(hipStream_t st, int n_cu, const GemvParams &p, int epi, int pro) {
     if (epi == 1) {
-        if (pro == 0) launch_one<WT, BS, 1, 0>(st, n_cu, p);
-        else if (pro == 1) launch_one<WT, BS, 1, 1>(st, n_cu, p);
-        else launch_one<WT, BS, 1, 2>(st, n_cu, p);
+        if (pro == 0) launch_one<WT, BS, 1, 0, 4>(st, n_cu, p);
+        else if (pro == 1) launch_one<WT, BS, 1, 1, 4>(st, n_cu, p);
+        else launch_one<WT, BS, 1, 2, 4>(st, n_cu, p);
     } else {
-        if (pro == 0) launch_one<WT, BS, 0, 0>(st, n_cu, p);
-        else if (pro == 1) launch_one<WT, BS, 0, 1>(st, n_cu, p);
-        else launch_one<WT, BS, 0, 2>(st, n_cu, p);
+        if (pro == 0) launch_one<WT, BS, 0, 0, 4>(st, n_cu, p);
+        else if (pro == 1) launch_one<WT, BS, 0, 1, 4>(st, n_cu, p);
+        else launch_one<WT, BS, 0, 2, 4>(st, n_cu, p);
     }
     return 0;
 }
@@ -1051,6 +1055,122 @@ int launch_wt(hipStream_t st, int n_cu, const GemvParams &p, int epi, int pro) {
     if (p.bs == 1) return launch_epi<WT, 1>(st, n_cu, p, epi, pro);
     if (p.bs <= 4) return launch_epi<WT, 4>(st, n_cu, p, epi, pro);
     return 3;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Batched mat-mul for Q4_K weights (prefill chunks, tree verify): 8 activation columns per workgroup, in-lane chains.
+// grid = (row-group tiles of 16, column groups of 8); a workgroup stages its 8 pre-quantized columns in LDS once
+// (quants transposed so that the 32 bytes a lane needs per super-block are contiguous: two ds_read_b128), every wave
+// then owns one row group: the weights of a unit are unpacked ONCE and meet the 8 columns, each column keeping the
+// reference's fma chains (acc[u], acc_m[v]) in this lane's registers.  Same arithmetic, same order as the mat-vec.
+template <int EPI>
+__global__ __launch_bounds__(1024) void gemm8_q4k_kernel(const GemvParams p) {
+    constexpr int C = 8;
+    constexpr uint32_t M = 0x0F0F0F0Fu;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int K = (int)p.K, n_units = K / 256, c0 = blockIdx.y * C, nc = min(C, (int)p.bs - c0);
+    const int col_bytes = K + n_units * 4 + K / 8; // [int8 q (transposed dwords)] [float d] [int bs32]; multiple of 16
+    // ---- stage the columns
+    for (int idx = threadIdx.x; idx < C * (K / 4); idx += 1024) {
+        const int c = idx / (K / 4), i = idx % (K / 4);
+        const int dw = c < nc ? ((const int *)(p.aq + (int64_t)(c0 + c) * K))[i] : 0;
+        const int unit = i >> 6, g = (i & 63) >> 3, uu = i & 7;
+        ((int *)(smem + c * col_bytes))[unit * 64 + uu * 8 + g] = dw;
+    }
+    for (int idx = threadIdx.x; idx < C * n_units; idx += 1024) {
+        const int c = idx / n_units, i = idx % n_units;
+        ((float *)(smem + c * col_bytes + K))[i] = c < nc ? p.ad[(int64_t)(c0 + c) * n_units + i] : 0.f;
+    }
+    for (int idx = threadIdx.x; idx < C * (K / 32); idx += 1024) {
+        const int c = idx / (K / 32), i = idx % (K / 32);
+        const int16_t *b = p.abs16 + (int64_t)(c0 + c) * (K / 16) + 2 * i;
+        ((int *)(smem + c * col_bytes + K + n_units * 4))[i] = c < nc ? (int)b[0] + (int)b[1] : 0;
+    }
+    __syncthreads();
+
+    const int r = lane >> 3, u = lane & 7, v = u & 3;
+    const int64_t n_tasks = (EPI == 1) ? p.w[0].n_groups : p.groups_total;
+    const int64_t task = (int64_t)blockIdx.x * 16 + wave;
+    if (task >= n_tasks) return;
+    float yg[C];
+#pragma unroll
+    for (int pass = 0; pass < (EPI == 1 ? 2 : 1); pass++) {
+        int wi = 0;
+        int64_t grp = task;
+        if (EPI == 1) {
+            wi = pass;
+        } else {
+            if (p.n_w > 1 && grp >= p.w[0].n_groups) { grp -= p.w[0].n_groups; wi = 1; }
+            if (p.n_w > 2 && wi == 1 && grp >= p.w[1].n_groups) { grp -= p.w[1].n_groups; wi = 2; }
+        }
+        const uint8_t *qs = p.w[0].qs, *ax = p.w[0].aux;
+        if (wi == 1) { qs = p.w[1].qs; ax = p.w[1].aux; }
+        if (wi == 2) { qs = p.w[2].qs; ax = p.w[2].aux; }
+        const uint8_t *qg = qs + grp * n_units * 1024 + lane * 16;
+        const uint8_t *ag = ax + grp * n_units * 128 + r * 16;
+        float acc0[C], accm[C];
+#pragma unroll
+        for (int c = 0; c < C; c++) { acc0[c] = 0.f; accm[c] = 0.f; }
+        uint4 q = ld_stream16(qg), h = *(const uint4 *)ag;
+        for (int un = 0; un < n_units; un++) {
+            uint4 qn = q, hn = h;
+            if (un + 1 < n_units) { qn = ld_stream16(qg + (int64_t)(un + 1) * 1024); hn = *(const uint4 *)(ag + (int64_t)(un + 1) * 128); }
+            // ---- this unit's weights, unpacked once for the 8 columns
+            const uint32_t sc03 = h.y & 0x3f3f3f3fu, sc47 = (h.w & 0x0f0f0f0fu) | (((h.y >> 6) & 0x03030303u) << 4);
+            const uint32_t mn03 = h.z & 0x3f3f3f3fu, mn47 = ((h.w >> 4) & 0x0f0f0f0fu) | (((h.z >> 6) & 0x03030303u) << 4);
+            const uint32_t sc16[4] = {__builtin_amdgcn_perm(0u, sc03, 0x0c010c00u), __builtin_amdgcn_perm(0u, sc03, 0x0c030c02u),
+                                      __builtin_amdgcn_perm(0u, sc47, 0x0c010c00u), __builtin_amdgcn_perm(0u, sc47, 0x0c030c02u)};
+            const uint32_t wq[4] = {q.x, q.y, q.z, q.w};
+            int wl[4], wh[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) { wl[j] = (int)(wq[j] & M); wh[j] = (int)((wq[j] >> 4) & M); }
+            const uint32_t mp = (v < 2) ? mn03 : mn47;
+            const int mna = bfe8(mp, (2 * v) & 3), mnb = bfe8(mp, (2 * v + 1) & 3);
+            const float dw = ps_h2f((uint16_t)(h.x & 0xffff)), dmw = ps_h2f((uint16_t)(h.x >> 16));
+#pragma unroll
+            for (int c = 0; c < C; c++) {
+                const char *col = smem + c * col_bytes;
+                const int4 y0 = *(const int4 *)(col + (un * 64 + u * 8) * 4), y1 = *(const int4 *)(col + (un * 64 + u * 8 + 4) * 4);
+                const int2 bs = *(const int2 *)(col + K + n_units * 4 + (un * 8 + 2 * v) * 4);
+                const float yd = ((const float *)(col + K))[un];
+                const int yl[4] = {y0.x, y0.z, y1.x, y1.z}, yh[4] = {y0.y, y0.w, y1.y, y1.w};
+                int s = 0;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int dl = dot4(wl[j], yl[j], 0), dh = dot4(wh[j], yh[j], 0);
+                    s = dot2_i16(__builtin_amdgcn_perm((uint32_t)dh, (uint32_t)dl, 0x05040100u), sc16[j], s);
+                }
+                const int pr   = __mul24(mna, bs.x) + __mul24(mnb, bs.y);
+                const float d  = __fmul_rn(yd, dw), dmin = __fmul_rn(-yd, dmw);
+                acc0[c] = __fmaf_rn(d, (float)s, acc0[c]);
+                accm[c] = __fmaf_rn(dmin, (float)pr, accm[c]);
+            }
+            q = qn; h = hn;
+        }
+        // ---- epilogue: lane with u == 0 owns row grp*8 + r
+        int64_t Nw = p.w[0].N, ldo = p.w[0].ldo;
+        float *o = p.w[0].out;
+        const float *b = p.w[0].bias;
+        if (wi == 1) { Nw = p.w[1].N; ldo = p.w[1].ldo; o = p.w[1].out; b = p.w[1].bias; }
+        if (wi == 2) { Nw = p.w[2].N; ldo = p.w[2].ldo; o = p.w[2].out; b = p.w[2].bias; }
+        const int64_t row = grp * 8 + r;
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            const float y = row_reduce<PS_Q4_K>(acc0[c], 0.f, accm[c]);
+            if (EPI == 1 && pass == 0) { yg[c] = y; continue; }
+            if (u == 0 && row < Nw && c < nc) {
+                if (EPI == 1) {
+                    p.w[0].out[(int64_t)(c0 + c) * p.w[0].ldo + row] = ps_silu_mul(yg[c], y);
+                } else {
+                    float val = y;
+                    if (b) val = __fadd_rn(val, b[row]);
+                    if (p.residual && wi == 0) val = __fadd_rn(p.residual[(int64_t)(c0 + c) * ldo + row], val);
+                    o[(int64_t)(c0 + c) * ldo + row] = val;
+                }
+            }
+        }
+    }
 }
 
 } // namespace
@@ -1080,7 +1200,45 @@ size_t psk_gemv_lds_col_bytes(int wt, int64_t K) {
     return (b + 15) / 16 * 16;
 }
 
-// bs <= 4 columns per launch; larger batches are split by the caller.
+// Batched Q4_K mat-mul from pre-quantized activations; returns -1 when the shape is not covered (caller falls back to
+// column groups through the mat-vec).
+int psk_gemm_q4k(hipStream_t st, int n_cu, const psk_gemv_args &a, ps_act act, int64_t K, int64_t bs) {
+    (void)n_cu;
+    if (a.pro != 0 || a.rope || a.n_w < 1 || K % 256) return -1;
+    GemvParams p{};
+    p.n_w = a.n_w; p.K = K; p.bs = bs; p.residual = a.residual;
+    p.aq = act.qs; p.ad = act.d; p.abs16 = act.bs16;
+    for (int i = 0; i < a.n_w; i++) {
+        if (a.w[i]->dtype != PS_Q4_K || a.w[i]->K != K) return -1;
+        const int64_t ng = (a.w[i]->N + 7) / 8;
+        p.w[i] = GemvW{a.w[i]->qs, a.w[i]->aux, a.out[i], a.bias[i], a.w[i]->N, a.ldo[i], ng};
+        p.groups_total += ng;
+    }
+    const int epi = a.silu_pair ? 1 : 0;
+    if (epi == 1 && (a.n_w != 2 || a.w[0]->N != a.w[1]->N)) return -1;
+    const size_t smem = (size_t)8 * (K + (K / 256) * 4 + K / 8);
+    if (smem > 158 * 1024) return -1;
+    const int64_t n_tasks = epi == 1 ? p.w[0].n_groups : p.groups_total;
+    const dim3 grid((unsigned)((n_tasks + 15) / 16), (unsigned)((bs + 7) / 8));
+    static bool attr[2] = {false, false};
+    if (!attr[epi]) {
+        if (epi) (void)hipFuncSetAttribute((const void *)gemm8_q4k_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+        else (void)hipFuncSetAttribute((const void *)gemm8_q4k_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+        attr[epi] = true;
+    }
+    if (epi) hipLaunchKernelGGL(gemm8_q4k_kernel<1>, grid, dim3(1024), smem, st, p);
+    else hipLaunchKernelGGL(gemm8_q4k_kernel<0>, grid, dim3(1024), smem, st, p);
+    return 0;
+}
+
+// up to psk_gemv_max_cols columns per launch (more than 4 only from pre-quantized activations); larger batches are
+// split by the caller.
+int psk_gemv_max_cols(int wt, int64_t K) {
+    const size_t cb = psk_gemv_lds_col_bytes(wt, K);
+    (void)cb;
+    return 4; // (the 8-column instantiations of the in-lane kernel measured slower than 4; Q4_K batches take psk_gemm_q4k)
+}
+
 int psk_gemv(hipStream_t st, int n_cu, const psk_gemv_args &a, ps_act act, int vdt, int64_t K, int64_t bs) {
     GemvParams p{};
     p.n_w          = a.n_w;
@@ -1104,7 +1262,7 @@ int psk_gemv(hipStream_t st, int n_cu, const psk_gemv_args &a, ps_act act, int v
     }
     (void)vdt;
     p.col_bytes = (int64_t)psk_gemv_lds_col_bytes(wt, K);
-    if ((size_t)p.col_bytes * (bs == 1 ? 1 : 4) > 150 * 1024) return 7;
+    if ((size_t)p.col_bytes * (bs == 1 ? 1 : 4) > 158 * 1024) return 7;
     const int epi = a.silu_pair ? 1 : (a.rope ? 2 : 0);
     if (a.rope) {
         if (a.n_w != 3 || bs != 1 || a.pro != 1) return 9;

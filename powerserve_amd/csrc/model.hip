@@ -15,7 +15,6 @@
 #include <cstdio>
 #include <cstring>
 
-int psk_gemm(hipStream_t st, int n_cu, const psk_gemv_args &a, ps_act act, int vdt, int64_t K, int64_t bs); // k_gemm.hip
 
 namespace {
 __global__ void set_state_kernel(ps_step_state *s, int pos0, int bs, int n_out) {
@@ -67,18 +66,28 @@ static int mm(ps_hip_model *m, psk_gemv_args &g, ps_act act, int64_t K, int64_t 
     ps_hip_ctx *c = m->ctx;
     const int vdt = ps_hip_vec_dot_type(g.w[0]->dtype);
     const int64_t blk = vdt == PS_Q8_0 ? 32 : 256;
+    psk_gemv_args gq = g;
+    int64_t step = 4;
     if (bs > 4) {
-        int rc = psk_gemm(c->stream, c->n_cu, g, act, vdt, K, bs);
-        if (rc == 0) return 0;
-        if (rc != -1) { c->err = "gemm launch rc=" + std::to_string(rc); return 2; }
-        // rc == -1: shape not covered by the MFMA kernel -> column groups through the GEMV
+        // batches: the activation is quantized ONCE (with its RMSNorm when the launch carries one) and the weights are
+        // streamed once per column group of up to 16 instead of once per 4 columns
+        if (g.pro) {
+            psk_quantize_act(c->stream, vdt, g.pro == 1 ? 1 : 0, g.pro_x, nullptr, g.pro_norm_w, g.pro_eps, K, bs, act);
+            gq.pro = 0; gq.pro_x = nullptr;
+        }
+        if (g.w[0]->dtype == PS_Q4_K && !gq.pro) {
+            const int rc = psk_gemm_q4k(c->stream, c->n_cu, gq, act, K, bs);
+            if (rc == 0) return 0;
+            if (rc != -1) { c->err = "gemm launch rc=" + std::to_string(rc); return 2; }
+        }
+        step = psk_gemv_max_cols(g.w[0]->dtype, K);
     }
-    for (int64_t c0 = 0; c0 < bs; c0 += 4) {
-        const int64_t nb = bs - c0 < 4 ? bs - c0 : 4;
-        psk_gemv_args gg = g;
+    for (int64_t c0 = 0; c0 < bs; c0 += step) {
+        const int64_t nb = bs - c0 < step ? bs - c0 : step;
+        psk_gemv_args gg = gq;
         for (int i = 0; i < g.n_w; i++) gg.out[i] = g.out[i] + c0 * g.ldo[i];
         if (g.residual) gg.residual = g.residual + c0 * g.ldo[0];
-        if (g.pro) gg.pro_x = g.pro_x + c0 * K;
+        if (gq.pro) gg.pro_x = g.pro_x + c0 * K;
         ps_act ac = act;
         ac.qs += c0 * K; ac.d += c0 * (K / blk); ac.bs16 += c0 * (K / 16);
         if (int rc = psk_gemv(c->stream, c->n_cu, gg, ac, vdt, K, nb)) { c->err = "gemv launch rc=" + std::to_string(rc); return 2; }
