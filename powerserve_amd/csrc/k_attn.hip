@@ -106,45 +106,13 @@ constexpr int PV_VSTR = PV_TILE + 32;  // row stride: the two half-waves of a wa
 constexpr int PV_NT   = 1024;          // one workgroup per CU
 constexpr int PV_NW   = PV_NT / 64;
 constexpr int PV_LPT  = (4 * PV_TILE / 4 + PV_NT - 1) / PV_NT; // float4 V loads per thread and tile
-// Fused softmax + V·p for one (4-channel group, kv head, batch column): grid (hs/4, n_kv_heads, bs), 1024 threads.
-//   t = 0   the first V tile and every score of the r2 rows are requested together (independent streams)
-//   phase 1 exact softmax numerators e_j (ggml_vec_soft_max_f32, ggml.c:2831-2866: ggml_v_expf on groups of 8 with
-//           the in-group sum tree, libm expf on the n%8 tail, double sum), rows spread over the 16 waves
-//   phase 2 out[h][d] = ggml_vec_dot_f32(V[d], p[h]) (ggml.c:2126-2160): 32 fma chains over columns 32i+c, one lane
-//           each, p_j = e_j * (float)(1/sum) formed at the read (same rounding as the reference's scale pass),
-//           GGML_F32x8_REDUCE tree, n%32 leftovers (mul, add).  V comes through LDS tiles (prefetched one ahead).
-__global__ __launch_bounds__(PV_NT) void attn_softmax_pv_kernel(psl_attn_args a) {
-    extern __shared__ __attribute__((aligned(16))) float pl[]; // [r2][n_ctx4] e_j, then [4][PV_VSTR] V tile
-    const int hs = a.head_size, dim = a.n_heads * hs, r2 = a.n_heads / a.n_kv_heads;
+// Exact softmax numerators of the r2 rows of (kv head kvh, column i) into LDS (pl[g][n_kv4]) and 1/sum per row (invs):
+// ggml_vec_soft_max_f32 (ggml.c:2831-2866).  All PV_NT threads; ends with the rows complete and invs visible after the
+// caller's next __syncthreads().
+__device__ __forceinline__ void attn_softmax_rows(const psl_attn_args &a, const int i, const int kvh, const int r2, const int pos0, const int bs,
+                                                  const int n_kv, float *pl, float (*redf)[PV_NW], double (*redd)[PV_NW], float *invs) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int kvh = blockIdx.y, i = blockIdx.z, bs = a.state->bs, pos0 = a.state->pos0;
-    const int n_kv = pos0 + bs, n8 = n_kv & ~7, np = n_kv & ~31, n_kv4 = (n_kv + 3) & ~3;
-    float *vt = pl + (size_t)r2 * (((size_t)a.n_ctx + 3) & ~(size_t)3);
-    __shared__ float redf[R2MAX][PV_NW];
-    __shared__ double redd[R2MAX][PV_NW];
-    __shared__ float invs[R2MAX];
-
-    // ---- V tile loads (registers -> LDS), one tile ahead of the chains
-    const float *vbase = a.v_cache + ((int64_t)kvh * hs + blockIdx.x * 4) * a.n_ctx;
-    float4 ld[PV_LPT];
-    auto load_tile = [&](int t0) { // columns [t0, t0 + PV_TILE) of the 4 channel rows (zero past n_kv)
-#pragma unroll
-        for (int k = 0; k < PV_LPT; k++) {
-            const int f = threadIdx.x + PV_NT * k, row = f / (PV_TILE / 4), col = (f % (PV_TILE / 4)) * 4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row < 4 && t0 + col < n_kv4) v = *(const float4 *)(vbase + (int64_t)row * a.n_ctx + t0 + col); // n_kv4 <= n_ctx4: in bounds
-            ld[k] = v;
-        }
-    };
-    auto store_tile = [&]() {
-#pragma unroll
-        for (int k = 0; k < PV_LPT; k++) {
-            const int f = threadIdx.x + PV_NT * k, row = f / (PV_TILE / 4), col = (f % (PV_TILE / 4)) * 4;
-            if (row < 4) *(float4 *)(vt + row * PV_VSTR + col) = ld[k];
-        }
-    };
-    load_tile(0);
-
+    const int n8 = n_kv & ~7, n_kv4 = (n_kv + 3) & ~3;
     // ---- phase 1a: scores -> masked, scaled logits in LDS; row maxima
     constexpr int EPT = 3; // elements per thread, row and trip: one trip covers n_kv <= 3072
     float rmax[R2MAX];
@@ -216,6 +184,48 @@ __global__ __launch_bounds__(PV_NT) void attn_softmax_pv_kernel(psl_attn_args a)
         for (int w = 0; w < wpr; w++) t += redd[threadIdx.x][w];
         invs[threadIdx.x] = (float)(1.0 / t);
     }
+}
+
+// Fused softmax + V·p for one (4-channel group, kv head, batch column): grid (hs/4, n_kv_heads, bs), 1024 threads.
+//   t = 0   the first V tile and every score of the r2 rows are requested together (independent streams)
+//   phase 1 exact softmax numerators e_j (ggml_vec_soft_max_f32, ggml.c:2831-2866: ggml_v_expf on groups of 8 with
+//           the in-group sum tree, libm expf on the n%8 tail, double sum), rows spread over the 16 waves
+//   phase 2 out[h][d] = ggml_vec_dot_f32(V[d], p[h]) (ggml.c:2126-2160): 32 fma chains over columns 32i+c, one lane
+//           each, p_j = e_j * (float)(1/sum) formed at the read (same rounding as the reference's scale pass),
+//           GGML_F32x8_REDUCE tree, n%32 leftovers (mul, add).  V comes through LDS tiles (prefetched one ahead).
+__global__ __launch_bounds__(PV_NT) void attn_softmax_pv_kernel(psl_attn_args a) {
+    extern __shared__ __attribute__((aligned(16))) float pl[]; // [r2][n_ctx4] e_j, then [4][PV_VSTR] V tile
+    const int hs = a.head_size, dim = a.n_heads * hs, r2 = a.n_heads / a.n_kv_heads;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int kvh = blockIdx.y, i = blockIdx.z, bs = a.state->bs, pos0 = a.state->pos0;
+    const int n_kv = pos0 + bs, n8 = n_kv & ~7, np = n_kv & ~31, n_kv4 = (n_kv + 3) & ~3;
+    float *vt = pl + (size_t)r2 * (((size_t)a.n_ctx + 3) & ~(size_t)3);
+    __shared__ float redf[R2MAX][PV_NW];
+    __shared__ double redd[R2MAX][PV_NW];
+    __shared__ float invs[R2MAX];
+
+    // ---- V tile loads (registers -> LDS), one tile ahead of the chains
+    const float *vbase = a.v_cache + ((int64_t)kvh * hs + blockIdx.x * 4) * a.n_ctx;
+    float4 ld[PV_LPT];
+    auto load_tile = [&](int t0) { // columns [t0, t0 + PV_TILE) of the 4 channel rows (zero past n_kv)
+#pragma unroll
+        for (int k = 0; k < PV_LPT; k++) {
+            const int f = threadIdx.x + PV_NT * k, row = f / (PV_TILE / 4), col = (f % (PV_TILE / 4)) * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < 4 && t0 + col < n_kv4) v = *(const float4 *)(vbase + (int64_t)row * a.n_ctx + t0 + col); // n_kv4 <= n_ctx4: in bounds
+            ld[k] = v;
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int k = 0; k < PV_LPT; k++) {
+            const int f = threadIdx.x + PV_NT * k, row = f / (PV_TILE / 4), col = (f % (PV_TILE / 4)) * 4;
+            if (row < 4) *(float4 *)(vt + row * PV_VSTR + col) = ld[k];
+        }
+    };
+    load_tile(0);
+
+    attn_softmax_rows(a, i, kvh, r2, pos0, bs, n_kv, pl, redf, redd, invs);
     store_tile();
     __syncthreads();
 
@@ -252,6 +262,76 @@ __global__ __launch_bounds__(PV_NT) void attn_softmax_pv_kernel(psl_attn_args a)
         }
     }
     if (live && c == 0) a.att[(int64_t)i * dim + ((int64_t)kvh * r2 + g) * hs + blockIdx.x * 4 + dl] = out;
+}
+
+// Batches (prefill chunks, tree verify): one workgroup per (kv head, CI batch columns).  The softmax of a row is computed
+// once (not once per channel tile as in the single-token kernel, whose grid has to fill the chip from one column), and a
+// V element fetched from L2 serves r2 heads x CI columns.  thread: chain c = tid & 31, channels (tid >> 5) + 32k.
+template <int CI>
+__global__ __launch_bounds__(PV_NT) void attn_softmax_pv_cols_kernel(psl_attn_args a) {
+    extern __shared__ __attribute__((aligned(16))) float pl[]; // [CI][r2][n_ctx4] e_j
+    const int hs = a.head_size, dim = a.n_heads * hs, r2 = a.n_heads / a.n_kv_heads;
+    const int kvh = blockIdx.x, i0 = blockIdx.y * CI, bs = a.state->bs, pos0 = a.state->pos0;
+    const size_t n_kv4 = (size_t)((pos0 + bs + 3) & ~3); // row stride in LDS (attn_softmax_rows)
+    __shared__ float redf[R2MAX][PV_NW];
+    __shared__ double redd[R2MAX][PV_NW];
+    __shared__ float invs[CI][R2MAX];
+    int n_kv_c[CI];
+#pragma unroll
+    for (int ci = 0; ci < CI; ci++) {
+        const int i = min(i0 + ci, bs - 1); // (an odd tail repeats the last column; its result is not stored twice)
+        n_kv_c[ci] = pos0 + bs; // the mask, not the length, implements causality (executor.cpp:210-224): every row spans n_kv
+        attn_softmax_rows(a, i, kvh, r2, pos0, bs, n_kv_c[ci], pl + (size_t)ci * r2 * n_kv4, redf, redd, invs[ci]);
+        __syncthreads();
+    }
+    const int n_kv = pos0 + bs, np = n_kv & ~31;
+    const int c = threadIdx.x & 31, dsub = threadIdx.x >> 5;
+    float inv[CI][R2MAX];
+#pragma unroll
+    for (int ci = 0; ci < CI; ci++)
+#pragma unroll
+        for (int g = 0; g < R2MAX; g++) inv[ci][g] = g < r2 ? invs[ci][g] : 0.f;
+    for (int d = dsub; d < hs; d += PV_NT / 32) {
+        const float *vr = a.v_cache + ((int64_t)kvh * hs + d) * a.n_ctx;
+        float acc[CI][R2MAX];
+#pragma unroll
+        for (int ci = 0; ci < CI; ci++)
+#pragma unroll
+            for (int g = 0; g < R2MAX; g++) acc[ci][g] = 0.f;
+        int j = c;
+        for (; j + 7 * 32 < np; j += 8 * 32) { // eight V loads in flight per chain
+            float vv[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) vv[k] = vr[j + 32 * k];
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+#pragma unroll
+                for (int ci = 0; ci < CI; ci++)
+#pragma unroll
+                    for (int g = 0; g < R2MAX; g++)
+                        if (g < r2) acc[ci][g] = __fmaf_rn(vv[k], __fmul_rn(pl[(size_t)(ci * r2 + g) * n_kv4 + j + 32 * k], inv[ci][g]), acc[ci][g]);
+        }
+        for (; j < np; j += 32) {
+            const float v = vr[j];
+#pragma unroll
+            for (int ci = 0; ci < CI; ci++)
+#pragma unroll
+                for (int g = 0; g < R2MAX; g++)
+                    if (g < r2) acc[ci][g] = __fmaf_rn(v, __fmul_rn(pl[(size_t)(ci * r2 + g) * n_kv4 + j], inv[ci][g]), acc[ci][g]);
+        }
+        const float vleft = (np + c < n_kv) ? vr[np + c] : 0.f; // the n%32 leftovers: one coalesced load, then in order
+#pragma unroll
+        for (int ci = 0; ci < CI; ci++)
+#pragma unroll
+            for (int g = 0; g < R2MAX; g++) {
+                if (g < r2) {
+                    float sres = reduce_f32x8x4(acc[ci][g]);
+                    for (int jj = np; jj < n_kv; jj++)
+                        sres = __fadd_rn(sres, __fmul_rn(__shfl(vleft, jj - np, 32), __fmul_rn(pl[(size_t)(ci * r2 + g) * n_kv4 + jj], inv[ci][g])));
+                    if (c == 0 && i0 + ci < bs) a.att[(int64_t)(i0 + ci) * dim + ((int64_t)kvh * r2 + g) * hs + d] = sres;
+                }
+            }
+    }
 }
 
 // ---------------------------------------------------------------- arg-max, first maximum (prob_array.cpp:65-67)
@@ -317,6 +397,19 @@ size_t psl_attn_softmax_pv_lds(const psl_attn_args &a) {
     return ((size_t)r2 * (((size_t)a.n_ctx + 3) & ~(size_t)3) + 4 * PV_VSTR) * 4;
 }
 void psl_attn_softmax_pv(hipStream_t st, const psl_attn_args &a, int bs) {
+    if (bs > 1) { // batches: one workgroup per (kv head, column pair)
+        const int r2 = a.n_heads / a.n_kv_heads;
+        const size_t row = ((size_t)a.n_ctx + 3) & ~(size_t)3, lds2 = 2 * r2 * row * 4, lds1 = r2 * row * 4;
+        static bool attr2 = false;
+        if (!attr2) {
+            (void)hipFuncSetAttribute((const void *)attn_softmax_pv_cols_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+            (void)hipFuncSetAttribute((const void *)attn_softmax_pv_cols_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+            attr2 = true;
+        }
+        if (lds2 <= 150 * 1024) hipLaunchKernelGGL(attn_softmax_pv_cols_kernel<2>, dim3((unsigned)a.n_kv_heads, (unsigned)((bs + 1) / 2)), dim3(PV_NT), lds2, st, a);
+        else hipLaunchKernelGGL(attn_softmax_pv_cols_kernel<1>, dim3((unsigned)a.n_kv_heads, (unsigned)bs), dim3(PV_NT), lds1, st, a);
+        return;
+    }
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void *)attn_softmax_pv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024); attr = true; }
     dim3 g((unsigned)(a.head_size / 4), (unsigned)a.n_kv_heads, (unsigned)bs);
