@@ -83,6 +83,23 @@ def test_mul_mat_quant_many_row_groups(ctx, oracle, hip, wt, K, N):
     W.free()
 
 
+@pytest.mark.parametrize("K,N,bs", [(4096, 520, 128), (2048, 96, 21), (14336, 72, 12), (256, 64, 9)])
+def test_mul_mat_q4k_batched(ctx, oracle, hip, K, N, bs):
+    """Prefill / tree-verify batches: activations quantized once, 8 columns per workgroup, ragged last column group and
+    a partial last row group; every column keeps the reference's accumulation order."""
+    from powerserve_amd import synth
+    rng = np.random.default_rng(K + N + bs)
+    w = synth.random_blocks(rng, 12, N, K)
+    x = rng.standard_normal((bs, K)).astype(np.float32)
+    want = oracle.mul_mat(12, w, K, N, x)
+    W = ctx.upload_weight(12, w, K, N)
+    dx, dy = ctx.to_device(x), ctx.empty((bs, N))
+    ctx.check(ctx.L.ps_hip_mul_mat(ctx.h, C.byref(dy.tensor()), C.byref(W.tensor()), C.byref(dx.tensor())))
+    got = dy.numpy()
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (rel_err(got, want), np.argwhere(got != want)[:8])
+    W.free()
+
+
 def test_mul_mat_f32_gqa_views(ctx, oracle, hip):
     """K-cache view x permuted q (norm_attention.cpp:115-129) and V-cache view x kq (:138-147)."""
     rng = np.random.default_rng(7)

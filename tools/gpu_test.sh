@@ -1,3 +1,3 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_gpu_ops.py -q -m gpu 2>&1 | tail -30
+timeout 900 python -m pytest tests -x -q -m gpu 2>&1 | tail -15
