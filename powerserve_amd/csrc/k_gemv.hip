@@ -749,7 +749,7 @@ __global__ __launch_bounds__(g3_waves(NW) * 64, 4) void gemv3_kernel(const GemvP
         mark_at(22); // slots placed
         issue(qA, hA, tA, uA, true); // (g1 > g0 always: the grid never exceeds the number of row groups)
         mark_at(23); // chunk A issued
-        constexpr bool B_EARLY = (PRO == 0) || (TPW <= 2); // otherwise the prologue needs the registers
+        constexpr bool B_EARLY = (PRO == 0) || (TPW <= 2) || (PRO == 2); // RMSNorm over long rows: the prologue needs the registers
         if (B_EARLY) issue(qB, hB, tB, uB, n_chunks > 1);
         mark(); // 1: loads issued
         // activation -> LDS once per workgroup

@@ -33,17 +33,15 @@ __device__ __forceinline__ void ps_quantize_tile(const float v[4], bool live, in
     } else { // Q8_K: the first element (index order) with the strictly largest |x| decides the sign of iscale
         float am = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
         const float amax = wave_max_dpp(am);                          // max is order-independent: exact
-        int cand = 0x7fffffff;                                        // smallest index attaining amax
-#pragma unroll
-        for (int i = 3; i >= 0; i--) if (fabsf(v[i]) == amax) cand = lane * 4 + i;
-        const int idx = wave_min_i_dpp(cand);
+        // smallest index attaining amax = lowest lane holding such an element (ballot + find-first-set, scalar) and, in
+        // that lane, the first of its four elements
+        const unsigned long long hits = __ballot(am == amax);
         if (amax == 0.f) {
             q[0] = q[1] = q[2] = q[3] = 0;
             if (live && lane == 0) d[t] = 0.f;
         } else {
-            const int sel = idx & 3;
-            const float mine = sel == 0 ? v[0] : sel == 1 ? v[1] : sel == 2 ? v[2] : v[3];
-            const float mx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine), idx >> 2));
+            const float mine = fabsf(v[0]) == amax ? v[0] : fabsf(v[1]) == amax ? v[1] : fabsf(v[2]) == amax ? v[2] : v[3];
+            const float mx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine), __ffsll((long long)hits) - 1));
             const float iscale = __fdiv_rn(-127.f, mx);
 #pragma unroll
             for (int i = 0; i < 4; i++) q[i] = min(127, __float2int_rn(__fmul_rn(iscale, v[i])));
