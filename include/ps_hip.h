@@ -189,7 +189,9 @@ int ps_hip_model_bench_gemv(ps_hip_model *m, int reps, int which, double *seq_ms
  * shader-clock ticks (s_memtime).  key = k1 + 100 * (k2 + 1) records a second launch family into a second block of
  * the same size (kernel-boundary gaps). */
 int ps_hip_debug_timeline(ps_hip_ctx *ctx, int key, uint64_t *host_out, int n_words);
-/* 0 = fused kernels + hipGraph (default); 1 = fused kernels, eager launches; used by tests/bench */
+/* bit 0: 0 = hipGraph replay of the decode step (default), 1 = eager launches (rocprofv3 needs them);
+ * bit 1: 1 = run the O / gate-up / down mat-vecs of a layer as ONE chained launch (device-wide barriers from relaxed
+ * atomics between the phases; needs every CU for this process; same results bit for bit) */
 int ps_hip_model_set_mode(ps_hip_model *m, int mode);
 
 #ifdef __cplusplus

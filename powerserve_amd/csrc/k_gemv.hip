@@ -627,17 +627,22 @@ __device__ __forceinline__ void rec_chain(const typename RecOf<WT>::T rc, const 
     }
 }
 
+__device__ __forceinline__ float coh_load_f(const float *p) { return __uint_as_float(__hip_atomic_load((const uint32_t *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
+__device__ __forceinline__ void coh_store_f(float *p, float v) { __hip_atomic_store((uint32_t *)p, __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 constexpr int g3_waves(int nw) { return nw + (nw >= 12 ? 2 : 1); } // producers + chain waves
 
-template <int WT, int UPW, int NW, int TPW, int EPI, int PRO>
-__global__ __launch_bounds__(g3_waves(NW) * 64, 4) void gemv3_kernel(const GemvParams p) {
+// One mat-vec phase of a workgroup.  HOOKED = false: a kernel of its own.  HOOKED = true: a phase of a chained kernel:
+// the weight loads go out first, then hook() (the device-wide barrier that makes the previous phase's results
+// visible), then the producers fetch the activation row with cache-bypassing loads (queued behind a chunk that has had
+// the whole barrier to land); COH: outputs and the residual are written / read cache-bypassing too.
+template <int WT, int UPW, int NW, int TPW, int EPI, int PRO, bool HOOKED, bool COH, typename Hook>
+__device__ __forceinline__ void g3_body(const GemvParams &p, char *smem, double *red, Hook hook) {
     constexpr int NC = g3_waves(NW) - NW; // chain waves: rows alternate between them
     using TR  = WTraits<WT>;
     using Rec = typename RecOf<WT>::T;
     constexpr int UPB = NW * UPW; // units per chunk
     // TPW: prologue tiles per wave, K <= g3_waves(NW)*TPW*256
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    __shared__ double red[16];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int64_t K = p.K;
@@ -728,14 +733,20 @@ __global__ __launch_bounds__(g3_waves(NW) * 64, 4) void gemv3_kernel(const GemvP
         }
     };
 
-    if (wave < NW) { // ---------------- producers (the chain waves never touch the vector-memory queue before their stores)
-        float4 xv[TPW], wv[TPW];
+    float4 xv[TPW], wv[TPW];
+    // the tiles go to as few (= the earliest started) waves as TPW allows: a late wave's activation load would sit
+    // behind the weight requests of all the earlier waves in the CU's vector-memory queue
+    const int nwl = min(NW, (int)((K + 255) / 256 + TPW - 1) / TPW);
+    constexpr bool B_EARLY = !HOOKED && ((PRO == 0) || (TPW <= 2) || (PRO == 2)); // RMSNorm over long rows / chained phase: the prologue needs the registers
+    auto begin_producers = [&]() { // the chain waves never touch the vector-memory queue before their stores
         // activation row first, the first chunks of weights right behind it (vmcnt retires in order: the prologue
         // only waits for the L2-resident activation while the weights stream in)
-        // the tiles go to as few (= the earliest started) waves as TPW allows: a late wave's activation load would sit
-        // behind the weight requests of all the earlier waves in the CU's vector-memory queue
-        const int nwl = min(NW, (int)((K + 255) / 256 + TPW - 1) / TPW);
-        if (PRO != 0) ps_qrow_load<(PRO == 1 ? 1 : 0), TPW>(p.x, p.nw, K, xv, wv, nwl);
+        if (!HOOKED) {
+            if (PRO != 0) ps_qrow_load<(PRO == 1 ? 1 : 0), TPW>(p.x, p.nw, K, xv, wv, nwl);
+        } else if (PRO == 1) { // only the (read-only) norm weights can be asked for before the barrier
+            float4 dummy[TPW];
+            ps_qrow_load<1, TPW>(p.nw, p.nw, K, dummy, wv, nwl);
+        }
         mark_at(21); // activation loads issued
 #pragma unroll
         for (int i = 0; i < UPW; i++) {
@@ -749,9 +760,10 @@ __global__ __launch_bounds__(g3_waves(NW) * 64, 4) void gemv3_kernel(const GemvP
         mark_at(22); // slots placed
         issue(qA, hA, tA, uA, true); // (g1 > g0 always: the grid never exceeds the number of row groups)
         mark_at(23); // chunk A issued
-        constexpr bool B_EARLY = (PRO == 0) || (TPW <= 2) || (PRO == 2); // RMSNorm over long rows: the prologue needs the registers
-        if (B_EARLY) issue(qB, hB, tB, uB, n_chunks > 1);
+        if (B_EARLY && !HOOKED) issue(qB, hB, tB, uB, n_chunks > 1); // (chained phase: one chunk across the barrier, the second right behind it)
         mark(); // 1: loads issued
+    };
+    auto run_producers = [&]() {
         // activation -> LDS once per workgroup
         if (Kp != K) {
             for (int i = (int)K + threadIdx.x * 4; i < Kp; i += NW * 64 * 4) *(int *)(lq + i) = 0;
@@ -782,7 +794,8 @@ __global__ __launch_bounds__(g3_waves(NW) * 64, 4) void gemv3_kernel(const GemvP
             issue(qB, hB, tB, uB, 2 * rd + 3 < n_chunks);
             __syncthreads();
         }
-    } else { // ---------------- chain waves: fp32 chains in unit order, one chunk behind the producers
+    };
+    auto run_chain = [&]() { // ---------------- chain waves: fp32 chains in unit order, one chunk behind the producers
         // the prologue's barriers, nothing else (ps_qrow_compute: one after the sum of squares, one at its end)
         if (PRO == 1) {
             if (lane == 0) red[wave] = 0.0;
@@ -838,12 +851,12 @@ __global__ __launch_bounds__(g3_waves(NW) * 64, 4) void gemv3_kernel(const GemvP
                 }
             } else if (u == 0 && row < Nw) {
                 if (EPI == 1) {
-                    o[row] = ps_silu_mul(ygate, y);
+                    if (COH) coh_store_f(o + row, ps_silu_mul(ygate, y)); else o[row] = ps_silu_mul(ygate, y);
                 } else {
                     float v = y;
                     if (b) v = __fadd_rn(v, b[row]);
-                    if (p.residual && wi == 0) v = __fadd_rn(p.residual[row], v);
-                    o[row] = v;
+                    if (p.residual && wi == 0) v = __fadd_rn(COH ? coh_load_f(p.residual + row) : p.residual[row], v);
+                    if (COH) coh_store_f(o + row, v); else o[row] = v;
                 }
             }
             acc0 = 0.f; acc1 = 0.f; accm = 0.f;
@@ -939,8 +952,86 @@ __global__ __launch_bounds__(g3_waves(NW) * 64, 4) void gemv3_kernel(const GemvP
                 }
             }
         }
+    };
+    if constexpr (!HOOKED) { // one contiguous producer path (the register allocator treats it best that way)
+        if (wave < NW) { begin_producers(); run_producers(); } else run_chain();
+    } else {
+        if (wave < NW) begin_producers();
+        if constexpr (HOOKED) {
+            hook(); // every wave; afterwards the previous phase's results are visible to cache-bypassing loads
+            mark_at(24); // device-wide barrier passed
+            // chunk A has had the whole barrier to land, so the (cache-bypassing) activation loads queued behind it come
+            // back at once; chunk B goes out behind them
+            if (wave < NW) {
+                if (PRO != 0) ps_qrow_load_coh<TPW>(p.x, K, xv, nwl);
+                if (B_EARLY) issue(qB, hB, tB, uB, n_chunks > 1);
+            }
+            mark_at(25); // activation and second chunk requested
+        }
+        if (wave < NW) run_producers(); else run_chain();
     }
+    if (COH && wave >= NW) __builtin_amdgcn_s_waitcnt(0x0070); // vmcnt(0) (expcnt/lgkmcnt untouched): this wave's output stores have landed
     if (dbg) { dbg[31] = __builtin_amdgcn_s_memtime(); dbg[30] = __builtin_amdgcn_s_memrealtime(); } // 31: done
+}
+
+
+struct G3NoHook { __device__ __forceinline__ void operator()() const {} };
+
+template <int WT, int UPW, int NW, int TPW, int EPI, int PRO>
+__global__ __launch_bounds__(g3_waves(NW) * 64, 4) void gemv3_kernel(const GemvParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ double red[16];
+    g3_body<WT, UPW, NW, TPW, EPI, PRO, false, false>(p, smem, red, G3NoHook{});
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Three dependent mat-vecs in ONE launch: O projection -> gate/up -> down.  Between the phases the 256 resident
+// workgroups meet at a device-wide barrier built from RELAXED agent-scope atomics (two levels: 8 leaf counters, one
+// root, one generation word; 2.5 us measured, tools/micro/gridbar2.hip -- the release/acquire flavour costs 10-38 us
+// on 8 XCDs because every fence flushes / invalidates a whole L2).  What crosses a barrier (x, h) is written and read
+// with cache-bypassing accesses by the phases themselves (g3_body<.., HOOKED, COH>), so no fence is needed.  A phase
+// puts its first two chunks of weight loads in flight BEFORE it waits for the previous phase: start-up, first-byte
+// latency and the previous phase's chain tail overlap with HBM traffic instead of idling it.
+struct G3Bar { // per launch site, zeroed once: [0] generation base, [32] generation, [32*(2+leaf)] leaf counters, [32*10] root, [32*11] error flag
+    unsigned *w;
+};
+struct G3GridHook {
+    unsigned *w;
+    unsigned gen; // generation this barrier completes
+    int nw;       // first chain wave
+    __device__ __forceinline__ void operator()() const {
+        __syncthreads(); // the chain waves have waited for their own output stores (end of g3_body)
+        if ((int)(threadIdx.x >> 6) == nw && (threadIdx.x & 63) == 0) { // a chain wave: nothing of its own in the memory pipeline
+            const unsigned leaf = blockIdx.x & 7, per_leaf = gridDim.x >> 3;
+            const unsigned a = __hip_atomic_fetch_add(w + 32 * (2 + leaf), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (a == gen * per_leaf - 1) {
+                const unsigned b = __hip_atomic_fetch_add(w + 32 * 10, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (b == gen * 8 - 1) __hip_atomic_store(w + 32, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            int spins = 0;
+            while (__hip_atomic_load(w + 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gen) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1 << 22)) { __hip_atomic_store(w + 32 * 11, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; } // never hang the GPU
+            }
+        }
+        __syncthreads();
+    }
+};
+struct GemvChain3 {
+    GemvParams p[3];
+    G3Bar bar;
+};
+
+template <int WT, int TPW0, int TPW2>
+__global__ __launch_bounds__(1024, 4) void gemv3_chain3_kernel(const GemvChain3 c) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ double red[16];
+    const unsigned base = __hip_atomic_load(c.bar.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // barriers completed by earlier launches
+    // (inlined on purpose: as out-of-line functions the phases read their parameters from a scratch copy -- 3x slower)
+    g3_body<WT, 4, 14, TPW0, 0, 2, false, true>(c.p[0], smem, red, G3NoHook{});                        // att -> x += Wo att
+    g3_body<WT, 4, 14, TPW0, 1, 1, true, true>(c.p[1], smem, red, G3GridHook{c.bar.w, base + 1, 14});  // h = silu(Wg n(x)) * (Wu n(x))
+    g3_body<WT, 4, 14, TPW2, 0, 2, true, true>(c.p[2], smem, red, G3GridHook{c.bar.w, base + 2, 14});  // x += Wd h
+    if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(c.bar.w, base + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 template <int WT, int UPW, int NW, int TPW, int EPI, int PRO>
@@ -1198,6 +1289,50 @@ size_t psk_gemv_lds_col_bytes(int wt, int64_t K) {
     const int64_t Kp = (K + unit - 1) / unit * unit;
     const size_t b = (size_t)Kp + (size_t)(Kp / blk) * 4 + (size_t)(Kp / 32) * 4 + (size_t)(Kp / 16) * 2;
     return (b + 15) / 16 * 16;
+}
+
+// O projection -> gate/up -> down of one layer in one launch (single token, Q4_K).  a[0]: Wo (pro 2, residual);
+// a[1]: Wgate|Wup (pro 1, silu_pair); a[2]: Wdown (pro 2, residual).  bar: 12*32 zero-initialised uints owned by this
+// launch site.  Returns -1 when the shapes are not covered (the caller launches the three mat-vecs separately).
+int psk_gemv_chain3(hipStream_t st, int n_cu, const psk_gemv_args a[3], unsigned *bar) {
+    GemvChain3 c{};
+    const int want_pro[3] = {2, 1, 2}, want_epi[3] = {0, 1, 0};
+    size_t smem = 0;
+    int64_t grid = (int64_t)n_cu; // one 16-wave workgroup per CU: all resident, which the barrier relies on
+    if (grid % 8) return -1;
+    for (int ph = 0; ph < 3; ph++) {
+        const psk_gemv_args &g = a[ph];
+        const int64_t K = g.w[0]->K;
+        GemvParams &p = c.p[ph];
+        if (g.pro != want_pro[ph] || (g.silu_pair ? 1 : 0) != want_epi[ph] || g.rope || g.n_w != (ph == 1 ? 2 : 1)) return -1;
+        p.n_w = g.n_w; p.K = K; p.bs = 1; p.residual = g.residual; p.x = g.pro_x; p.nw = g.pro_norm_w; p.eps = g.pro_eps;
+        for (int i = 0; i < g.n_w; i++) {
+            if (g.w[i]->dtype != PS_Q4_K || g.w[i]->K != K || g.bias[i]) return -1;
+            const int64_t ng = (g.w[i]->N + 7) / 8;
+            p.w[i] = GemvW{g.w[i]->qs, g.w[i]->aux, g.out[i], nullptr, g.w[i]->N, g.ldo[i], ng};
+            p.groups_total += ng;
+        }
+        if (ph == 1 && g.w[0]->N != g.w[1]->N) return -1;
+        if (K % 1024) return -1;                                    // rows end on multiples of four units
+        if (ph < 2 ? K > 14 * 2 * 256 : K > 14 * 4 * 256) return -1; // prologue register tiles (TPW 2 / 4)
+        const int64_t n_tasks = ph == 1 ? p.w[0].n_groups : p.groups_total;
+        if (n_tasks < grid) return -1; // every workgroup needs at least one row group in every phase
+        p.split_q = (int)(n_tasks / grid);
+        p.split_r = (int)(n_tasks % grid);
+        p.col_bytes = (int64_t)psk_gemv_lds_col_bytes(PS_Q4_K, K);
+        if (g_dbg_buf && g_dbg_key % 100 == 20 + ph) p.dbg = g_dbg_buf; // timeline of one phase (tools/gpu_timeline.py 20 21 22)
+        const size_t need = (size_t)p.col_bytes + (size_t)2 * 56 * 64 * 8; // activation image + records
+        smem = need > smem ? need : smem;
+    }
+    if (smem > 156 * 1024) return -1;
+    c.bar.w = bar;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void *)gemv3_chain3_kernel<PS_Q4_K, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+        attr = true;
+    }
+    hipLaunchKernelGGL((gemv3_chain3_kernel<PS_Q4_K, 2, 4>), dim3((unsigned)grid), dim3(1024), smem, st, c);
+    return 0;
 }
 
 // Batched Q4_K mat-mul from pre-quantized activations; returns -1 when the shape is not covered (caller falls back to

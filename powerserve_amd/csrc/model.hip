@@ -40,6 +40,7 @@ struct ps_hip_model {
     std::vector<const ps_weight *> wq, wk, wv, wo, wg, wu, wd;
     // arena
     float *x = nullptr, *q = nullptr, *k = nullptr, *v = nullptr, *att = nullptr, *hb = nullptr, *g1 = nullptr, *u1 = nullptr;
+    unsigned *bars = nullptr; // device-wide barrier words of the chained launches, [n_layers][12*32]
     float *scores = nullptr, *logits = nullptr, *rope_table = nullptr;
     void *act_mem = nullptr;
     std::vector<float *> k_cache, v_cache;
@@ -138,17 +139,24 @@ static int enqueue_forward(ps_hip_model *m, int bs, bool lm_head, bool use_tree,
         psk_gemv_args go{};
         go.n_w = 1; go.w[0] = m->wo[L]; go.out[0] = m->x; go.ldo[0] = dim; go.residual = m->x;
         go.pro = 2; go.pro_x = m->att;
-        if (mm(m, go, a1, dim, bs)) return 2;
-
         ps_act a2 = act_for(hid);
         const int vdt_d = ps_hip_vec_dot_type(m->wd[L]->dtype);
         psk_gemv_args gf{};
         gf.n_w = 2; gf.w[0] = m->wg[L]; gf.w[1] = m->wu[L]; gf.out[0] = m->hb; gf.out[1] = m->hb; gf.ldo[0] = hid; gf.ldo[1] = hid;
         gf.silu_pair = 1;
         gf.pro = 1; gf.pro_x = m->x; gf.pro_norm_w = m->ffn_norm[L]; gf.pro_eps = f.norm_eps;
-        if (mm(m, gf, a1, dim, bs)) return 2;
         psk_gemv_args gd{};
         gd.n_w = 1; gd.w[0] = m->wd[L]; gd.out[0] = m->x; gd.ldo[0] = dim; gd.residual = m->x;
+        if (bs == 1 && (m->mode & 2)) { // opt-in: the three dependent mat-vecs of the layer in ONE launch (break-even today)
+            gd.pro = 2; gd.pro_x = m->hb;
+            const psk_gemv_args ch[3] = {go, gf, gd};
+            const int rc = psk_gemv_chain3(st, c->n_cu, ch, m->bars + (size_t)L * 12 * 32);
+            if (rc == 0) continue;
+            if (rc != -1) { c->err = "gemv chain launch rc=" + std::to_string(rc); return 2; }
+            gd.pro = 0; gd.pro_x = nullptr;
+        }
+        if (mm(m, go, a1, dim, bs)) return 2;
+        if (mm(m, gf, a1, dim, bs)) return 2;
         if (psk_gemv_lds_col_bytes(m->wd[L]->dtype, hid) * (bs == 1 ? 1 : 4) <= 64 * 1024 && (hid <= 8192 || bs == 1)) {
             gd.pro = 2; gd.pro_x = m->hb; // short rows: quantize in the prologue
         } else {
@@ -206,6 +214,7 @@ int ps_hip_model_create(ps_hip_ctx *c, const ps_model_desc *d, ps_hip_model **ou
         dmalloc(m, (void **)&m->k, mb * kvd * 4) || dmalloc(m, (void **)&m->v, mb * kvd * 4) ||
         dmalloc(m, (void **)&m->att, mb * dim * 4) || dmalloc(m, (void **)&m->hb, mb * hid * 4) ||
         dmalloc(m, (void **)&m->g1, mb * hid * 4) || dmalloc(m, (void **)&m->u1, mb * hid * 4) ||
+        dmalloc(m, (void **)&m->bars, (size_t)f.n_layers * 12 * 32 * 4) ||
         dmalloc(m, (void **)&m->scores, mb * f.n_heads * nctx * 4) || dmalloc(m, (void **)&m->logits, mb * f.vocab_size * 4) ||
         dmalloc(m, (void **)&m->rope_table, nctx * f.head_size * 4) ||
         dmalloc(m, &m->act_mem, ps_act_bytes(dim > hid ? dim : hid, mb)) ||
@@ -213,6 +222,7 @@ int ps_hip_model_create(ps_hip_ctx *c, const ps_model_desc *d, ps_hip_model **ou
         dmalloc(m, (void **)&m->argmax_dev, mb * 4) || dmalloc(m, (void **)&m->ids_dev, (nctx + 1) * 4) ||
         dmalloc(m, (void **)&m->tree_dev, mb * mb) || dmalloc(m, (void **)&m->am_v, mb * 64 * 4) || dmalloc(m, (void **)&m->am_i, mb * 64 * 4))
         return fail();
+    (void)hipMemsetAsync(m->bars, 0, (size_t)f.n_layers * 12 * 32 * 4, c->stream);
     m->k_cache.assign(L, nullptr); m->v_cache.assign(L, nullptr);
     for (uint32_t i = 0; i < L; i++) {
         if (dmalloc(m, (void **)&m->k_cache[i], nctx * kvd * 4) || dmalloc(m, (void **)&m->v_cache[i], nctx * kvd * 4)) return fail();
@@ -288,7 +298,7 @@ int ps_hip_model_decode_greedy(ps_hip_model *m, int32_t token, int steps, int32_
     hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(1), 0, c->stream, m->state, (int)m->position, 1, 0);
     PS_CHECK(c, hipStreamSynchronize(c->stream));
     int s = 0;
-    if (m->mode == 0 && !m->step_graph) {
+    if ((m->mode & 1) == 0 && !m->step_graph) {
         // first step runs eagerly (also performs every one-time hipFuncSetAttribute), then the identical
         // launch sequence is captured; capture itself executes nothing
         if (int rc = enqueue_forward(m, 1, true, false, true)) return rc;
@@ -303,7 +313,7 @@ int ps_hip_model_decode_greedy(ps_hip_model *m, int32_t token, int steps, int32_
         (void)hipGraphDestroy(g);
     }
     for (; s < steps; s++) {
-        if (m->mode == 0) {
+        if ((m->mode & 1) == 0) {
             PS_CHECK(c, hipGraphLaunch(m->step_graph, c->stream));
         } else {
             if (int rc = enqueue_forward(m, 1, true, false, true)) return rc;
@@ -391,6 +401,10 @@ int ps_hip_model_bench_gemv(ps_hip_model *m, int reps, int which, double *seq_ms
 }
 
 int ps_hip_model_set_mode(ps_hip_model *m, int mode) {
+    if (((m->mode ^ mode) & 2) && m->step_graph) { // the captured step bakes the launch plan in
+        (void)hipGraphExecDestroy(m->step_graph);
+        m->step_graph = nullptr;
+    }
     m->mode = mode;
     return 0;
 }

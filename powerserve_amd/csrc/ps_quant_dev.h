@@ -74,6 +74,23 @@ __device__ __forceinline__ void ps_qrow_load(const float *x, const float *w, int
         wv[i] = (MODE == 1 && in) ? *(const float4 *)(w + e) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 }
+// the same tile map, activation only, fetched with cache-bypassing (agent-scope relaxed atomic) 64-bit loads: the row was
+// written by other workgroups of the SAME kernel (chained mat-vec phases) and must not be served from a stale L2 line
+template <int TPW>
+__device__ __forceinline__ void ps_qrow_load_coh(const float *x, int64_t K, float4 (&xv)[TPW], int nwl) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t n_tiles = (K + 255) / 256;
+#pragma unroll
+    for (int i = 0; i < TPW; i++) {
+        const int64_t t = wave < nwl ? wave + (int64_t)i * nwl : n_tiles, e = t * 256 + lane * 4;
+        unsigned long long lo = 0, hi = 0;
+        if (t < n_tiles && e < K) { // K % 4 == 0 on this path
+            lo = __hip_atomic_load((const unsigned long long *)(x + e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            hi = __hip_atomic_load((const unsigned long long *)(x + e + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        xv[i] = make_float4(__uint_as_float((unsigned)lo), __uint_as_float((unsigned)(lo >> 32)), __uint_as_float((unsigned)hi), __uint_as_float((unsigned)(hi >> 32)));
+    }
+}
 template <int VDT, int MODE, int TPW>
 __device__ __forceinline__ void ps_qrow_compute(const float4 (&xv)[TPW], const float4 (&wv)[TPW], float eps, int64_t K, int8_t *qs,
                                                 float *d, int16_t *bs16, double *red, int nwl = 0) {

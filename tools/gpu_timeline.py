@@ -56,6 +56,8 @@ for key in keys:
             print(f"    {i:2d}: {v.mean():7.2f} {v.min():7.2f} {v.max():7.2f} | {own.mean():7.2f}   n={ok.sum()}")
 
 # boundary between two consecutive kernels: gate/up (5) then down (2) of the same layer
+if os.environ.get('TL_BOUNDARY', '0') != '1':
+    sys.exit(0)
 ctx.check(ctx.L.ps_hip_debug_timeline(ctx.h, 5 + 100 * (2 + 1), None, 0))
 for _ in range(3):
     m.decode_greedy(7, 4)
