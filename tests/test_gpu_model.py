@@ -94,6 +94,42 @@ def test_chained_launch_is_bit_identical(ctx, oracle, tmp_path):
     om.close()
 
 
+def test_tree_mask_plumbing(ctx, tmp_path):
+    """The batch forward takes an optional [bs][bs] tree mask (speculative verify; the reference's CPU
+    executor ignores mask objects, executor.cpp:210-224, so there is no CPU golden for a real tree).  A tree mask that
+    IS the causal triangle must reproduce the causal forward bit for bit, and a branching tree must make a node blind to
+    its sibling: the sibling's logits equal those of the chain without it."""
+    from powerserve_amd import hip, synth
+    d = str(tmp_path / "m")
+    synth.write_model_dir(d, "small-llama-hs128", 12, n_ctx=64, seed=4)
+    gm = hip.Model(ctx, d, max_batch=16)
+    rng = np.random.default_rng(8)
+    prompt = rng.integers(0, gm.cfg.vocab_size, 6)
+    toks = rng.integers(0, gm.cfg.vocab_size, 5)
+
+    def run(tokens, pos, tree):
+        gm.reset()
+        gm.forward(prompt, np.arange(6), lm_head=False)
+        lg, _ = gm.forward(tokens, pos, lm_head=True, tree=tree)
+        return lg
+
+    causal = run(toks, np.arange(6, 11), None)
+    tri = np.tril(np.ones((5, 5), dtype=np.uint8))
+    assert np.array_equal(run(toks, np.arange(6, 11), tri).view(np.uint32), causal.view(np.uint32))
+    # nodes 0 -> 1 -> 2 and a node 3 that hangs off node 0 (rows = who each node may see among the batch).  Cache slots /
+    # RoPE positions stay consecutive, as the reference's KV append requires (norm_attention.cpp:82-91).
+    tree = np.zeros((4, 4), dtype=np.uint8)
+    tree[0, 0] = 1
+    tree[1, [0, 1]] = 1
+    tree[2, [0, 1, 2]] = 1
+    tree[3, [0, 3]] = 1
+    lg = run(toks[:4], np.arange(6, 10), tree)
+    chain4 = run(toks[:4], np.arange(6, 10), None)
+    assert np.array_equal(lg[:3].view(np.uint32), chain4[:3].view(np.uint32))   # same visible sets
+    assert not np.array_equal(lg[3], chain4[3])                                  # node 3 is blind to nodes 1 and 2
+    gm.close()
+
+
 def test_batched_forward_logits(ctx, oracle, tmp_path):
     """lm_head over a whole batch (LlamaModel::forward returns vocab x bs logits) + batch-size invariance."""
     from oracle import binding as B
