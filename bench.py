@@ -110,6 +110,11 @@ def max_over_ranks(dist, values, device="cuda"):
 
 def main():
     args = parse()
+    # the contract is ONE JSON line on stdout: libraries that chat on fd 1 (RCCL prints its library path at init) are
+    # sent to stderr for the duration of the run
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -211,7 +216,9 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        print(json.dumps(out), flush=True)
 
 
 def _pmc_traffic(kernel_key):
