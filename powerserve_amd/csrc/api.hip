@@ -261,11 +261,11 @@ int ps_hip_mul_mat(ps_hip_ctx *c, const ps_tensor *dst, const ps_tensor *src0, c
         const int vdt = ps_hip_vec_dot_type(w->dtype);
         if (ensure(c, &c->act_buf, &c->act_cap, ps_act_bytes(K, bs))) return 1;
         ps_act a = ps_act_carve(c->act_buf, K, bs);
-        if (bs > 4 && w->dtype == PS_Q4_K) { // batches: quantize once, 8 columns per workgroup (psk_gemm_q4k)
+        if (bs > 4) { // batches: quantize once, 8 columns per workgroup (psk_gemm8)
             psk_quantize_act(c->stream, vdt, 0, (const float *)src1->data, nullptr, nullptr, 0.f, K, bs, a);
             psk_gemv_args g{};
             g.n_w = 1; g.w[0] = w; g.out[0] = (float *)dst->data; g.ldo[0] = w->N;
-            const int rc = psk_gemm_q4k(c->stream, c->n_cu, g, a, K, bs);
+            const int rc = psk_gemm8(c->stream, c->n_cu, g, a, K, bs);
             if (rc == 0) { PS_CHECK(c, hipGetLastError()); return 0; }
             if (rc != -1) { c->err = "mul_mat: gemm launch rc=" + std::to_string(rc); return 2; }
         }

@@ -1149,38 +1149,51 @@ int launch_wt(hipStream_t st, int n_cu, const GemvParams &p, int epi, int pro) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Batched mat-mul for Q4_K weights (prefill chunks, tree verify): 8 activation columns per workgroup, in-lane chains.
+// Batched mat-mul (prefill chunks, tree verify): 8 activation columns per workgroup, in-lane chains.
 // grid = (row-group tiles of 16, column groups of 8); a workgroup stages its 8 pre-quantized columns in LDS once
-// (quants transposed so that the 32 bytes a lane needs per super-block are contiguous: two ds_read_b128), every wave
-// then owns one row group: the weights of a unit are unpacked ONCE and meet the 8 columns, each column keeping the
-// reference's fma chains (acc[u], acc_m[v]) in this lane's registers.  Same arithmetic, same order as the mat-vec.
-template <int EPI>
-__global__ __launch_bounds__(1024) void gemm8_q4k_kernel(const GemvParams p) {
+// (quants transposed so that the bytes a lane needs per unit are contiguous: ds_read_b128), every wave then owns one
+// row group: the weights of a unit are unpacked ONCE and meet the 8 columns, each column keeping the reference's fma
+// chains in this lane's registers.  Same arithmetic, same order as the mat-vec.
+template <int WT, int EPI>
+__global__ __launch_bounds__(1024) void gemm8_kernel(const GemvParams p) {
+    using TR = WTraits<WT>;
     constexpr int C = 8;
     constexpr uint32_t M = 0x0F0F0F0Fu;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int K = (int)p.K, n_units = K / 256, c0 = blockIdx.y * C, nc = min(C, (int)p.bs - c0);
-    const int col_bytes = K + n_units * 4 + K / 8; // [int8 q (transposed dwords)] [float d] [int bs32]; multiple of 16
-    // ---- stage the columns
+    const int K = (int)p.K, n_units = K / TR::UNIT, nblk = K / TR::BLK, c0 = blockIdx.y * C, nc = min(C, (int)p.bs - c0);
+    // column image: [int8 q, transposed dwords][float d per block][Q4_K: int sums of 32]; multiple of 16 bytes
+    const int col_bytes = K + nblk * 4 + (WT == PS_Q4_K ? K / 8 : 0);
     for (int idx = threadIdx.x; idx < C * (K / 4); idx += 1024) {
         const int c = idx / (K / 4), i = idx % (K / 4);
         const int dw = c < nc ? ((const int *)(p.aq + (int64_t)(c0 + c) * K))[i] : 0;
-        const int unit = i >> 6, g = (i & 63) >> 3, uu = i & 7;
-        ((int *)(smem + c * col_bytes))[unit * 64 + uu * 8 + g] = dw;
+        int t;
+        if (WT == PS_Q4_K) { // unit = 64 dwords: dword (g, u) -> [u][g]
+            t = (i & ~63) + (i & 7) * 8 + ((i & 63) >> 3);
+        } else if (WT == PS_Q8_0) { // unit = 32 dwords: dword (block b, d) -> [d][b]
+            t = (i & ~31) + (i & 7) * 4 + ((i & 31) >> 3);
+        } else { // Q4_0: dword (b, half*4 + u') -> [u'][b][half]
+            t = (i & ~31) + (i & 3) * 8 + ((i & 31) >> 3) * 2 + ((i >> 2) & 1);
+        }
+        ((int *)(smem + c * col_bytes))[t] = dw;
     }
-    for (int idx = threadIdx.x; idx < C * n_units; idx += 1024) {
-        const int c = idx / n_units, i = idx % n_units;
-        ((float *)(smem + c * col_bytes + K))[i] = c < nc ? p.ad[(int64_t)(c0 + c) * n_units + i] : 0.f;
+    for (int idx = threadIdx.x; idx < C * nblk; idx += 1024) {
+        const int c = idx / nblk, i = idx % nblk;
+        ((float *)(smem + c * col_bytes + K))[i] = c < nc ? p.ad[(int64_t)(c0 + c) * nblk + i] : 0.f;
     }
-    for (int idx = threadIdx.x; idx < C * (K / 32); idx += 1024) {
-        const int c = idx / (K / 32), i = idx % (K / 32);
-        const int16_t *b = p.abs16 + (int64_t)(c0 + c) * (K / 16) + 2 * i;
-        ((int *)(smem + c * col_bytes + K + n_units * 4))[i] = c < nc ? (int)b[0] + (int)b[1] : 0;
+    if (WT == PS_Q4_K) {
+        for (int idx = threadIdx.x; idx < C * (K / 32); idx += 1024) {
+            const int c = idx / (K / 32), i = idx % (K / 32);
+            const int16_t *b = p.abs16 + (int64_t)(c0 + c) * (K / 16) + 2 * i;
+            ((int *)(smem + c * col_bytes + K + nblk * 4))[i] = c < nc ? (int)b[0] + (int)b[1] : 0;
+        }
     }
     __syncthreads();
 
-    const int r = lane >> 3, u = lane & 7, v = u & 3;
+    const int r = (WT == PS_Q4_0) ? (lane >> 2) : (lane >> 3);
+    const int u = (WT == PS_Q4_0) ? (lane & 3) : (lane & 7);
+    const int v = u & 3;
+    constexpr int AUXR = (WT == PS_Q4_K) ? 16 : 8;
     const int64_t n_tasks = (EPI == 1) ? p.w[0].n_groups : p.groups_total;
     const int64_t task = (int64_t)blockIdx.x * 16 + wave;
     if (task >= n_tasks) return;
@@ -1199,56 +1212,96 @@ __global__ __launch_bounds__(1024) void gemm8_q4k_kernel(const GemvParams p) {
         if (wi == 1) { qs = p.w[1].qs; ax = p.w[1].aux; }
         if (wi == 2) { qs = p.w[2].qs; ax = p.w[2].aux; }
         const uint8_t *qg = qs + grp * n_units * 1024 + lane * 16;
-        const uint8_t *ag = ax + grp * n_units * 128 + r * 16;
-        float acc0[C], accm[C];
+        const uint8_t *ag = ax + grp * n_units * (TR::RG * AUXR) + r * AUXR;
+        float acc0[C], acc1[C];
 #pragma unroll
-        for (int c = 0; c < C; c++) { acc0[c] = 0.f; accm[c] = 0.f; }
-        uint4 q = ld_stream16(qg), h = *(const uint4 *)ag;
+        for (int c = 0; c < C; c++) { acc0[c] = 0.f; acc1[c] = 0.f; }
+        auto load_h = [&](int un) {
+            uint4 h = make_uint4(0, 0, 0, 0);
+            if (WT == PS_Q4_K) h = *(const uint4 *)(ag + (int64_t)un * (TR::RG * AUXR));
+            else { const uint2 t2 = *(const uint2 *)(ag + (int64_t)un * (TR::RG * AUXR)); h.x = t2.x; h.y = t2.y; }
+            return h;
+        };
+        uint4 q = ld_stream16(qg), h = load_h(0);
         for (int un = 0; un < n_units; un++) {
             uint4 qn = q, hn = h;
-            if (un + 1 < n_units) { qn = ld_stream16(qg + (int64_t)(un + 1) * 1024); hn = *(const uint4 *)(ag + (int64_t)(un + 1) * 128); }
-            // ---- this unit's weights, unpacked once for the 8 columns
-            const uint32_t sc03 = h.y & 0x3f3f3f3fu, sc47 = (h.w & 0x0f0f0f0fu) | (((h.y >> 6) & 0x03030303u) << 4);
-            const uint32_t mn03 = h.z & 0x3f3f3f3fu, mn47 = ((h.w >> 4) & 0x0f0f0f0fu) | (((h.z >> 6) & 0x03030303u) << 4);
-            const uint32_t sc16[4] = {__builtin_amdgcn_perm(0u, sc03, 0x0c010c00u), __builtin_amdgcn_perm(0u, sc03, 0x0c030c02u),
-                                      __builtin_amdgcn_perm(0u, sc47, 0x0c010c00u), __builtin_amdgcn_perm(0u, sc47, 0x0c030c02u)};
+            if (un + 1 < n_units) { qn = ld_stream16(qg + (int64_t)(un + 1) * 1024); hn = load_h(un + 1); }
             const uint32_t wq[4] = {q.x, q.y, q.z, q.w};
-            int wl[4], wh[4];
+            if constexpr (WT == PS_Q4_K) {
+                // ---- this unit's weights, unpacked once for the 8 columns (acc1 plays acc_m)
+                const uint32_t sc03 = h.y & 0x3f3f3f3fu, sc47 = (h.w & 0x0f0f0f0fu) | (((h.y >> 6) & 0x03030303u) << 4);
+                const uint32_t mn03 = h.z & 0x3f3f3f3fu, mn47 = ((h.w >> 4) & 0x0f0f0f0fu) | (((h.z >> 6) & 0x03030303u) << 4);
+                const uint32_t sc16[4] = {__builtin_amdgcn_perm(0u, sc03, 0x0c010c00u), __builtin_amdgcn_perm(0u, sc03, 0x0c030c02u),
+                                          __builtin_amdgcn_perm(0u, sc47, 0x0c010c00u), __builtin_amdgcn_perm(0u, sc47, 0x0c030c02u)};
+                int wl[4], wh[4];
 #pragma unroll
-            for (int j = 0; j < 4; j++) { wl[j] = (int)(wq[j] & M); wh[j] = (int)((wq[j] >> 4) & M); }
-            const uint32_t mp = (v < 2) ? mn03 : mn47;
-            const int mna = bfe8(mp, (2 * v) & 3), mnb = bfe8(mp, (2 * v + 1) & 3);
-            const float dw = ps_h2f((uint16_t)(h.x & 0xffff)), dmw = ps_h2f((uint16_t)(h.x >> 16));
+                for (int j = 0; j < 4; j++) { wl[j] = (int)(wq[j] & M); wh[j] = (int)((wq[j] >> 4) & M); }
+                const uint32_t mp = (v < 2) ? mn03 : mn47;
+                const int mna = bfe8(mp, (2 * v) & 3), mnb = bfe8(mp, (2 * v + 1) & 3);
+                const float dw = ps_h2f((uint16_t)(h.x & 0xffff)), dmw = ps_h2f((uint16_t)(h.x >> 16));
 #pragma unroll
-            for (int c = 0; c < C; c++) {
-                const char *col = smem + c * col_bytes;
-                const int4 y0 = *(const int4 *)(col + (un * 64 + u * 8) * 4), y1 = *(const int4 *)(col + (un * 64 + u * 8 + 4) * 4);
-                const int2 bs = *(const int2 *)(col + K + n_units * 4 + (un * 8 + 2 * v) * 4);
-                const float yd = ((const float *)(col + K))[un];
-                const int yl[4] = {y0.x, y0.z, y1.x, y1.z}, yh[4] = {y0.y, y0.w, y1.y, y1.w};
-                int s = 0;
+                for (int c = 0; c < C; c++) {
+                    const char *col = smem + c * col_bytes;
+                    const int4 y0 = *(const int4 *)(col + (un * 64 + u * 8) * 4), y1 = *(const int4 *)(col + (un * 64 + u * 8 + 4) * 4);
+                    const int2 bs = *(const int2 *)(col + K + nblk * 4 + (un * 8 + 2 * v) * 4);
+                    const float yd = ((const float *)(col + K))[un];
+                    const int yl[4] = {y0.x, y0.z, y1.x, y1.z}, yh[4] = {y0.y, y0.w, y1.y, y1.w};
+                    int s = 0;
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const int dl = dot4(wl[j], yl[j], 0), dh = dot4(wh[j], yh[j], 0);
-                    s = dot2_i16(__builtin_amdgcn_perm((uint32_t)dh, (uint32_t)dl, 0x05040100u), sc16[j], s);
+                    for (int j = 0; j < 4; j++) {
+                        const int dl = dot4(wl[j], yl[j], 0), dh = dot4(wh[j], yh[j], 0);
+                        s = dot2_i16(__builtin_amdgcn_perm((uint32_t)dh, (uint32_t)dl, 0x05040100u), sc16[j], s);
+                    }
+                    const int pr   = __mul24(mna, bs.x) + __mul24(mnb, bs.y);
+                    const float d  = __fmul_rn(yd, dw), dmin = __fmul_rn(-yd, dmw);
+                    acc0[c] = __fmaf_rn(d, (float)s, acc0[c]);
+                    acc1[c] = __fmaf_rn(dmin, (float)pr, acc1[c]);
                 }
-                const int pr   = __mul24(mna, bs.x) + __mul24(mnb, bs.y);
-                const float d  = __fmul_rn(yd, dw), dmin = __fmul_rn(-yd, dmw);
-                acc0[c] = __fmaf_rn(d, (float)s, acc0[c]);
-                accm[c] = __fmaf_rn(dmin, (float)pr, accm[c]);
+            } else {
+                const float dh[4] = {ps_h2f((uint16_t)(h.x & 0xffff)), ps_h2f((uint16_t)(h.x >> 16)), ps_h2f((uint16_t)(h.y & 0xffff)), ps_h2f((uint16_t)(h.y >> 16))};
+                int wl[4], wh[4];
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    if (WT == PS_Q8_0) { wl[b] = (int)wq[b]; wh[b] = 0; }
+                    else { // nibble - 8 as signed bytes, once: dot4(n - 8, y) == dot4(n, y) - 8 * sum(y), the reference's integer
+                        wl[b] = (int)((((wq[b] & M) | 0x80808080u) - 0x08080808u) ^ 0x80808080u);
+                        wh[b] = (int)(((((wq[b] >> 4) & M) | 0x80808080u) - 0x08080808u) ^ 0x80808080u);
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < C; c++) {
+                    const char *col = smem + c * col_bytes;
+                    const float4 yd = *(const float4 *)(col + K + un * 16);
+                    const float ydv[4] = {yd.x, yd.y, yd.z, yd.w};
+                    if constexpr (WT == PS_Q8_0) {
+                        const int4 y = *(const int4 *)(col + (un * 32 + u * 4) * 4);
+                        const int yv[4] = {y.x, y.y, y.z, y.w};
+#pragma unroll
+                        for (int b = 0; b < 4; b++) acc0[c] = __fmaf_rn(__fmul_rn(dh[b], ydv[b]), (float)dot4(wl[b], yv[b], 0), acc0[c]);
+                    } else {
+                        const int4 y0 = *(const int4 *)(col + (un * 32 + u * 8) * 4), y1 = *(const int4 *)(col + (un * 32 + u * 8 + 4) * 4);
+                        const int yl[4] = {y0.x, y0.z, y1.x, y1.z}, yh[4] = {y0.y, y0.w, y1.y, y1.w};
+#pragma unroll
+                        for (int b = 0; b < 4; b++) {
+                            const float d = __fmul_rn(dh[b], ydv[b]);
+                            acc0[c] = __fmaf_rn(d, (float)dot4(wl[b], yl[b], 0), acc0[c]);
+                            acc1[c] = __fmaf_rn(d, (float)dot4(wh[b], yh[b], 0), acc1[c]);
+                        }
+                    }
+                }
             }
             q = qn; h = hn;
         }
-        // ---- epilogue: lane with u == 0 owns row grp*8 + r
+        // ---- epilogue: lane with u == 0 owns row grp*RG + r
         int64_t Nw = p.w[0].N, ldo = p.w[0].ldo;
         float *o = p.w[0].out;
         const float *b = p.w[0].bias;
         if (wi == 1) { Nw = p.w[1].N; ldo = p.w[1].ldo; o = p.w[1].out; b = p.w[1].bias; }
         if (wi == 2) { Nw = p.w[2].N; ldo = p.w[2].ldo; o = p.w[2].out; b = p.w[2].bias; }
-        const int64_t row = grp * 8 + r;
+        const int64_t row = grp * TR::RG + r;
 #pragma unroll
         for (int c = 0; c < C; c++) {
-            const float y = row_reduce<PS_Q4_K>(acc0[c], 0.f, accm[c]);
+            const float y = (WT == PS_Q4_K) ? row_reduce<WT>(acc0[c], 0.f, acc1[c]) : row_reduce<WT>(acc0[c], acc1[c], 0.f);
             if (EPI == 1 && pass == 0) { yg[c] = y; continue; }
             if (u == 0 && row < Nw && c < nc) {
                 if (EPI == 1) {
@@ -1335,35 +1388,47 @@ int psk_gemv_chain3(hipStream_t st, int n_cu, const psk_gemv_args a[3], unsigned
     return 0;
 }
 
-// Batched Q4_K mat-mul from pre-quantized activations; returns -1 when the shape is not covered (caller falls back to
+// Batched mat-mul from pre-quantized activations; returns -1 when the shape is not covered (caller falls back to
 // column groups through the mat-vec).
-int psk_gemm_q4k(hipStream_t st, int n_cu, const psk_gemv_args &a, ps_act act, int64_t K, int64_t bs) {
+template <int WT>
+static int launch_gemm8(hipStream_t st, const GemvParams &p, int epi, const dim3 grid, size_t smem) {
+    static bool attr[2] = {false, false};
+    if (!attr[epi]) {
+        if (epi) (void)hipFuncSetAttribute((const void *)gemm8_kernel<WT, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+        else (void)hipFuncSetAttribute((const void *)gemm8_kernel<WT, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+        attr[epi] = true;
+    }
+    if (epi) hipLaunchKernelGGL((gemm8_kernel<WT, 1>), grid, dim3(1024), smem, st, p);
+    else hipLaunchKernelGGL((gemm8_kernel<WT, 0>), grid, dim3(1024), smem, st, p);
+    return 0;
+}
+int psk_gemm8(hipStream_t st, int n_cu, const psk_gemv_args &a, ps_act act, int64_t K, int64_t bs) {
     (void)n_cu;
-    if (a.pro != 0 || a.rope || a.n_w < 1 || K % 256) return -1;
+    if (a.pro != 0 || a.rope || a.n_w < 1) return -1;
+    const int wt = a.w[0]->dtype;
+    if (wt != PS_Q4_K && wt != PS_Q8_0 && wt != PS_Q4_0) return -1;
+    const int64_t unit = wt == PS_Q4_K ? 256 : 128, blk = wt == PS_Q4_K ? 256 : 32, rg = wt == PS_Q4_0 ? 16 : 8;
+    if (K % unit) return -1;
     GemvParams p{};
     p.n_w = a.n_w; p.K = K; p.bs = bs; p.residual = a.residual;
     p.aq = act.qs; p.ad = act.d; p.abs16 = act.bs16;
     for (int i = 0; i < a.n_w; i++) {
-        if (a.w[i]->dtype != PS_Q4_K || a.w[i]->K != K) return -1;
-        const int64_t ng = (a.w[i]->N + 7) / 8;
+        if (a.w[i]->dtype != wt || a.w[i]->K != K) return -1;
+        const int64_t ng = (a.w[i]->N + rg - 1) / rg;
         p.w[i] = GemvW{a.w[i]->qs, a.w[i]->aux, a.out[i], a.bias[i], a.w[i]->N, a.ldo[i], ng};
         p.groups_total += ng;
     }
     const int epi = a.silu_pair ? 1 : 0;
     if (epi == 1 && (a.n_w != 2 || a.w[0]->N != a.w[1]->N)) return -1;
-    const size_t smem = (size_t)8 * (K + (K / 256) * 4 + K / 8);
+    const size_t smem = (size_t)8 * (K + (K / blk) * 4 + (wt == PS_Q4_K ? K / 8 : 0));
     if (smem > 158 * 1024) return -1;
     const int64_t n_tasks = epi == 1 ? p.w[0].n_groups : p.groups_total;
     const dim3 grid((unsigned)((n_tasks + 15) / 16), (unsigned)((bs + 7) / 8));
-    static bool attr[2] = {false, false};
-    if (!attr[epi]) {
-        if (epi) (void)hipFuncSetAttribute((const void *)gemm8_q4k_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
-        else (void)hipFuncSetAttribute((const void *)gemm8_q4k_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
-        attr[epi] = true;
+    switch (wt) {
+    case PS_Q4_K: return launch_gemm8<PS_Q4_K>(st, p, epi, grid, smem);
+    case PS_Q8_0: return launch_gemm8<PS_Q8_0>(st, p, epi, grid, smem);
+    default: return launch_gemm8<PS_Q4_0>(st, p, epi, grid, smem);
     }
-    if (epi) hipLaunchKernelGGL(gemm8_q4k_kernel<1>, grid, dim3(1024), smem, st, p);
-    else hipLaunchKernelGGL(gemm8_q4k_kernel<0>, grid, dim3(1024), smem, st, p);
-    return 0;
 }
 
 // up to psk_gemv_max_cols columns per launch (more than 4 only from pre-quantized activations); larger batches are
@@ -1371,7 +1436,7 @@ int psk_gemm_q4k(hipStream_t st, int n_cu, const psk_gemv_args &a, ps_act act, i
 int psk_gemv_max_cols(int wt, int64_t K) {
     const size_t cb = psk_gemv_lds_col_bytes(wt, K);
     (void)cb;
-    return 4; // (the 8-column instantiations of the in-lane kernel measured slower than 4; Q4_K batches take psk_gemm_q4k)
+    return 4; // (the 8-column instantiations of the in-lane kernel measured slower than 4; batches take psk_gemm8)
 }
 
 int psk_gemv(hipStream_t st, int n_cu, const psk_gemv_args &a, ps_act act, int vdt, int64_t K, int64_t bs) {

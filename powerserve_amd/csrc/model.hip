@@ -76,8 +76,8 @@ static int mm(ps_hip_model *m, psk_gemv_args &g, ps_act act, int64_t K, int64_t 
             psk_quantize_act(c->stream, vdt, g.pro == 1 ? 1 : 0, g.pro_x, nullptr, g.pro_norm_w, g.pro_eps, K, bs, act);
             gq.pro = 0; gq.pro_x = nullptr;
         }
-        if (g.w[0]->dtype == PS_Q4_K && !gq.pro) {
-            const int rc = psk_gemm_q4k(c->stream, c->n_cu, gq, act, K, bs);
+        if (!gq.pro) {
+            const int rc = psk_gemm8(c->stream, c->n_cu, gq, act, K, bs);
             if (rc == 0) return 0;
             if (rc != -1) { c->err = "gemm launch rc=" + std::to_string(rc); return 2; }
         }
