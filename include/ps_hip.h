@@ -169,6 +169,15 @@ int ps_hip_model_kv_move(ps_hip_model *m, size_t dst_index, size_t src_index);
  * position by n (m_kv->advance, llama_model.cpp:109). */
 int ps_hip_model_forward(ps_hip_model *m, const int32_t *tokens, int n, const int32_t *pos, const uint8_t *tree,
                          int lm_head, int32_t *argmax_host);
+/* Token-tree forward (speculative verify / draft, src/speculative/token_tree.cpp): the n tokens are appended at the
+ * cache slots kv_position .. kv_position+n-1, column i is rotated with RoPE position rope_pos[i] (its depth in the tree,
+ * not its slot) and sees the cached prefix (minus slots hidden with ps_hip_model_kv_mask) plus the batch columns j with
+ * tree[i*n + j] != 0 (NULL: causal).  advance = 0 leaves kv_position where it was: the caller keeps the accepted path
+ * with ps_hip_model_kv_move(dst, src) + ps_hip_model_kv_advance(1) per node, as TokenTree::verify does. */
+int ps_hip_model_forward_tree(ps_hip_model *m, const int32_t *tokens, int n, const int32_t *rope_pos, const uint8_t *tree,
+                              int lm_head, int32_t *argmax_host, int advance);
+/* KVCacheInterface::mask / unmask (core/kv_cache.hpp:97-163): hide / show one cached slot in every later forward */
+int ps_hip_model_kv_mask(ps_hip_model *m, size_t index, int visible);
 /* Greedy single-token steps, the decode hot loop (model/model.hpp:170-183): feeds `token` at the current
  * KV position, then its own arg-max, `steps` times, without host round trips (hipGraph replay).  out_ids
  * HOST int32[steps]. */

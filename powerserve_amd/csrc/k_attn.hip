@@ -33,11 +33,12 @@ __global__ void rope_append_kernel(psl_attn_args a, int bs) {
             const int nh = isq ? a.n_heads : a.n_kv_heads;
             const int pi = (int)(oo % (hs / 2));
             const int h = (int)((oo / (hs / 2)) % nh), i = (int)(oo / ((int64_t)(hs / 2) * nh));
-            const int p = pos0 + i, i0 = 2 * pi;
+            const int p = pos0 + i, i0 = 2 * pi;                 // p: cache slot
+            const int rp = a.rope_pos ? a.rope_pos[i] : p;      // RoPE position
             const float *src = isq ? a.q + (int64_t)i * dim + h * hs : a.k + (int64_t)i * kvd + h * hs;
             float *dst = isq ? a.q + (int64_t)i * dim + h * hs : a.k_cache + (int64_t)p * kvd + h * hs;
             if (i0 >= a.n_dims) { dst[i0] = src[i0]; dst[i0 + 1] = src[i0 + 1]; continue; }
-            const float c = a.rope_table[(int64_t)p * hs + i0], s = a.rope_table[(int64_t)p * hs + i0 + 1];
+            const float c = a.rope_table[(int64_t)rp * hs + i0], s = a.rope_table[(int64_t)rp * hs + i0 + 1];
             const int ia = a.neox ? pi : i0, ib = a.neox ? pi + half : i0 + 1;
             const float x0 = src[ia], x1 = src[ib];
             dst[ia] = __fsub_rn(__fmul_rn(x0, c), __fmul_rn(x1, s));
@@ -131,7 +132,7 @@ __device__ __forceinline__ void attn_softmax_rows(const psl_attn_args &a, const 
         for (int t = 0; t < EPT; t++) {
             const int j = j0 + PV_NT * t;
             if (j < n_kv) {
-                const bool ok = (j < pos0) ? true : (a.tree ? a.tree[i * bs + (j - pos0)] != 0 : (j - pos0) <= i);
+                const bool ok = (j < pos0) ? (a.kv_vis ? a.kv_vis[j] != 0 : true) : (a.tree ? a.tree[i * bs + (j - pos0)] != 0 : (j - pos0) <= i);
 #pragma unroll
                 for (int g = 0; g < R2MAX; g++) {
                     if (g < r2) {

@@ -833,7 +833,8 @@ __device__ __forceinline__ void g3_body(const GemvParams &p, char *smem, double 
                 constexpr int LPR = 64 / TR::RG; // lanes per row
                 const float vp = __shfl_xor(v, LPR, 64);
                 const psk_rope_kv &R = p.rope;
-                const int pos = R.state->pos0;
+                const int pos = R.state->pos0;                         // cache slot
+                const int rpos = R.rope_pos ? R.rope_pos[0] : pos;     // RoPE position (differs inside a token tree)
                 if (u == 0 && row < Nw) {
                     if (wi == 2) {
                         R.v_cache[row * R.n_ctx + pos] = v;
@@ -842,7 +843,7 @@ __device__ __forceinline__ void g3_body(const GemvParams &p, char *smem, double 
                         float res = v;
                         if (e < R.n_dims) {
                             const int i0 = e & ~1;
-                            const float c = R.rope_table[(int64_t)pos * R.head_size + i0], sn = R.rope_table[(int64_t)pos * R.head_size + i0 + 1];
+                            const float c = R.rope_table[(int64_t)rpos * R.head_size + i0], sn = R.rope_table[(int64_t)rpos * R.head_size + i0 + 1];
                             const float x0 = (e & 1) ? vp : v, x1 = (e & 1) ? v : vp;
                             res = (e & 1) ? __fadd_rn(__fmul_rn(x0, sn), __fmul_rn(x1, c)) : __fsub_rn(__fmul_rn(x0, c), __fmul_rn(x1, sn));
                         }

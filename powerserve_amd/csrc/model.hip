@@ -49,6 +49,10 @@ struct ps_hip_model {
     float *am_v = nullptr;
     int *am_i = nullptr;
     uint8_t *tree_dev = nullptr;
+    int32_t *rope_pos_dev = nullptr; // [max_batch] RoPE positions of a tree forward
+    uint8_t *kv_vis_dev = nullptr;   // [n_ctx] 1 = visible (KVCacheInterface::mask / unmask)
+    std::vector<uint8_t> kv_vis_host;
+    size_t n_hidden = 0;
     size_t position = 0;
     int mode = 0;
     hipGraphExec_t step_graph = nullptr;
@@ -97,7 +101,7 @@ static int mm(ps_hip_model *m, psk_gemv_args &g, ps_act act, int64_t K, int64_t 
 }
 
 // enqueue one forward over `bs` tokens whose ids are in tokens_dev and whose state is in m->state
-static int enqueue_forward(ps_hip_model *m, int bs, bool lm_head, bool use_tree, bool advance = false) {
+static int enqueue_forward(ps_hip_model *m, int bs, bool lm_head, bool use_tree, bool advance = false, bool use_rope_pos = false) {
     ps_hip_ctx *c = m->ctx;
     hipStream_t st = c->stream;
     const ps_llm_config &f = m->cfg;
@@ -114,6 +118,8 @@ static int enqueue_forward(ps_hip_model *m, int bs, bool lm_head, bool use_tree,
     aa.neox = (f.rope.mode & 2) ? 1 : 0; aa.n_dims = f.rope.n_dims; aa.state = m->state; aa.rope_table = m->rope_table;
     aa.q = m->q; aa.k = m->k; aa.v = m->v; aa.scores = m->scores; aa.att = m->att;
     aa.tree = use_tree ? m->tree_dev : nullptr;
+    aa.rope_pos = use_rope_pos ? m->rope_pos_dev : nullptr;
+    aa.kv_vis = m->n_hidden ? m->kv_vis_dev : nullptr;
     aa.scale = 1.0f / sqrtf((float)f.head_size);
 
     for (uint32_t L = 0; L < f.n_layers; L++) {
@@ -128,7 +134,7 @@ static int enqueue_forward(ps_hip_model *m, int bs, bool lm_head, bool use_tree,
         aa.k_cache = m->k_cache[L]; aa.v_cache = m->v_cache[L];
         // single token, adjacent-pair RoPE: rotation and the KV append ride in the mat-vec epilogue
         const bool fuse_rope = bs == 1 && !aa.neox && psk_gemv_rope_ok(m->wq[L]->dtype, dim) && m->wk[L]->dtype == m->wq[L]->dtype && m->wv[L]->dtype == m->wq[L]->dtype;
-        psk_rope_kv rk{m->state, m->rope_table, aa.k_cache, aa.v_cache, (int)f.head_size, (int)f.rope.n_dims, (int)f.seq_len, (int)kvd};
+        psk_rope_kv rk{m->state, m->rope_table, aa.k_cache, aa.v_cache, (int)f.head_size, (int)f.rope.n_dims, (int)f.seq_len, (int)kvd, aa.rope_pos};
         if (fuse_rope) g.rope = &rk;
         if (mm(m, g, a1, dim, bs)) return 2;
 
@@ -220,9 +226,11 @@ int ps_hip_model_create(ps_hip_ctx *c, const ps_model_desc *d, ps_hip_model **ou
         dmalloc(m, &m->act_mem, ps_act_bytes(dim > hid ? dim : hid, mb)) ||
         dmalloc(m, (void **)&m->state, sizeof(ps_step_state)) || dmalloc(m, (void **)&m->tokens_dev, mb * 4) ||
         dmalloc(m, (void **)&m->argmax_dev, mb * 4) || dmalloc(m, (void **)&m->ids_dev, (nctx + 1) * 4) ||
-        dmalloc(m, (void **)&m->tree_dev, mb * mb) || dmalloc(m, (void **)&m->am_v, mb * 64 * 4) || dmalloc(m, (void **)&m->am_i, mb * 64 * 4))
+        dmalloc(m, (void **)&m->tree_dev, mb * mb) || dmalloc(m, (void **)&m->rope_pos_dev, mb * 4) || dmalloc(m, (void **)&m->kv_vis_dev, nctx) || dmalloc(m, (void **)&m->am_v, mb * 64 * 4) || dmalloc(m, (void **)&m->am_i, mb * 64 * 4))
         return fail();
     (void)hipMemsetAsync(m->bars, 0, (size_t)f.n_layers * 12 * 32 * 4, c->stream);
+    (void)hipMemsetAsync(m->kv_vis_dev, 1, nctx, c->stream);
+    m->kv_vis_host.assign(nctx, 1);
     m->k_cache.assign(L, nullptr); m->v_cache.assign(L, nullptr);
     for (uint32_t i = 0; i < L; i++) {
         if (dmalloc(m, (void **)&m->k_cache[i], nctx * kvd * 4) || dmalloc(m, (void **)&m->v_cache[i], nctx * kvd * 4)) return fail();
@@ -248,8 +256,20 @@ void ps_hip_model_destroy(ps_hip_model *m) {
 
 size_t ps_hip_model_kv_position(const ps_hip_model *m) { return m->position; }
 int ps_hip_model_kv_truncate(ps_hip_model *m, size_t n) { if (n < m->position) m->position = n; return 0; }
+// KVCache::advance_tokens unmasks the slots it walks over (core/kv_cache.hpp:249-255)
+static void unmask_range(ps_hip_model *m, size_t from, size_t n) {
+    if (!m->n_hidden) return;
+    for (size_t i = from; i < from + n && i < m->cfg.seq_len; i++) {
+        if (!m->kv_vis_host[i]) {
+            m->kv_vis_host[i] = 1;
+            m->n_hidden--;
+            (void)hipMemcpyAsync(m->kv_vis_dev + i, &m->kv_vis_host[i], 1, hipMemcpyHostToDevice, m->ctx->stream);
+        }
+    }
+}
 int ps_hip_model_kv_advance(ps_hip_model *m, size_t n) {
     if (m->position + n > m->cfg.seq_len) { m->ctx->err = "kv_advance: KV cache is full (n_ctx)"; return 2; }
+    unmask_range(m, m->position, n);
     m->position += n;
     return 0;
 }
@@ -284,13 +304,48 @@ int ps_hip_model_forward(ps_hip_model *m, const int32_t *tokens, int n, const in
     if (int rc = enqueue_forward(m, n, lm_head != 0, tree != nullptr)) return rc;
     if (lm_head && argmax_host) PS_CHECK(c, hipMemcpyAsync(argmax_host, m->argmax_dev, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
     PS_CHECK(c, hipStreamSynchronize(c->stream));
+    unmask_range(m, (size_t)pos[0], (size_t)n);
     m->position = (size_t)pos[0] + (size_t)n; // m_kv->advance (llama_model.cpp:109)
+    return 0;
+}
+
+int ps_hip_model_forward_tree(ps_hip_model *m, const int32_t *tokens, int n, const int32_t *rope_pos, const uint8_t *tree, int lm_head,
+                              int32_t *argmax_host, int advance) {
+    ps_hip_ctx *c = m->ctx;
+    if (n <= 0 || n > m->max_batch) PS_FAIL(c, "model_forward_tree: batch size out of range");
+    if (m->position + (size_t)n > m->cfg.seq_len) PS_FAIL(c, "model_forward_tree: KV cache is full (n_ctx)");
+    for (int i = 0; i < n; i++) {
+        if (tokens[i] < 0 || (uint32_t)tokens[i] >= m->cfg.vocab_size) PS_FAIL(c, "model_forward_tree: token id out of range");
+        if (rope_pos[i] < 0 || (uint32_t)rope_pos[i] >= m->cfg.seq_len) PS_FAIL(c, "model_forward_tree: position out of range");
+    }
+    PS_CHECK(c, hipSetDevice(c->device));
+    PS_CHECK(c, hipMemcpyAsync(m->tokens_dev, tokens, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    PS_CHECK(c, hipMemcpyAsync(m->rope_pos_dev, rope_pos, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    if (tree) PS_CHECK(c, hipMemcpyAsync(m->tree_dev, tree, (size_t)n * n, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(1), 0, c->stream, m->state, (int)m->position, n, 0);
+    PS_CHECK(c, hipStreamSynchronize(c->stream));
+    if (int rc = enqueue_forward(m, n, lm_head != 0, tree != nullptr, false, true)) return rc;
+    if (lm_head && argmax_host) PS_CHECK(c, hipMemcpyAsync(argmax_host, m->argmax_dev, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    PS_CHECK(c, hipStreamSynchronize(c->stream));
+    if (advance) { unmask_range(m, m->position, (size_t)n); m->position += (size_t)n; }
+    return 0;
+}
+
+int ps_hip_model_kv_mask(ps_hip_model *m, size_t index, int visible) {
+    ps_hip_ctx *c = m->ctx;
+    if (index >= m->cfg.seq_len) PS_FAIL(c, "kv_mask: index out of range");
+    const uint8_t v = visible ? 1 : 0;
+    if (m->kv_vis_host[index] == v) return 0;
+    m->kv_vis_host[index] = v;
+    if (v) m->n_hidden--; else m->n_hidden++;
+    PS_CHECK(c, hipMemcpyAsync(m->kv_vis_dev + index, &m->kv_vis_host[index], 1, hipMemcpyHostToDevice, c->stream));
     return 0;
 }
 
 int ps_hip_model_decode_greedy(ps_hip_model *m, int32_t token, int steps, int32_t *out_ids) {
     ps_hip_ctx *c = m->ctx;
     if (steps <= 0) return 0;
+    if (m->n_hidden) PS_FAIL(c, "decode_greedy: hidden KV slots (kv_mask) are not part of the captured step; unmask first");
     if (m->position + (size_t)steps > m->cfg.seq_len) PS_FAIL(c, "decode_greedy: KV cache would overflow n_ctx");
     if (token < 0 || (uint32_t)token >= m->cfg.vocab_size) PS_FAIL(c, "decode_greedy: token id out of range");
     PS_CHECK(c, hipSetDevice(c->device));

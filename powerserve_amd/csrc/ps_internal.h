@@ -102,6 +102,7 @@ struct psk_rope_kv {
     const float *rope_table;           // [n_ctx][head_size] (cos, sin) pairs
     float *k_cache, *v_cache;          // [n_ctx][kv_dim], [kv_dim][n_ctx]
     int head_size, n_dims, n_ctx, kv_dim;
+    const int32_t *rope_pos;           // optional: RoPE position of the token (default: its cache slot)
 };
 struct psk_gemv_args {
     int n_w;                 // 1..3 matrices sharing the activation

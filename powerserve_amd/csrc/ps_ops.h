@@ -33,6 +33,8 @@ struct psl_attn_args {
     float *scores;           // [bs][n_heads][n_ctx] scratch
     float *att;              // [bs][n_heads*hs]
     const uint8_t *tree;     // optional [bs][bs] tree mask
+    const int32_t *rope_pos; // optional [bs]: RoPE position of each batch column (default: its cache slot pos0 + i)
+    const uint8_t *kv_vis;   // optional [n_ctx]: 0 hides a cached slot (KVCacheInterface::mask / unmask)
     float scale;
 };
 void psl_rope_append(hipStream_t st, const psl_attn_args &a, int bs);

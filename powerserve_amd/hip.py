@@ -30,7 +30,7 @@ EXPORTS = [
     "ps_hip_get_embedding", "ps_hip_get_mask", "ps_hip_argmax", "ps_hip_model_create", "ps_hip_model_destroy",
     "ps_hip_model_kv_position", "ps_hip_model_kv_truncate", "ps_hip_model_kv_advance", "ps_hip_model_kv_rollback", "ps_hip_model_kv_move",
     "ps_hip_model_forward", "ps_hip_model_decode_greedy", "ps_hip_model_logits", "ps_hip_model_k_cache",
-    "ps_hip_model_v_cache", "ps_hip_model_weight_bytes_per_token", "ps_hip_model_set_mode", "ps_hip_model_bench_gemv", "ps_hip_debug_timeline",
+    "ps_hip_model_v_cache", "ps_hip_model_weight_bytes_per_token", "ps_hip_model_set_mode", "ps_hip_model_bench_gemv", "ps_hip_debug_timeline", "ps_hip_model_forward_tree", "ps_hip_model_kv_mask",
 ]
 
 
@@ -110,6 +110,7 @@ def lib() -> C.CDLL:
         "ps_hip_model_kv_position": (sz, [vp]), "ps_hip_model_kv_truncate": (i32, [vp, sz]), "ps_hip_model_kv_advance": (i32, [vp, sz]),
         "ps_hip_model_kv_rollback": (i32, [vp, sz]), "ps_hip_model_kv_move": (i32, [vp, sz, sz]),
         "ps_hip_model_forward": (i32, [vp, vp, i32, vp, vp, i32, vp]),
+        "ps_hip_model_forward_tree": (i32, [vp, vp, i32, vp, vp, i32, vp, i32]), "ps_hip_model_kv_mask": (i32, [vp, sz, i32]),
         "ps_hip_model_decode_greedy": (i32, [vp, i32, i32, vp]), "ps_hip_model_logits": (vp, [vp]),
         "ps_hip_model_k_cache": (vp, [vp, i32]), "ps_hip_model_v_cache": (vp, [vp, i32]),
         "ps_hip_model_weight_bytes_per_token": (C.c_uint64, [vp]), "ps_hip_model_set_mode": (i32, [vp, i32]),
@@ -339,6 +340,34 @@ class Model:
             logits = np.empty((n, self.cfg.vocab_size), dtype=np.float32)
             self.ctx.check(self.ctx.L.ps_hip_memcpy_d2h(self.ctx.h, _ptr(logits), self.ctx.L.ps_hip_model_logits(self.h), logits.nbytes))
         return logits, am
+
+    def forward_tree(self, tokens, rope_pos, tree=None, lm_head=True, want_logits=False, advance=False):
+        """Token-tree forward (src/speculative/token_tree.cpp): tokens appended at the current KV position, column i rotated
+        with rope_pos[i], visible batch columns given by tree[i][j] (None: causal).  Returns (logits | None, argmax)."""
+        tokens = np.ascontiguousarray(tokens, dtype=np.int32)
+        rp = np.ascontiguousarray(rope_pos, dtype=np.int32)
+        n = tokens.size
+        am = np.empty(n, dtype=np.int32)
+        tr = np.ascontiguousarray(tree, dtype=np.uint8) if tree is not None else None
+        self.ctx.check(self.ctx.L.ps_hip_model_forward_tree(self.h, _ptr(tokens), n, _ptr(rp), _ptr(tr) if tr is not None else None,
+                                                            int(lm_head), _ptr(am), int(advance)))
+        logits = None
+        if lm_head and want_logits:
+            logits = np.empty((n, self.cfg.vocab_size), dtype=np.float32)
+            self.ctx.check(self.ctx.L.ps_hip_memcpy_d2h(self.ctx.h, _ptr(logits), self.ctx.L.ps_hip_model_logits(self.h), logits.nbytes))
+        return logits, am
+
+    def kv_mask(self, index: int, visible: bool):
+        self.ctx.check(self.ctx.L.ps_hip_model_kv_mask(self.h, int(index), int(bool(visible))))
+
+    def kv_move(self, dst: int, src: int):
+        self.ctx.check(self.ctx.L.ps_hip_model_kv_move(self.h, int(dst), int(src)))
+
+    def kv_advance(self, n: int):
+        self.ctx.check(self.ctx.L.ps_hip_model_kv_advance(self.h, int(n)))
+
+    def kv_rollback(self, n: int):
+        self.ctx.check(self.ctx.L.ps_hip_model_kv_rollback(self.h, int(n)))
 
     def decode_greedy(self, token: int, steps: int) -> np.ndarray:
         out = np.empty(steps, dtype=np.int32)
