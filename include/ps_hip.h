@@ -183,6 +183,8 @@ int ps_hip_model_kv_mask(ps_hip_model *m, size_t index, int visible);
  * HOST int32[steps]. */
 int ps_hip_model_decode_greedy(ps_hip_model *m, int32_t token, int steps, int32_t *out_ids);
 const float *ps_hip_model_logits(const ps_hip_model *m); /* device [max_batch][vocab] */
+/* diagnostics: device scratch tensors of the most recent forward, last layer (0 x, 1 q, 2 att, 3 ffn hidden, 4 scores) */
+const float *ps_hip_model_scratch(const ps_hip_model *m, int which);
 const float *ps_hip_model_k_cache(const ps_hip_model *m, int layer);
 const float *ps_hip_model_v_cache(const ps_hip_model *m, int layer);
 /* per-forward accounting for the roofline: GGUF bytes of all mat-mul weights streamed by one token */

@@ -100,6 +100,8 @@ class Oracle:
         L.pso_model_kv_position.restype = C.c_size_t
         L.pso_model_kv_position.argtypes = [C.c_void_p]
         L.pso_model_reset.argtypes = [C.c_void_p]
+        L.pso_model_rollback.argtypes = [C.c_void_p, C.c_size_t]
+        L.pso_model_rollback.restype = None
         L.pso_model_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
         L.pso_model_generate.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_void_p]
@@ -213,6 +215,9 @@ class OracleModel:
 
     def reset(self):
         self.o.L.pso_model_reset(self.h)
+
+    def rollback(self, n):
+        self.o.L.pso_model_rollback(self.h, int(n))
 
     def forward(self, tokens, pos, lm_head=True):
         tokens, pos = _i32(tokens), _i32(pos)

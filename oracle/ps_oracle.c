@@ -554,6 +554,7 @@ int pso_model_set_tensor(pso_model *m, const char *name, int type, const void *d
 }
 size_t pso_model_kv_position(const pso_model *m) { return m->position; }
 void pso_model_reset(pso_model *m) { m->position = 0; } /* truncate_tokens(kv_size = 0) */
+void pso_model_rollback(pso_model *m, size_t n) { m->position -= n < m->position ? n : m->position; } /* rollback_tokens (kv_cache.hpp:256-264) */
 const float *pso_model_k_cache(const pso_model *m, int L) { return m->k_cache[L]; }
 const float *pso_model_v_cache(const pso_model *m, int L) { return m->v_cache[L]; }
 

@@ -83,6 +83,7 @@ void pso_model_destroy(pso_model *m);
 int pso_model_set_tensor(pso_model *m, const char *name, int type, const void *data, int64_t ne0, int64_t ne1);
 size_t pso_model_kv_position(const pso_model *m);
 void pso_model_reset(pso_model *m);
+void pso_model_rollback(pso_model *m, size_t n); /* rollback_tokens: the last n slots become free again */
 int pso_model_forward(pso_model *m, const int32_t *tokens, int n, const int32_t *pos, int lm_head, float *logits_out);
 int pso_model_generate(pso_model *m, const int32_t *prompt, int n_prompt, int batch_size, int steps,
                        int32_t *out_tokens, float *logits_out, double *t_prefill_s, double *t_decode_s);

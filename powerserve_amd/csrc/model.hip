@@ -381,6 +381,16 @@ int ps_hip_model_decode_greedy(ps_hip_model *m, int32_t token, int steps, int32_
 }
 
 const float *ps_hip_model_logits(const ps_hip_model *m) { return m->logits; }
+const float *ps_hip_model_scratch(const ps_hip_model *m, int which) {
+    switch (which) {
+    case 0: return m->x;      // [max_batch][dim]     residual stream after the last layer
+    case 1: return m->q;      // [max_batch][dim]     rotated q of the last layer
+    case 2: return m->att;    // [max_batch][dim]     attention output of the last layer
+    case 3: return m->hb;     // [max_batch][hidden]  silu(gate)*up of the last layer
+    case 4: return m->scores; // [max_batch][n_heads][n_ctx] raw scores of the last layer
+    }
+    return nullptr;
+}
 const float *ps_hip_model_k_cache(const ps_hip_model *m, int L) { return m->k_cache[L]; }
 const float *ps_hip_model_v_cache(const ps_hip_model *m, int L) { return m->v_cache[L]; }
 uint64_t ps_hip_model_weight_bytes_per_token(const ps_hip_model *m) { return m->weight_bytes; }

@@ -29,7 +29,7 @@ EXPORTS = [
     "ps_hip_rms_norm", "ps_hip_rope", "ps_hip_softmax_ext", "ps_hip_add", "ps_hip_dup", "ps_hip_silu_hadamard",
     "ps_hip_get_embedding", "ps_hip_get_mask", "ps_hip_argmax", "ps_hip_model_create", "ps_hip_model_destroy",
     "ps_hip_model_kv_position", "ps_hip_model_kv_truncate", "ps_hip_model_kv_advance", "ps_hip_model_kv_rollback", "ps_hip_model_kv_move",
-    "ps_hip_model_forward", "ps_hip_model_decode_greedy", "ps_hip_model_logits", "ps_hip_model_k_cache",
+    "ps_hip_model_forward", "ps_hip_model_decode_greedy", "ps_hip_model_logits", "ps_hip_model_scratch", "ps_hip_model_k_cache",
     "ps_hip_model_v_cache", "ps_hip_model_weight_bytes_per_token", "ps_hip_model_set_mode", "ps_hip_model_bench_gemv", "ps_hip_debug_timeline", "ps_hip_model_forward_tree", "ps_hip_model_kv_mask",
 ]
 
@@ -111,7 +111,7 @@ def lib() -> C.CDLL:
         "ps_hip_model_kv_rollback": (i32, [vp, sz]), "ps_hip_model_kv_move": (i32, [vp, sz, sz]),
         "ps_hip_model_forward": (i32, [vp, vp, i32, vp, vp, i32, vp]),
         "ps_hip_model_forward_tree": (i32, [vp, vp, i32, vp, vp, i32, vp, i32]), "ps_hip_model_kv_mask": (i32, [vp, sz, i32]),
-        "ps_hip_model_decode_greedy": (i32, [vp, i32, i32, vp]), "ps_hip_model_logits": (vp, [vp]),
+        "ps_hip_model_decode_greedy": (i32, [vp, i32, i32, vp]), "ps_hip_model_logits": (vp, [vp]), "ps_hip_model_scratch": (vp, [vp, i32]),
         "ps_hip_model_k_cache": (vp, [vp, i32]), "ps_hip_model_v_cache": (vp, [vp, i32]),
         "ps_hip_model_weight_bytes_per_token": (C.c_uint64, [vp]), "ps_hip_model_set_mode": (i32, [vp, i32]),
         "ps_hip_debug_timeline": (i32, [vp, i32, vp, i32]),
@@ -385,6 +385,13 @@ class Model:
             self.forward(prompt[done:done + bs], np.arange(self.position, self.position + bs), lm_head=False)
             done += bs
         return self.decode_greedy(int(prompt[-1]), steps)
+
+    def scratch(self, which: int, rows: int) -> np.ndarray:
+        """Diagnostics: last-layer scratch tensor of the most recent forward (0 x, 1 q, 2 att, 3 ffn hidden, 4 scores)."""
+        width = {0: self.cfg.dim, 1: self.cfg.dim, 2: self.cfg.dim, 3: self.cfg.hidden_dim, 4: self.cfg.n_heads * self.cfg.seq_len}[which]
+        out = np.empty((rows, width), dtype=np.float32)
+        self.ctx.check(self.ctx.L.ps_hip_memcpy_d2h(self.ctx.h, _ptr(out), self.ctx.L.ps_hip_model_scratch(self.h, which), out.nbytes))
+        return out
 
     def k_cache(self, layer: int) -> np.ndarray:
         out = np.empty((self.cfg.seq_len, self.cfg.kv_dim), dtype=np.float32)

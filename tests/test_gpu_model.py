@@ -130,6 +130,49 @@ def test_tree_mask_plumbing(ctx, tmp_path):
     gm.close()
 
 
+def test_long_context_batches_match_oracle(ctx, oracle, tmp_path):
+    """Batches appended behind a long KV prefix (n_kv > 256: several 32-column chain rounds, leftovers, softmax tails):
+    bit-exact against the oracle for decode steps and for batches of 3 and 12, and a tree whose root only sees itself
+    gives the root the logits of the causal batch (the children are masked exactly like future tokens)."""
+    from oracle import binding as B
+    from powerserve_amd import hip, synth
+    d = str(tmp_path / "m")
+    mj = synth.write_model_dir(d, "small-llama-hs128", 12, n_ctx=512, seed=5)
+    cfg = B.make_config(mj["llm_config"])
+    om = oracle.model(cfg, mj["model_arch"], load_tensors(os.path.join(d, "ggml/weights.gguf")), n_threads=16)
+    gm = hip.Model(ctx, d, max_batch=128, n_ctx=512)
+    P = 250
+    prompt = np.random.default_rng(42).integers(0, cfg.vocab_size, P)
+    for mdl in (om, gm):
+        done = 0
+        while done < P - 1:
+            bs = min(128, P - 1 - done)
+            mdl.forward(prompt[done:done + bs], np.arange(done, done + bs), False)
+            done += bs
+    cur = int(prompt[-1])
+    for s in range(14):  # pos0 249..262: single-token steps, then a batch of 3 and of 12 at the same position (rolled back)
+        p0 = gm.position
+        for bs in (3, 12):
+            toks = np.array([cur] + [(7 * s + u) % cfg.vocab_size for u in range(1, bs)])
+            want = om.forward(toks, np.arange(p0, p0 + bs), True)
+            om_pos = om.position
+            got, am = gm.forward(toks, np.arange(p0, p0 + bs), True)
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (s, bs, rel_err(got, want))
+            tree = np.eye(bs, dtype=np.uint8); tree[:, 0] = 1
+            rp = np.array([p0] + [p0 + 1] * (bs - 1))
+            gm.kv_rollback(bs)
+            tl, _ = gm.forward_tree(toks, rp, tree, lm_head=True, want_logits=True, advance=False)
+            assert np.array_equal(tl[0].view(np.uint32), want[0].view(np.uint32)), (s, bs)
+            om.rollback(bs)
+            assert om.position == om_pos - bs == gm.position
+        want1 = om.forward([cur], [p0], True)
+        got1, am1 = gm.forward([cur], [p0], True)
+        assert np.array_equal(got1.view(np.uint32), want1.view(np.uint32)), (s, rel_err(got1, want1))
+        cur = int(am1[0])
+    gm.close()
+    om.close()
+
+
 def test_batched_forward_logits(ctx, oracle, tmp_path):
     """lm_head over a whole batch (LlamaModel::forward returns vocab x bs logits) + batch-size invariance."""
     from oracle import binding as B
