@@ -255,12 +255,18 @@ int ps_hip_mul_mat(ps_hip_ctx *c, const ps_tensor *dst, const ps_tensor *src0, c
     if (is_quant(src0->dtype)) {
         const ps_weight *w = (const ps_weight *)src0->data;
         if (!w || w->dtype != src0->dtype || w->K != src0->ne[0] || w->N != src0->ne[1]) PS_FAIL(c, "mul_mat: weight handle mismatch");
-        if (w->dtype == PS_Q6_K) PS_FAIL(c, "mul_mat: Q6_K mat-mul not implemented yet");
         const int64_t K = w->K, bs = src1->ne[1] * src1->ne[2] * src1->ne[3];
         if (src1->nb[1] != (uint64_t)K * 4 || dst->nb[1] != (uint64_t)w->N * 4) PS_FAIL(c, "mul_mat: quantized path needs contiguous rows");
         const int vdt = ps_hip_vec_dot_type(w->dtype);
         if (ensure(c, &c->act_buf, &c->act_cap, ps_act_bytes(K, bs))) return 1;
         ps_act a = ps_act_carve(c->act_buf, K, bs);
+        if (w->dtype == PS_Q6_K) { // one wave per row (k_gemv6.hip)
+            psk_quantize_act(c->stream, vdt, 0, (const float *)src1->data, nullptr, nullptr, 0.f, K, bs, a);
+            psk_gemv6_args g6{w, (float *)dst->data, w->N, nullptr, nullptr};
+            if (int rc = psk_gemv6(c->stream, c->n_cu, g6, a, K, bs)) { c->err = "mul_mat: Q6_K launch rc=" + std::to_string(rc); return 2; }
+            PS_CHECK(c, hipGetLastError());
+            return 0;
+        }
         if (bs > 4) { // batches: quantize once, 8 columns per workgroup (psk_gemm8)
             psk_quantize_act(c->stream, vdt, 0, (const float *)src1->data, nullptr, nullptr, 0.f, K, bs, a);
             psk_gemv_args g{};

@@ -1,0 +1,140 @@
+// Q6_K weights x Q8_K activations: y[c][row] = ggml_vec_dot_q6_K_q8_K(K, W[row], act[c])  
+//
+// Reference numerics (AVX2 branch, libs/ggml/src/ggml-quants.c:9040-9115):
+// per super-block of 256 weights an EXACT int32 vector sumi[8] is formed (lane u owns weights 4u..4u+3 of each of the
+// eight 32-element sub-vectors, each 16-element half scaled by its int8 scale), then ONE fma per super-block and lane,
+//   acc[u] = fma(d_w * d_act, (float)sumi[u], acc[u]),
+// and hsum_float_8 over the lanes at the end.  So the fp32 chain is only K/256 steps long and everything else is
+// integer work that may be done in any order.
+//
+// Mapping: one wave per weight row, lane = (sbl, u): eight consecutive super-blocks x the eight AVX lanes.  The device
+// layout (ps_internal.h) makes the wave's ql / qh fetch one contiguous 1 KiB / 512 B request per 8 super-blocks.  Every
+// lane computes its sumi with v_dot4; the chain is then walked in super-block order with two lane broadcasts per step
+// (all 64 lanes redundantly carry acc[u] of their own u, so no second exchange is needed before the lane reduction).
+// HBM-bound: 210 B per 256 weights, no reuse; activations (K bytes per column) stay in L1/L2.
+#include "ps_dev.h"
+#include "ps_internal.h"
+
+namespace {
+
+struct Gemv6Params {
+    const uint8_t *ql, *qh;
+    const uint8_t *sc;
+    const uint16_t *d;
+    int64_t K, N;
+    int nsb;
+    const int8_t *aq;  // [bs][K]
+    const float *ad;   // [bs][K/256]
+    float *out;        // [bs][ldo]
+    int64_t ldo;
+    const float *bias;     // [N] or null
+    const float *residual; // [bs][ldo] or null
+    int nc;                // live columns (<= BS)
+};
+
+__device__ __forceinline__ int sbyte(uint32_t v, int byte) { return (int)(v << (24 - 8 * byte)) >> 24; }
+
+template <int BS>
+__global__ __launch_bounds__(256) void gemv6_kernel(Gemv6Params p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sbl = lane >> 3, u = lane & 7, hi = u >> 2;
+    const int nsb = p.nsb, nit = (nsb + 7) >> 3;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < p.N; row += (int64_t)gridDim.x * 4) {
+        float acc[BS];
+#pragma unroll
+        for (int c = 0; c < BS; c++) acc[c] = 0.f;
+        const int64_t rb = row * nsb;
+        for (int it = 0; it < nit; it++) {
+            const int sb0 = it * 8, sbr = sb0 + sbl;
+            const int sb = sbr < nsb ? sbr : nsb - 1; // lanes past the row end re-read the last block; never chained
+            const uint4 L = ld_stream16(p.ql + (rb + sb) * 128 + u * 16);
+            const uint2 H = *(const uint2 *)(p.qh + (rb + sb) * 64 + u * 8);
+            const uint4 S = *(const uint4 *)(p.sc + (rb + sb) * 16);
+            const float dw = ps_h2f(p.d[rb + sb]);
+            // 6-bit weights of this lane: q[j][sub] holds weights 4u..4u+3 of sub-vector 4j+sub as bytes 0..63
+            uint32_t q[2][4];
+            {
+                const uint32_t A0 = L.x, B0 = L.y, A1 = L.z, B1 = L.w;
+                q[0][0] = (A0 & 0x0F0F0F0Fu) | ((H.x & 0x03030303u) << 4);
+                q[0][1] = (B0 & 0x0F0F0F0Fu) | (((H.x >> 2) & 0x03030303u) << 4);
+                q[0][2] = ((A0 >> 4) & 0x0F0F0F0Fu) | (((H.x >> 4) & 0x03030303u) << 4);
+                q[0][3] = ((B0 >> 4) & 0x0F0F0F0Fu) | (((H.x >> 6) & 0x03030303u) << 4);
+                q[1][0] = (A1 & 0x0F0F0F0Fu) | ((H.y & 0x03030303u) << 4);
+                q[1][1] = (B1 & 0x0F0F0F0Fu) | (((H.y >> 2) & 0x03030303u) << 4);
+                q[1][2] = ((A1 >> 4) & 0x0F0F0F0Fu) | (((H.y >> 4) & 0x03030303u) << 4);
+                q[1][3] = ((B1 >> 4) & 0x0F0F0F0Fu) | (((H.y >> 6) & 0x03030303u) << 4);
+            }
+            // scale of (j, sub) for this lane: scales[8j + 2 sub + (u >= 4)]
+            int scl[2][4];
+            {
+                const uint32_t Sw[4] = {S.x, S.y, S.z, S.w};
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    scl[j][0] = sbyte(Sw[2 * j], hi);
+                    scl[j][1] = sbyte(Sw[2 * j], 2 + hi);
+                    scl[j][2] = sbyte(Sw[2 * j + 1], hi);
+                    scl[j][3] = sbyte(Sw[2 * j + 1], 2 + hi);
+                }
+            }
+            const int nlive = nsb - sb0 < 8 ? nsb - sb0 : 8; // wave-uniform
+#pragma unroll
+            for (int c = 0; c < BS; c++) {
+                const int cc = c < p.nc ? c : p.nc - 1;
+                const int8_t *a = p.aq + (int64_t)cc * p.K + (int64_t)sb * 256 + 4 * u;
+                int sumi = 0;
+#pragma unroll
+                for (int j = 0; j < 2; j++)
+#pragma unroll
+                    for (int sub = 0; sub < 4; sub++) {
+                        const int av = *(const int *)(a + j * 128 + sub * 32);
+                        // sum (q - 32) * a : maddubs(q, a) - maddubs(32, a) of the reference, exact in int32
+                        const int s = dot4((int)q[j][sub], av, 0) - dot4(0x20202020, av, 0);
+                        sumi += scl[j][sub] * s;
+                    }
+                const float t  = (float)sumi;
+                const float dd = __fmul_rn(p.ad[(int64_t)cc * nsb + sb], dw); // y[i].d * GGML_FP16_TO_FP32(x[i].d)
+                float ac = acc[c];
+                for (int s = 0; s < nlive; s++) {
+                    const float ds = __shfl(dd, s * 8 + u, 64), ts = __shfl(t, s * 8 + u, 64);
+                    ac = __fmaf_rn(ds, ts, ac);
+                }
+                acc[c] = ac;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < BS; c++) { // hsum_float_8 (ggml-quants.c:62-68): (a4+a0, a5+a1, a6+a2, a7+a3) -> (r0+r2, r1+r3) -> sum
+            float v = acc[c];
+            v = __fadd_rn(v, __shfl_xor(v, 4, 64));
+            v = __fadd_rn(v, __shfl_xor(v, 2, 64));
+            v = __fadd_rn(v, __shfl_xor(v, 1, 64));
+            if (lane == 0 && c < p.nc) {
+                if (p.bias) v = __fadd_rn(v, p.bias[row]);
+                if (p.residual) v = __fadd_rn(p.residual[(int64_t)c * p.ldo + row], v);
+                p.out[(int64_t)c * p.ldo + row] = v;
+            }
+        }
+    }
+}
+
+} // namespace
+
+int psk_gemv6(hipStream_t st, int n_cu, const psk_gemv6_args &a, ps_act act, int64_t K, int64_t bs) {
+    const ps_weight *w = a.w;
+    if (w->dtype != PS_Q6_K || w->K != K || K % 256) return 4;
+    Gemv6Params p{};
+    p.ql = w->qs; p.qh = w->qh; p.sc = w->sc; p.d = (const uint16_t *)w->aux;
+    p.K = K; p.N = w->N; p.nsb = (int)(K / 256);
+    p.ldo = a.ldo; p.bias = a.bias;
+    const int64_t nwg = (w->N + 3) / 4;
+    const unsigned grid = (unsigned)(nwg < (int64_t)n_cu * 16 ? nwg : (int64_t)n_cu * 16);
+    for (int64_t c0 = 0; c0 < bs; c0 += 8) {
+        const int nc = (int)(bs - c0 < 8 ? bs - c0 : 8);
+        p.aq = act.qs + c0 * K; p.ad = act.d + c0 * (K / 256);
+        p.out = a.out + c0 * a.ldo; p.residual = a.residual ? a.residual + c0 * a.ldo : nullptr; p.nc = nc;
+        if (nc == 1) hipLaunchKernelGGL(gemv6_kernel<1>, dim3(grid), dim3(256), 0, st, p);
+        else if (nc == 2) hipLaunchKernelGGL(gemv6_kernel<2>, dim3(grid), dim3(256), 0, st, p);
+        else if (nc <= 4) hipLaunchKernelGGL(gemv6_kernel<4>, dim3(grid), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL(gemv6_kernel<8>, dim3(grid), dim3(256), 0, st, p);
+    }
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}

@@ -211,12 +211,13 @@ __global__ void get_rows_kernel(WView w, const int32_t *tokens, int n, float *ou
             v = __fsub_rn(__fmul_rn(__fmul_rn(d, (float)sc), (float)q), __fmul_rn(mn, (float)m));
         } else { // Q6_K
             const int64_t sb = e / 256; const int r = (int)(e % 256), half = r / 128, rr = r % 128, sub = rr / 32, l = rr % 32;
-            const uint8_t *ql = w.qs + row * (K / 2) + sb * 128 + half * 64;
-            const uint8_t *qh = w.qh + row * (K / 4) + sb * 64 + half * 32;
+            const uint8_t *ql = w.qs + row * (K / 2) + sb * 128; // lane-major inside the super-block (ps_internal.h)
+            const uint8_t *qh = w.qh + row * (K / 4) + sb * 64;
             const int8_t *sc  = (const int8_t *)w.sc + row * (K / 16) + sb * 16 + half * 8;
-            int lo = (sub & 1) ? ql[32 + l] : ql[l];
+            const int u6 = l >> 2;
+            int lo = ql[(u6 * 4 + 2 * half + (sub & 1)) * 4 + (l & 3)];
             lo     = (sub >= 2) ? (lo >> 4) : (lo & 0xF);
-            const int q = (int)(int8_t)(lo | (((qh[l] >> (2 * sub)) & 3) << 4)) - 32;
+            const int q = (int)(int8_t)(lo | (((qh[(u6 * 2 + half) * 4 + (l & 3)] >> (2 * sub)) & 3) << 4)) - 32;
             const float d = ps_h2f(((const uint16_t *)w.aux)[row * (K / 256) + sb]);
             v = __fmul_rn(__fmul_rn(d, (float)sc[l / 16 + 2 * sub]), (float)q);
         }

@@ -140,8 +140,13 @@ __global__ void repack_q6_K_kernel(const uint8_t *raw, int64_t nblk, uint8_t *ql
     const int64_t b  = i / 105;
     const int p      = (int)(i % 105);
     const uint16_t v = ((const uint16_t *)raw)[i];
-    if (p < 64) ((uint16_t *)ql)[b * 64 + p] = v;
-    else if (p < 96) ((uint16_t *)qh)[b * 32 + (p - 64)] = v;
+    if (p < 64) { // ql dword (k*8 + u) = bytes k*32 + 4u.. of the block -> lane-major dword u*4 + k
+        const int sd = p >> 1, k = sd >> 3, u = sd & 7;
+        ((uint16_t *)ql)[b * 64 + (u * 4 + k) * 2 + (p & 1)] = v;
+    } else if (p < 96) { // qh dword (j*8 + u) -> u*2 + j
+        const int q = p - 64, sd = q >> 1, j = sd >> 3, u = sd & 7;
+        ((uint16_t *)qh)[b * 32 + (u * 2 + j) * 2 + (q & 1)] = v;
+    }
     else if (p < 104) ((uint16_t *)sc)[b * 8 + (p - 96)] = v;
     else ((uint16_t *)d)[b] = v;
 }

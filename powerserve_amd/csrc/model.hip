@@ -67,8 +67,34 @@ static int dmalloc(ps_hip_model *m, void **p, size_t bytes) {
     return 0;
 }
 
+static int mm(ps_hip_model *m, psk_gemv_args &g, ps_act act, int64_t K, int64_t bs);
+// Launches whose matrices are not all of one lane-major type (stock Q4_K_M files: attn_v / ffn_down / output in Q6_K next
+// to Q4_K): one launch per matrix, exactly the reference's op sequence (mat-mul, + bias, silu_hadamard).
+static int mm_each(ps_hip_model *m, psk_gemv_args &g, ps_act act, int64_t K, int64_t bs) {
+    ps_hip_ctx *c = m->ctx;
+    float *tmp[2] = {m->g1, m->u1};
+    for (int i = 0; i < g.n_w; i++) {
+        psk_gemv_args s{};
+        s.n_w = 1; s.w[0] = g.w[i]; s.out[0] = g.silu_pair ? tmp[i] : g.out[i]; s.bias[0] = g.bias[i];
+        s.ldo[0] = g.ldo[i]; s.residual = (i == 0 && !g.silu_pair) ? g.residual : nullptr;
+        s.pro = g.pro; s.pro_x = g.pro_x; s.pro_norm_w = g.pro_norm_w; s.pro_eps = g.pro_eps;
+        if (g.w[i]->dtype == PS_Q6_K) {
+            if (g.pro) psk_quantize_act(c->stream, PS_Q8_K, g.pro == 1 ? 1 : 0, g.pro_x, nullptr, g.pro_norm_w, g.pro_eps, K, bs, act);
+            psk_gemv6_args a6{g.w[i], s.out[0], s.ldo[0], s.bias[0], s.residual};
+            if (int rc = psk_gemv6(c->stream, c->n_cu, a6, act, K, bs)) { c->err = "Q6_K mat-vec launch rc=" + std::to_string(rc); return 2; }
+        } else if (mm(m, s, act, K, bs)) {
+            return 2;
+        }
+    }
+    if (g.silu_pair) psl_silu_hadamard(c->stream, g.out[0], tmp[0], tmp[1], (int64_t)g.ldo[0] * bs);
+    return 0;
+}
+
 static int mm(ps_hip_model *m, psk_gemv_args &g, ps_act act, int64_t K, int64_t bs) {
     ps_hip_ctx *c = m->ctx;
+    bool each = g.w[0]->dtype == PS_Q6_K;
+    for (int i = 1; i < g.n_w; i++) each = each || g.w[i]->dtype != g.w[0]->dtype;
+    if (each) return mm_each(m, g, act, K, bs);
     const int vdt = ps_hip_vec_dot_type(g.w[0]->dtype);
     const int64_t blk = vdt == PS_Q8_0 ? 32 : 256;
     psk_gemv_args gq = g;

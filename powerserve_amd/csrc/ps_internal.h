@@ -35,7 +35,9 @@ struct ps_hip_ctx {
 //                                       aux[group][b4][r][4] fp16 d
 //   Q4_0 (RG 16, unit = 4 blocks):      qs [group][b4][r][u'=0..3][blk][4 B] = bytes 4u'..4u'+3 of the block
 //                                       (low nibbles: quad u', high nibbles: quad u'+4);  aux as Q8_0
-//   Q6_K : plane layout  qs [N][K/256][128] (ql)  qh [N][K/256][64]  sc [N][K/16] int8  aux [N][K/256] fp16
+//   Q6_K : planes per row, lane-major inside a super-block (k_gemv6.hip: one wave per row, lane = (sb % 8, u)):
+//          qs [N][K/256][u=0..7][16 B] = ql bytes {4u.., 32+4u.., 64+4u.., 96+4u..}   qh [N][K/256][u][8 B] = qh bytes
+//          {4u.., 32+4u..}   sc [N][K/16] int8   aux [N][K/256] fp16 d
 //   F32  : qs [N][K] float
 struct ps_weight {
     int dtype;
@@ -128,5 +130,14 @@ int psk_gemv_chain3(hipStream_t st, int n_cu, const psk_gemv_args a[3], unsigned
 int psk_gemv_max_cols(int wt, int64_t K); // widest column group one launch takes (16, 8 or 4; > 4 needs pro == 0)
 static inline int64_t ps_w_rg(int dtype) { return dtype == PS_Q4_0 ? 16 : 8; }
 static inline int64_t ps_w_unit(int dtype) { return dtype == PS_Q4_K ? 256 : 128; }
+// Q6_K x Q8_K (k_gemv6.hip): one matrix, any number of columns (groups of 8 inside); act must be quantized (Q8_K)
+struct psk_gemv6_args {
+    const ps_weight *w;
+    float *out;            // [bs][ldo]
+    int64_t ldo;
+    const float *bias;     // optional [N]
+    const float *residual; // optional, same layout as out (may alias out)
+};
+int psk_gemv6(hipStream_t st, int n_cu, const psk_gemv6_args &a, ps_act act, int64_t K, int64_t bs);
 int psk_gemv_debug(int key, uint64_t *host_out, int n_words); // timeline buffer: arm / read back
 int psk_gemv(hipStream_t st, int n_cu, const psk_gemv_args &a, ps_act act, int vdt, int64_t K, int64_t bs);

@@ -83,23 +83,34 @@ def random_blocks(rng: np.random.Generator, t: int, n_rows: int, k: int, std: fl
     return out.reshape(-1)
 
 
+Q4_K_M = 1015  # pseudo type: the per-tensor mix llama.cpp's "Q4_K_M" file type uses (Q4_K with Q6_K for the sensitive tensors)
+
+
+def _more_bits(i: int, n: int) -> bool:  # llama.cpp use_more_bits(i_layer, n_layers)
+    return i < n // 8 or i >= 7 * n // 8 or (i - n // 8) % 3 == 2
+
+
 def tensor_plan(cfg: dict, arch: str, wtype: int, tied: bool, embd_type: int | None = None):
     """[(name, type, ne)] in file order."""
     dim, hid, L, kvd, vocab = cfg["embed_dim"], cfg["ffn_dim"], cfg["n_layers"], cfg["kv_dim"], cfg["vocab_size"]
-    et = wtype if embd_type is None else embd_type
+    mix = wtype == Q4_K_M
+    if mix:
+        wtype = Q4_K
+    et = (Q6_K if (mix and tied) else wtype) if embd_type is None else embd_type
     plan = [("token_embd.weight", et, (dim, vocab))]
     for i in range(L):
         b = f"blk.{i}."
+        hi = Q6_K if (mix and _more_bits(i, L)) else wtype
         plan += [(b + "attn_norm.weight", F32, (dim,)), (b + "attn_q.weight", wtype, (dim, dim)),
-                 (b + "attn_k.weight", wtype, (dim, kvd)), (b + "attn_v.weight", wtype, (dim, kvd)),
+                 (b + "attn_k.weight", wtype, (dim, kvd)), (b + "attn_v.weight", hi, (dim, kvd)),
                  (b + "attn_output.weight", wtype, (dim, dim)), (b + "ffn_norm.weight", F32, (dim,)),
                  (b + "ffn_gate.weight", wtype, (dim, hid)), (b + "ffn_up.weight", wtype, (dim, hid)),
-                 (b + "ffn_down.weight", wtype, (hid, dim))]
+                 (b + "ffn_down.weight", hi, (hid, dim))]
         if arch == "qwen2":
             plan += [(b + "attn_q.bias", F32, (dim,)), (b + "attn_k.bias", F32, (kvd,)), (b + "attn_v.bias", F32, (kvd,))]
     plan.append(("output_norm.weight", F32, (dim,)))
     if not tied:
-        plan.append(("output.weight", wtype, (dim, vocab)))
+        plan.append(("output.weight", Q6_K if mix else wtype, (dim, vocab)))
     return plan
 
 
@@ -110,7 +121,7 @@ def write_model_dir(out_dir: str, preset: str, wtype: int, n_ctx: int, seed: int
     tied = PRESETS[preset][10]
     cfg = llm_config(preset, n_ctx)
     os.makedirs(os.path.join(out_dir, "ggml"), exist_ok=True)
-    mj = {"version": 1, "model_arch": arch, "model_id": model_id or f"{preset}-{gguf.TYPE_NAME[wtype]}",
+    mj = {"version": 1, "model_arch": arch, "model_id": model_id or f"{preset}-{'Q4_K_M' if wtype == Q4_K_M else gguf.TYPE_NAME[wtype]}",
           "llm_config": cfg}
     with open(os.path.join(out_dir, "model.json"), "w") as f:
         json.dump(mj, f, indent=1)
