@@ -292,7 +292,8 @@ __global__ __launch_bounds__(PV_NT) void attn_softmax_pv_cols_kernel(psl_attn_ar
     for (int ci = 0; ci < CI; ci++)
 #pragma unroll
         for (int g = 0; g < R2MAX; g++) inv[ci][g] = g < r2 ? invs[ci][g] : 0.f;
-    for (int d = dsub; d < hs; d += PV_NT / 32) {
+    const int dspan = hs / (int)gridDim.z, d_lo = (int)blockIdx.z * dspan; // small grids: the channels are split over blockIdx.z (softmax recomputed)
+    for (int d = d_lo + dsub; d < d_lo + dspan; d += PV_NT / 32) {
         const float *vr = a.v_cache + ((int64_t)kvh * hs + d) * a.n_ctx;
         float acc[CI][R2MAX];
 #pragma unroll
@@ -407,8 +408,13 @@ void psl_attn_softmax_pv(hipStream_t st, const psl_attn_args &a, int bs) {
             (void)hipFuncSetAttribute((const void *)attn_softmax_pv_cols_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
             attr2 = true;
         }
-        if (lds2 <= 150 * 1024) hipLaunchKernelGGL(attn_softmax_pv_cols_kernel<2>, dim3((unsigned)a.n_kv_heads, (unsigned)((bs + 1) / 2)), dim3(PV_NT), lds2, st, a);
-        else hipLaunchKernelGGL(attn_softmax_pv_cols_kernel<1>, dim3((unsigned)a.n_kv_heads, (unsigned)bs), dim3(PV_NT), lds1, st, a);
+        // few (kv head, column pair) workgroups (tree verify, prefill tails): split the head channels over blockIdx.z
+        const bool two = lds2 <= 150 * 1024;
+        const int wgs = a.n_kv_heads * (two ? (bs + 1) / 2 : bs);
+        unsigned nz = 1;
+        while (nz * 32 < (unsigned)a.head_size && wgs * (int)nz * 2 <= 256 && a.head_size % (nz * 2 * 32) == 0) nz *= 2;
+        if (two) hipLaunchKernelGGL(attn_softmax_pv_cols_kernel<2>, dim3((unsigned)a.n_kv_heads, (unsigned)((bs + 1) / 2), nz), dim3(PV_NT), lds2, st, a);
+        else hipLaunchKernelGGL(attn_softmax_pv_cols_kernel<1>, dim3((unsigned)a.n_kv_heads, (unsigned)bs, nz), dim3(PV_NT), lds1, st, a);
         return;
     }
     static bool attr = false;

@@ -1155,8 +1155,9 @@ int launch_wt(hipStream_t st, int n_cu, const GemvParams &p, int epi, int pro) {
 // (quants transposed so that the bytes a lane needs per unit are contiguous: ds_read_b128), every wave then owns one
 // row group: the weights of a unit are unpacked ONCE and meet the 8 columns, each column keeping the reference's fma
 // chains in this lane's registers.  Same arithmetic, same order as the mat-vec.
-template <int WT, int EPI>
-__global__ __launch_bounds__(1024) void gemm8_kernel(const GemvParams p) {
+template <int WT, int EPI, int NWV>
+__global__ __launch_bounds__(NWV * 64) void gemm8_kernel(const GemvParams p) {
+    constexpr int NT = NWV * 64;
     using TR = WTraits<WT>;
     constexpr int C = 8;
     constexpr uint32_t M = 0x0F0F0F0Fu;
@@ -1165,25 +1166,37 @@ __global__ __launch_bounds__(1024) void gemm8_kernel(const GemvParams p) {
     const int K = (int)p.K, n_units = K / TR::UNIT, nblk = K / TR::BLK, c0 = blockIdx.y * C, nc = min(C, (int)p.bs - c0);
     // column image: [int8 q, transposed dwords][float d per block][Q4_K: int sums of 32]; multiple of 16 bytes
     const int col_bytes = K + nblk * 4 + (WT == PS_Q4_K ? K / 8 : 0);
-    for (int idx = threadIdx.x; idx < C * (K / 4); idx += 1024) {
-        const int c = idx / (K / 4), i = idx % (K / 4);
-        const int dw = c < nc ? ((const int *)(p.aq + (int64_t)(c0 + c) * K))[i] : 0;
-        int t;
-        if (WT == PS_Q4_K) { // unit = 64 dwords: dword (g, u) -> [u][g]
-            t = (i & ~63) + (i & 7) * 8 + ((i & 63) >> 3);
-        } else if (WT == PS_Q8_0) { // unit = 32 dwords: dword (block b, d) -> [d][b]
-            t = (i & ~31) + (i & 7) * 4 + ((i & 31) >> 3);
-        } else { // Q4_0: dword (b, half*4 + u') -> [u'][b][half]
-            t = (i & ~31) + (i & 3) * 8 + ((i & 31) >> 3) * 2 + ((i >> 2) & 1);
+    auto tpos = [](int i) { // dword i of a column -> its place in the transposed image
+        if (WT == PS_Q4_K) return (i & ~63) + (i & 7) * 8 + ((i & 63) >> 3);       // unit = 64 dwords: (g, u) -> [u][g]
+        if (WT == PS_Q8_0) return (i & ~31) + (i & 7) * 4 + ((i & 31) >> 3);       // unit = 32 dwords: (block b, d) -> [d][b]
+        return (i & ~31) + (i & 3) * 8 + ((i & 31) >> 3) * 2 + ((i >> 2) & 1);     // Q4_0: (b, half*4 + u') -> [u'][b][half]
+    };
+    {   // 16-byte global loads, SB of them in flight per thread, then the transposed dword stores
+        constexpr int SB = 8;
+        const int n16 = C * (K / 16); // int4 pieces of the 8 columns (K % 128 == 0)
+        for (int base = threadIdx.x; base < n16; base += NT * SB) {
+            int4 v[SB];
+#pragma unroll
+            for (int k = 0; k < SB; k++) {
+                const int idx = base + k * NT, c = idx / (K / 16), i = idx % (K / 16);
+                v[k] = (idx < n16 && c < nc) ? ((const int4 *)(p.aq + (int64_t)(c0 + c) * K))[i] : make_int4(0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int k = 0; k < SB; k++) {
+                const int idx = base + k * NT, c = idx / (K / 16), i = (idx % (K / 16)) * 4;
+                if (idx < n16) {
+                    int *col = (int *)(smem + c * col_bytes);
+                    col[tpos(i)] = v[k].x; col[tpos(i + 1)] = v[k].y; col[tpos(i + 2)] = v[k].z; col[tpos(i + 3)] = v[k].w;
+                }
+            }
         }
-        ((int *)(smem + c * col_bytes))[t] = dw;
     }
-    for (int idx = threadIdx.x; idx < C * nblk; idx += 1024) {
+    for (int idx = threadIdx.x; idx < C * nblk; idx += NT) {
         const int c = idx / nblk, i = idx % nblk;
         ((float *)(smem + c * col_bytes + K))[i] = c < nc ? p.ad[(int64_t)(c0 + c) * nblk + i] : 0.f;
     }
     if (WT == PS_Q4_K) {
-        for (int idx = threadIdx.x; idx < C * (K / 32); idx += 1024) {
+        for (int idx = threadIdx.x; idx < C * (K / 32); idx += NT) {
             const int c = idx / (K / 32), i = idx % (K / 32);
             const int16_t *b = p.abs16 + (int64_t)(c0 + c) * (K / 16) + 2 * i;
             ((int *)(smem + c * col_bytes + K + nblk * 4))[i] = c < nc ? (int)b[0] + (int)b[1] : 0;
@@ -1196,7 +1209,7 @@ __global__ __launch_bounds__(1024) void gemm8_kernel(const GemvParams p) {
     const int v = u & 3;
     constexpr int AUXR = (WT == PS_Q4_K) ? 16 : 8;
     const int64_t n_tasks = (EPI == 1) ? p.w[0].n_groups : p.groups_total;
-    const int64_t task = (int64_t)blockIdx.x * 16 + wave;
+    const int64_t task = (int64_t)blockIdx.x * NWV + wave;
     if (task >= n_tasks) return;
     float yg[C];
 #pragma unroll
@@ -1223,10 +1236,7 @@ __global__ __launch_bounds__(1024) void gemm8_kernel(const GemvParams p) {
             else { const uint2 t2 = *(const uint2 *)(ag + (int64_t)un * (TR::RG * AUXR)); h.x = t2.x; h.y = t2.y; }
             return h;
         };
-        uint4 q = ld_stream16(qg), h = load_h(0);
-        for (int un = 0; un < n_units; un++) {
-            uint4 qn = q, hn = h;
-            if (un + 1 < n_units) { qn = ld_stream16(qg + (int64_t)(un + 1) * 1024); hn = load_h(un + 1); }
+        auto unit = [&](const int un, const uint4 q, const uint4 h) {
             const uint32_t wq[4] = {q.x, q.y, q.z, q.w};
             if constexpr (WT == PS_Q4_K) {
                 // ---- this unit's weights, unpacked once for the 8 columns (acc1 plays acc_m)
@@ -1291,7 +1301,33 @@ __global__ __launch_bounds__(1024) void gemm8_kernel(const GemvParams p) {
                     }
                 }
             }
-            q = qn; h = hn;
+        };
+        if constexpr (NWV == 16) { // 128 VGPRs per lane: one unit ahead
+            uint4 q = ld_stream16(qg), h = load_h(0);
+            for (int un = 0; un < n_units; un++) {
+                uint4 qn = q, hn = h;
+                if (un + 1 < n_units) { qn = ld_stream16(qg + (int64_t)(un + 1) * 1024); hn = load_h(un + 1); }
+                unit(un, q, h);
+                q = qn; h = hn;
+            }
+        } else {
+            // small launches leave less than one wave per SIMD, so the walk is latency-bound: PF units in flight per
+            // wave; loads are unconditional (index clamped to the last unit) so that the compiler counts them exactly
+            constexpr int PF = 4;
+            uint4 qb[PF], hb[PF];
+#pragma unroll
+            for (int s = 0; s < PF; s++) { const int uc = min(s, n_units - 1); qb[s] = ld_stream16(qg + (int64_t)uc * 1024); hb[s] = load_h(uc); }
+            for (int un0 = 0; un0 < n_units; un0 += PF) {
+#pragma unroll
+                for (int s = 0; s < PF; s++) {
+                    const int un = un0 + s;
+                    if (un >= n_units) break;
+                    const uint4 q = qb[s], h = hb[s];
+                    const int nx = min(un + PF, n_units - 1);
+                    qb[s] = ld_stream16(qg + (int64_t)nx * 1024); hb[s] = load_h(nx);
+                    unit(un, q, h);
+                }
+            }
         }
         // ---- epilogue: lane with u == 0 owns row grp*RG + r
         int64_t Nw = p.w[0].N, ldo = p.w[0].ldo;
@@ -1391,20 +1427,19 @@ int psk_gemv_chain3(hipStream_t st, int n_cu, const psk_gemv_args a[3], unsigned
 
 // Batched mat-mul from pre-quantized activations; returns -1 when the shape is not covered (caller falls back to
 // column groups through the mat-vec).
+template <int WT, int EPI, int NWV>
+static void launch_gemm8_k(hipStream_t st, const GemvParams &p, const dim3 grid, size_t smem) {
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void *)gemm8_kernel<WT, EPI, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024); attr = true; }
+    hipLaunchKernelGGL((gemm8_kernel<WT, EPI, NWV>), grid, dim3(NWV * 64), smem, st, p);
+}
 template <int WT>
-static int launch_gemm8(hipStream_t st, const GemvParams &p, int epi, const dim3 grid, size_t smem) {
-    static bool attr[2] = {false, false};
-    if (!attr[epi]) {
-        if (epi) (void)hipFuncSetAttribute((const void *)gemm8_kernel<WT, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
-        else (void)hipFuncSetAttribute((const void *)gemm8_kernel<WT, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
-        attr[epi] = true;
-    }
-    if (epi) hipLaunchKernelGGL((gemm8_kernel<WT, 1>), grid, dim3(1024), smem, st, p);
-    else hipLaunchKernelGGL((gemm8_kernel<WT, 0>), grid, dim3(1024), smem, st, p);
+static int launch_gemm8(hipStream_t st, const GemvParams &p, int epi, int nwv, const dim3 grid, size_t smem) {
+    if (nwv == 16) { if (epi) launch_gemm8_k<WT, 1, 16>(st, p, grid, smem); else launch_gemm8_k<WT, 0, 16>(st, p, grid, smem); }
+    else { if (epi) launch_gemm8_k<WT, 1, 4>(st, p, grid, smem); else launch_gemm8_k<WT, 0, 4>(st, p, grid, smem); }
     return 0;
 }
 int psk_gemm8(hipStream_t st, int n_cu, const psk_gemv_args &a, ps_act act, int64_t K, int64_t bs) {
-    (void)n_cu;
     if (a.pro != 0 || a.rope || a.n_w < 1) return -1;
     const int wt = a.w[0]->dtype;
     if (wt != PS_Q4_K && wt != PS_Q8_0 && wt != PS_Q4_0) return -1;
@@ -1424,11 +1459,15 @@ int psk_gemm8(hipStream_t st, int n_cu, const psk_gemv_args &a, ps_act act, int6
     const size_t smem = (size_t)8 * (K + (K / blk) * 4 + (wt == PS_Q4_K ? K / 8 : 0));
     if (smem > 158 * 1024) return -1;
     const int64_t n_tasks = epi == 1 ? p.w[0].n_groups : p.groups_total;
-    const dim3 grid((unsigned)((n_tasks + 15) / 16), (unsigned)((bs + 7) / 8));
+    // one wave per row group; 16-wave workgroups amortise the LDS staging of the 8 columns, 4-wave workgroups spread a
+    // small launch (tree verify, short prefill tails) over all CUs
+    const int64_t ncg = (bs + 7) / 8;
+    const int nwv = ((n_tasks + 15) / 16) * ncg < (int64_t)n_cu ? 4 : 16;
+    const dim3 grid((unsigned)((n_tasks + nwv - 1) / nwv), (unsigned)ncg);
     switch (wt) {
-    case PS_Q4_K: return launch_gemm8<PS_Q4_K>(st, p, epi, grid, smem);
-    case PS_Q8_0: return launch_gemm8<PS_Q8_0>(st, p, epi, grid, smem);
-    default: return launch_gemm8<PS_Q4_0>(st, p, epi, grid, smem);
+    case PS_Q4_K: return launch_gemm8<PS_Q4_K>(st, p, epi, nwv, grid, smem);
+    case PS_Q8_0: return launch_gemm8<PS_Q8_0>(st, p, epi, nwv, grid, smem);
+    default: return launch_gemm8<PS_Q4_0>(st, p, epi, nwv, grid, smem);
     }
 }
 
