@@ -267,14 +267,10 @@ auto load_model(const std::string &model_dir, const std::shared_ptr<Platform> &p
 
 // ---------------------------------------------------------------- C driver API (ctypes / tests / tools)
 using namespace powerserve;
-struct psh_model {
-    std::shared_ptr<Platform> platform;
-    std::shared_ptr<Model> model;
-    std::string err;
-};
 static thread_local std::string g_err;
 extern "C" {
 const char *psh_last_error(void) { return g_err.c_str(); }
+void psh_set_error(const char *msg) { g_err = msg; }
 void *psh_model_load(const char *model_dir, int device, int max_batch, int n_ctx_cap) {
     try {
         auto h = new psh_model();

@@ -84,3 +84,10 @@ auto load_model(const std::string &model_dir, const std::shared_ptr<Platform> &p
     -> std::shared_ptr<Model>;
 
 } // namespace powerserve
+
+// handle behind the C driver API (psh_model_*, psh_spec_*)
+struct psh_model {
+    std::shared_ptr<powerserve::Platform> platform;
+    std::shared_ptr<powerserve::Model> model;
+    std::string err;
+};

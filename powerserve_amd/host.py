@@ -10,7 +10,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libps_host.so")
 EXPORTS = ["psh_last_error", "psh_model_load", "psh_model_free", "psh_model_set_fused", "psh_model_kv_position", "psh_model_reset",
-           "psh_model_vocab", "psh_model_forward", "psh_model_generate"]
+           "psh_model_vocab", "psh_model_forward", "psh_model_generate", "psh_spec_generate", "psh_draft_sample"]
 _LIB = None
 
 
@@ -32,6 +32,8 @@ def lib() -> C.CDLL:
         L.psh_model_vocab.argtypes = [C.c_void_p]
         L.psh_model_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
         L.psh_model_generate.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.psh_spec_generate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.psh_draft_sample.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]
         _LIB = L
     return _LIB
 
@@ -81,3 +83,26 @@ class HostModel:
         if self.L.psh_model_generate(self.h, p.ctypes.data, p.size, batch_size, steps, out.ctypes.data):
             raise HostError(self.L.psh_last_error().decode())
         return out
+
+
+def draft_sample(logits, top_k: int = 15, temperature: float = 1.5):
+    """TopK -> Temperature -> Softmax of the C++ mirror (csrc/host/speculative.cpp): (tokens, probs) sorted by probability."""
+    L = lib()
+    lg = np.ascontiguousarray(logits, dtype=np.float32)
+    k = min(top_k, lg.size)
+    toks, probs = np.empty(k, dtype=np.int32), np.empty(k, dtype=np.float32)
+    n = L.psh_draft_sample(lg.ctypes.data, lg.size, top_k, temperature, toks.ctypes.data, probs.ctypes.data)
+    if n < 0:
+        raise HostError(L.psh_last_error().decode())
+    return toks[:n], probs[:n]
+
+
+def spec_generate(target: HostModel, draft: HostModel, prompt, batch_size: int, steps: int, draft_batch_size: int = 12):
+    """SpeculativeModel::generate of the C++ mirror: (token ids, stats dict)."""
+    L = lib()
+    p = np.ascontiguousarray(prompt, dtype=np.int32)
+    out, st = np.empty(steps, dtype=np.int32), np.zeros(5, dtype=np.uint64)
+    if L.psh_spec_generate(target.h, draft.h, p.ctypes.data, p.size, batch_size, steps, draft_batch_size, out.ctypes.data, st.ctypes.data):
+        raise HostError(L.psh_last_error().decode())
+    keys = ("n_draft_times", "n_draft_tokens", "n_accepted_tokens", "n_iterations", "n_generated_tokens")
+    return out, {k: int(v) for k, v in zip(keys, st)}

@@ -77,3 +77,33 @@ def test_tree_forward_positions_and_masks(ctx, tmp_path):
     assert not np.array_equal(base, hid)
     assert np.array_equal(base.view(np.uint32), back.view(np.uint32))
     gm.close()
+
+
+@pytest.mark.parametrize("draft_seed", [77, 5])
+def test_cpp_speculative_mirror(tmp_path, draft_seed):
+    """The C++ host mirror (csrc/host/speculative.cpp: TokenTree / SpeculativeModel over the C-ABI) produces the target's
+    greedy output, and the same statistics as the Python mirror on the same pair of models."""
+    from powerserve_amd import hip, host, speculative, synth
+    td, dd = str(tmp_path / "t"), str(tmp_path / "d")
+    synth.write_model_dir(td, "small-llama-hs128", 12, n_ctx=160, seed=5)
+    synth.write_model_dir(dd, "small-llama-hs128", 12, n_ctx=160, seed=draft_seed)
+    prompt = np.random.default_rng(11).integers(0, 1024, 13)
+    steps = 40
+    target, draft = host.HostModel(td, max_batch=16), host.HostModel(dd, max_batch=16)
+    want = target.generate(prompt, 8, steps)
+    got, st = host.spec_generate(target, draft, prompt, 8, steps)
+    assert np.array_equal(got, want), (got, want)
+    assert st["n_generated_tokens"] >= steps and st["n_iterations"] > 0
+    assert np.array_equal(target.generate(prompt, 8, steps), want)  # nothing hidden is left behind
+    target.close()
+    draft.close()
+    c = hip.Ctx(0)
+    pt, pd = hip.Model(c, td, max_batch=16), hip.Model(c, dd, max_batch=16)
+    spec = speculative.SpeculativeModel(pt, pd)
+    assert np.array_equal(spec.generate(prompt, steps, batch_size=8), want)
+    ps = spec.stat()
+    # same trees up to last-ulp differences of the two softmax implementations: iteration counts agree closely
+    assert abs(st["n_iterations"] - ps["n_iterations"]) <= 2, (st, ps)
+    pt.close()
+    pd.close()
+    c.close()
