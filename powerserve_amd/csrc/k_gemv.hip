@@ -1164,12 +1164,15 @@ __global__ __launch_bounds__(NWV * 64) void gemm8_kernel(const GemvParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int K = (int)p.K, n_units = K / TR::UNIT, nblk = K / TR::BLK, c0 = blockIdx.y * C, nc = min(C, (int)p.bs - c0);
-    // column image: [int8 q, transposed dwords][float d per block][Q4_K: int sums of 32]; multiple of 16 bytes
-    const int col_bytes = K + nblk * 4 + (WT == PS_Q4_K ? K / 8 : 0);
-    auto tpos = [](int i) { // dword i of a column -> its place in the transposed image
-        if (WT == PS_Q4_K) return (i & ~63) + (i & 7) * 8 + ((i & 63) >> 3);       // unit = 64 dwords: (g, u) -> [u][g]
-        if (WT == PS_Q8_0) return (i & ~31) + (i & 7) * 4 + ((i & 31) >> 3);       // unit = 32 dwords: (block b, d) -> [d][b]
-        return (i & ~31) + (i & 3) * 8 + ((i & 31) >> 3) * 2 + ((i >> 2) & 1);     // Q4_0: (b, half*4 + u') -> [u'][b][half]
+    // LDS image: one record per (unit, column), records of a unit adjacent, so that every per-column read of the inner
+    // loop is  base(unit, lane) + compile-time offset:
+    //   Q4_K  REC 304: [256 B quants, dwords transposed (g, u) -> [u][g]] [8 int sums of 32] [float d] [pad]
+    //   Q8_0 / Q4_0  REC 144: [128 B quants, transposed] [4 float d]
+    constexpr int REC = (WT == PS_Q4_K) ? 304 : 144, UDW = TR::UNIT / 4; // dwords of quants per unit and column
+    auto tpos = [](int i) { // dword i of a unit -> its place in the transposed record
+        if (WT == PS_Q4_K) return (i & 7) * 8 + (i >> 3);                 // (g, u) -> [u][g]
+        if (WT == PS_Q8_0) return (i & 7) * 4 + (i >> 3);                 // (block b, d) -> [d][b]
+        return (i & 3) * 8 + (i >> 3) * 2 + ((i >> 2) & 1);               // Q4_0: (b, half*4 + u') -> [u'][b][half]
     };
     {   // 16-byte global loads, SB of them in flight per thread, then the transposed dword stores
         constexpr int SB = 8;
@@ -1185,21 +1188,23 @@ __global__ __launch_bounds__(NWV * 64) void gemm8_kernel(const GemvParams p) {
             for (int k = 0; k < SB; k++) {
                 const int idx = base + k * NT, c = idx / (K / 16), i = (idx % (K / 16)) * 4;
                 if (idx < n16) {
-                    int *col = (int *)(smem + c * col_bytes);
-                    col[tpos(i)] = v[k].x; col[tpos(i + 1)] = v[k].y; col[tpos(i + 2)] = v[k].z; col[tpos(i + 3)] = v[k].w;
+                    int *rec = (int *)(smem + ((i / UDW) * C + c) * REC);
+                    const int w = i % UDW; // (four consecutive dwords never straddle a unit)
+                    rec[tpos(w)] = v[k].x; rec[tpos(w + 1)] = v[k].y; rec[tpos(w + 2)] = v[k].z; rec[tpos(w + 3)] = v[k].w;
                 }
             }
         }
     }
+    constexpr int BPU = TR::UNIT / TR::BLK; // scales per unit (1 or 4)
     for (int idx = threadIdx.x; idx < C * nblk; idx += NT) {
         const int c = idx / nblk, i = idx % nblk;
-        ((float *)(smem + c * col_bytes + K))[i] = c < nc ? p.ad[(int64_t)(c0 + c) * nblk + i] : 0.f;
+        *(float *)(smem + ((i / BPU) * C + c) * REC + (WT == PS_Q4_K ? 288 : 128) + (i % BPU) * 4) = c < nc ? p.ad[(int64_t)(c0 + c) * nblk + i] : 0.f;
     }
     if (WT == PS_Q4_K) {
         for (int idx = threadIdx.x; idx < C * (K / 32); idx += NT) {
             const int c = idx / (K / 32), i = idx % (K / 32);
             const int16_t *b = p.abs16 + (int64_t)(c0 + c) * (K / 16) + 2 * i;
-            ((int *)(smem + c * col_bytes + K + nblk * 4))[i] = c < nc ? (int)b[0] + (int)b[1] : 0;
+            *(int *)(smem + ((i / 8) * C + c) * REC + 256 + (i % 8) * 4) = c < nc ? (int)b[0] + (int)b[1] : 0;
         }
     }
     __syncthreads();
@@ -1252,17 +1257,17 @@ __global__ __launch_bounds__(NWV * 64) void gemm8_kernel(const GemvParams p) {
                 const float dw = ps_h2f((uint16_t)(h.x & 0xffff)), dmw = ps_h2f((uint16_t)(h.x >> 16));
 #pragma unroll
                 for (int c = 0; c < C; c++) {
-                    const char *col = smem + c * col_bytes;
-                    const int4 y0 = *(const int4 *)(col + (un * 64 + u * 8) * 4), y1 = *(const int4 *)(col + (un * 64 + u * 8 + 4) * 4);
-                    const int2 bs = *(const int2 *)(col + K + nblk * 4 + (un * 8 + 2 * v) * 4);
-                    const float yd = ((const float *)(col + K))[un];
+                    const char *rec = smem + (un * C + c) * REC;
+                    const int4 y0 = *(const int4 *)(rec + u * 32), y1 = *(const int4 *)(rec + u * 32 + 16);
+                    const int2 bs = *(const int2 *)(rec + 256 + v * 8);
+                    const float yd = *(const float *)(rec + 288);
                     const int yl[4] = {y0.x, y0.z, y1.x, y1.z}, yh[4] = {y0.y, y0.w, y1.y, y1.w};
-                    int s = 0;
+                    int s = 0, dlo[4], dhi[4];
+                    dot4x4(dlo, wl[0], wl[1], wl[2], wl[3], yl[0], yl[1], yl[2], yl[3]);
+                    dot4x4(dhi, wh[0], wh[1], wh[2], wh[3], yh[0], yh[1], yh[2], yh[3]);
 #pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        const int dl = dot4(wl[j], yl[j], 0), dh = dot4(wh[j], yh[j], 0);
-                        s = dot2_i16(__builtin_amdgcn_perm((uint32_t)dh, (uint32_t)dl, 0x05040100u), sc16[j], s);
-                    }
+                    for (int j = 0; j < 4; j++)
+                        s = dot2_i16(__builtin_amdgcn_perm((uint32_t)dhi[j], (uint32_t)dlo[j], 0x05040100u), sc16[j], s);
                     const int pr   = __mul24(mna, bs.x) + __mul24(mnb, bs.y);
                     const float d  = __fmul_rn(yd, dw), dmin = __fmul_rn(-yd, dmw);
                     acc0[c] = __fmaf_rn(d, (float)s, acc0[c]);
@@ -1281,16 +1286,16 @@ __global__ __launch_bounds__(NWV * 64) void gemm8_kernel(const GemvParams p) {
                 }
 #pragma unroll
                 for (int c = 0; c < C; c++) {
-                    const char *col = smem + c * col_bytes;
-                    const float4 yd = *(const float4 *)(col + K + un * 16);
+                    const char *rec = smem + (un * C + c) * REC;
+                    const float4 yd = *(const float4 *)(rec + 128);
                     const float ydv[4] = {yd.x, yd.y, yd.z, yd.w};
                     if constexpr (WT == PS_Q8_0) {
-                        const int4 y = *(const int4 *)(col + (un * 32 + u * 4) * 4);
+                        const int4 y = *(const int4 *)(rec + u * 16);
                         const int yv[4] = {y.x, y.y, y.z, y.w};
 #pragma unroll
                         for (int b = 0; b < 4; b++) acc0[c] = __fmaf_rn(__fmul_rn(dh[b], ydv[b]), (float)dot4(wl[b], yv[b], 0), acc0[c]);
                     } else {
-                        const int4 y0 = *(const int4 *)(col + (un * 32 + u * 8) * 4), y1 = *(const int4 *)(col + (un * 32 + u * 8 + 4) * 4);
+                        const int4 y0 = *(const int4 *)(rec + u * 32), y1 = *(const int4 *)(rec + u * 32 + 16);
                         const int yl[4] = {y0.x, y0.z, y1.x, y1.z}, yh[4] = {y0.y, y0.w, y1.y, y1.w};
 #pragma unroll
                         for (int b = 0; b < 4; b++) {
@@ -1456,7 +1461,7 @@ int psk_gemm8(hipStream_t st, int n_cu, const psk_gemv_args &a, ps_act act, int6
     }
     const int epi = a.silu_pair ? 1 : 0;
     if (epi == 1 && (a.n_w != 2 || a.w[0]->N != a.w[1]->N)) return -1;
-    const size_t smem = (size_t)8 * (K + (K / blk) * 4 + (wt == PS_Q4_K ? K / 8 : 0));
+    const size_t smem = (size_t)(K / unit) * 8 * (wt == PS_Q4_K ? 304 : 144); // [unit][column] records (gemm8_kernel)
     if (smem > 158 * 1024) return -1;
     const int64_t n_tasks = epi == 1 ? p.w[0].n_groups : p.groups_total;
     // one wave per row group; 16-wave workgroups amortise the LDS staging of the 8 columns, 4-wave workgroups spread a

@@ -125,7 +125,21 @@ __device__ __forceinline__ int dot4(int a, int b, int acc) {
     return __builtin_amdgcn_sdot4(a, b, acc, false);
 }
 
-// (no inline-asm dot4: DOT results need wait states before their first use on gfx950 and the hazard recognizer
+// 4 independent v_dot4_i32_i8 in the VOP3P form with src2 = 0.  (The builtin only ever selects the accumulating VOP2
+// form, v_dot4c, which costs a v_mov 0 per product when nothing is accumulated.)  A DOT result must not be read or
+// overwritten by a different VALU instruction within 3 wait states and the hazard recognizer cannot see into an asm
+// statement: the trailing s_nop 2 covers the last product, the earlier ones are covered by the products after them.
+__device__ __forceinline__ void dot4x4(int (&d)[4], const int a0, const int a1, const int a2, const int a3, const int b0, const int b1,
+                                       const int b2, const int b3) {
+    asm("v_dot4_i32_i8 %0, %4, %8, 0\n\t"
+        "v_dot4_i32_i8 %1, %5, %9, 0\n\t"
+        "v_dot4_i32_i8 %2, %6, %10, 0\n\t"
+        "v_dot4_i32_i8 %3, %7, %11, 0\n\t"
+        "s_nop 2"
+        : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3])
+        : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(b0), "v"(b1), "v"(b2), "v"(b3));
+}
+// (single inline-asm dot4s are not used: DOT results need wait states before their first use on gfx950 and the hazard recognizer
 //  cannot see inside an asm statement -- measured: wrong sums)
 // two signed 16-bit products + 32-bit accumulator (v_dot2_i32_i16)
 typedef short ps_i16x2 __attribute__((ext_vector_type(2)));
