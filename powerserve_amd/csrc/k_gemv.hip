@@ -568,24 +568,26 @@ __device__ __forceinline__ typename RecOf<WT>::T unit_rec(const uint4 q, const u
         for (int j = 0; j < 4; j++) { ylv[j] = a.q32[base + j * 16]; yhv[j] = a.q32[base + j * 16 + 8]; }
         const int v = u & 3;
         const int bsa = a.bs32[unit * 8 + 2 * v], bsb = a.bs32[unit * 8 + 2 * v + 1];
+        int dlo[4], dhi[4]; // the eight quad dots as plain v_dot4 (no zeroed accumulators)
+        dot4x4(dlo, (int)(wq[0] & M), (int)(wq[1] & M), (int)(wq[2] & M), (int)(wq[3] & M), ylv[0], ylv[1], ylv[2], ylv[3]);
+        dot4x4(dhi, (int)((wq[0] >> 4) & M), (int)((wq[1] >> 4) & M), (int)((wq[2] >> 4) & M), (int)((wq[3] >> 4) & M), yhv[0], yhv[1], yhv[2], yhv[3]);
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             // |dot4| <= 4*15*127 fits int16, the 6-bit scales too: the two quad dots of a 64-element group are packed into
             // one dword and meet their scale pair in a single v_dot2_i32_i16 (exact integer arithmetic, 32-bit accumulate)
-            const int yl = ylv[j], yh = yhv[j];
             const uint32_t scp  = (j < 2) ? sc03 : sc47;
             const uint32_t sc16 = __builtin_amdgcn_perm(0u, scp, (j & 1) ? 0x0c030c02u : 0x0c010c00u); // {scale[2j], scale[2j+1]} as int16
-            const int dl = dot4((int)(wq[j] & M), yl, 0), dh = dot4((int)((wq[j] >> 4) & M), yh, 0);
-            const uint32_t d16 = __builtin_amdgcn_perm((uint32_t)dh, (uint32_t)dl, 0x05040100u);       // {dl, dh} as int16
+            const uint32_t d16 = __builtin_amdgcn_perm((uint32_t)dhi[j], (uint32_t)dlo[j], 0x05040100u); // {dl, dh} as int16
             s = dot2_i16(d16, sc16, s);
         }
         const uint32_t mp = (v < 2) ? mn03 : mn47;
         const int pr = __mul24(bfe8(mp, (2 * v) & 3), bsa) + __mul24(bfe8(mp, (2 * v + 1) & 3), bsb);
         return make_int2(s, u < 4 ? pr : (int)h.x);
     } else if constexpr (WT == PS_Q8_0) {
-        int s[4];
+        int s[4], y[4];
 #pragma unroll
-        for (int b = 0; b < 4; b++) s[b] = dot4((int)wq[b], a.q32[(unit * 4 + b) * 8 + u], 0);
+        for (int b = 0; b < 4; b++) y[b] = a.q32[(unit * 4 + b) * 8 + u];
+        dot4x4(s, (int)wq[0], (int)wq[1], (int)wq[2], (int)wq[3], y[0], y[1], y[2], y[3]);
         return make_int4(s[0], s[1], s[2], s[3]);
     } else { // |sum (q-8)*y| over a quad <= 4*8*127: the low/high partials travel as an int16 pair
         int s[4];
@@ -1292,16 +1294,21 @@ __global__ __launch_bounds__(NWV * 64) void gemm8_kernel(const GemvParams p) {
                     if constexpr (WT == PS_Q8_0) {
                         const int4 y = *(const int4 *)(rec + u * 16);
                         const int yv[4] = {y.x, y.y, y.z, y.w};
+                        int sd[4];
+                        dot4x4(sd, wl[0], wl[1], wl[2], wl[3], yv[0], yv[1], yv[2], yv[3]);
 #pragma unroll
-                        for (int b = 0; b < 4; b++) acc0[c] = __fmaf_rn(__fmul_rn(dh[b], ydv[b]), (float)dot4(wl[b], yv[b], 0), acc0[c]);
+                        for (int b = 0; b < 4; b++) acc0[c] = __fmaf_rn(__fmul_rn(dh[b], ydv[b]), (float)sd[b], acc0[c]);
                     } else {
                         const int4 y0 = *(const int4 *)(rec + u * 32), y1 = *(const int4 *)(rec + u * 32 + 16);
                         const int yl[4] = {y0.x, y0.z, y1.x, y1.z}, yh[4] = {y0.y, y0.w, y1.y, y1.w};
+                        int sl[4], sh[4];
+                        dot4x4(sl, wl[0], wl[1], wl[2], wl[3], yl[0], yl[1], yl[2], yl[3]);
+                        dot4x4(sh, wh[0], wh[1], wh[2], wh[3], yh[0], yh[1], yh[2], yh[3]);
 #pragma unroll
                         for (int b = 0; b < 4; b++) {
                             const float d = __fmul_rn(dh[b], ydv[b]);
-                            acc0[c] = __fmaf_rn(d, (float)dot4(wl[b], yl[b], 0), acc0[c]);
-                            acc1[c] = __fmaf_rn(d, (float)dot4(wh[b], yh[b], 0), acc1[c]);
+                            acc0[c] = __fmaf_rn(d, (float)sl[b], acc0[c]);
+                            acc1[c] = __fmaf_rn(d, (float)sh[b], acc1[c]);
                         }
                     }
                 }
