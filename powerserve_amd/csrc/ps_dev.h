@@ -111,12 +111,17 @@ __device__ __forceinline__ int group4_sum_i_dpp(int v) { // aligned groups of 4 
 // ---- GGML_F32x8_REDUCE (libs/ggml/src/ggml.c:1354-1371) over the 32 fp32 chains of ggml_vec_dot_f32's AVX build,
 //      held by 32 consecutive lanes (c = lane & 31 = accumulator*8 + simd lane): acc0+=acc2, acc1+=acc3 (xor 16),
 //      acc0+=acc1 (xor 8), low+high 128 bits (xor 4), two hadds (xor 1, xor 2).  Valid in the lane with c == 0.
+//      Only the lane with c == 0 needs the result, so every step is a one-directional fetch (lane c reads lane c + n):
+//      c + 16 through v_permlane16_swap (gfx950: swaps the odd 16-lane rows of one operand with the even rows of the other;
+//      with both operands = v the second result holds row 1 in row 0 and row 3 in row 2), the rest as DPP row shifts —
+//      VALU-speed, no ds_bpermute round trips.  Same partners and the same association as the xor butterfly.
 __device__ __forceinline__ float reduce_f32x8x4(float v) {
-    v = __fadd_rn(v, __shfl_xor(v, 16, 64));
-    v = __fadd_rn(v, __shfl_xor(v, 8, 64));
-    v = __fadd_rn(v, __shfl_xor(v, 4, 64));
-    v = __fadd_rn(v, __shfl_xor(v, 1, 64));
-    v = __fadd_rn(v, __shfl_xor(v, 2, 64));
+    const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __fadd_rn(v, __uint_as_float(sw[1])); // c < 16: + lane c + 16   (acc0 += acc2, acc1 += acc3)
+    v = __fadd_rn(v, dpp_f<0x108>(v));        // c < 8:  + lane c + 8    (acc0 += acc1)
+    v = __fadd_rn(v, dpp_f<0x104>(v));        // c < 4:  + lane c + 4    (low + high 128 bits)
+    v = __fadd_rn(v, dpp_f<0x101>(v));        // c = 0, 2: + lane c + 1  (hadd)
+    v = __fadd_rn(v, dpp_f<0x102>(v));        // c = 0:  + lane 2        (hadd)
     return v;
 }
 
