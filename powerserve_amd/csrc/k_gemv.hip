@@ -125,18 +125,20 @@ __device__ __forceinline__ void unit_dot(const uint4 q, const uint4 h, const int
 // hsum_float_8 association (+ acc_m for Q4_K): valid in the lane with u == 0
 template <int WT>
 __device__ __forceinline__ float row_reduce(float acc0, float acc1, float accm) {
+    // only u == 0 keeps the result: one-directional DPP row shifts (lane u reads lane u + n inside its row of 16) give the
+    // same partners and association as the xor butterfly without any ds_bpermute round trip on the chain waves' path
     if (WT == PS_Q4_0) {
         float r = __fadd_rn(acc1, acc0); // a[k+4] + a[k]
-        r = __fadd_rn(r, __shfl_xor(r, 2, 64));
-        r = __fadd_rn(r, __shfl_xor(r, 1, 64));
+        r = __fadd_rn(r, dpp_f<0x102>(r));
+        r = __fadd_rn(r, dpp_f<0x101>(r));
         return r;
     }
-    float r = __fadd_rn(acc0, __shfl_xor(acc0, 4, 64));
-    r = __fadd_rn(r, __shfl_xor(r, 2, 64));
-    r = __fadd_rn(r, __shfl_xor(r, 1, 64));
+    float r = __fadd_rn(acc0, dpp_f<0x104>(acc0));
+    r = __fadd_rn(r, dpp_f<0x102>(r));
+    r = __fadd_rn(r, dpp_f<0x101>(r));
     if (WT == PS_Q4_K) {
-        float m = __fadd_rn(accm, __shfl_xor(accm, 2, 64)); // (m0+m2), (m1+m3)
-        m = __fadd_rn(m, __shfl_xor(m, 1, 64));
+        float m = __fadd_rn(accm, dpp_f<0x102>(accm)); // (m0+m2), (m1+m3)
+        m = __fadd_rn(m, dpp_f<0x101>(m));
         r = __fadd_rn(r, m);
     }
     return r;
@@ -833,7 +835,7 @@ __device__ __forceinline__ void g3_body(const GemvParams &p, char *smem, double 
                 float v = y;
                 if (b && row < Nw) v = __fadd_rn(v, b[row]);
                 constexpr int LPR = 64 / TR::RG; // lanes per row
-                const float vp = __shfl_xor(v, LPR, 64);
+                const float vp = (LPR == 8) ? dpp_f<0x128>(v) : __shfl_xor(v, LPR, 64); // partner row (row_ror:8 swaps the two row groups of 8 lanes)
                 const psk_rope_kv &R = p.rope;
                 const int pos = R.state->pos0;                         // cache slot
                 const int rpos = R.rope_pos ? R.rope_pos[0] : pos;     // RoPE position (differs inside a token tree)

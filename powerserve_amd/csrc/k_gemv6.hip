@@ -93,20 +93,22 @@ __global__ __launch_bounds__(256) void gemv6_kernel(Gemv6Params p) {
                     }
                 const float t  = (float)sumi;
                 const float dd = __fmul_rn(p.ad[(int64_t)cc * nsb + sb], dw); // y[i].d * GGML_FP16_TO_FP32(x[i].d)
+                float ds[8], ts[8]; // all sixteen lane broadcasts in flight, then the chain in super-block order
+#pragma unroll
+                for (int s = 0; s < 8; s++) { ds[s] = __shfl(dd, s * 8 + u, 64); ts[s] = __shfl(t, s * 8 + u, 64); }
                 float ac = acc[c];
-                for (int s = 0; s < nlive; s++) {
-                    const float ds = __shfl(dd, s * 8 + u, 64), ts = __shfl(t, s * 8 + u, 64);
-                    ac = __fmaf_rn(ds, ts, ac);
-                }
+#pragma unroll
+                for (int s = 0; s < 8; s++)
+                    if (s < nlive) ac = __fmaf_rn(ds[s], ts[s], ac);
                 acc[c] = ac;
             }
         }
 #pragma unroll
         for (int c = 0; c < BS; c++) { // hsum_float_8 (ggml-quants.c:62-68): (a4+a0, a5+a1, a6+a2, a7+a3) -> (r0+r2, r1+r3) -> sum
             float v = acc[c];
-            v = __fadd_rn(v, __shfl_xor(v, 4, 64));
-            v = __fadd_rn(v, __shfl_xor(v, 2, 64));
-            v = __fadd_rn(v, __shfl_xor(v, 1, 64));
+            v = __fadd_rn(v, dpp_f<0x104>(v)); // one-directional row shifts: lane 0 of each 8-group ends with the reference's sum
+            v = __fadd_rn(v, dpp_f<0x102>(v));
+            v = __fadd_rn(v, dpp_f<0x101>(v));
             if (lane == 0 && c < p.nc) {
                 if (p.bias) v = __fadd_rn(v, p.bias[row]);
                 if (p.residual) v = __fadd_rn(p.residual[(int64_t)c * p.ldo + row], v);
