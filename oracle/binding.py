@@ -248,6 +248,14 @@ class OracleModel:
 
 
 # --------------------------------------------------------------------------- real reference
+class SamplerCfg(C.Structure):
+    """plain-C view of HyperParams::SamplerConfig + the vocabulary ids the chain needs (psh_sampler_cfg / ref_sampler_cfg)"""
+    _fields_ = [("seed", C.c_uint64), ("temperature", C.c_float), ("top_p", C.c_float), ("top_k", C.c_uint64),
+                ("penalty_last_n", C.c_int32), ("penalty_repeat", C.c_float), ("penalty_freq", C.c_float),
+                ("penalty_present", C.c_float), ("penalize_nl", C.c_int32), ("ignore_eos", C.c_int32), ("n_vocabs", C.c_int32),
+                ("special_eos_id", C.c_int32), ("linefeed_id", C.c_int32)]
+
+
 class RefTensor(C.Structure):
     _fields_ = [("type", C.c_int32), ("_pad", C.c_int32), ("ne", C.c_int64 * 4), ("nb", C.c_uint64 * 4),
                 ("data", C.c_void_p)]
@@ -289,6 +297,11 @@ class Ref:
         L.ref_dup.argtypes = [C.c_void_p] * 3
         L.ref_silu_hadamard.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64]
         L.ref_get_embedding.argtypes = [C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_void_p]
+        L.ref_sampler_create.restype = C.c_void_p
+        L.ref_sampler_create.argtypes = [C.c_void_p]
+        L.ref_sampler_free.argtypes = [C.c_void_p]
+        L.ref_sampler_sample.restype = C.c_int32
+        L.ref_sampler_sample.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.ref_model_create.restype = C.c_void_p
         L.ref_model_create.argtypes = [C.c_char_p, C.c_char_p, C.c_void_p, C.c_int]
         L.ref_model_destroy.argtypes = [C.c_void_p]

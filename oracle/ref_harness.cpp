@@ -8,7 +8,9 @@
 //       like GGMLBackend::matmul does (src/backend/ggml/ggml_wrapper.cpp:20-40), and
 //   (b) the end-to-end LlamaModel/Qwen2Model::forward (src/model/llama/llama_model.cpp:52-117)
 //       on a GGUF file, with greedy arg-max sampling (top_k=1 == max_element,
-//       src/sampler/prob_array.cpp:65-67).
+//       src/sampler/prob_array.cpp:65-67), and
+//   (c) the reference's sampler classes chained in the order of SamplerChain::build_from_config
+//       (src/sampler/sampler_chain.cpp:19-51; built with append<> because build_from_config wants a Tokenizer).
 // Nothing here is shipped in the product; tests/, smoke() and bench.py's cpu_baseline leg load the
 // resulting oracle/_ref/libps_ref.so through ctypes.
 
@@ -22,6 +24,7 @@
 #include "model/llama/llama_model.hpp"
 #include "model/module/norm_attention.hpp"
 #include "model/qwen2/qwen2_model.hpp"
+#include "sampler/sampler_chain.hpp"
 
 #include <atomic>
 #include <chrono>
@@ -428,3 +431,36 @@ int ref_model_generate(void *h, const int32_t *prompt, int n_prompt, int batch_s
 }
 
 } // extern "C"
+
+// ---------------------------------------------------------------- (c) the reference's sampler chain
+extern "C" {
+struct ref_sampler_cfg { // same layout as psh_sampler_cfg (powerserve_amd/csrc/host/model.cpp)
+    uint64_t seed;
+    float temperature, top_p;
+    uint64_t top_k;
+    int32_t penalty_last_n;
+    float penalty_repeat, penalty_freq, penalty_present;
+    int32_t penalize_nl, ignore_eos, n_vocabs, special_eos_id, linefeed_id;
+};
+void *ref_sampler_create(const ref_sampler_cfg *c) {
+    auto *ch = new SamplerChain();
+    ch->append<RepeatPenaltySampler>(c->n_vocabs, c->special_eos_id, c->linefeed_id, c->penalty_last_n, c->penalty_repeat, c->penalty_freq,
+                                     c->penalty_present, c->penalize_nl != 0, c->ignore_eos != 0);
+    ch->append<TopKSampler>((size_t)c->top_k);
+    ch->append<TemperatureSampler>(c->temperature);
+    ch->append<SoftmaxSampler>();
+    ch->append<TopPSampler>(c->top_p);
+    ch->append<NormalizeSampler>();
+    ch->append<StochasticSampler>(c->seed);
+    return ch;
+}
+void ref_sampler_free(void *s) { delete (SamplerChain *)s; }
+int32_t ref_sampler_sample(void *s, const float *logits, int n) { // ModelTokenIterator::decode: apply, probs[0], accept
+    auto *ch = (SamplerChain *)s;
+    ProbArray probs(std::span<const float>(logits, (size_t)n));
+    ch->apply(probs);
+    const Token next = probs[0].token;
+    ch->accept(next);
+    return next;
+}
+}

@@ -51,7 +51,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     return so
 
 
-HOST_SOURCES = ["json_gguf.cpp", "graph.cpp", "hip_backend.cpp", "model.cpp", "speculative.cpp"]
+HOST_SOURCES = ["json_gguf.cpp", "graph.cpp", "hip_backend.cpp", "model.cpp", "speculative.cpp", "sampler.cpp"]
 
 
 def build_host(force: bool = False, verbose: bool = True) -> str:

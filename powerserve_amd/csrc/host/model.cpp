@@ -255,6 +255,29 @@ auto Model::generate(const std::vector<Token> &prompt, int steps, size_t batch_s
     return out;
 }
 
+auto Model::generate(const std::vector<Token> &prompt, int steps, size_t batch_size, SamplerChain &sampler) -> std::vector<Token> {
+    std::vector<Token> out;
+    if (steps <= 0 || prompt.empty()) return out;
+    auto &id = m_config->model_id;
+    m_platform->reset_kv_position(id);
+    size_t n_prefilled = 0;
+    while (n_prefilled < prompt.size() - 1) {
+        const size_t bs = std::min(batch_size, prompt.size() - n_prefilled - 1);
+        std::vector<Token> toks(prompt.begin() + n_prefilled, prompt.begin() + n_prefilled + bs);
+        std::vector<int> pos(bs);
+        std::iota(pos.begin(), pos.end(), (int)m_platform->get_kv_position(id));
+        decode(toks, pos, false);
+        n_prefilled += bs;
+    }
+    Token cur = prompt.back();
+    for (int s = 0; s < steps; s++) {
+        auto ret = forward({cur}, {(int)m_platform->get_kv_position(id)}, CausalAttentionMask(1), true);
+        cur = sampler.sample(ret.logits_vector[0]);
+        out.push_back(cur);
+    }
+    return out;
+}
+
 auto load_model(const std::string &model_dir, const std::shared_ptr<Platform> &platform, int device, size_t max_batch, int n_ctx_cap)
     -> std::shared_ptr<Model> {
     auto config = std::make_shared<ModelConfig>(model_dir + "/model.json");
@@ -291,6 +314,39 @@ int psh_model_forward(void *h, const int32_t *tokens, int n, const int32_t *pos,
         auto r = m->model->forward(t, p, CausalAttentionMask(n), lm_head != 0);
         if (lm_head && logits_out)
             for (int i = 0; i < n; i++) memcpy(logits_out + (size_t)i * r.logits_vector[i].size(), r.logits_vector[i].data(), r.logits_vector[i].size() * 4);
+        return 0;
+    } catch (const std::exception &e) { g_err = e.what(); return 1; }
+}
+// sampler chain alone (tests against the reference's samplers) and sampled generation
+struct psh_sampler_cfg { // plain-C view of SamplerConfig + the two vocabulary ids the chain needs
+    uint64_t seed;
+    float temperature, top_p;
+    uint64_t top_k;
+    int32_t penalty_last_n;
+    float penalty_repeat, penalty_freq, penalty_present;
+    int32_t penalize_nl, ignore_eos, n_vocabs, special_eos_id, linefeed_id;
+};
+static SamplerChain *make_chain(const psh_sampler_cfg *c) {
+    SamplerConfig sc;
+    sc.seed = c->seed; sc.temperature = c->temperature; sc.top_p = c->top_p; sc.top_k = (size_t)c->top_k;
+    sc.penalty_last_n = c->penalty_last_n; sc.penalty_repeat = c->penalty_repeat; sc.penalty_freq = c->penalty_freq;
+    sc.penalty_present = c->penalty_present; sc.penalize_nl = c->penalize_nl != 0; sc.ignore_eos = c->ignore_eos != 0;
+    return new SamplerChain(sc, c->n_vocabs, c->special_eos_id, c->linefeed_id);
+}
+void *psh_sampler_create(const psh_sampler_cfg *c) {
+    try { return make_chain(c); } catch (const std::exception &e) { g_err = e.what(); return nullptr; }
+}
+void psh_sampler_free(void *s) { delete (SamplerChain *)s; }
+int32_t psh_sampler_sample(void *s, const float *logits, int n) {
+    try { return ((SamplerChain *)s)->sample(std::span<const float>(logits, (size_t)n)); } catch (const std::exception &e) { g_err = e.what(); return -1; }
+}
+int psh_model_generate_sampled(void *h, const int32_t *prompt, int n_prompt, int batch_size, int steps, const psh_sampler_cfg *c, int32_t *out) {
+    try {
+        auto m = (psh_model *)h;
+        std::unique_ptr<SamplerChain> chain(make_chain(c));
+        std::vector<Token> p(prompt, prompt + n_prompt);
+        auto r = m->model->generate(p, steps, (size_t)batch_size, *chain);
+        memcpy(out, r.data(), r.size() * 4);
         return 0;
     } catch (const std::exception &e) { g_err = e.what(); return 1; }
 }

@@ -7,6 +7,7 @@
 //   load_model                    src/model/model_loader.cpp:23-41
 #pragma once
 #include "hip_backend.hpp"
+#include "sampler.hpp"
 
 #include <deque>
 #include <span>
@@ -67,6 +68,8 @@ struct Model {
     // ModelTokenIterator: prefill all but the last prompt token in chunks of batch_size (no lm_head), then `steps`
     // single-token greedy steps
     auto generate(const std::vector<Token> &prompt, int steps, size_t batch_size) -> std::vector<Token>;
+    // the same loop with a sampler chain instead of arg-max: logits come back to the host every step (model.hpp:170-183)
+    auto generate(const std::vector<Token> &prompt, int steps, size_t batch_size, SamplerChain &sampler) -> std::vector<Token>;
 
     hip::HIPBackend &backend() { return *m_platform->hip_backends[m_config->model_id]; }
 

@@ -49,25 +49,11 @@ struct Candidate {
 } // namespace
 
 std::vector<ProbIndex> draft_sample(std::span<const float> logits, size_t top_k, float temperature) {
-    POWERSERVE_ASSERT(top_k > 0 && temperature > 0);
-    std::vector<ProbIndex> probs(logits.size());
-    for (size_t i = 0; i < logits.size(); i++) probs[i] = {logits[i], (Token)i};
-    const size_t k = std::min(top_k, probs.size());
-    // TopKSampler: partial sort, descending (ties: lower token id first, to be deterministic)
-    std::partial_sort(probs.begin(), probs.begin() + k, probs.end(),
-                      [](const ProbIndex &a, const ProbIndex &b) { return a.prob != b.prob ? a.prob > b.prob : a.token < b.token; });
-    probs.resize(k);
-    if (temperature != 1.0f) // TemperatureSampler
-        for (auto &p : probs) p.prob /= temperature;
-    // ProbArray::softmax: exp(x - max), summed in double from the smallest to the largest
-    const float mx = probs[0].prob;
-    double sum = 0;
-    for (auto it = probs.rbegin(); it != probs.rend(); ++it) {
-        it->prob = std::exp(it->prob - mx);
-        sum += it->prob;
-    }
-    for (auto &p : probs) p.prob = (float)(p.prob / sum);
-    return probs;
+    ProbArray probs(logits); // the draft sampler chain of token_tree.cpp:35-39
+    TopKSampler(top_k).apply(probs);
+    TemperatureSampler(temperature).apply(probs);
+    SoftmaxSampler().apply(probs);
+    return probs.m_probs;
 }
 
 std::vector<int32_t> TokenTree::tokens() const {

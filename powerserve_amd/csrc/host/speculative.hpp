@@ -8,6 +8,7 @@
 // mask and per-node RoPE positions; the longest path the target agrees with is kept by moving its KV entries into place.
 #pragma once
 #include "model.hpp"
+#include "sampler.hpp"
 
 #include <functional>
 #include <queue>
@@ -28,10 +29,6 @@ struct SpeculativeConfig {
     } token_tree;
 };
 
-struct ProbIndex { // src/sampler/prob_array.hpp:24-36
-    float prob  = 0.0f;
-    Token token = -1;
-};
 // TopK -> Temperature -> Softmax over one logits row (sampler.cpp:19-58, prob_array.cpp:37-59): sorted by probability
 std::vector<ProbIndex> draft_sample(std::span<const float> logits, size_t top_k, float temperature);
 

@@ -10,7 +10,8 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libps_host.so")
 EXPORTS = ["psh_last_error", "psh_model_load", "psh_model_free", "psh_model_set_fused", "psh_model_kv_position", "psh_model_reset",
-           "psh_model_vocab", "psh_model_forward", "psh_model_generate", "psh_spec_generate", "psh_draft_sample"]
+           "psh_model_vocab", "psh_model_forward", "psh_model_generate", "psh_spec_generate", "psh_draft_sample", "psh_sampler_create", "psh_sampler_free", "psh_sampler_sample",
+           "psh_model_generate_sampled"]
 _LIB = None
 
 
@@ -34,8 +35,29 @@ def lib() -> C.CDLL:
         L.psh_model_generate.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.psh_spec_generate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.psh_draft_sample.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]
+        L.psh_sampler_create.restype = C.c_void_p
+        L.psh_sampler_create.argtypes = [C.c_void_p]
+        L.psh_sampler_free.argtypes = [C.c_void_p]
+        L.psh_sampler_sample.restype = C.c_int32
+        L.psh_sampler_sample.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.psh_model_generate_sampled.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         _LIB = L
     return _LIB
+
+
+class SamplerCfg(C.Structure):
+    """HyperParams::SamplerConfig (src/core/config.hpp:34-47) + the vocabulary ids SamplerChain::build_from_config takes
+    from the tokenizer (n_vocabs, special_eos_id, linefeed_id; -1 = none)."""
+    _fields_ = [("seed", C.c_uint64), ("temperature", C.c_float), ("top_p", C.c_float), ("top_k", C.c_uint64),
+                ("penalty_last_n", C.c_int32), ("penalty_repeat", C.c_float), ("penalty_freq", C.c_float),
+                ("penalty_present", C.c_float), ("penalize_nl", C.c_int32), ("ignore_eos", C.c_int32), ("n_vocabs", C.c_int32),
+                ("special_eos_id", C.c_int32), ("linefeed_id", C.c_int32)]
+
+    @classmethod
+    def make(cls, n_vocabs, seed=0, temperature=0.8, top_p=0.95, top_k=40, penalty_last_n=64, penalty_repeat=1.0, penalty_freq=0.0,
+             penalty_present=0.0, penalize_nl=False, ignore_eos=False, special_eos_id=-1, linefeed_id=-1):
+        return cls(seed, temperature, top_p, top_k, penalty_last_n, penalty_repeat, penalty_freq, penalty_present, int(penalize_nl),
+                   int(ignore_eos), n_vocabs, special_eos_id, linefeed_id)
 
 
 class HostError(RuntimeError):
@@ -106,3 +128,36 @@ def spec_generate(target: HostModel, draft: HostModel, prompt, batch_size: int, 
         raise HostError(L.psh_last_error().decode())
     keys = ("n_draft_times", "n_draft_tokens", "n_accepted_tokens", "n_iterations", "n_generated_tokens")
     return out, {k: int(v) for k, v in zip(keys, st)}
+
+
+class Sampler:
+    """SamplerChain of the C++ mirror (csrc/host/sampler.cpp): sample(logits) = apply + probs[0] + accept."""
+
+    def __init__(self, cfg: SamplerCfg):
+        self.L = lib()
+        self.cfg = cfg
+        self.h = self.L.psh_sampler_create(C.byref(cfg))
+        if not self.h:
+            raise HostError(self.L.psh_last_error().decode())
+
+    def sample(self, logits) -> int:
+        lg = np.ascontiguousarray(logits, dtype=np.float32)
+        t = self.L.psh_sampler_sample(self.h, lg.ctypes.data, lg.size)
+        if t < 0:
+            raise HostError(self.L.psh_last_error().decode())
+        return int(t)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.psh_sampler_free(self.h)
+            self.h = None
+
+
+def generate_sampled(model: HostModel, prompt, batch_size: int, steps: int, cfg: SamplerCfg):
+    """Model::generate with a sampler chain (host loop: forward, logits to the host, sample, accept)."""
+    L = lib()
+    p = np.ascontiguousarray(prompt, dtype=np.int32)
+    out = np.empty(steps, dtype=np.int32)
+    if L.psh_model_generate_sampled(model.h, p.ctypes.data, p.size, batch_size, steps, C.byref(cfg), out.ctypes.data):
+        raise HostError(L.psh_last_error().decode())
+    return out

@@ -56,3 +56,38 @@ def test_host_errors_surface(tmp_path):
     with pytest.raises(host.HostError):
         host.HostModel(str(tmp_path / "missing"), 0)
     hm.close()
+
+
+@pytest.mark.parametrize("kw", [dict(seed=7), dict(seed=3, temperature=1.3, top_k=50, penalty_repeat=1.2, penalty_last_n=8, penalize_nl=True)])
+def test_sampled_generation_matches_reference_pipeline(oracle, ref, tmp_path, kw):
+    """Model::generate with the sampler chain on the GPU path == CPU oracle logits fed through the reference's own sampler
+    classes (oracle/_ref): the logits are bit-identical, so the sampled token streams must be too."""
+    import ctypes as C
+    from oracle import binding as B
+    from powerserve_amd import host, synth
+    d = str(tmp_path / "m")
+    mj = synth.write_model_dir(d, "small-llama-hs128", 12, n_ctx=96, seed=5)
+    cfg = B.make_config(mj["llm_config"])
+    om = oracle.model(cfg, mj["model_arch"], load_tensors(os.path.join(d, "ggml/weights.gguf")), n_threads=8)
+    hm = host.HostModel(d, 0, max_batch=16)
+    prompt = np.random.default_rng(2).integers(0, cfg.vocab_size, 11)
+    steps = 24
+    scfg = host.SamplerCfg.make(cfg.vocab_size, **kw)
+    got = host.generate_sampled(hm, prompt, 8, steps, scfg)
+    assert np.array_equal(got, host.generate_sampled(hm, prompt, 8, steps, scfg))  # same seed, same stream
+    # reference pipeline: oracle forward + the reference's SamplerChain
+    rc = B.SamplerCfg.from_buffer_copy(bytes(scfg))
+    rh = ref.L.ref_sampler_create(C.byref(rc))
+    om.forward(prompt[:8], np.arange(8), False)
+    om.forward(prompt[8:10], np.arange(8, 10), False)
+    cur, want = int(prompt[-1]), []
+    for s in range(steps):
+        lg = om.forward([cur], [om.position], True)
+        cur = ref.L.ref_sampler_sample(rh, lg.ctypes.data, cfg.vocab_size)
+        want.append(cur)
+    ref.L.ref_sampler_free(rh)
+    assert list(got) == want
+    # top_k = 1 through the chain is the greedy path
+    g1 = host.generate_sampled(hm, prompt, 8, steps, host.SamplerCfg.make(cfg.vocab_size, top_k=1))
+    assert np.array_equal(g1, hm.generate(prompt, 8, steps))
+    hm.close(); om.close()
