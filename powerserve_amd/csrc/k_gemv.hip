@@ -741,7 +741,13 @@ __device__ __forceinline__ void g3_body(const GemvParams &p, char *smem, double 
     // the tiles go to as few (= the earliest started) waves as TPW allows: a late wave's activation load would sit
     // behind the weight requests of all the earlier waves in the CU's vector-memory queue
     const int nwl = min(NW, (int)((K + 255) / 256 + TPW - 1) / TPW);
-    constexpr bool B_EARLY = !HOOKED && ((PRO == 0) || (TPW <= 2) || (PRO == 2)); // RMSNorm over long rows / chained phase: the prologue needs the registers
+    // When does the second chunk go out?  The CU's vector-memory path holds about one chunk of outstanding requests: a
+    // wave that issues more stalls IN the issue until earlier data returns, and so arrives late at the prologue's
+    // barriers (measured: all of A + B before the prologue -> last producer wave at the first barrier after 4.8 us
+    // instead of 2.4 us).  So B follows the first prologue barrier (RMSNorm: B_MID) or the prologue (plain quantize);
+    // only a launch without a prologue sends it at once.
+    constexpr bool B_EARLY = !HOOKED && (PRO == 0);
+    constexpr bool B_MID   = !HOOKED && (PRO == 1) && (TPW <= 2); // (long rows keep the registers for the prologue) // RMSNorm over long rows / chained phase: the prologue needs the registers
     auto begin_producers = [&]() { // the chain waves never touch the vector-memory queue before their stores
         // activation row first, the first chunks of weights right behind it (vmcnt retires in order: the prologue
         // only waits for the L2-resident activation while the weights stream in)
@@ -780,12 +786,18 @@ __device__ __forceinline__ void g3_body(const GemvParams &p, char *smem, double 
             for (int i = threadIdx.x; i < nb16_k; i += NW * 64) l16[i] = p.abs16[i];
             __syncthreads();
         } else {
-            ps_qrow_compute<TR::VDT, (PRO == 1 ? 1 : 0), TPW>(xv, wv, p.eps, K, lq, ld, l16, red, nwl);
+            ps_qrow_compute<TR::VDT, (PRO == 1 ? 1 : 0), TPW>(xv, wv, p.eps, K, lq, ld, l16, red, nwl, [&](int k, float dep) {
+                asm volatile("" ::"v"(dep));
+                mark_at(k);
+                if (B_MID && k == 25) issue(qB, hB, tB, uB, n_chunks > 1); // behind the sum-of-squares barrier
+                // (diagnostic) arrival of every producer wave at the first prologue barrier: chain-role slots 12 + wave
+                if (k == 24 && p.dbg && blockIdx.x < G3_DBG_WGS && lane == 0) p.dbg[((size_t)blockIdx.x * 2 + 1) * 32 + 12 + wave] = __builtin_amdgcn_s_memtime();
+            });
         }
         for (int i = threadIdx.x; i < nb32; i += NW * 64) lb[i] = (int)l16[2 * i] + (int)l16[2 * i + 1];
         __syncthreads();
         mark(); // 2: activation in LDS
-        if (!B_EARLY) issue(qB, hB, tB, uB, n_chunks > 1);
+        if (!B_EARLY && !B_MID) issue(qB, hB, tB, uB, n_chunks > 1);
         for (int rd = 0; rd < n_rounds; rd++) { // chunk 2rd from A, 2rd+1 from B
             produce(qA, hA, uA, 0);
             mark(); // producers: 3, 5, ...: chunk A done

@@ -91,9 +91,10 @@ __device__ __forceinline__ void ps_qrow_load_coh(const float *x, int64_t K, floa
         xv[i] = make_float4(__uint_as_float((unsigned)lo), __uint_as_float((unsigned)(lo >> 32)), __uint_as_float((unsigned)hi), __uint_as_float((unsigned)(hi >> 32)));
     }
 }
-template <int VDT, int MODE, int TPW>
+struct PsNoMark { __device__ __forceinline__ void operator()(int, float) const {} }; // timeline hook: (event, value the event depends on)
+template <int VDT, int MODE, int TPW, class Mark = PsNoMark>
 __device__ __forceinline__ void ps_qrow_compute(const float4 (&xv)[TPW], const float4 (&wv)[TPW], float eps, int64_t K, int8_t *qs,
-                                                float *d, int16_t *bs16, double *red, int nwl = 0) {
+                                                float *d, int16_t *bs16, double *red, int nwl = 0, Mark mk = Mark()) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6, nwt = nwl ? nwl : nw;
     const int64_t n_tiles = (K + 255) / 256;
     float scale = 1.0f;
@@ -107,13 +108,16 @@ __device__ __forceinline__ void ps_qrow_compute(const float4 (&xv)[TPW], const f
             s += (double)__fmul_rn(xv[i].z, xv[i].z);
             s += (double)__fmul_rn(xv[i].w, xv[i].w);
         }
+        mk(24, (float)s); // activation row arrived, squares summed in the lane
         s = wave_sum_d_dpp(s);
         if (lane == 0) red[wave] = s;
         __syncthreads();
+        mk(25, 0.f); // partial sums exchanged
         double tot = 0.0;
         for (int i = 0; i < nw; i++) tot += red[i];
         const float mean = (float)(tot / (double)K);
         scale            = __fdiv_rn(1.0f, sqrtf(__fadd_rn(mean, eps)));
+        mk(26, scale); // scale known
     }
 #pragma unroll
     for (int i = 0; i < TPW; i++) {
@@ -129,6 +133,7 @@ __device__ __forceinline__ void ps_qrow_compute(const float4 (&xv)[TPW], const f
         }
         ps_quantize_tile<VDT>(v, live, e, t, qs, d, bs16);
     }
+    mk(27, 0.f); // tiles quantized
     __syncthreads();
 }
 

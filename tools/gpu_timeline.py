@@ -55,6 +55,11 @@ for key in keys:
             own = (e[ok, i] - ev[ok, 0, 0]) / mhz
             print(f"    {i:2d}: {v.mean():7.2f} {v.min():7.2f} {v.max():7.2f} | {own.mean():7.2f}   n={ok.sum()}")
 
+    arr = ev[:, 1, 12:28]
+    if (arr > 0).any():
+        rel = (arr - ev[:, 0, 0][:, None]) / mhz
+        rel[arr <= 0] = np.nan
+        print("  producer waves 0..15 at the first prologue barrier (us since workgroup entry, mean):", np.nanmean(rel, axis=0).round(2))
 # boundary between two consecutive kernels: gate/up (5) then down (2) of the same layer
 if os.environ.get('TL_BOUNDARY', '0') != '1':
     sys.exit(0)
