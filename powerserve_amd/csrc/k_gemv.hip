@@ -747,7 +747,8 @@ __device__ __forceinline__ void g3_body(const GemvParams &p, char *smem, double 
     // instead of 2.4 us).  So B follows the first prologue barrier (RMSNorm: B_MID) or the prologue (plain quantize);
     // only a launch without a prologue sends it at once.
     constexpr bool B_EARLY = !HOOKED && (PRO == 0);
-    constexpr bool B_MID   = !HOOKED && (PRO == 1) && (TPW <= 2); // (long rows keep the registers for the prologue) // RMSNorm over long rows / chained phase: the prologue needs the registers
+    constexpr bool B_MID   = !HOOKED && (PRO == 1) && (TPW <= 2); // (long rows keep the registers for the prologue)
+    constexpr bool B_TAIL  = !HOOKED && (PRO != 0) && !B_MID;      // once this wave's tiles are quantized (their registers are free) // RMSNorm over long rows / chained phase: the prologue needs the registers
     auto begin_producers = [&]() { // the chain waves never touch the vector-memory queue before their stores
         // activation row first, the first chunks of weights right behind it (vmcnt retires in order: the prologue
         // only waits for the L2-resident activation while the weights stream in)
@@ -790,6 +791,7 @@ __device__ __forceinline__ void g3_body(const GemvParams &p, char *smem, double 
                 asm volatile("" ::"v"(dep));
                 mark_at(k);
                 if (B_MID && k == 25) issue(qB, hB, tB, uB, n_chunks > 1); // behind the sum-of-squares barrier
+                if (B_TAIL && k == 27) issue(qB, hB, tB, uB, n_chunks > 1);
                 // (diagnostic) arrival of every producer wave at the first prologue barrier: chain-role slots 12 + wave
                 if (k == 24 && p.dbg && blockIdx.x < G3_DBG_WGS && lane == 0) p.dbg[((size_t)blockIdx.x * 2 + 1) * 32 + 12 + wave] = __builtin_amdgcn_s_memtime();
             });
@@ -797,7 +799,7 @@ __device__ __forceinline__ void g3_body(const GemvParams &p, char *smem, double 
         for (int i = threadIdx.x; i < nb32; i += NW * 64) lb[i] = (int)l16[2 * i] + (int)l16[2 * i + 1];
         __syncthreads();
         mark(); // 2: activation in LDS
-        if (!B_EARLY && !B_MID) issue(qB, hB, tB, uB, n_chunks > 1);
+        if (!B_EARLY && !B_MID && !B_TAIL) issue(qB, hB, tB, uB, n_chunks > 1);
         for (int rd = 0; rd < n_rounds; rd++) { // chunk 2rd from A, 2rd+1 from B
             produce(qA, hA, uA, 0);
             mark(); // producers: 3, 5, ...: chunk A done
