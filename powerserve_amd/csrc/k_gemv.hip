@@ -685,6 +685,13 @@ __device__ __forceinline__ void g3_body(const GemvParams &p, char *smem, double 
     if (dbg) dbg[29] = __builtin_amdgcn_s_memrealtime(); // 29/30: 100 MHz reference at entry / exit
     if (n_chunks > 0) mark_at(20); // kernel arguments have arrived
 
+    // activation row first: its address needs nothing but the arguments, and the prologue (not the weight stream) is what
+    // the short launches (QKV, O) wait for
+    float4 xv[TPW], wv[TPW];
+    const int nwl = min(NW, (int)((K + 255) / 256 + TPW - 1) / TPW); // the tiles go to as few (= the earliest started) waves as TPW allows
+    if (!HOOKED && PRO != 0 && wave < NW) ps_qrow_load<(PRO == 1 ? 1 : 0), TPW>(p.x, p.nw, K, xv, wv, nwl);
+    mark_at(28); // activation loads issued
+
     // matrices of the launch, in scalar registers
     const G3Mats mats{p.w[0].qs, p.w[1].qs, p.w[2].qs, p.w[0].aux, p.w[1].aux, p.w[2].aux,
                       (int)p.w[0].n_groups, (int)p.w[1].n_groups, p.n_w, n_units};
@@ -737,10 +744,6 @@ __device__ __forceinline__ void g3_body(const GemvParams &p, char *smem, double 
         }
     };
 
-    float4 xv[TPW], wv[TPW];
-    // the tiles go to as few (= the earliest started) waves as TPW allows: a late wave's activation load would sit
-    // behind the weight requests of all the earlier waves in the CU's vector-memory queue
-    const int nwl = min(NW, (int)((K + 255) / 256 + TPW - 1) / TPW);
     // When does the second chunk go out?  The CU's vector-memory path holds about one chunk of outstanding requests: a
     // wave that issues more stalls IN the issue until earlier data returns, and so arrives late at the prologue's
     // barriers (measured: all of A + B before the prologue -> last producer wave at the first barrier after 4.8 us
@@ -752,9 +755,7 @@ __device__ __forceinline__ void g3_body(const GemvParams &p, char *smem, double 
     auto begin_producers = [&]() { // the chain waves never touch the vector-memory queue before their stores
         // activation row first, the first chunks of weights right behind it (vmcnt retires in order: the prologue
         // only waits for the L2-resident activation while the weights stream in)
-        if (!HOOKED) {
-            if (PRO != 0) ps_qrow_load<(PRO == 1 ? 1 : 0), TPW>(p.x, p.nw, K, xv, wv, nwl);
-        } else if (PRO == 1) { // only the (read-only) norm weights can be asked for before the barrier
+        if (HOOKED && PRO == 1) { // only the (read-only) norm weights can be asked for before the barrier
             float4 dummy[TPW];
             ps_qrow_load<1, TPW>(p.nw, p.nw, K, dummy, wv, nwl);
         }
