@@ -781,11 +781,14 @@ __device__ __forceinline__ void g3_body(const GemvParams &p, char *smem, double 
             for (int i = (int)K + threadIdx.x * 4; i < Kp; i += NW * 64 * 4) *(int *)(lq + i) = 0;
             for (int i = nblk_k + threadIdx.x; i < nblk; i += NW * 64) ld[i] = 0.f;
             for (int i = nb16_k + threadIdx.x; i < nb16; i += NW * 64) l16[i] = 0;
+            for (int i = nb16_k / 2 + threadIdx.x; i < nb32; i += NW * 64) lb[i] = 0;
         }
+        // (the int sums of 32 are written together with the quants: no second pass, no second barrier)
         if (PRO == 0) {
             for (int64_t i = threadIdx.x * 16; i < K; i += NW * 64 * 16) *(int4 *)(lq + i) = *(const int4 *)(p.aq + i);
             for (int i = threadIdx.x; i < nblk_k; i += NW * 64) ld[i] = p.ad[i];
             for (int i = threadIdx.x; i < nb16_k; i += NW * 64) l16[i] = p.abs16[i];
+            for (int i = threadIdx.x; i < nb16_k / 2; i += NW * 64) lb[i] = (int)p.abs16[2 * i] + (int)p.abs16[2 * i + 1];
             __syncthreads();
         } else {
             ps_qrow_compute<TR::VDT, (PRO == 1 ? 1 : 0), TPW>(xv, wv, p.eps, K, lq, ld, l16, red, nwl, [&](int k, float dep) {
@@ -795,10 +798,8 @@ __device__ __forceinline__ void g3_body(const GemvParams &p, char *smem, double 
                 if (B_TAIL && k == 27) issue(qB, hB, tB, uB, n_chunks > 1);
                 // (diagnostic) arrival of every producer wave at the first prologue barrier: chain-role slots 12 + wave
                 if (k == 24 && p.dbg && blockIdx.x < G3_DBG_WGS && lane == 0) p.dbg[((size_t)blockIdx.x * 2 + 1) * 32 + 12 + wave] = __builtin_amdgcn_s_memtime();
-            });
+            }, lb);
         }
-        for (int i = threadIdx.x; i < nb32; i += NW * 64) lb[i] = (int)l16[2 * i] + (int)l16[2 * i + 1];
-        __syncthreads();
         mark(); // 2: activation in LDS
         if (!B_EARLY && !B_MID && !B_TAIL) issue(qB, hB, tB, uB, n_chunks > 1);
         for (int rd = 0; rd < n_rounds; rd++) { // chunk 2rd from A, 2rd+1 from B
@@ -820,7 +821,6 @@ __device__ __forceinline__ void g3_body(const GemvParams &p, char *smem, double 
             if (lane == 0) red[wave] = 0.0;
             __syncthreads();
         }
-        __syncthreads();
         __syncthreads();
         mark();
         mark();

@@ -19,7 +19,7 @@ __device__ __forceinline__ float ps_silu_mul(float g, float u) {
 // quantize the 4 values of this lane (elements e..e+3 of tile t of the row); wave-collective
 template <int VDT>
 __device__ __forceinline__ void ps_quantize_tile(const float v[4], bool live, int64_t e, int64_t t, int8_t *qs, float *d,
-                                                 int16_t *bs16) {
+                                                 int16_t *bs16, int *bs32 = nullptr) { // bs32: optional int sums of 32 (two bs16)
     const int lane = threadIdx.x & 63;
     int q[4];
     if (VDT == PS_Q8_0) {
@@ -54,6 +54,10 @@ __device__ __forceinline__ void ps_quantize_tile(const float v[4], bool live, in
                                 ((uint32_t)(q[2] & 0xff) << 16) | ((uint32_t)(q[3] & 0xff) << 24);
         *(uint32_t *)(qs + e) = packed;
         if ((lane & 3) == 0) bs16[e / 16] = (int16_t)s16;
+    }
+    if (bs32) {
+        const int s32 = s16 + dpp_i<0x104>(s16); // lane & 7 == 0: + the next four lanes' 16-sum
+        if (live && (lane & 7) == 0) bs32[e / 32] = s32;
     }
 }
 
@@ -94,7 +98,7 @@ __device__ __forceinline__ void ps_qrow_load_coh(const float *x, int64_t K, floa
 struct PsNoMark { __device__ __forceinline__ void operator()(int, float) const {} }; // timeline hook: (event, value the event depends on)
 template <int VDT, int MODE, int TPW, class Mark = PsNoMark>
 __device__ __forceinline__ void ps_qrow_compute(const float4 (&xv)[TPW], const float4 (&wv)[TPW], float eps, int64_t K, int8_t *qs,
-                                                float *d, int16_t *bs16, double *red, int nwl = 0, Mark mk = Mark()) {
+                                                float *d, int16_t *bs16, double *red, int nwl = 0, Mark mk = Mark(), int *bs32 = nullptr) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6, nwt = nwl ? nwl : nw;
     const int64_t n_tiles = (K + 255) / 256;
     float scale = 1.0f;
@@ -131,7 +135,7 @@ __device__ __forceinline__ void ps_qrow_compute(const float4 (&xv)[TPW], const f
             v[2] = __fmul_rn(v[2], __fmul_rn(wv[i].z, scale));
             v[3] = __fmul_rn(v[3], __fmul_rn(wv[i].w, scale));
         }
-        ps_quantize_tile<VDT>(v, live, e, t, qs, d, bs16);
+        ps_quantize_tile<VDT>(v, live, e, t, qs, d, bs16, bs32);
     }
     mk(27, 0.f); // tiles quantized
     __syncthreads();
