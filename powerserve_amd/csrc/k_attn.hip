@@ -94,6 +94,68 @@ __global__ __launch_bounds__(256) void attn_scores_kernel(psl_attn_args a) {
     }
 }
 
+// Batches: the same scores on the matrix cores, still bit-exact.  v_mfma_f32_16x16x4_f32 is a k-ordered f32 fma chain
+// (D = fma(a_k3, b_k3, fma(a_k2, b_k2, fma(a_k1, b_k1, fma(a_k0, b_k0, C)))), one rounding per product), and chain c of
+// ggml_vec_dot_f32 is exactly such a chain over the elements c, c + 32, c + 64, c + 96 of the head: one MFMA per chain c
+// with k = the 32-element block index gives the 16 x 16 tile of chain-c partials (16 positions x 16 (column, head)
+// pairs), and GGML_F32x8_REDUCE becomes 31 element-wise adds of tiles in its own association.  No cross-lane reduction
+// at all; a K row is fetched once per 16 positions and meets every column of the batch.
+// grid (ceil(n_ctx / 64), n_kv_heads, SCM_Z): one wave per 16 positions, the column tiles split over blockIdx.z.
+typedef float ps_f32x4 __attribute__((ext_vector_type(4)));
+constexpr int SCM_Z = 4;
+template <int NV>
+__global__ __launch_bounds__(256, 2) void attn_scores_mfma_kernel(psl_attn_args a) {
+    const int hs = NV * 32, dim = a.n_heads * hs, kvd = a.n_kv_heads * hs, r2 = a.n_heads / a.n_kv_heads;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int kvh = blockIdx.y, bs = a.state->bs, n_kv = a.state->pos0 + bs;
+    const int j0 = ((int)blockIdx.x * 4 + wave) * 16;
+    if (j0 >= n_kv) return;
+    const int rl = lane & 15, m = lane >> 4; // A: row rl (position), k = m;  B: k = m, column rl
+    // A operand of chain c: K[j0 + rl][32 m + c]
+    float ka[32];
+    {
+        const float *kr = a.k_cache + (int64_t)min(j0 + rl, n_kv - 1) * kvd + kvh * hs + 32 * m;
+#pragma unroll
+        for (int q4 = 0; q4 < 8; q4++) {
+            const float4 t = (m < NV) ? *(const float4 *)(kr + 4 * q4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            ka[4 * q4] = t.x; ka[4 * q4 + 1] = t.y; ka[4 * q4 + 2] = t.z; ka[4 * q4 + 3] = t.w;
+        }
+    }
+    const int N = bs * r2, n_tiles = (N + 15) / 16;
+    const ps_f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    for (int tile = blockIdx.z; tile < n_tiles; tile += SCM_Z) {
+        const int n = min(tile * 16 + rl, N - 1), i = n / r2, g = n - i * r2;
+        float qb[32]; // B operand of chain c: q[i][kvh * r2 + g][32 m + c]
+        {
+            const float *qr = a.q + (int64_t)i * dim + (int64_t)(kvh * r2 + g) * hs + 32 * m;
+#pragma unroll
+            for (int q4 = 0; q4 < 8; q4++) {
+                const float4 t = (m < NV) ? *(const float4 *)(qr + 4 * q4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                qb[4 * q4] = t.x; qb[4 * q4 + 1] = t.y; qb[4 * q4 + 2] = t.z; qb[4 * q4 + 3] = t.w;
+            }
+        }
+        auto chain = [&](int c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(ka[c], qb[c], zero, 0, 0, 0); }; // sum = x*y + sum, x = K row
+        ps_f32x4 t3[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) { // GGML_F32x8_REDUCE: (c, c+16), then (.., c+8), then (.., c+4); the two hadds below
+            const ps_f32x4 ta = chain(c) + chain(c + 16), tb = chain(c + 8) + chain(c + 24);
+            const ps_f32x4 tc = chain(c + 4) + chain(c + 20), td = chain(c + 12) + chain(c + 28);
+            t3[c] = (ta + tb) + (tc + td);
+            __builtin_amdgcn_sched_barrier(0); // eight products at a time (all 32 at once cost 128 accumulator registers)
+        }
+        const ps_f32x4 res = (t3[0] + t3[1]) + (t3[2] + t3[3]);
+        // D: column = lane & 15 (the (i, g) pair), rows 4 * (lane >> 4) + r (positions)
+        if (tile * 16 + rl < N) {
+            float *sb = a.scores + ((int64_t)i * a.n_heads + (int64_t)kvh * r2 + g) * a.n_ctx;
+            const int jb = j0 + 4 * m;
+            if (jb + 3 < n_kv) *(float4 *)(sb + jb) = make_float4(res[0], res[1], res[2], res[3]);
+            else
+#pragma unroll
+                for (int r = 0; r < 4; r++) if (jb + r < n_kv) sb[jb + r] = res[r];
+        }
+    }
+}
+
 // ---------------------------------------------------------------- softmax + V·p in one launch
 // out[i][h][d] = V^T[kvh*hs + d][0..n_kv) · softmax(scale·s[i][h][:] + mask)
 // grid (hs/4, n_kv_heads, bs), 256 threads.  Phase 1: one wave per q head of the kv group turns its raw score row
@@ -387,6 +449,14 @@ void psl_rope_append(hipStream_t st, const psl_attn_args &a, int bs) {
 }
 
 void psl_attn_scores(hipStream_t st, const psl_attn_args &a, int bs) {
+    if (bs >= 8) { // batches: matrix cores (exact f32 chains), one wave per 16 positions
+        dim3 gm((unsigned)((a.n_ctx + 63) / 64), (unsigned)a.n_kv_heads, (unsigned)SCM_Z);
+        if (a.head_size == 128) hipLaunchKernelGGL(attn_scores_mfma_kernel<4>, gm, dim3(256), 0, st, a);
+        else if (a.head_size == 64) hipLaunchKernelGGL(attn_scores_mfma_kernel<2>, gm, dim3(256), 0, st, a);
+        else if (a.head_size == 32) hipLaunchKernelGGL(attn_scores_mfma_kernel<1>, gm, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(attn_scores_mfma_kernel<3>, gm, dim3(256), 0, st, a);
+        return;
+    }
     dim3 g((unsigned)((a.n_ctx + 31) / 32), (unsigned)a.n_kv_heads, (unsigned)bs);
     if (a.head_size == 128) hipLaunchKernelGGL(attn_scores_kernel<4>, g, dim3(256), 0, st, a);
     else if (a.head_size == 64) hipLaunchKernelGGL(attn_scores_kernel<2>, g, dim3(256), 0, st, a);
