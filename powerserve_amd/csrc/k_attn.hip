@@ -398,6 +398,72 @@ __global__ __launch_bounds__(PV_NT) void attn_softmax_pv_cols_kernel(psl_attn_ar
     }
 }
 
+// Large batches (prefill chunks): soft-max and V·p as two launches, the second one on the matrix cores.
+//  (1) attn_softmax_probs_kernel: grid (n_kv_heads, bs); the r2 score rows of (kv head, column) become probabilities IN PLACE
+//      (p_j = e_j * (float)(1/sum), masked positions +0): attn_softmax_rows + ggml_vec_scale_f32.
+//  (2) attn_pv_mfma_kernel: out[i][h][d] = ggml_vec_dot_f32(n_kv, V^T[d], p[i][h]).  Chain c of that dot runs over the
+//      positions c, c + 32, c + 64, ... in order — a k-ordered fma chain, which is what v_mfma_f32_16x16x4_f32 computes
+//      when its accumulator is chained from one instruction to the next: per chain c one accumulator tile of 16 channels
+//      x 16 (column, head) pairs, k = four consecutive 32-position blocks per instruction.  After the last block the 32
+//      tiles are added in GGML_F32x8_REDUCE's association and the n_kv % 32 leftovers follow one by one (mul, then add).
+//      grid (ceil(bs * r2 / 16), n_kv_heads), one wave per 16 head channels.
+__global__ __launch_bounds__(PV_NT) void attn_softmax_probs_kernel(psl_attn_args a) {
+    extern __shared__ __attribute__((aligned(16))) float pl[]; // [r2][n_kv4]
+    const int r2 = a.n_heads / a.n_kv_heads, kvh = blockIdx.x, i = blockIdx.y, bs = a.state->bs, pos0 = a.state->pos0;
+    const int n_kv = pos0 + bs, n_kv4 = (n_kv + 3) & ~3;
+    __shared__ float redf[R2MAX][PV_NW];
+    __shared__ double redd[R2MAX][PV_NW];
+    __shared__ float invs[R2MAX];
+    attn_softmax_rows(a, i, kvh, r2, pos0, bs, n_kv, pl, redf, redd, invs);
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < r2 * n_kv; idx += PV_NT) {
+        const int g = idx / n_kv, j = idx - g * n_kv;
+        a.scores[((int64_t)i * a.n_heads + (int64_t)kvh * r2 + g) * a.n_ctx + j] = __fmul_rn(pl[(size_t)g * n_kv4 + j], invs[g]);
+    }
+}
+
+__global__ __launch_bounds__(512, 1) void attn_pv_mfma_kernel(psl_attn_args a) {
+    const int hs = a.head_size, dim = a.n_heads * hs, r2 = a.n_heads / a.n_kv_heads;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int kvh = blockIdx.y, bs = a.state->bs, n_kv = a.state->pos0 + bs, np = n_kv & ~31, nblk = np >> 5;
+    const int rl = lane & 15, m = lane >> 4; // A: row rl (channel), k = m;  B: k = m, column rl
+    const int N = bs * r2, n = min((int)blockIdx.x * 16 + rl, N - 1), i = n / r2, g = n - i * r2;
+    const int d0 = wave * 16; // (blockDim.x = hs / 16 waves)
+    const float *vr = a.v_cache + ((int64_t)kvh * hs + d0 + rl) * a.n_ctx;                     // A: V^T row of channel d0 + rl
+    const float *pr = a.scores + ((int64_t)i * a.n_heads + (int64_t)kvh * r2 + g) * a.n_ctx;   // B: probabilities of column n
+    ps_f32x4 acc[32];
+#pragma unroll
+    for (int c = 0; c < 32; c++) acc[c] = ps_f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int b0 = 0; b0 < nblk; b0 += 4) { // four 32-position blocks per instruction: k = m <-> block b0 + m
+        const bool in = b0 + m < nblk;
+        const float *va = vr + (int64_t)(b0 + m) * 32, *pb = pr + (int64_t)(b0 + m) * 32;
+        float av[32], bv[32];
+#pragma unroll
+        for (int q4 = 0; q4 < 8; q4++) {
+            const float4 t = in ? *(const float4 *)(va + 4 * q4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 w = in ? *(const float4 *)(pb + 4 * q4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            av[4 * q4] = t.x; av[4 * q4 + 1] = t.y; av[4 * q4 + 2] = t.z; av[4 * q4 + 3] = t.w;
+            bv[4 * q4] = w.x; bv[4 * q4 + 1] = w.y; bv[4 * q4 + 2] = w.z; bv[4 * q4 + 3] = w.w;
+        }
+#pragma unroll
+        for (int c = 0; c < 32; c++) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c], bv[c], acc[c], 0, 0, 0); // sum = x*y + sum, x = V row
+    }
+    ps_f32x4 t3[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) // GGML_F32x8_REDUCE
+        t3[c] = ((acc[c] + acc[c + 16]) + (acc[c + 8] + acc[c + 24])) + ((acc[c + 4] + acc[c + 20]) + (acc[c + 12] + acc[c + 28]));
+    ps_f32x4 res = (t3[0] + t3[1]) + (t3[2] + t3[3]);
+    // D: column = lane & 15 (the (i, g) pair), rows d0 + 4 * (lane >> 4) + r.  Leftovers: sumf += x[j] * y[j], in order
+    const float *vl = a.v_cache + ((int64_t)kvh * hs + d0 + 4 * m) * a.n_ctx;
+    for (int jj = np; jj < n_kv; jj++) {
+        const float pj = pr[jj];
+#pragma unroll
+        for (int r = 0; r < 4; r++) res[r] = __fadd_rn(res[r], __fmul_rn(vl[(int64_t)r * a.n_ctx + jj], pj));
+    }
+    if ((int)blockIdx.x * 16 + rl < N)
+        *(float4 *)(a.att + (int64_t)i * dim + ((int64_t)kvh * r2 + g) * hs + d0 + 4 * m) = make_float4(res[0], res[1], res[2], res[3]);
+}
+
 // ---------------------------------------------------------------- arg-max, first maximum (prob_array.cpp:65-67)
 constexpr int AM_PARTS = 64;
 __global__ __launch_bounds__(256) void argmax_partial_kernel(const float *src, int64_t n, float *pv, int *pi) {
@@ -469,6 +535,15 @@ size_t psl_attn_softmax_pv_lds(const psl_attn_args &a) {
     return ((size_t)r2 * (((size_t)a.n_ctx + 3) & ~(size_t)3) + 4 * PV_VSTR) * 4;
 }
 void psl_attn_softmax_pv(hipStream_t st, const psl_attn_args &a, int bs) {
+    if (bs >= 8 && a.head_size % 16 == 0) { // prefill chunks / wide trees: soft-max in place, then V·p on the matrix cores
+        static bool attrp = false;
+        if (!attrp) { (void)hipFuncSetAttribute((const void *)attn_softmax_probs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024); attrp = true; }
+        const int r2p = a.n_heads / a.n_kv_heads;
+        const size_t ldsp = (size_t)r2p * (((size_t)a.n_ctx + 3) & ~(size_t)3) * 4;
+        hipLaunchKernelGGL(attn_softmax_probs_kernel, dim3((unsigned)a.n_kv_heads, (unsigned)bs), dim3(PV_NT), ldsp, st, a);
+        hipLaunchKernelGGL(attn_pv_mfma_kernel, dim3((unsigned)((bs * r2p + 15) / 16), (unsigned)a.n_kv_heads), dim3((unsigned)(a.head_size / 16 * 64)), 0, st, a);
+        return;
+    }
     if (bs > 1) { // batches: one workgroup per (kv head, column pair)
         const int r2 = a.n_heads / a.n_kv_heads;
         const size_t row = ((size_t)a.n_ctx + 3) & ~(size_t)3, lds2 = 2 * r2 * row * 4, lds1 = r2 * row * 4;
