@@ -1168,21 +1168,13 @@ int launch_wt(hipStream_t st, int n_cu, const GemvParams &p, int epi, int pro) {
     return 3;
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// Batched mat-mul (prefill chunks, tree verify): 8 activation columns per workgroup, in-lane chains.
-// grid = (row-group tiles of 16, column groups of 8); a workgroup stages its 8 pre-quantized columns in LDS once
-// (quants transposed so that the bytes a lane needs per unit are contiguous: ds_read_b128), every wave then owns one
-// row group: the weights of a unit are unpacked ONCE and meet the 8 columns, each column keeping the reference's fma
-// chains in this lane's registers.  Same arithmetic, same order as the mat-vec.
-template <int WT, int EPI, int NWV>
-__global__ __launch_bounds__(NWV * 64) void gemm8_kernel(const GemvParams p) {
-    constexpr int NT = NWV * 64;
+// Activation image of 8 pre-quantized columns in LDS, shared by gemm8_kernel and gemm8m_kernel.
+template <int WT, int NT>
+__device__ __forceinline__ void gemm8_stage(const int8_t *aq, const float *ad, const int16_t *abs16, const int K, char *smem, const int c0,
+                                            const int nc) {
     using TR = WTraits<WT>;
     constexpr int C = 8;
-    constexpr uint32_t M = 0x0F0F0F0Fu;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int K = (int)p.K, n_units = K / TR::UNIT, nblk = K / TR::BLK, c0 = blockIdx.y * C, nc = min(C, (int)p.bs - c0);
+    const int nblk = K / TR::BLK;
     // LDS image: one record per (unit, column), records of a unit adjacent, so that every per-column read of the inner
     // loop is  base(unit, lane) + compile-time offset:
     //   Q4_K  REC 304: [256 B quants, dwords transposed (g, u) -> [u][g]] [8 int sums of 32] [float d] [pad]
@@ -1201,7 +1193,7 @@ __global__ __launch_bounds__(NWV * 64) void gemm8_kernel(const GemvParams p) {
 #pragma unroll
             for (int k = 0; k < SB; k++) {
                 const int idx = base + k * NT, c = idx / (K / 16), i = idx % (K / 16);
-                v[k] = (idx < n16 && c < nc) ? ((const int4 *)(p.aq + (int64_t)(c0 + c) * K))[i] : make_int4(0, 0, 0, 0);
+                v[k] = (idx < n16 && c < nc) ? ((const int4 *)(aq + (int64_t)(c0 + c) * K))[i] : make_int4(0, 0, 0, 0);
             }
 #pragma unroll
             for (int k = 0; k < SB; k++) {
@@ -1217,15 +1209,34 @@ __global__ __launch_bounds__(NWV * 64) void gemm8_kernel(const GemvParams p) {
     constexpr int BPU = TR::UNIT / TR::BLK; // scales per unit (1 or 4)
     for (int idx = threadIdx.x; idx < C * nblk; idx += NT) {
         const int c = idx / nblk, i = idx % nblk;
-        *(float *)(smem + ((i / BPU) * C + c) * REC + (WT == PS_Q4_K ? 288 : 128) + (i % BPU) * 4) = c < nc ? p.ad[(int64_t)(c0 + c) * nblk + i] : 0.f;
+        *(float *)(smem + ((i / BPU) * C + c) * REC + (WT == PS_Q4_K ? 288 : 128) + (i % BPU) * 4) = c < nc ? ad[(int64_t)(c0 + c) * nblk + i] : 0.f;
     }
     if (WT == PS_Q4_K) {
         for (int idx = threadIdx.x; idx < C * (K / 32); idx += NT) {
             const int c = idx / (K / 32), i = idx % (K / 32);
-            const int16_t *b = p.abs16 + (int64_t)(c0 + c) * (K / 16) + 2 * i;
+            const int16_t *b = abs16 + (int64_t)(c0 + c) * (K / 16) + 2 * i;
             *(int *)(smem + ((i / 8) * C + c) * REC + 256 + (i % 8) * 4) = c < nc ? (int)b[0] + (int)b[1] : 0;
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Batched mat-mul (prefill chunks, tree verify): 8 activation columns per workgroup, in-lane chains.
+// grid = (row-group tiles of 16, column groups of 8); a workgroup stages its 8 pre-quantized columns in LDS once
+// (quants transposed so that the bytes a lane needs per unit are contiguous: ds_read_b128), every wave then owns one
+// row group: the weights of a unit are unpacked ONCE and meet the 8 columns, each column keeping the reference's fma
+// chains in this lane's registers.  Same arithmetic, same order as the mat-vec.
+template <int WT, int EPI, int NWV>
+__global__ __launch_bounds__(NWV * 64) void gemm8_kernel(const GemvParams p) {
+    constexpr int NT = NWV * 64;
+    using TR = WTraits<WT>;
+    constexpr int C = 8;
+    constexpr uint32_t M = 0x0F0F0F0Fu;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int K = (int)p.K, n_units = K / TR::UNIT, nblk = K / TR::BLK, c0 = blockIdx.y * C, nc = min(C, (int)p.bs - c0);
+    constexpr int REC = (WT == PS_Q4_K) ? 304 : 144; // (gemm8_stage)
+    gemm8_stage<WT, NT>(p.aq, p.ad, p.abs16, K, smem, c0, nc);
     __syncthreads();
 
     const int r = (WT == PS_Q4_0) ? (lane >> 2) : (lane >> 3);
@@ -1383,6 +1394,162 @@ __global__ __launch_bounds__(NWV * 64) void gemm8_kernel(const GemvParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Q4_K batched mat-mul with the quad dots on the matrix cores (exact: everything before the fp32 chain is integer).
+// v_mfma_i32_4x4x4_16B_i8 computes 16 independent 4 x 4 products with K = 4 — a "quad" of the reference (the four
+// elements one AVX lane u owns in a 32-element sub-block).  Block b = lane >> 2; result lane l, register r holds
+// dot4(A operand of lane 4b + r, B operand of lane l) (tools/micro/mfma4probe.hip).  Lane roles:
+//   qs = lane >> 4 (owns u = qs and u = qs + 4), rq = (lane >> 3) & 1, cq = (lane >> 2) & 1, s = lane & 3
+//   A operand: weight row rq*4 + s of the row group;  B operand and results: column cq*4 + s;  registers: rows rq*4 + r.
+// The 6-bit sub-block scale is folded into the A operand as two 3-bit factors (quad nibbles * factor <= 105 stay bytes:
+// one v_pk_mul_lo_u16), so the eight quads of a 256-element unit accumulate in the MFMA and
+//   sumi[u] = 8 * S_hi + S_lo = sum_j scale_j * dot_j  exactly;  the fp32 chain (d * sumi, dmin * mins.bsums) is the
+// reference's, 4 rows x 2 u per lane.  Per unit and lane: 32 MFMAs and ~130 VALU instructions instead of ~220.
+typedef int ps_i32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short ps_u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int pk_mul_u16(uint32_t a, uint32_t b) { // two independent 16-bit products
+    ps_u16x2 va, vb;
+    __builtin_memcpy(&va, &a, 4);
+    __builtin_memcpy(&vb, &b, 4);
+    const ps_u16x2 vr = va * vb;
+    int r;
+    __builtin_memcpy(&r, &vr, 4);
+    return r;
+}
+template <int EPI, int NWV>
+__global__ __launch_bounds__(NWV * 64) void gemm8m_kernel(const GemvParams p) {
+    constexpr int NT = NWV * 64, C = 8, REC = 304;
+    constexpr uint32_t M = 0x0F0F0F0Fu;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int K = (int)p.K, n_units = K / 256, c0 = blockIdx.y * C, nc = min(C, (int)p.bs - c0);
+    gemm8_stage<PS_Q4_K, NT>(p.aq, p.ad, p.abs16, K, smem, c0, nc);
+    __syncthreads();
+
+    const int qs = lane >> 4, rq = (lane >> 3) & 1, cq = (lane >> 2) & 1, s4 = lane & 3;
+    const int arow = rq * 4 + s4, bcol = cq * 4 + s4;
+    const int64_t n_tasks = (EPI == 1) ? p.w[0].n_groups : p.groups_total;
+    const int64_t task = (int64_t)blockIdx.x * NWV + wave;
+    if (task >= n_tasks) return;
+    float yg[4];
+#pragma unroll
+    for (int pass = 0; pass < (EPI == 1 ? 2 : 1); pass++) {
+        int wi = 0;
+        int64_t grp = task;
+        if (EPI == 1) {
+            wi = pass;
+        } else {
+            if (p.n_w > 1 && grp >= p.w[0].n_groups) { grp -= p.w[0].n_groups; wi = 1; }
+            if (p.n_w > 2 && wi == 1 && grp >= p.w[1].n_groups) { grp -= p.w[1].n_groups; wi = 2; }
+        }
+        const uint8_t *qsb = p.w[0].qs, *ax = p.w[0].aux;
+        if (wi == 1) { qsb = p.w[1].qs; ax = p.w[1].aux; }
+        if (wi == 2) { qsb = p.w[2].qs; ax = p.w[2].aux; }
+        const uint8_t *qg = qsb + grp * n_units * 1024 + (arow * 8 + qs) * 16; // piece (row, u = qs); (row, qs + 4) sits 64 bytes on
+        const uint8_t *ag = ax + grp * n_units * 128 + arow * 16;
+        float acc0[2][4], accm[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) { acc0[0][r] = 0.f; acc0[1][r] = 0.f; accm[r] = 0.f; }
+
+        auto unit = [&](const int un, const uint4 qa, const uint4 qb, const uint4 h) {
+            // ---- this lane's weight row: scales as two 3-bit factors, replicated into both 16-bit halves
+            const uint32_t sc03 = h.y & 0x3f3f3f3fu, sc47 = (h.w & 0x0f0f0f0fu) | (((h.y >> 6) & 0x03030303u) << 4);
+            const uint32_t mn03 = h.z & 0x3f3f3f3fu, mn47 = ((h.w >> 4) & 0x0f0f0f0fu) | (((h.z >> 6) & 0x03030303u) << 4);
+            const uint32_t lo[2] = {sc03 & 0x07070707u, sc47 & 0x07070707u}, hi[2] = {(sc03 >> 3) & 0x07070707u, (sc47 >> 3) & 0x07070707u};
+            const uint32_t mp = (qs < 2) ? mn03 : mn47;
+            const int mnp = (int)(bfe8(mp, (2 * qs) & 3) | (bfe8(mp, (2 * qs + 1) & 3) << 16)); // {min[2 qs], min[2 qs + 1]} as int16 pair
+            const float dwf = ps_h2f((uint16_t)(h.x & 0xffff)), dmf = ps_h2f((uint16_t)(h.x >> 16));
+            // ---- this lane's column: quants of u = qs and u = qs + 4 (dword 2 jj + half of a record = quad (jj, half))
+            const char *rec = smem + (un * C + bcol) * REC;
+            const int4 ya0 = *(const int4 *)(rec + qs * 32), ya1 = *(const int4 *)(rec + qs * 32 + 16);
+            const int4 yb0 = *(const int4 *)(rec + (qs + 4) * 32), yb1 = *(const int4 *)(rec + (qs + 4) * 32 + 16);
+            const int2 bs = *(const int2 *)(rec + 256 + qs * 8);
+            const float yd = *(const float *)(rec + 288);
+            const int ya[8] = {ya0.x, ya0.y, ya0.z, ya0.w, ya1.x, ya1.y, ya1.z, ya1.w};
+            const int yb[8] = {yb0.x, yb0.y, yb0.z, yb0.w, yb1.x, yb1.y, yb1.z, yb1.w};
+            const uint32_t wa[4] = {qa.x, qa.y, qa.z, qa.w}, wb[4] = {qb.x, qb.y, qb.z, qb.w};
+            ps_i32x4 slo[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}}, shi[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+#pragma unroll
+            for (int sbi = 0; sbi < 8; sbi++) { // sub-block 2 jj + half: low / high nibbles of dword jj
+                const int jj = sbi >> 1, half = sbi & 1;
+                const uint32_t sel = 0x0c000c00u | (uint32_t)(sbi & 3) | ((uint32_t)(sbi & 3) << 16); // byte sbi & 3 -> both halves
+                const uint32_t flo = __builtin_amdgcn_perm(0u, lo[sbi >> 2], sel), fhi = __builtin_amdgcn_perm(0u, hi[sbi >> 2], sel);
+                const uint32_t na = (half ? wa[jj] >> 4 : wa[jj]) & M, nb = (half ? wb[jj] >> 4 : wb[jj]) & M;
+                slo[0] = __builtin_amdgcn_mfma_i32_4x4x4i8(pk_mul_u16(na, flo), ya[sbi], slo[0], 0, 0, 0);
+                shi[0] = __builtin_amdgcn_mfma_i32_4x4x4i8(pk_mul_u16(na, fhi), ya[sbi], shi[0], 0, 0, 0);
+                slo[1] = __builtin_amdgcn_mfma_i32_4x4x4i8(pk_mul_u16(nb, flo), yb[sbi], slo[1], 0, 0, 0);
+                shi[1] = __builtin_amdgcn_mfma_i32_4x4x4i8(pk_mul_u16(nb, fhi), yb[sbi], shi[1], 0, 0, 0);
+            }
+            // ---- fp32 chains of rows rq*4 + r: the row's d, dmin, mins come from lane r of this quad
+            const int bsp = (bs.x & 0xffff) | (bs.y << 16); // (|bsums of 32| <= 4064)
+#define PS_G8M_ROW(r, CTRL)                                                                                     \
+            {                                                                                                   \
+                const float dwr = dpp_f<CTRL>(dwf), dmr = dpp_f<CTRL>(dmf);                                     \
+                const int mnr   = dpp_i<CTRL>(mnp);                                                             \
+                const float d = __fmul_rn(yd, dwr), dmin = __fmul_rn(-yd, dmr);                                 \
+                acc0[0][r] = __fmaf_rn(d, (float)(shi[0][r] * 8 + slo[0][r]), acc0[0][r]);                      \
+                acc0[1][r] = __fmaf_rn(d, (float)(shi[1][r] * 8 + slo[1][r]), acc0[1][r]);                      \
+                accm[r]    = __fmaf_rn(dmin, (float)dot2_i16((uint32_t)mnr, (uint32_t)bsp, 0), accm[r]);        \
+            }
+            PS_G8M_ROW(0, 0x00) PS_G8M_ROW(1, 0x55) PS_G8M_ROW(2, 0xAA) PS_G8M_ROW(3, 0xFF)
+#undef PS_G8M_ROW
+        };
+        auto load_h = [&](int un) { return *(const uint4 *)(ag + (int64_t)un * 128); };
+        if constexpr (NWV == 16) { // one unit ahead
+            uint4 qa = ld_stream16(qg), qb = ld_stream16(qg + 64), h = load_h(0);
+            for (int un = 0; un < n_units; un++) {
+                uint4 qan = qa, qbn = qb, hn = h;
+                if (un + 1 < n_units) { qan = ld_stream16(qg + (int64_t)(un + 1) * 1024); qbn = ld_stream16(qg + (int64_t)(un + 1) * 1024 + 64); hn = load_h(un + 1); }
+                unit(un, qa, qb, h);
+                qa = qan; qb = qbn; h = hn;
+            }
+        } else { // small launches: four units in flight per wave, unconditional loads (index clamped)
+            constexpr int PF = 4;
+            uint4 qar[PF], qbr[PF], hr[PF];
+#pragma unroll
+            for (int s = 0; s < PF; s++) { const int uc = min(s, n_units - 1); qar[s] = ld_stream16(qg + (int64_t)uc * 1024); qbr[s] = ld_stream16(qg + (int64_t)uc * 1024 + 64); hr[s] = load_h(uc); }
+            for (int un0 = 0; un0 < n_units; un0 += PF) {
+#pragma unroll
+                for (int s = 0; s < PF; s++) {
+                    const int un = un0 + s;
+                    if (un >= n_units) break;
+                    const uint4 qa = qar[s], qb = qbr[s], h = hr[s];
+                    const int nx = min(un + PF, n_units - 1);
+                    qar[s] = ld_stream16(qg + (int64_t)nx * 1024); qbr[s] = ld_stream16(qg + (int64_t)nx * 1024 + 64); hr[s] = load_h(nx);
+                    unit(un, qa, qb, h);
+                }
+            }
+        }
+        // ---- epilogue: hsum_float_8 over u (u and u + 4 are this lane's; u +- 2, u +- 1 sit 32 and 16 lanes away) + acc_m
+        int64_t Nw = p.w[0].N, ldo = p.w[0].ldo;
+        float *o = p.w[0].out;
+        const float *b = p.w[0].bias;
+        if (wi == 1) { Nw = p.w[1].N; ldo = p.w[1].ldo; o = p.w[1].out; b = p.w[1].bias; }
+        if (wi == 2) { Nw = p.w[2].N; ldo = p.w[2].ldo; o = p.w[2].out; b = p.w[2].bias; }
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            float v = __fadd_rn(acc0[0][r], acc0[1][r]);
+            v = __fadd_rn(v, __shfl_xor(v, 32, 64));
+            v = __fadd_rn(v, __shfl_xor(v, 16, 64));
+            float mm = __fadd_rn(accm[r], __shfl_xor(accm[r], 32, 64));
+            mm = __fadd_rn(mm, __shfl_xor(mm, 16, 64));
+            const float y = __fadd_rn(v, mm);
+            if (EPI == 1 && pass == 0) { yg[r] = y; continue; }
+            const int64_t row = grp * 8 + rq * 4 + r;
+            if (qs == 0 && row < Nw && bcol < nc) {
+                if (EPI == 1) {
+                    p.w[0].out[(int64_t)(c0 + bcol) * p.w[0].ldo + row] = ps_silu_mul(yg[r], y);
+                } else {
+                    float val = y;
+                    if (b) val = __fadd_rn(val, b[row]);
+                    if (p.residual && wi == 0) val = __fadd_rn(p.residual[(int64_t)(c0 + bcol) * ldo + row], val);
+                    o[(int64_t)(c0 + bcol) * ldo + row] = val;
+                }
+            }
+        }
+    }
+}
+
 } // namespace
 
 int psk_gemv_debug(int key, uint64_t *host_out, int n_words) {
@@ -1462,8 +1629,20 @@ static void launch_gemm8_k(hipStream_t st, const GemvParams &p, const dim3 grid,
     if (!attr) { (void)hipFuncSetAttribute((const void *)gemm8_kernel<WT, EPI, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024); attr = true; }
     hipLaunchKernelGGL((gemm8_kernel<WT, EPI, NWV>), grid, dim3(NWV * 64), smem, st, p);
 }
+template <int EPI, int NWV>
+static void launch_gemm8m_k(hipStream_t st, const GemvParams &p, const dim3 grid, size_t smem) {
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void *)gemm8m_kernel<EPI, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024); attr = true; }
+    hipLaunchKernelGGL((gemm8m_kernel<EPI, NWV>), grid, dim3(NWV * 64), smem, st, p);
+}
 template <int WT>
 static int launch_gemm8(hipStream_t st, const GemvParams &p, int epi, int nwv, const dim3 grid, size_t smem) {
+    static const bool valu_only = getenv("PS_GEMM8_VALU") != nullptr; // (A/B switch for measurements)
+    if (WT == PS_Q4_K && !valu_only) { // quad dots on the matrix cores
+        if (nwv == 16) { if (epi) launch_gemm8m_k<1, 16>(st, p, grid, smem); else launch_gemm8m_k<0, 16>(st, p, grid, smem); }
+        else { if (epi) launch_gemm8m_k<1, 4>(st, p, grid, smem); else launch_gemm8m_k<0, 4>(st, p, grid, smem); }
+        return 0;
+    }
     if (nwv == 16) { if (epi) launch_gemm8_k<WT, 1, 16>(st, p, grid, smem); else launch_gemm8_k<WT, 0, 16>(st, p, grid, smem); }
     else { if (epi) launch_gemm8_k<WT, 1, 4>(st, p, grid, smem); else launch_gemm8_k<WT, 0, 4>(st, p, grid, smem); }
     return 0;
