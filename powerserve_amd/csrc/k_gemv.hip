@@ -1495,16 +1495,8 @@ __global__ __launch_bounds__(NWV * 64) void gemm8m_kernel(const GemvParams p) {
 #undef PS_G8M_ROW
         };
         auto load_h = [&](int un) { return *(const uint4 *)(ag + (int64_t)un * 128); };
-        if constexpr (NWV == 16) { // one unit ahead
-            uint4 qa = ld_stream16(qg), qb = ld_stream16(qg + 64), h = load_h(0);
-            for (int un = 0; un < n_units; un++) {
-                uint4 qan = qa, qbn = qb, hn = h;
-                if (un + 1 < n_units) { qan = ld_stream16(qg + (int64_t)(un + 1) * 1024); qbn = ld_stream16(qg + (int64_t)(un + 1) * 1024 + 64); hn = load_h(un + 1); }
-                unit(un, qa, qb, h);
-                qa = qan; qb = qbn; h = hn;
-            }
-        } else { // small launches: four units in flight per wave, unconditional loads (index clamped)
-            constexpr int PF = 4;
+        {   // PF units in flight per wave (register ring, no copies); loads unconditional (index clamped to the last unit)
+            constexpr int PF = (NWV == 16) ? 2 : 4;
             uint4 qar[PF], qbr[PF], hr[PF];
 #pragma unroll
             for (int s = 0; s < PF; s++) { const int uc = min(s, n_units - 1); qar[s] = ld_stream16(qg + (int64_t)uc * 1024); qbr[s] = ld_stream16(qg + (int64_t)uc * 1024 + 64); hr[s] = load_h(uc); }
