@@ -1169,11 +1169,10 @@ int launch_wt(hipStream_t st, int n_cu, const GemvParams &p, int epi, int pro) {
 }
 
 // Activation image of 8 pre-quantized columns in LDS, shared by gemm8_kernel and gemm8m_kernel.
-template <int WT, int NT>
+template <int WT, int NT, int C = 8>
 __device__ __forceinline__ void gemm8_stage(const int8_t *aq, const float *ad, const int16_t *abs16, const int K, char *smem, const int c0,
                                             const int nc) {
     using TR = WTraits<WT>;
-    constexpr int C = 8;
     const int nblk = K / TR::BLK;
     // LDS image: one record per (unit, column), records of a unit adjacent, so that every per-column read of the inner
     // loop is  base(unit, lane) + compile-time offset:
@@ -1416,14 +1415,14 @@ __device__ __forceinline__ int pk_mul_u16(uint32_t a, uint32_t b) { // two indep
     __builtin_memcpy(&r, &vr, 4);
     return r;
 }
-template <int EPI, int NWV>
+template <int EPI, int NWV, int C>
 __global__ __launch_bounds__(NWV * 64) void gemm8m_kernel(const GemvParams p) {
-    constexpr int NT = NWV * 64, C = 8, REC = 304;
+    constexpr int NT = NWV * 64, REC = 304, NCS = C / 8; // NCS column sets of 8: lane's columns are bcol + 8 cs
     constexpr uint32_t M = 0x0F0F0F0Fu;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int K = (int)p.K, n_units = K / 256, c0 = blockIdx.y * C, nc = min(C, (int)p.bs - c0);
-    gemm8_stage<PS_Q4_K, NT>(p.aq, p.ad, p.abs16, K, smem, c0, nc);
+    gemm8_stage<PS_Q4_K, NT, C>(p.aq, p.ad, p.abs16, K, smem, c0, nc);
     __syncthreads();
 
     const int qs = lane >> 4, rq = (lane >> 3) & 1, cq = (lane >> 2) & 1, s4 = lane & 3;
@@ -1431,7 +1430,7 @@ __global__ __launch_bounds__(NWV * 64) void gemm8m_kernel(const GemvParams p) {
     const int64_t n_tasks = (EPI == 1) ? p.w[0].n_groups : p.groups_total;
     const int64_t task = (int64_t)blockIdx.x * NWV + wave;
     if (task >= n_tasks) return;
-    float yg[4];
+    float yg[NCS][4];
 #pragma unroll
     for (int pass = 0; pass < (EPI == 1 ? 2 : 1); pass++) {
         int wi = 0;
@@ -1447,9 +1446,11 @@ __global__ __launch_bounds__(NWV * 64) void gemm8m_kernel(const GemvParams p) {
         if (wi == 2) { qsb = p.w[2].qs; ax = p.w[2].aux; }
         const uint8_t *qg = qsb + grp * n_units * 1024 + (arow * 8 + qs) * 16; // piece (row, u = qs); (row, qs + 4) sits 64 bytes on
         const uint8_t *ag = ax + grp * n_units * 128 + arow * 16;
-        float acc0[2][4], accm[4];
+        float acc0[NCS][2][4], accm[NCS][4];
 #pragma unroll
-        for (int r = 0; r < 4; r++) { acc0[0][r] = 0.f; acc0[1][r] = 0.f; accm[r] = 0.f; }
+        for (int cs = 0; cs < NCS; cs++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) { acc0[cs][0][r] = 0.f; acc0[cs][1][r] = 0.f; accm[cs][r] = 0.f; }
 
         auto unit = [&](const int un, const uint4 qa, const uint4 qb, const uint4 h) {
             // ---- this lane's weight row: scales as two 3-bit factors, replicated into both 16-bit halves
@@ -1459,40 +1460,53 @@ __global__ __launch_bounds__(NWV * 64) void gemm8m_kernel(const GemvParams p) {
             const uint32_t mp = (qs < 2) ? mn03 : mn47;
             const int mnp = (int)(bfe8(mp, (2 * qs) & 3) | (bfe8(mp, (2 * qs + 1) & 3) << 16)); // {min[2 qs], min[2 qs + 1]} as int16 pair
             const float dwf = ps_h2f((uint16_t)(h.x & 0xffff)), dmf = ps_h2f((uint16_t)(h.x >> 16));
-            // ---- this lane's column: quants of u = qs and u = qs + 4 (dword 2 jj + half of a record = quad (jj, half))
-            const char *rec = smem + (un * C + bcol) * REC;
-            const int4 ya0 = *(const int4 *)(rec + qs * 32), ya1 = *(const int4 *)(rec + qs * 32 + 16);
-            const int4 yb0 = *(const int4 *)(rec + (qs + 4) * 32), yb1 = *(const int4 *)(rec + (qs + 4) * 32 + 16);
-            const int2 bs = *(const int2 *)(rec + 256 + qs * 8);
-            const float yd = *(const float *)(rec + 288);
-            const int ya[8] = {ya0.x, ya0.y, ya0.z, ya0.w, ya1.x, ya1.y, ya1.z, ya1.w};
-            const int yb[8] = {yb0.x, yb0.y, yb0.z, yb0.w, yb1.x, yb1.y, yb1.z, yb1.w};
+            // ---- B operands: this lane's column of every set, quants of u = qs and u = qs + 4 (dword 2 jj + half = quad (jj, half))
             const uint32_t wa[4] = {qa.x, qa.y, qa.z, qa.w}, wb[4] = {qb.x, qb.y, qb.z, qb.w};
-            ps_i32x4 slo[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}}, shi[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+            int ya[NCS][8], yb[NCS][8];
+            ps_i32x4 slo[NCS][2], shi[NCS][2];
 #pragma unroll
-            for (int sbi = 0; sbi < 8; sbi++) { // sub-block 2 jj + half: low / high nibbles of dword jj
+            for (int cs = 0; cs < NCS; cs++) {
+                const char *rec = smem + (un * C + bcol + 8 * cs) * REC;
+                const int4 ya0 = *(const int4 *)(rec + qs * 32), ya1 = *(const int4 *)(rec + qs * 32 + 16);
+                const int4 yb0 = *(const int4 *)(rec + (qs + 4) * 32), yb1 = *(const int4 *)(rec + (qs + 4) * 32 + 16);
+                ya[cs][0] = ya0.x; ya[cs][1] = ya0.y; ya[cs][2] = ya0.z; ya[cs][3] = ya0.w; ya[cs][4] = ya1.x; ya[cs][5] = ya1.y; ya[cs][6] = ya1.z; ya[cs][7] = ya1.w;
+                yb[cs][0] = yb0.x; yb[cs][1] = yb0.y; yb[cs][2] = yb0.z; yb[cs][3] = yb0.w; yb[cs][4] = yb1.x; yb[cs][5] = yb1.y; yb[cs][6] = yb1.z; yb[cs][7] = yb1.w;
+                slo[cs][0] = slo[cs][1] = shi[cs][0] = shi[cs][1] = ps_i32x4{0, 0, 0, 0};
+            }
+#pragma unroll
+            for (int sbi = 0; sbi < 8; sbi++) { // sub-block 2 jj + half: low / high nibbles of dword jj; A operands once for all sets
                 const int jj = sbi >> 1, half = sbi & 1;
                 const uint32_t sel = 0x0c000c00u | (uint32_t)(sbi & 3) | ((uint32_t)(sbi & 3) << 16); // byte sbi & 3 -> both halves
                 const uint32_t flo = __builtin_amdgcn_perm(0u, lo[sbi >> 2], sel), fhi = __builtin_amdgcn_perm(0u, hi[sbi >> 2], sel);
                 const uint32_t na = (half ? wa[jj] >> 4 : wa[jj]) & M, nb = (half ? wb[jj] >> 4 : wb[jj]) & M;
-                slo[0] = __builtin_amdgcn_mfma_i32_4x4x4i8(pk_mul_u16(na, flo), ya[sbi], slo[0], 0, 0, 0);
-                shi[0] = __builtin_amdgcn_mfma_i32_4x4x4i8(pk_mul_u16(na, fhi), ya[sbi], shi[0], 0, 0, 0);
-                slo[1] = __builtin_amdgcn_mfma_i32_4x4x4i8(pk_mul_u16(nb, flo), yb[sbi], slo[1], 0, 0, 0);
-                shi[1] = __builtin_amdgcn_mfma_i32_4x4x4i8(pk_mul_u16(nb, fhi), yb[sbi], shi[1], 0, 0, 0);
+                const int alo0 = pk_mul_u16(na, flo), ahi0 = pk_mul_u16(na, fhi), alo1 = pk_mul_u16(nb, flo), ahi1 = pk_mul_u16(nb, fhi);
+#pragma unroll
+                for (int cs = 0; cs < NCS; cs++) {
+                    slo[cs][0] = __builtin_amdgcn_mfma_i32_4x4x4i8(alo0, ya[cs][sbi], slo[cs][0], 0, 0, 0);
+                    shi[cs][0] = __builtin_amdgcn_mfma_i32_4x4x4i8(ahi0, ya[cs][sbi], shi[cs][0], 0, 0, 0);
+                    slo[cs][1] = __builtin_amdgcn_mfma_i32_4x4x4i8(alo1, yb[cs][sbi], slo[cs][1], 0, 0, 0);
+                    shi[cs][1] = __builtin_amdgcn_mfma_i32_4x4x4i8(ahi1, yb[cs][sbi], shi[cs][1], 0, 0, 0);
+                }
             }
             // ---- fp32 chains of rows rq*4 + r: the row's d, dmin, mins come from lane r of this quad
-            const int bsp = (bs.x & 0xffff) | (bs.y << 16); // (|bsums of 32| <= 4064)
+#pragma unroll
+            for (int cs = 0; cs < NCS; cs++) {
+                const char *rec = smem + (un * C + bcol + 8 * cs) * REC;
+                const int2 bs = *(const int2 *)(rec + 256 + qs * 8);
+                const float yd = *(const float *)(rec + 288);
+                const int bsp = (bs.x & 0xffff) | (bs.y << 16); // (|bsums of 32| <= 4064)
 #define PS_G8M_ROW(r, CTRL)                                                                                     \
-            {                                                                                                   \
-                const float dwr = dpp_f<CTRL>(dwf), dmr = dpp_f<CTRL>(dmf);                                     \
-                const int mnr   = dpp_i<CTRL>(mnp);                                                             \
-                const float d = __fmul_rn(yd, dwr), dmin = __fmul_rn(-yd, dmr);                                 \
-                acc0[0][r] = __fmaf_rn(d, (float)(shi[0][r] * 8 + slo[0][r]), acc0[0][r]);                      \
-                acc0[1][r] = __fmaf_rn(d, (float)(shi[1][r] * 8 + slo[1][r]), acc0[1][r]);                      \
-                accm[r]    = __fmaf_rn(dmin, (float)dot2_i16((uint32_t)mnr, (uint32_t)bsp, 0), accm[r]);        \
-            }
-            PS_G8M_ROW(0, 0x00) PS_G8M_ROW(1, 0x55) PS_G8M_ROW(2, 0xAA) PS_G8M_ROW(3, 0xFF)
+                {                                                                                               \
+                    const float dwr = dpp_f<CTRL>(dwf), dmr = dpp_f<CTRL>(dmf);                                 \
+                    const int mnr   = dpp_i<CTRL>(mnp);                                                         \
+                    const float d = __fmul_rn(yd, dwr), dmin = __fmul_rn(-yd, dmr);                             \
+                    acc0[cs][0][r] = __fmaf_rn(d, (float)(shi[cs][0][r] * 8 + slo[cs][0][r]), acc0[cs][0][r]);  \
+                    acc0[cs][1][r] = __fmaf_rn(d, (float)(shi[cs][1][r] * 8 + slo[cs][1][r]), acc0[cs][1][r]);  \
+                    accm[cs][r]    = __fmaf_rn(dmin, (float)dot2_i16((uint32_t)mnr, (uint32_t)bsp, 0), accm[cs][r]); \
+                }
+                PS_G8M_ROW(0, 0x00) PS_G8M_ROW(1, 0x55) PS_G8M_ROW(2, 0xAA) PS_G8M_ROW(3, 0xFF)
 #undef PS_G8M_ROW
+            }
         };
         auto load_h = [&](int un) { return *(const uint4 *)(ag + (int64_t)un * 128); };
         {   // PF units in flight per wave (register ring, no copies); loads unconditional (index clamped to the last unit)
@@ -1519,23 +1533,26 @@ __global__ __launch_bounds__(NWV * 64) void gemm8m_kernel(const GemvParams p) {
         if (wi == 1) { Nw = p.w[1].N; ldo = p.w[1].ldo; o = p.w[1].out; b = p.w[1].bias; }
         if (wi == 2) { Nw = p.w[2].N; ldo = p.w[2].ldo; o = p.w[2].out; b = p.w[2].bias; }
 #pragma unroll
+        for (int cs = 0; cs < NCS; cs++)
+#pragma unroll
         for (int r = 0; r < 4; r++) {
-            float v = __fadd_rn(acc0[0][r], acc0[1][r]);
+            float v = __fadd_rn(acc0[cs][0][r], acc0[cs][1][r]);
             v = __fadd_rn(v, __shfl_xor(v, 32, 64));
             v = __fadd_rn(v, __shfl_xor(v, 16, 64));
-            float mm = __fadd_rn(accm[r], __shfl_xor(accm[r], 32, 64));
+            float mm = __fadd_rn(accm[cs][r], __shfl_xor(accm[cs][r], 32, 64));
             mm = __fadd_rn(mm, __shfl_xor(mm, 16, 64));
             const float y = __fadd_rn(v, mm);
-            if (EPI == 1 && pass == 0) { yg[r] = y; continue; }
+            if (EPI == 1 && pass == 0) { yg[cs][r] = y; continue; }
             const int64_t row = grp * 8 + rq * 4 + r;
-            if (qs == 0 && row < Nw && bcol < nc) {
+            const int col = bcol + 8 * cs;
+            if (qs == 0 && row < Nw && col < nc) {
                 if (EPI == 1) {
-                    p.w[0].out[(int64_t)(c0 + bcol) * p.w[0].ldo + row] = ps_silu_mul(yg[r], y);
+                    p.w[0].out[(int64_t)(c0 + col) * p.w[0].ldo + row] = ps_silu_mul(yg[cs][r], y);
                 } else {
                     float val = y;
                     if (b) val = __fadd_rn(val, b[row]);
-                    if (p.residual && wi == 0) val = __fadd_rn(p.residual[(int64_t)(c0 + bcol) * ldo + row], val);
-                    o[(int64_t)(c0 + bcol) * ldo + row] = val;
+                    if (p.residual && wi == 0) val = __fadd_rn(p.residual[(int64_t)(c0 + col) * ldo + row], val);
+                    o[(int64_t)(c0 + col) * ldo + row] = val;
                 }
             }
         }
@@ -1621,18 +1638,19 @@ static void launch_gemm8_k(hipStream_t st, const GemvParams &p, const dim3 grid,
     if (!attr) { (void)hipFuncSetAttribute((const void *)gemm8_kernel<WT, EPI, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024); attr = true; }
     hipLaunchKernelGGL((gemm8_kernel<WT, EPI, NWV>), grid, dim3(NWV * 64), smem, st, p);
 }
-template <int EPI, int NWV>
+template <int EPI, int NWV, int C>
 static void launch_gemm8m_k(hipStream_t st, const GemvParams &p, const dim3 grid, size_t smem) {
     static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void *)gemm8m_kernel<EPI, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024); attr = true; }
-    hipLaunchKernelGGL((gemm8m_kernel<EPI, NWV>), grid, dim3(NWV * 64), smem, st, p);
+    if (!attr) { (void)hipFuncSetAttribute((const void *)gemm8m_kernel<EPI, NWV, C>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024); attr = true; }
+    hipLaunchKernelGGL((gemm8m_kernel<EPI, NWV, C>), grid, dim3(NWV * 64), smem, st, p);
 }
 template <int WT>
 static int launch_gemm8(hipStream_t st, const GemvParams &p, int epi, int nwv, const dim3 grid, size_t smem) {
     static const bool valu_only = getenv("PS_GEMM8_VALU") != nullptr; // (A/B switch for measurements)
     if (WT == PS_Q4_K && !valu_only) { // quad dots on the matrix cores
-        if (nwv == 16) { if (epi) launch_gemm8m_k<1, 16>(st, p, grid, smem); else launch_gemm8m_k<0, 16>(st, p, grid, smem); }
-        else { if (epi) launch_gemm8m_k<1, 4>(st, p, grid, smem); else launch_gemm8m_k<0, 4>(st, p, grid, smem); }
+        if (nwv == 8) { if (epi) launch_gemm8m_k<1, 8, 16>(st, p, grid, smem); else launch_gemm8m_k<0, 8, 16>(st, p, grid, smem); } // 16 columns
+        else if (nwv == 16) { if (epi) launch_gemm8m_k<1, 16, 8>(st, p, grid, smem); else launch_gemm8m_k<0, 16, 8>(st, p, grid, smem); }
+        else { if (epi) launch_gemm8m_k<1, 4, 8>(st, p, grid, smem); else launch_gemm8m_k<0, 4, 8>(st, p, grid, smem); }
         return 0;
     }
     if (nwv == 16) { if (epi) launch_gemm8_k<WT, 1, 16>(st, p, grid, smem); else launch_gemm8_k<WT, 0, 16>(st, p, grid, smem); }
@@ -1661,13 +1679,18 @@ int psk_gemm8(hipStream_t st, int n_cu, const psk_gemv_args &a, ps_act act, int6
     const int64_t n_tasks = epi == 1 ? p.w[0].n_groups : p.groups_total;
     // one wave per row group; 16-wave workgroups amortise the LDS staging of the 8 columns, 4-wave workgroups spread a
     // small launch (tree verify, short prefill tails) over all CUs
-    const int64_t ncg = (bs + 7) / 8;
-    const int nwv = ((n_tasks + 15) / 16) * ncg < (int64_t)n_cu ? 4 : 16;
+    int64_t ncg = (bs + 7) / 8;
+    int nwv = ((n_tasks + 15) / 16) * ncg < (int64_t)n_cu ? 4 : 16;
+    size_t smem_l = smem;
+    // Q4_K, short rows, wide batches: 16 columns per workgroup of 8 waves (the weight-side work of a unit is shared by
+    // twice the columns; the image of 16 columns has to fit the LDS)
+    static const bool no16 = getenv("PS_GEMM8_C8") != nullptr;
+    if (wt == PS_Q4_K && !no16 && nwv == 16 && bs > 8 && 2 * smem <= 80 * 1024) { nwv = 8; ncg = (bs + 15) / 16; smem_l = 2 * smem; }
     const dim3 grid((unsigned)((n_tasks + nwv - 1) / nwv), (unsigned)ncg);
     switch (wt) {
-    case PS_Q4_K: return launch_gemm8<PS_Q4_K>(st, p, epi, nwv, grid, smem);
-    case PS_Q8_0: return launch_gemm8<PS_Q8_0>(st, p, epi, nwv, grid, smem);
-    default: return launch_gemm8<PS_Q4_0>(st, p, epi, nwv, grid, smem);
+    case PS_Q4_K: return launch_gemm8<PS_Q4_K>(st, p, epi, nwv, grid, smem_l);
+    case PS_Q8_0: return launch_gemm8<PS_Q8_0>(st, p, epi, nwv, grid, smem_l);
+    default: return launch_gemm8<PS_Q4_0>(st, p, epi, nwv, grid, smem_l);
     }
 }
 
