@@ -267,7 +267,7 @@ int ps_hip_mul_mat(ps_hip_ctx *c, const ps_tensor *dst, const ps_tensor *src0, c
             PS_CHECK(c, hipGetLastError());
             return 0;
         }
-        if (bs > 4) { // batches: quantize once, 8 columns per workgroup (psk_gemm8)
+        if (bs >= 2) { // batches: quantize once, 8 / 16 columns per workgroup (psk_gemm8)
             psk_quantize_act(c->stream, vdt, 0, (const float *)src1->data, nullptr, nullptr, 0.f, K, bs, a);
             psk_gemv_args g{};
             g.n_w = 1; g.w[0] = w; g.out[0] = (float *)dst->data; g.ldo[0] = w->N;

@@ -99,7 +99,7 @@ static int mm(ps_hip_model *m, psk_gemv_args &g, ps_act act, int64_t K, int64_t 
     const int64_t blk = vdt == PS_Q8_0 ? 32 : 256;
     psk_gemv_args gq = g;
     int64_t step = 4;
-    static const int gemm_min_bs = getenv("PS_GEMM8_MIN_BS") ? atoi(getenv("PS_GEMM8_MIN_BS")) : 5;
+    static const int gemm_min_bs = getenv("PS_GEMM8_MIN_BS") ? atoi(getenv("PS_GEMM8_MIN_BS")) : 2; // (2-4 columns: 4.8-4.9 ms per 8B forward through the batched kernel, 5.4-6.3 ms through the 4-column mat-vec)
     if (bs >= gemm_min_bs) {
         // batches: the activation is quantized ONCE (with its RMSNorm when the launch carries one) and the weights are
         // streamed once per column group of up to 16 instead of once per 4 columns
