@@ -1559,6 +1559,155 @@ __global__ __launch_bounds__(NWV * 64) void gemm8m_kernel(const GemvParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Q8_0 / Q4_0 batched mat-mul with the quad dots on the matrix cores (same idea as gemm8m_kernel; here every quad dot
+// meets its own fp32 block scale, so the MFMAs do not accumulate: D = dot4(weight quad, activation quad), then
+// acc[u] = fma(d_w * d_y, (float)D, acc[u]) block after block as in ggml_vec_dot_q8_0_q8_0 / q4_0_q8_0).
+//   Q8_0 (row groups of 8):  qs = lane >> 4 owns u = qs, qs + 4;  A row (lane >> 3 & 1) * 4 + s;  column (lane >> 2 & 1) * 4 + s
+//   Q4_0 (row groups of 16): qs = lane >> 4: the low nibbles of piece (row, qs) are u = qs, the high ones u = qs + 4;
+//                            A row (lane >> 2 & 3) * 4 + s;  columns s and s + 4 (two sets)
+template <int WT, int EPI, int NWV>
+__global__ __launch_bounds__(NWV * 64) void gemm8b_kernel(const GemvParams p) {
+    using TR = WTraits<WT>;
+    constexpr int NT = NWV * 64, C = 8, REC = 144, NCS = (WT == PS_Q4_0) ? 2 : 1;
+    constexpr uint32_t M = 0x0F0F0F0Fu;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int K = (int)p.K, n_units = K / 128, c0 = blockIdx.y * C, nc = min(C, (int)p.bs - c0);
+    gemm8_stage<WT, NT, C>(p.aq, p.ad, p.abs16, K, smem, c0, nc);
+    __syncthreads();
+
+    const int qs = lane >> 4, s4 = lane & 3;
+    const int rqi  = (WT == PS_Q4_0) ? (lane >> 2) & 3 : (lane >> 3) & 1; // row quad of the row group
+    const int arow = rqi * 4 + s4;
+    const int col0 = (WT == PS_Q4_0) ? s4 : ((lane >> 2) & 1) * 4 + s4;   // column of set cs: col0 + 4 cs (Q4_0 only has cs = 1)
+    const int64_t n_tasks = (EPI == 1) ? p.w[0].n_groups : p.groups_total;
+    const int64_t task = (int64_t)blockIdx.x * NWV + wave;
+    if (task >= n_tasks) return;
+    float yg[NCS][4];
+#pragma unroll
+    for (int pass = 0; pass < (EPI == 1 ? 2 : 1); pass++) {
+        int wi = 0;
+        int64_t grp = task;
+        if (EPI == 1) {
+            wi = pass;
+        } else {
+            if (p.n_w > 1 && grp >= p.w[0].n_groups) { grp -= p.w[0].n_groups; wi = 1; }
+            if (p.n_w > 2 && wi == 1 && grp >= p.w[1].n_groups) { grp -= p.w[1].n_groups; wi = 2; }
+        }
+        const uint8_t *qsb = p.w[0].qs, *ax = p.w[0].aux;
+        if (wi == 1) { qsb = p.w[1].qs; ax = p.w[1].aux; }
+        if (wi == 2) { qsb = p.w[2].qs; ax = p.w[2].aux; }
+        // Q8_0: pieces (row, qs) and (row, qs + 4), 64 bytes apart;  Q4_0: the one piece (row, qs)
+        const uint8_t *qg = qsb + grp * n_units * 1024 + ((WT == PS_Q4_0) ? (arow * 4 + qs) : (arow * 8 + qs)) * 16;
+        const uint8_t *ag = ax + grp * n_units * (TR::RG * 8) + arow * 8;
+        float acc[NCS][2][4];
+#pragma unroll
+        for (int cs = 0; cs < NCS; cs++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) { acc[cs][0][r] = 0.f; acc[cs][1][r] = 0.f; }
+
+        auto unit = [&](const int un, const uint4 qa, const uint4 qb, const uint2 h) {
+            // A operands: [u half][block]
+            int wa[2][4];
+            const uint32_t w0[4] = {qa.x, qa.y, qa.z, qa.w}, w1[4] = {qb.x, qb.y, qb.z, qb.w};
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                if (WT == PS_Q8_0) { wa[0][b] = (int)w0[b]; wa[1][b] = (int)w1[b]; }
+                else { // nibble - 8 as signed bytes
+                    wa[0][b] = (int)((((w0[b] & M) | 0x80808080u) - 0x08080808u) ^ 0x80808080u);
+                    wa[1][b] = (int)(((((w0[b] >> 4) & M) | 0x80808080u) - 0x08080808u) ^ 0x80808080u);
+                }
+            }
+            // this lane's row: the four fp16 block scales as floats
+            const float dwo[4] = {ps_h2f((uint16_t)(h.x & 0xffff)), ps_h2f((uint16_t)(h.x >> 16)), ps_h2f((uint16_t)(h.y & 0xffff)), ps_h2f((uint16_t)(h.y >> 16))};
+#pragma unroll
+            for (int cs = 0; cs < NCS; cs++) {
+                const char *rec = smem + (un * C + col0 + 4 * cs) * REC;
+                int y[2][4]; // [u half][block]
+                if (WT == PS_Q8_0) {
+                    const int4 t0 = *(const int4 *)(rec + qs * 16), t1 = *(const int4 *)(rec + (qs + 4) * 16);
+                    y[0][0] = t0.x; y[0][1] = t0.y; y[0][2] = t0.z; y[0][3] = t0.w;
+                    y[1][0] = t1.x; y[1][1] = t1.y; y[1][2] = t1.z; y[1][3] = t1.w;
+                } else { // record of u' = qs: dword 2 b + half
+                    const int4 t0 = *(const int4 *)(rec + qs * 32), t1 = *(const int4 *)(rec + qs * 32 + 16);
+                    y[0][0] = t0.x; y[1][0] = t0.y; y[0][1] = t0.z; y[1][1] = t0.w;
+                    y[0][2] = t1.x; y[1][2] = t1.y; y[0][3] = t1.z; y[1][3] = t1.w;
+                }
+                const float4 yd = *(const float4 *)(rec + 128);
+                const float ydv[4] = {yd.x, yd.y, yd.z, yd.w};
+#define PS_G8B_ROW(r, CTRL)                                                                                  \
+                    {                                                                                        \
+                        const float d = __fmul_rn(dpp_f<CTRL>(dwo[b]), ydv[b]);                               \
+                        acc[cs][0][r] = __fmaf_rn(d, (float)D0[r], acc[cs][0][r]);                            \
+                        acc[cs][1][r] = __fmaf_rn(d, (float)D1[r], acc[cs][1][r]);                            \
+                    }
+#pragma unroll
+                for (int b = 0; b < 4; b++) { // block after block: the products of a block are consumed before the next ones exist
+                    const ps_i32x4 D0 = __builtin_amdgcn_mfma_i32_4x4x4i8(wa[0][b], y[0][b], ps_i32x4{0, 0, 0, 0}, 0, 0, 0);
+                    const ps_i32x4 D1 = __builtin_amdgcn_mfma_i32_4x4x4i8(wa[1][b], y[1][b], ps_i32x4{0, 0, 0, 0}, 0, 0, 0);
+                    PS_G8B_ROW(0, 0x00) PS_G8B_ROW(1, 0x55) PS_G8B_ROW(2, 0xAA) PS_G8B_ROW(3, 0xFF)
+                }
+#undef PS_G8B_ROW
+            }
+        };
+        auto load_h = [&](int un) { return *(const uint2 *)(ag + (int64_t)un * (TR::RG * 8)); };
+        {   // PF units in flight per wave (register ring); loads unconditional (index clamped to the last unit)
+            constexpr int PF = (NWV == 4) ? 4 : 2;
+            uint4 qar[PF], qbr[PF];
+            uint2 hr[PF];
+#pragma unroll
+            for (int s = 0; s < PF; s++) {
+                const int uc = min(s, n_units - 1);
+                qar[s] = ld_stream16(qg + (int64_t)uc * 1024);
+                qbr[s] = (WT == PS_Q8_0) ? ld_stream16(qg + (int64_t)uc * 1024 + 64) : make_uint4(0, 0, 0, 0);
+                hr[s] = load_h(uc);
+            }
+            for (int un0 = 0; un0 < n_units; un0 += PF) {
+#pragma unroll
+                for (int s = 0; s < PF; s++) {
+                    const int un = un0 + s;
+                    if (un >= n_units) break;
+                    const uint4 qa = qar[s], qb = qbr[s];
+                    const uint2 h = hr[s];
+                    const int nx = min(un + PF, n_units - 1);
+                    qar[s] = ld_stream16(qg + (int64_t)nx * 1024);
+                    if (WT == PS_Q8_0) qbr[s] = ld_stream16(qg + (int64_t)nx * 1024 + 64);
+                    hr[s] = load_h(nx);
+                    unit(un, qa, qb, h);
+                }
+            }
+        }
+        // ---- epilogue: hsum_float_8 over u (u and u + 4 are this lane's; u +- 2, u +- 1 sit 32 and 16 lanes away)
+        int64_t Nw = p.w[0].N, ldo = p.w[0].ldo;
+        float *o = p.w[0].out;
+        const float *b = p.w[0].bias;
+        if (wi == 1) { Nw = p.w[1].N; ldo = p.w[1].ldo; o = p.w[1].out; b = p.w[1].bias; }
+        if (wi == 2) { Nw = p.w[2].N; ldo = p.w[2].ldo; o = p.w[2].out; b = p.w[2].bias; }
+#pragma unroll
+        for (int cs = 0; cs < NCS; cs++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            float v = __fadd_rn(acc[cs][1][r], acc[cs][0][r]); // a[k + 4] + a[k]
+            v = __fadd_rn(v, __shfl_xor(v, 32, 64));
+            v = __fadd_rn(v, __shfl_xor(v, 16, 64));
+            if (EPI == 1 && pass == 0) { yg[cs][r] = v; continue; }
+            const int64_t row = grp * TR::RG + rqi * 4 + r;
+            const int col = col0 + 4 * cs;
+            if (qs == 0 && row < Nw && col < nc) {
+                if (EPI == 1) {
+                    p.w[0].out[(int64_t)(c0 + col) * p.w[0].ldo + row] = ps_silu_mul(yg[cs][r], v);
+                } else {
+                    float val = v;
+                    if (b) val = __fadd_rn(val, b[row]);
+                    if (p.residual && wi == 0) val = __fadd_rn(p.residual[(int64_t)(c0 + col) * ldo + row], val);
+                    o[(int64_t)(c0 + col) * ldo + row] = val;
+                }
+            }
+        }
+    }
+}
+
 } // namespace
 
 int psk_gemv_debug(int key, uint64_t *host_out, int n_words) {
@@ -1644,9 +1793,23 @@ static void launch_gemm8m_k(hipStream_t st, const GemvParams &p, const dim3 grid
     if (!attr) { (void)hipFuncSetAttribute((const void *)gemm8m_kernel<EPI, NWV, C>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024); attr = true; }
     hipLaunchKernelGGL((gemm8m_kernel<EPI, NWV, C>), grid, dim3(NWV * 64), smem, st, p);
 }
+template <int WT, int EPI, int NWV>
+static void launch_gemm8b_k(hipStream_t st, const GemvParams &p, const dim3 grid, size_t smem) {
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void *)gemm8b_kernel<WT, EPI, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024); attr = true; }
+    hipLaunchKernelGGL((gemm8b_kernel<WT, EPI, NWV>), grid, dim3(NWV * 64), smem, st, p);
+}
 template <int WT>
 static int launch_gemm8(hipStream_t st, const GemvParams &p, int epi, int nwv, const dim3 grid, size_t smem) {
     static const bool valu_only = getenv("PS_GEMM8_VALU") != nullptr; // (A/B switch for measurements)
+    if constexpr (WT != PS_Q4_K) {
+        if (!valu_only) { // quad dots on the matrix cores
+            if (nwv == 8) launch_gemm8b_k<WT, 1, 8>(st, p, grid, smem); // (Q4_0 gate/up: see psk_gemm8)
+            else if (nwv == 16) { if (epi) launch_gemm8b_k<WT, 1, 16>(st, p, grid, smem); else launch_gemm8b_k<WT, 0, 16>(st, p, grid, smem); }
+            else { if (epi) launch_gemm8b_k<WT, 1, 4>(st, p, grid, smem); else launch_gemm8b_k<WT, 0, 4>(st, p, grid, smem); }
+            return 0;
+        }
+    }
     if (WT == PS_Q4_K && !valu_only) { // quad dots on the matrix cores
         if (nwv == 8) { if (epi) launch_gemm8m_k<1, 8, 16>(st, p, grid, smem); else launch_gemm8m_k<0, 8, 16>(st, p, grid, smem); } // 16 columns
         else if (nwv == 16) { if (epi) launch_gemm8m_k<1, 16, 8>(st, p, grid, smem); else launch_gemm8m_k<0, 16, 8>(st, p, grid, smem); }
@@ -1686,6 +1849,8 @@ int psk_gemm8(hipStream_t st, int n_cu, const psk_gemv_args &a, ps_act act, int6
     // twice the columns; the image of 16 columns has to fit the LDS)
     static const bool no16 = getenv("PS_GEMM8_C8") != nullptr;
     if (wt == PS_Q4_K && !no16 && nwv == 16 && bs > 8 && 2 * smem <= 80 * 1024) { nwv = 8; ncg = (bs + 15) / 16; smem_l = 2 * smem; }
+    static const bool valu_q40 = getenv("PS_GEMM8_VALU") != nullptr;
+    if (wt == PS_Q4_0 && epi == 1 && nwv == 16 && !valu_q40) nwv = 8; // two column sets + the held gate rows need more than the 128 VGPRs of a 16-wave workgroup
     const dim3 grid((unsigned)((n_tasks + nwv - 1) / nwv), (unsigned)ncg);
     switch (wt) {
     case PS_Q4_K: return launch_gemm8<PS_Q4_K>(st, p, epi, nwv, grid, smem_l);
