@@ -698,7 +698,7 @@ __device__ __forceinline__ void g3_body(const GemvParams &p, char *smem, double 
     const int ng0 = mats.ng0, ng1 = mats.ng1, n_w = mats.n_w;
     auto locate = [&](int task, int un, const uint8_t *&qg, const uint8_t *&ag, int &ul) { g3_locate<EPI, AUXU>(mats, task, un, qg, ag, ul); };
 
-    static_assert(UPW == 4, "ps_vmwait4");
+    static_assert(UPW == 4, "four units per producer wave and chunk");
     using HT = typename std::conditional<WT == PS_Q4_K, ps_u32x4, ps_u32x2>::type;
     constexpr int LPC = 2 * UPW; // loads per chunk and lane
     ps_u32x4 qA[UPW], qB[UPW];

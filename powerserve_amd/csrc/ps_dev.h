@@ -163,31 +163,10 @@ __device__ __forceinline__ uint4 ld_stream16(const void *p) {
     return make_uint4(v.x, v.y, v.z, v.w);
 }
 
-// ---- explicitly scheduled global loads.  The compiler's own s_waitcnt insertion gives up (vmcnt(0)) as soon as
-//      loads sit in loops with any control flow, which serializes a software pipeline.  These issue the load as
-//      inline asm (SGPR base + 32-bit VGPR offset) and the kernel waits with ps_vmwait<N>(regs...): "at most N
-//      younger loads still in flight".  Loads return in order, so everything issued before those N has landed.
-//      Every register filled this way must pass through a ps_vmwait before its first use.
+// (No inline-asm global loads: the compiler cannot see that an asm load's destination is still in flight, copies such
+//  registers freely and reads garbage; the mat-vec instead keeps every load unconditional so that the compiler's own
+//  s_waitcnt counts stay exact.)
 typedef uint32_t ps_u32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void ps_gld16_nt(ps_u32x4 &dst, const void *sbase, uint32_t voff) {
-    asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(dst) : "v"(voff), "s"(sbase));
-}
-__device__ __forceinline__ void ps_gld16(ps_u32x4 &dst, const void *sbase, uint32_t voff) {
-    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase));
-}
-__device__ __forceinline__ void ps_gld8(ps_u32x2 &dst, const void *sbase, uint32_t voff) {
-    asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase));
-}
-template <int N, typename A, typename B>
-__device__ __forceinline__ void ps_vmwait2(A &a, B &b) {
-    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N));
-}
-template <int N, typename A, typename B>
-__device__ __forceinline__ void ps_vmwait4(A (&a)[4], B (&b)[4]) {
-    asm volatile("s_waitcnt vmcnt(%8)"
-                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3])
-                 : "n"(N));
-}
 
 // ---- ggml_v_expf (AVX2+FMA variant, libs/ggml/src/ggml.c:2685-2723), one lane.  Same operation
 //      sequence with explicit fmaf so softmax matches the reference to the last bit on the vector part.
