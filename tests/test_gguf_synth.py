@@ -41,3 +41,25 @@ def test_model_dir_layout(tmp_path):
     r = gguf.GGUFReader(os.path.join(d, "ggml", "weights.gguf"))
     assert "blk.1.attn_q.bias" in r.tensors and "output.weight" not in r.tensors  # tied lm_head
     assert r.tensors["blk.0.ffn_down.weight"].ne == (512, 256)
+
+
+def test_q4_k_m_recipe(tmp_path):
+    """synth.Q4_K_M follows llama.cpp's per-tensor recipe: Q4_K everywhere, Q6_K for attn_v / ffn_down in the "more bits"
+    layers (first and last eighth, every third in between) and for output.weight; the file reads back with those types."""
+    from powerserve_amd import gguf, synth
+    d = str(tmp_path / "m")
+    synth.write_model_dir(d, "small-llama", synth.Q4_K_M, n_ctx=32, seed=1)  # 3 layers, tied embeddings
+    rd = gguf.GGUFReader(d + "/ggml/weights.gguf")
+    t = {n: ti.type for n, ti in rd.tensors.items()}
+    more = [synth._more_bits(i, 3) for i in range(3)]
+    assert any(more) and not all(more)
+    for i in range(3):
+        want = gguf.Q6_K if more[i] else gguf.Q4_K
+        assert t[f"blk.{i}.attn_v.weight"] == want and t[f"blk.{i}.ffn_down.weight"] == want
+        for n in ("attn_q", "attn_k", "attn_output", "ffn_gate", "ffn_up"):
+            assert t[f"blk.{i}.{n}.weight"] == gguf.Q4_K
+    assert t["token_embd.weight"] == gguf.Q6_K and "output.weight" not in t  # tied: the table takes the output's type
+    d2 = str(tmp_path / "m2")
+    synth.write_model_dir(d2, "small-llama-hs128", synth.Q4_K_M, n_ctx=32, seed=1)  # untied
+    t2 = {n: ti.type for n, ti in gguf.GGUFReader(d2 + "/ggml/weights.gguf").tensors.items()}
+    assert t2["output.weight"] == gguf.Q6_K and t2["token_embd.weight"] == gguf.Q4_K
