@@ -192,6 +192,7 @@ uint64_t ps_hip_model_weight_bytes_per_token(const ps_hip_model *m);
 /* Measurement helper (bench.py roofline): replays mat-vec launches of one single-token forward exactly as the decode
  * step issues them (same kernels and fused prologues, every layer's own weights) `reps` times between HIP events on
  * the ctx stream -> seq_ms per token.  which = 0: all quantized mat-vecs; 1: the gate/up launch of every layer only.
+* (which: 0 every quantized mat-vec of a token, 1 gate/up, 2 QKV, 3 O, 4 down, 5 lm_head)
  * null_ms = the same number of empty launches (launch-boundary cost); n_launches = launches per token. */
 int ps_hip_model_bench_gemv(ps_hip_model *m, int reps, int which, double *seq_ms, double *null_ms, int *n_launches);
 /* Diagnostic: in-kernel timeline of the decode mat-vec (tools/gpu_timeline.py).  With host_out == NULL, arm
@@ -200,6 +201,9 @@ int ps_hip_model_bench_gemv(ps_hip_model *m, int reps, int which, double *seq_ms
  * shader-clock ticks (s_memtime).  key = k1 + 100 * (k2 + 1) records a second launch family into a second block of
  * the same size (kernel-boundary gaps). */
 int ps_hip_debug_timeline(ps_hip_ctx *ctx, int key, uint64_t *host_out, int n_words);
+/* Diagnostic: tunables of the library (process-wide).  key 1: wave configuration of the decode mat-vec (k_gemv4.hip,
+ * tools/g4_variants.py).  Returns non-zero for an unknown key. */
+int ps_hip_debug_set(int key, int value);
 /* bit 0: 0 = hipGraph replay of the decode step (default), 1 = eager launches (rocprofv3 needs them);
  * bit 1: 1 = run the O / gate-up / down mat-vecs of a layer as ONE chained launch (device-wide barriers from relaxed
  * atomics between the phases; needs every CU for this process; same results bit for bit) */

@@ -390,4 +390,10 @@ int ps_hip_debug_timeline(ps_hip_ctx *ctx, int key, uint64_t *host_out, int n_wo
     return psk_gemv_debug(key, host_out, n_words);
 }
 
+int ps_hip_debug_set(int key, int value) {
+    extern int g_g4_cfg;
+    if (key == 1) { g_g4_cfg = value; return 0; }
+    return 1;
+}
+
 } // extern "C"

@@ -1,0 +1,402 @@
+// Decode mat-vec, second generation (single activation column, Q4_K weights): the same bit-exact arithmetic as
+// gemv3_kernel (k_gemv.hip: producers turn 1 KiB units into the reference's integer partials, a chain wave runs the
+// fp32 fma chains of ggml_vec_dot_q4_K_q8_K in unit order, libs/ggml/src/ggml-quants.c:7809-7873), restructured around
+// what the launch-boundary micro-benchmark (tools/micro/overlap.hip, profiles/r02_micro_boundary.txt) showed on MI355X:
+//   * a dependent kernel boundary costs 2.8-3.1 us behind 1024-thread workgroups but 1.3-1.6 us behind 512-thread ones,
+//     and a 16.8 MB streaming launch takes 4.2-4.5 us with 8 waves per CU against 6.1 us with 16: 64 KiB of loads in
+//     flight per CU already saturate HBM (6.2 TB/s), more only queue -> NW = 7 or 8 producer waves + ONE chain wave;
+//   * the activation row is requested FIRST (vmcnt retires in order) and its tiles are dealt to all producers; the two
+//     first chunks of weights go out right behind it, before any barrier;
+//   * every address of a wave's four units of a chunk comes from ONE scalar computation (the four units are consecutive
+//     1 KiB pieces of one row group: rows end on multiples of four units), so the inner loop carries a handful of SALU
+//     instructions per chunk instead of ~60 per unit;
+//   * chunks are sized so that whole rows fit (K = 4096: 8 producers, 32 units = 2 row groups; K = 14336: 7 producers,
+//     28 units = half a row group).
+// Epilogues as gemv3: EPI 0 bias / residual, EPI 1 SiLU(gate)*up, EPI 2 RoPE + KV-cache append (QKV).
+#include "ps_gemv_dev.h"
+
+namespace {
+
+// silu_hadamard (src/backend/ggml/ggml.cpp:115-129) with glibc's expf table read from LDS: a table lookup in global /
+// constant memory is a vector-memory round trip (> 1 us behind the weight stream) on the chain wave's critical path
+__device__ __forceinline__ float g4_silu_mul(float g, float u, const uint64_t *tab) {
+    float val = g;
+    val       = __fmul_rn(val, __fdiv_rn(1.0f, __fadd_rn(1.0f, ps_expf_glibc(-val, tab))));
+    return __fmul_rn(val, u);
+}
+
+struct G4Mat {
+    const uint8_t *qs, *aux;
+    float *out;
+    const float *bias;
+    int64_t N;
+    int n_groups;
+};
+struct G4Params {
+    G4Mat w[3];
+    int n_w, n_units, n_tasks;  // tasks: row groups (EPI 0 / 2) or gate/up row-group pairs (EPI 1)
+    int split_q, split_r;       // tasks per workgroup = split_q (+1 for the first split_r workgroups)
+    int K, col_bytes;
+    const float *residual;
+    const float *x, *nw;        // PRO 1: rmsnorm(x, nw, eps) then quantize;  PRO 2: quantize(x)
+    float eps;
+    const int8_t *aq;           // PRO 0: activation already quantized
+    const float *ad;
+    const int16_t *abs16;
+    unsigned long long *dbg;
+    psk_rope_kv rope;           // EPI 2
+};
+
+// NW producer waves, DC chunks of weight loads in flight per wave (register ring), TPW activation tiles per producer,
+// XW: wait for the activation row before the first weight request goes out (short launches: the row does not queue
+// behind the whole chip's first burst of weights)
+template <int NW, int DC, int TPW, int XW, int EPI, int PRO>
+__global__ __launch_bounds__((NW + 1) * 64) void gemv4_kernel(const G4Params p) {
+    constexpr int WT = PS_Q4_K;
+    using TR  = WTraits<WT>;
+    // record of one (unit, lane): {d * yd, (float)sumi, -dmin * yd, (float)(mins . bsums)} -- everything up to the two
+    // fmas of the chain is done by the producers, in parallel (a lone chain wave issues one instruction every ~4 cycles:
+    // at 12 instructions per record it was the bottleneck of the launch, 1.3 us per 32-unit chunk)
+    using Rec = float4;
+    constexpr int UPW = 4, UPB = NW * UPW;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ double red[16];
+    __shared__ uint64_t exp_tab[PS_EXP2F_N];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int K = p.K, n_units = p.n_units;
+    const int nb32 = K / 32;
+    int8_t *lq   = (int8_t *)smem;
+    float *ld    = (float *)(smem + K);
+    int *lb      = (int *)(ld + n_units);
+    int16_t *l16 = (int16_t *)(lb + nb32);
+    Rec *recs    = (Rec *)(smem + p.col_bytes); // [2][UPB][64]
+    float *epA   = (float *)(recs + 2 * UPB * 64);  // [3][ep_cap * 8]: epilogue operands of this workgroup's rows
+    LAct A;
+    A.q32 = (const int *)lq; A.d = ld; A.bs32 = lb;
+    const int r = lane >> 3, u = lane & 7;
+
+    const int tot = (EPI == 1) ? 2 * n_units : n_units; // stream units per task (EPI 1: gate units then up units)
+    const int t0  = (int)blockIdx.x * p.split_q + min((int)blockIdx.x, p.split_r);
+    const int nt  = p.split_q + ((int)blockIdx.x < p.split_r ? 1 : 0);
+    const int s_end    = nt * tot;                  // stream units of this workgroup
+    const int n_chunks = (s_end + UPB - 1) / UPB;
+    const int n_iters  = (n_chunks + DC - 1) / DC;
+    unsigned long long *const dbg = (p.dbg && blockIdx.x < 1024 && lane == 0 && (wave == 0 || wave == NW)) ? p.dbg + ((size_t)blockIdx.x * 2 + (wave == NW)) * 32 : nullptr;
+    int dbg_n = 0;
+    auto mark = [&]() { if (dbg && dbg_n < 28) dbg[dbg_n++] = __builtin_amdgcn_s_memtime(); };
+    mark(); // 0: entry
+    if (dbg) dbg[29] = __builtin_amdgcn_s_memrealtime();
+    if (p.dbg && blockIdx.x < 1024 && lane == 0 && wave < 16) p.dbg[((size_t)blockIdx.x * 2 + 1) * 32 + 12 + wave] = __builtin_amdgcn_s_memtime(); // every wave's entry
+
+    if (wave < NW) { // ------------------------------------------------------------------ producers
+        // 1. the activation row, dealt tile by tile to the producers (tile t -> wave t % NW)
+        float4 xv[TPW], wv[TPW];
+        if (PRO != 0) ps_qrow_load<(PRO == 1 ? 1 : 0), TPW>(p.x, p.nw, K, xv, wv, NW);
+        // 2. this wave's slots of chunks 0 .. DC-1: (local task, unit inside the task); a slot is four consecutive units
+        //    of one row group
+        const int step_t = (DC * UPB) / tot, step_u = (DC * UPB) % tot; // a slot moves DC chunks per trip
+        int tS[DC], uS[DC];
+#pragma unroll
+        for (int d = 0; d < DC; d++) {
+            int t = 0, un = d * UPB + wave * UPW;
+            while (un >= tot) { un -= tot; t++; }
+            tS[d] = t; uS[d] = un;
+        }
+        ps_u32x4 q[DC][UPW], h[DC][UPW];
+        const uint32_t lane16 = (uint32_t)lane * 16u, raux = (uint32_t)r * 16u;
+        // loads are UNCONDITIONAL (a slot past the range re-reads the workgroup's first unit) so that the compiler counts
+        // vmcnt exactly and a chunk is consumed while the next ones are in flight
+        auto issue = [&](ps_u32x4 (&q)[UPW], ps_u32x4 (&h)[UPW], int tl, int un) {
+            const bool live = tl < nt;
+            int grp = t0 + (live ? tl : 0), ul = live ? un : 0;
+            const uint8_t *qb = p.w[0].qs, *ab = p.w[0].aux;
+            if (EPI == 1) {
+                if (ul >= n_units) { ul -= n_units; qb = p.w[1].qs; ab = p.w[1].aux; }
+            } else if (p.n_w > 1 && grp >= p.w[0].n_groups) {
+                grp -= p.w[0].n_groups; qb = p.w[1].qs; ab = p.w[1].aux;
+                if (p.n_w > 2 && grp >= p.w[1].n_groups) { grp -= p.w[1].n_groups; qb = p.w[2].qs; ab = p.w[2].aux; }
+            }
+            const uint32_t idx = (uint32_t)(grp * n_units + ul);
+            const uint8_t *qg = qb + ((uint64_t)idx << 10), *ag = ab + ((uint64_t)idx << 7);
+            // a dead slot costs one cache line: every lane asks for the same 16 bytes of the workgroup's first unit
+            const uint32_t lo = live ? lane16 : 0u, ro = live ? raux : 0u, st = live ? 1u : 0u;
+#pragma unroll
+            for (int i = 0; i < UPW; i++) {
+                q[i] = __builtin_nontemporal_load((const ps_u32x4 *)(qg + i * (1024 * st) + lo));
+                h[i] = *(const ps_u32x4 *)(ag + i * (128 * st) + ro);
+            }
+        };
+        auto produce = [&](const ps_u32x4 (&q)[UPW], const ps_u32x4 (&h)[UPW], int tl, int un, int buf) {
+            if (tl >= nt) return; // wave-uniform: nothing of this chunk belongs to the wave
+            const int ul = (EPI == 1 && un >= n_units) ? un - n_units : un;
+#pragma unroll
+            for (int i = 0; i < UPW; i++) {
+                const int2 rc  = unit_rec<WT>(make_uint4(q[i].x, q[i].y, q[i].z, q[i].w), make_uint4(h[i].x, h[i].y, h[i].z, h[i].w), ul + i, u, A);
+                const float yd = A.d[ul + i];
+                const float d    = __fmul_rn(yd, ps_h2f((uint16_t)(h[i].x & 0xffff)));
+                const float dmin = __fmul_rn(-yd, ps_h2f((uint16_t)(h[i].x >> 16)));
+                recs[(buf * UPB + wave * UPW + i) * 64 + lane] = make_float4(d, (float)rc.x, dmin, (float)rc.y); // (lanes u >= 4: .w is not a product, their acc_m is never read)
+                __builtin_amdgcn_sched_barrier(0); // one unit at a time: interleaving four of them costs registers, hides nothing
+            }
+        };
+        auto advance = [&](int &tl, int &un) {
+            tl += step_t; un += step_u;
+            if (un >= tot) { un -= tot; tl++; }
+        };
+        // XW (staged issue): only chunk 0 goes out before the prologue.  The CU's vector-memory queue is served in order at
+        // 64 B per clock and a wave whose requests do not fit stalls IN the issue: with two chunks (16 KiB + headers per
+        // wave) up front the waves spent 1.2 us issuing before they could look at the activation row, and the slowest
+        // reached the sum-of-squares barrier 1 us after the first.  The later chunks follow behind the prologue's barriers.
+        constexpr bool STAGED = XW && PRO != 0;
+        issue(q[0], h[0], tS[0], uS[0]);
+        if (!STAGED) {
+#pragma unroll
+            for (int d = 1; d < DC; d++) issue(q[d], h[d], tS[d], uS[d]);
+        }
+        mark(); // 1: loads issued
+        // 3. activation -> LDS (the chain wave joins the barriers)
+        if (PRO == 0) {
+            for (int i = threadIdx.x * 16; i < K; i += NW * 64 * 16) *(int4 *)(lq + i) = *(const int4 *)(p.aq + i);
+            for (int i = threadIdx.x; i < n_units; i += NW * 64) ld[i] = p.ad[i];
+            for (int i = threadIdx.x; i < nb32; i += NW * 64) lb[i] = (int)p.abs16[2 * i] + (int)p.abs16[2 * i + 1];
+            __syncthreads();
+        } else {
+            // (timeline: prologue events 24..27 of wave 0 land in the chain role's slots 24..27)
+            ps_qrow_compute<TR::VDT, (PRO == 1 ? 1 : 0), TPW>(xv, wv, p.eps, K, lq, ld, l16, red, NW, [&](int k, float dep) {
+                asm volatile("" ::"v"(dep));
+                if (dbg && wave == 0) dbg[32 + k] = __builtin_amdgcn_s_memtime();
+                if (STAGED && DC > 1 && k == (PRO == 1 ? 25 : 27)) issue(q[1], h[1], tS[1], uS[1]);
+                if (STAGED && DC > 2 && k == 27) {
+#pragma unroll
+                    for (int d = 2; d < DC; d++) issue(q[d], h[d], tS[d], uS[d]);
+                }
+            }, lb);
+        }
+        mark(); // 2: activation in LDS
+        // 4. chunk it * DC + d from ring slot d
+        for (int it = 0; it < n_iters; it++) {
+#pragma unroll
+            for (int d = 0; d < DC; d++) {
+                produce(q[d], h[d], tS[d], uS[d], (it * DC + d) & 1);
+                mark(); // 3, 6, ...: chunk produced
+                advance(tS[d], uS[d]);
+                issue(q[d], h[d], tS[d], uS[d]);
+                mark(); // 4, 7, ...: next loads issued
+                __syncthreads();
+                mark(); // 5, 8, ...: barrier passed
+            }
+        }
+    } else { // ------------------------------------------------------------------------- chain wave
+        // Everything the epilogue reads from memory is fetched NOW, while this wave has nothing to do, into LDS: a global
+        // load on the chain's path costs a vector-memory round trip behind the weight stream (> 1 us) per row group
+        // (measured: 2 us per chunk of the gate/up launch with the expf table in constant memory, 7 chunks per launch).
+        const int ep_n = (p.split_q + 1) * 8;
+        float *const epB = epA + ep_n, *const epC = epB + ep_n;
+        int kv_pos = 0;
+        if (EPI == 1) {
+            if (lane < PS_EXP2F_N) exp_tab[lane] = ps_exp2f_tab[lane];
+        } else {
+            int rpos = 0;
+            if (EPI == 2) { kv_pos = p.rope.state->pos0; rpos = p.rope.rope_pos ? p.rope.rope_pos[0] : kv_pos; }
+            for (int tl0 = 0; tl0 < nt; tl0 += 8) { // lane (r, u): row r of local task tl0 + u
+                const int tl = tl0 + u;
+                if (tl >= nt) continue;
+                int wi = 0, grp = t0 + tl;
+                if (p.n_w > 1 && grp >= p.w[0].n_groups) { grp -= p.w[0].n_groups; wi = 1; }
+                if (p.n_w > 2 && wi == 1 && grp >= p.w[1].n_groups) { grp -= p.w[1].n_groups; wi = 2; }
+                const int64_t Nw = wi == 0 ? p.w[0].N : (wi == 1 ? p.w[1].N : p.w[2].N);
+                const float *b   = wi == 0 ? p.w[0].bias : (wi == 1 ? p.w[1].bias : p.w[2].bias);
+                const int64_t row = (int64_t)grp * TR::RG + r;
+                float va = 0.f, vb = 0.f, vc = 0.f;
+                if (row < Nw) {
+                    if (b) vc = b[row];
+                    if (EPI == 0) {
+                        if (p.residual && wi == 0) va = p.residual[row];
+                    } else if (wi != 2) { // (cos, sin) of the rotation pair this row belongs to
+                        const int e = (int)(row % p.rope.head_size);
+                        if (e < p.rope.n_dims) {
+                            const int64_t i0 = (int64_t)rpos * p.rope.head_size + (e & ~1);
+                            va = p.rope.rope_table[i0]; vb = p.rope.rope_table[i0 + 1];
+                        }
+                    }
+                }
+                epA[tl * 8 + r] = va; epB[tl * 8 + r] = vb; epC[tl * 8 + r] = vc;
+            }
+        }
+        if (PRO == 1) {
+            if (lane == 0) red[wave] = 0.0; // its slot of the sum-of-squares exchange
+            __syncthreads();
+        }
+        __syncthreads();
+        mark(); // 1: activation in LDS
+        __builtin_amdgcn_s_setprio(3); // one wave serves NW producers: it gets the issue slots first
+        float acc0 = 0.f, acc1 = 0.f, accm = 0.f, ygate = 0.f;
+        int tl = 0, un = 0; // local task, units of it already chained
+        auto row_done = [&]() {
+            const float y = row_reduce<WT>(acc0, acc1, accm);
+            int wi = 0, grp = t0 + tl;
+            if (EPI != 1) {
+                if (p.n_w > 1 && grp >= p.w[0].n_groups) { grp -= p.w[0].n_groups; wi = 1; }
+                if (p.n_w > 2 && wi == 1 && grp >= p.w[1].n_groups) { grp -= p.w[1].n_groups; wi = 2; }
+            }
+            int64_t Nw = p.w[0].N;
+            float *o = p.w[0].out;
+            const float *b = p.w[0].bias;
+            if (wi == 1) { Nw = p.w[1].N; o = p.w[1].out; b = p.w[1].bias; }
+            if (wi == 2) { Nw = p.w[2].N; o = p.w[2].out; b = p.w[2].bias; }
+            const int64_t row = (int64_t)grp * TR::RG + r;
+            const float ea = EPI != 1 ? epA[tl * 8 + r] : 0.f, eb = EPI == 2 ? epB[tl * 8 + r] : 0.f, ec = EPI != 1 ? epC[tl * 8 + r] : 0.f;
+            if constexpr (EPI == 2) { // q / k: rotate adjacent pairs (rows 2i, 2i+1 sit in neighbouring lane groups); v: transpose-append
+                float v = y;
+                if (b && row < Nw) v = __fadd_rn(v, ec);
+                const float vp = dpp_f<0x128>(v); // partner row (row_ror:8 swaps the two row groups of 8 lanes)
+                const psk_rope_kv &R = p.rope;
+                if (u == 0 && row < Nw) {
+                    if (wi == 2) {
+                        R.v_cache[row * R.n_ctx + kv_pos] = v;
+                    } else {
+                        const int e = (int)(row % R.head_size);
+                        float res = v;
+                        if (e < R.n_dims) {
+                            const float c = ea, sn = eb;
+                            const float x0 = (e & 1) ? vp : v, x1 = (e & 1) ? v : vp;
+                            res = (e & 1) ? __fadd_rn(__fmul_rn(x0, sn), __fmul_rn(x1, c)) : __fsub_rn(__fmul_rn(x0, c), __fmul_rn(x1, sn));
+                        }
+                        if (wi == 0) o[row] = res; else R.k_cache[(int64_t)kv_pos * R.kv_dim + row] = res;
+                    }
+                }
+            } else if (u == 0 && row < Nw) {
+                if (EPI == 1) {
+                    o[row] = g4_silu_mul(ygate, y, exp_tab);
+                } else {
+                    float v = y;
+                    if (b) v = __fadd_rn(v, ec);
+                    if (p.residual && wi == 0) v = __fadd_rn(ea, v);
+                    o[row] = v;
+                }
+            }
+            acc0 = 0.f; acc1 = 0.f; accm = 0.f;
+            un = 0;
+            tl++;
+        };
+        auto batch = [&](auto nconst, const Rec *rb, const int k0) { // N records in one LDS round trip, then the two fma chains
+            constexpr int N = decltype(nconst)::value;
+            Rec rc[N];
+#pragma unroll
+            for (int k = 0; k < N; k++) rc[k] = rb[(k0 + k) * 64];
+#pragma unroll
+            for (int k = 0; k < N; k++) {
+                acc0 = __fmaf_rn(rc[k].x, rc[k].y, acc0);
+                accm = __fmaf_rn(rc[k].z, rc[k].w, accm); // lanes u >= 4: not an acc_m lane, never read
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        for (int c = 0; c < DC * n_iters; c++) {
+            mark(); // 2, 4, ...: previous chunk chained, waiting
+            __syncthreads();
+            mark(); // 3, 5, ...: chunk c handed over
+            if (c >= n_chunks) continue;
+            const Rec *rb  = recs + (size_t)(c & 1) * UPB * 64 + lane;
+            const int kend = min(UPB, s_end - c * UPB);
+            for (int k0 = 0; k0 < kend;) { // runs: units of one row (EPI 1: of one half of a gate/up pair); lengths are multiples of 4
+                const int bound = (EPI == 1 && un < n_units) ? n_units : tot;
+                const int len   = min(bound - un, kend - k0);
+                int kk = k0, rem = len;
+                for (; rem >= 16; rem -= 16, kk += 16) batch(std::integral_constant<int, 16>{}, rb, kk);
+                if (rem >= 8) { batch(std::integral_constant<int, 8>{}, rb, kk); rem -= 8; kk += 8; }
+                if (rem >= 4) batch(std::integral_constant<int, 4>{}, rb, kk);
+                un += len;
+                k0 += len;
+                if (EPI == 1 && un == n_units) { // gate row finished: reduce it, restart the chains for the up row
+                    ygate = row_reduce<WT>(acc0, acc1, accm);
+                    acc0 = 0.f; acc1 = 0.f; accm = 0.f;
+                }
+                if (un == tot) row_done();
+            }
+        }
+    }
+    if (dbg) { dbg[31] = __builtin_amdgcn_s_memtime(); dbg[30] = __builtin_amdgcn_s_memrealtime(); }
+}
+
+template <int NW, int DC, int TPW, int XW, int EPI, int PRO>
+void launch_g4(hipStream_t st, int grid, const G4Params &p) {
+    const size_t smem = (size_t)p.col_bytes + (size_t)2 * NW * 4 * 64 * sizeof(float4) + (size_t)3 * (p.split_q + 1) * 8 * sizeof(float);
+    static bool attr = false;
+    if (!attr && smem > 48 * 1024) {
+        (void)hipFuncSetAttribute((const void *)gemv4_kernel<NW, DC, TPW, XW, EPI, PRO>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        attr = true;
+    }
+    hipLaunchKernelGGL((gemv4_kernel<NW, DC, TPW, XW, EPI, PRO>), dim3((unsigned)grid), dim3((NW + 1) * 64), smem, st, p);
+}
+
+// KC: row-length class (tiles of 256 per row <= 16 << KC)
+template <int NW, int DC, int XW, int KC>
+int launch_g4_ep(hipStream_t st, int grid, const G4Params &p, int epi, int pro) {
+    constexpr int TPW = ((16 << KC) + NW - 1) / NW;
+    if (epi == 2) { if (pro != 1) return -1; launch_g4<NW, DC, TPW, XW, 2, 1>(st, grid, p); return 0; }
+    if (epi == 1) {
+        if (pro == 1) launch_g4<NW, DC, TPW, XW, 1, 1>(st, grid, p);
+        else if (pro == 0) launch_g4<NW, DC, TPW, XW, 1, 0>(st, grid, p);
+        else return -1;
+        return 0;
+    }
+    if (pro == 0) launch_g4<NW, DC, TPW, XW, 0, 0>(st, grid, p);
+    else if (pro == 1) launch_g4<NW, DC, TPW, XW, 0, 1>(st, grid, p);
+    else launch_g4<NW, DC, TPW, XW, 0, 2>(st, grid, p);
+    return 0;
+}
+template <int NW, int DC, int XW>
+int launch_g4_kc(hipStream_t st, int grid, const G4Params &p, int epi, int pro) {
+    if (p.n_units <= 16) return launch_g4_ep<NW, DC, XW, 0>(st, grid, p, epi, pro);
+    if (p.n_units <= 64) return launch_g4_ep<NW, DC, XW, 2>(st, grid, p, epi, pro);
+    return -1;
+}
+
+} // namespace
+
+int g_g4_cfg = 0; // ps_hip_debug_set(1, cfg)
+
+// Single-column Q4_K mat-vec.  Returns -1 when the launch is not covered (the caller falls back to gemv3 / gemv1).
+int psk_gemv4(hipStream_t st, int n_cu, const psk_gemv_args &a, ps_act act, int64_t K) {
+    static const bool off = getenv("PS_NO_GEMV4") != nullptr; // (A/B switch for measurements)
+    if (off) return -1;
+    if (a.n_w < 1 || a.n_w > 3 || K % 1024 || K > 16384) return -1; // rows end on multiples of four units
+    G4Params p{};
+    int groups_total = 0;
+    for (int i = 0; i < a.n_w; i++) {
+        if (a.w[i]->dtype != PS_Q4_K || a.w[i]->K != K) return -1;
+        const int ng = (int)((a.w[i]->N + 7) / 8);
+        p.w[i] = G4Mat{a.w[i]->qs, a.w[i]->aux, a.out[i], a.bias[i], a.w[i]->N, ng};
+        groups_total += ng;
+    }
+    const int epi = a.silu_pair ? 1 : (a.rope ? 2 : 0);
+    if (epi == 1 && (a.n_w != 2 || a.w[0]->N != a.w[1]->N)) return -1;
+    if (epi == 2) {
+        if (a.n_w != 3 || a.pro != 1) return -1;
+        p.rope = *a.rope;
+    }
+    p.n_w = a.n_w; p.n_units = (int)(K / 256); p.K = (int)K;
+    p.n_tasks = epi == 1 ? p.w[0].n_groups : groups_total;
+    p.residual = a.residual; p.x = a.pro_x; p.nw = a.pro_norm_w; p.eps = a.pro_eps;
+    p.aq = act.qs; p.ad = act.d; p.abs16 = act.bs16;
+    p.col_bytes = (int)psk_gemv_lds_col_bytes(PS_Q4_K, K);
+    int grid = p.n_tasks < n_cu ? p.n_tasks : n_cu;
+    if (grid < 1) return -1;
+    p.split_q = p.n_tasks / grid; p.split_r = p.n_tasks % grid;
+    p.dbg = psk_gemv_dbg_buf(epi, a.pro);
+    // wave configuration (measured, tools/g4_variants.py): rows of a multiple of 7 units take 7 (14) producers
+    const bool seven = p.n_units % 7 == 0;
+    switch (g_g4_cfg) {
+    case 1: return seven ? launch_g4_kc<7, 3, 0>(st, grid, p, epi, a.pro) : launch_g4_kc<8, 3, 0>(st, grid, p, epi, a.pro);
+    case 2: return seven ? launch_g4_kc<7, 3, 1>(st, grid, p, epi, a.pro) : launch_g4_kc<8, 3, 1>(st, grid, p, epi, a.pro);
+    case 3: return launch_g4_kc<7, 4, 0>(st, grid, p, epi, a.pro);
+    case 4: return launch_g4_kc<11, 2, 0>(st, grid, p, epi, a.pro);
+    case 5: return launch_g4_kc<11, 3, 0>(st, grid, p, epi, a.pro);
+    case 6: return seven ? launch_g4_kc<14, 2, 0>(st, grid, p, epi, a.pro) : launch_g4_kc<15, 2, 0>(st, grid, p, epi, a.pro);
+    case 7: return launch_g4_kc<7, 4, 1>(st, grid, p, epi, a.pro);
+    case 8: return seven ? launch_g4_kc<7, 2, 1>(st, grid, p, epi, a.pro) : launch_g4_kc<8, 2, 1>(st, grid, p, epi, a.pro);
+    case 9: return launch_g4_kc<11, 2, 1>(st, grid, p, epi, a.pro);
+    default: return seven ? launch_g4_kc<7, 2, 0>(st, grid, p, epi, a.pro) : launch_g4_kc<8, 2, 0>(st, grid, p, epi, a.pro);
+    }
+}

@@ -436,26 +436,32 @@ int ps_hip_model_bench_gemv(ps_hip_model *m, int reps, int which, double *seq_ms
     int launches = 0;
     auto pass = [&](bool count) -> int {
         ps_act a1 = ps_act_carve(m->act_mem, dim, m->max_batch), a2 = ps_act_carve(m->act_mem, hid, m->max_batch);
+        const bool qkv = which == 0 || which == 2, op = which == 0 || which == 3, gu = which == 0 || which == 1, dn = which == 0 || which == 4;
         for (uint32_t L = 0; L < f.n_layers; L++) {
-            if (which == 0) {
+            if (qkv) {
                 psk_gemv_args g{};
                 g.n_w = 3; g.w[0] = m->wq[L]; g.w[1] = m->wk[L]; g.w[2] = m->wv[L];
                 g.out[0] = m->q; g.out[1] = m->k; g.out[2] = m->v; g.ldo[0] = dim; g.ldo[1] = kvd; g.ldo[2] = kvd;
                 if (m->qwen2) { g.bias[0] = m->bq[L]; g.bias[1] = m->bk[L]; g.bias[2] = m->bv[L]; }
                 g.pro = 1; g.pro_x = m->x; g.pro_norm_w = m->attn_norm[L]; g.pro_eps = f.norm_eps;
                 if (mm(m, g, a1, dim, 1)) return 2;
+                if (count) launches += 1;
+            }
+            if (op) {
                 psk_gemv_args go{};
                 go.n_w = 1; go.w[0] = m->wo[L]; go.out[0] = m->hb; go.ldo[0] = dim; // (not into x: the replay must not drift)
                 go.pro = 2; go.pro_x = m->att;
                 if (mm(m, go, a1, dim, 1)) return 2;
-                if (count) launches += 2;
+                if (count) launches += 1;
             }
-            psk_gemv_args gf{};
-            gf.n_w = 2; gf.w[0] = m->wg[L]; gf.w[1] = m->wu[L]; gf.out[0] = m->g1; gf.out[1] = m->g1; gf.ldo[0] = hid; gf.ldo[1] = hid; gf.silu_pair = 1;
-            gf.pro = 1; gf.pro_x = m->x; gf.pro_norm_w = m->ffn_norm[L]; gf.pro_eps = f.norm_eps;
-            if (mm(m, gf, a1, dim, 1)) return 2;
-            if (count) launches += 1;
-            if (which == 0) {
+            if (gu) {
+                psk_gemv_args gf{};
+                gf.n_w = 2; gf.w[0] = m->wg[L]; gf.w[1] = m->wu[L]; gf.out[0] = m->g1; gf.out[1] = m->g1; gf.ldo[0] = hid; gf.ldo[1] = hid; gf.silu_pair = 1;
+                gf.pro = 1; gf.pro_x = m->x; gf.pro_norm_w = m->ffn_norm[L]; gf.pro_eps = f.norm_eps;
+                if (mm(m, gf, a1, dim, 1)) return 2;
+                if (count) launches += 1;
+            }
+            if (dn) {
                 psk_gemv_args gd{};
                 gd.n_w = 1; gd.w[0] = m->wd[L]; gd.out[0] = m->att; gd.ldo[0] = dim;
                 gd.pro = 2; gd.pro_x = m->g1;
@@ -463,7 +469,7 @@ int ps_hip_model_bench_gemv(ps_hip_model *m, int reps, int which, double *seq_ms
                 if (count) launches += 1;
             }
         }
-        if (which == 0) {
+        if (which == 0 || which == 5) {
             psk_gemv_args gl{};
             gl.n_w = 1; gl.w[0] = m->output ? m->output : m->token_embd; gl.out[0] = m->logits; gl.ldo[0] = f.vocab_size;
             gl.pro = 1; gl.pro_x = m->x; gl.pro_norm_w = m->output_norm; gl.pro_eps = f.norm_eps;

@@ -141,3 +141,6 @@ struct psk_gemv6_args {
 int psk_gemv6(hipStream_t st, int n_cu, const psk_gemv6_args &a, ps_act act, int64_t K, int64_t bs);
 int psk_gemv_debug(int key, uint64_t *host_out, int n_words); // timeline buffer: arm / read back
 int psk_gemv(hipStream_t st, int n_cu, const psk_gemv_args &a, ps_act act, int vdt, int64_t K, int64_t bs);
+// second-generation single-column Q4_K mat-vec (k_gemv4.hip); -1: not covered, the caller falls back
+int psk_gemv4(hipStream_t st, int n_cu, const psk_gemv_args &a, ps_act act, int64_t K);
+unsigned long long *psk_gemv_dbg_buf(int epi, int pro); // timeline slot armed for this (epilogue, prologue) pair, or null

@@ -11,6 +11,7 @@ d = tempfile.mkdtemp(prefix="ps_tl_")
 synth.write_model_dir(d, "llama-8b-dims-4l", 12, n_ctx=512, seed=1)
 ctx = hip.Ctx(0)
 m = hip.Model(ctx, d, max_batch=8, n_ctx=512)
+ctx.check(ctx.L.ps_hip_debug_set(1, int(os.environ.get('G4_CFG', '0'))))
 mode = int(os.environ.get('TL_MODE', '1'))  # 1 eager launches, 0 hipGraph replay
 m.set_mode(mode)
 if mode == 0:
@@ -59,7 +60,7 @@ for key in keys:
     if (arr > 0).any():
         rel = (arr - ev[:, 0, 0][:, None]) / mhz
         rel[arr <= 0] = np.nan
-        print("  producer waves 0..15 at the first prologue barrier (us since workgroup entry, mean):", np.nanmean(rel, axis=0).round(2))
+        print("  waves 0..15: entry (gemv4) / arrival at the first prologue barrier (gemv3), us since workgroup entry, mean:", np.nanmean(rel, axis=0).round(2))
 # boundary between two consecutive kernels: gate/up (5) then down (2) of the same layer
 if os.environ.get('TL_BOUNDARY', '0') != '1':
     sys.exit(0)
