@@ -25,6 +25,33 @@ __device__ __forceinline__ float g4_silu_mul(float g, float u, const uint64_t *t
     return __fmul_rn(val, u);
 }
 
+// Q8_K quantization of one 256-element tile held 4 values per lane (quantize_row_q8_K_ref, ggml-quants.c:3799-3835), the
+// prologue's version of ps_quantize_tile: every tile is full (K % 256 == 0), no 16-sums, and the scale / 32-sums are
+// written by every lane of their group (same value, same address) instead of behind exec-mask branches -- the prologue is
+// issue-bound on a single wave per tile, so instructions are what it costs.
+__device__ __forceinline__ void g4_quantize_tile(const float v[4], const int e, const int t, int8_t *qs, float *d, int *bs32) {
+    int q[4];
+    const float am   = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    const float amax = wave_max_dpp(am); // max is order-independent: exact
+    float dd = 0.f;
+    if (amax == 0.f) { // wave-uniform
+        q[0] = q[1] = q[2] = q[3] = 0;
+    } else { // the first element (index order) with the largest |x| decides the sign of iscale
+        const unsigned long long hits = __ballot(am == amax);
+        const float mine = fabsf(v[0]) == amax ? v[0] : fabsf(v[1]) == amax ? v[1] : fabsf(v[2]) == amax ? v[2] : v[3];
+        const float mx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine), __ffsll((long long)hits) - 1));
+        const float iscale = __fdiv_rn(-127.f, mx);
+#pragma unroll
+        for (int i = 0; i < 4; i++) q[i] = min(127, __float2int_rn(__fmul_rn(iscale, v[i])));
+        dd = __fdiv_rn(1.0f, iscale);
+    }
+    int s = q[0] + q[1] + q[2] + q[3];
+    s += dpp_i<0xB1>(s); s += dpp_i<0x4E>(s); s += dpp_i<0x141>(s); // all 8 lanes of a 32-element group hold its sum
+    *(uint32_t *)(qs + e) = (uint32_t)(q[0] & 0xff) | ((uint32_t)(q[1] & 0xff) << 8) | ((uint32_t)(q[2] & 0xff) << 16) | ((uint32_t)(q[3] & 0xff) << 24);
+    d[t] = dd;
+    bs32[e >> 5] = s;
+}
+
 struct G4Mat {
     const uint8_t *qs, *aux;
     float *out;
@@ -162,16 +189,52 @@ __global__ __launch_bounds__((NW + 1) * 64) void gemv4_kernel(const G4Params p) 
             for (int i = threadIdx.x; i < nb32; i += NW * 64) lb[i] = (int)p.abs16[2 * i] + (int)p.abs16[2 * i + 1];
             __syncthreads();
         } else {
-            // (timeline: prologue events 24..27 of wave 0 land in the chain role's slots 24..27)
-            ps_qrow_compute<TR::VDT, (PRO == 1 ? 1 : 0), TPW>(xv, wv, p.eps, K, lq, ld, l16, red, NW, [&](int k, float dep) {
-                asm volatile("" ::"v"(dep));
-                if (dbg && wave == 0) dbg[32 + k] = __builtin_amdgcn_s_memtime();
-                if (STAGED && DC > 1 && k == (PRO == 1 ? 25 : 27)) issue(q[1], h[1], tS[1], uS[1]);
-                if (STAGED && DC > 2 && k == 27) {
+            // RMSNorm (PRO 1: ggml.c:12667-12720, double sum of squares, scale = 1/sqrtf(mean + eps), y = x * (w * scale)) and
+            // Q8_K quantization of this wave's tiles (tile t = wave + i * NW); timeline events 24..27 of wave 0 land in the
+            // chain role's slots 24..27
+            auto pmark = [&](int k) { if (dbg && wave == 0) dbg[32 + k] = __builtin_amdgcn_s_memtime(); };
+            float scale = 1.0f;
+            if (PRO == 1) {
+                double ss = 0.0;
 #pragma unroll
-                    for (int d = 2; d < DC; d++) issue(q[d], h[d], tS[d], uS[d]);
+                for (int i = 0; i < TPW; i++) {
+                    ss += (double)__fmul_rn(xv[i].x, xv[i].x);
+                    ss += (double)__fmul_rn(xv[i].y, xv[i].y);
+                    ss += (double)__fmul_rn(xv[i].z, xv[i].z);
+                    ss += (double)__fmul_rn(xv[i].w, xv[i].w);
                 }
-            }, lb);
+                pmark(24); // the row has arrived
+                ss = wave_sum_d_dpp(ss);
+                if (lane == 0) red[wave] = ss;
+                __syncthreads();
+                pmark(25);
+                if (STAGED && DC > 1) issue(q[1], h[1], tS[1], uS[1]);
+                double tot_ss = 0.0;
+#pragma unroll
+                for (int i = 0; i <= NW; i++) tot_ss += red[i];
+                const float mean = (float)(tot_ss / (double)K);
+                scale            = __fdiv_rn(1.0f, sqrtf(__fadd_rn(mean, p.eps)));
+                pmark(26);
+            }
+#pragma unroll
+            for (int i = 0; i < TPW; i++) {
+                const int t = wave + i * NW;
+                if (t >= n_units) continue; // wave-uniform (n_units tiles of 256)
+                float v[4] = {xv[i].x, xv[i].y, xv[i].z, xv[i].w};
+                if (PRO == 1) {
+                    v[0] = __fmul_rn(v[0], __fmul_rn(wv[i].x, scale));
+                    v[1] = __fmul_rn(v[1], __fmul_rn(wv[i].y, scale));
+                    v[2] = __fmul_rn(v[2], __fmul_rn(wv[i].z, scale));
+                    v[3] = __fmul_rn(v[3], __fmul_rn(wv[i].w, scale));
+                }
+                g4_quantize_tile(v, t * 256 + lane * 4, t, lq, ld, lb);
+            }
+            pmark(27);
+            if (STAGED) {
+#pragma unroll
+                for (int d = (PRO == 1 ? 2 : 1); d < DC; d++) issue(q[d], h[d], tS[d], uS[d]);
+            }
+            __syncthreads();
         }
         mark(); // 2: activation in LDS
         // 4. chunk it * DC + d from ring slot d
@@ -193,12 +256,15 @@ __global__ __launch_bounds__((NW + 1) * 64) void gemv4_kernel(const G4Params p) 
         // (measured: 2 us per chunk of the gate/up launch with the expf table in constant memory, 7 chunks per launch).
         const int ep_n = (p.split_q + 1) * 8;
         float *const epB = epA + ep_n, *const epC = epB + ep_n;
-        int kv_pos = 0;
+        int kv_pos = 0, rpos = 0;
+        if (EPI == 2) { kv_pos = p.rope.state->pos0; rpos = p.rope.rope_pos ? p.rope.rope_pos[0] : kv_pos; }
+        if (PRO == 1) { // the sum-of-squares exchange first: nobody waits for this wave's loads there
+            if (lane == 0) red[wave] = 0.0;
+            __syncthreads();
+        }
         if (EPI == 1) {
             if (lane < PS_EXP2F_N) exp_tab[lane] = ps_exp2f_tab[lane];
         } else {
-            int rpos = 0;
-            if (EPI == 2) { kv_pos = p.rope.state->pos0; rpos = p.rope.rope_pos ? p.rope.rope_pos[0] : kv_pos; }
             for (int tl0 = 0; tl0 < nt; tl0 += 8) { // lane (r, u): row r of local task tl0 + u
                 const int tl = tl0 + u;
                 if (tl >= nt) continue;
@@ -223,10 +289,6 @@ __global__ __launch_bounds__((NW + 1) * 64) void gemv4_kernel(const G4Params p) 
                 }
                 epA[tl * 8 + r] = va; epB[tl * 8 + r] = vb; epC[tl * 8 + r] = vc;
             }
-        }
-        if (PRO == 1) {
-            if (lane == 0) red[wave] = 0.0; // its slot of the sum-of-squares exchange
-            __syncthreads();
         }
         __syncthreads();
         mark(); // 1: activation in LDS
@@ -355,7 +417,8 @@ int launch_g4_kc(hipStream_t st, int grid, const G4Params &p, int epi, int pro) 
 
 } // namespace
 
-int g_g4_cfg = 0; // ps_hip_debug_set(1, cfg)
+int g_g4_cfg = 0;   // ps_hip_debug_set(1, cfg)
+int g_g4_flags = 0; // ps_hip_debug_set(2, flags): reserved for what-if switches
 
 // Single-column Q4_K mat-vec.  Returns -1 when the launch is not covered (the caller falls back to gemv3 / gemv1).
 int psk_gemv4(hipStream_t st, int n_cu, const psk_gemv_args &a, ps_act act, int64_t K) {
@@ -387,16 +450,10 @@ int psk_gemv4(hipStream_t st, int n_cu, const psk_gemv_args &a, ps_act act, int6
     p.dbg = psk_gemv_dbg_buf(epi, a.pro);
     // wave configuration (measured, tools/g4_variants.py): rows of a multiple of 7 units take 7 (14) producers
     const bool seven = p.n_units % 7 == 0;
-    switch (g_g4_cfg) {
-    case 1: return seven ? launch_g4_kc<7, 3, 0>(st, grid, p, epi, a.pro) : launch_g4_kc<8, 3, 0>(st, grid, p, epi, a.pro);
-    case 2: return seven ? launch_g4_kc<7, 3, 1>(st, grid, p, epi, a.pro) : launch_g4_kc<8, 3, 1>(st, grid, p, epi, a.pro);
-    case 3: return launch_g4_kc<7, 4, 0>(st, grid, p, epi, a.pro);
-    case 4: return launch_g4_kc<11, 2, 0>(st, grid, p, epi, a.pro);
-    case 5: return launch_g4_kc<11, 3, 0>(st, grid, p, epi, a.pro);
-    case 6: return seven ? launch_g4_kc<14, 2, 0>(st, grid, p, epi, a.pro) : launch_g4_kc<15, 2, 0>(st, grid, p, epi, a.pro);
-    case 7: return launch_g4_kc<7, 4, 1>(st, grid, p, epi, a.pro);
-    case 8: return seven ? launch_g4_kc<7, 2, 1>(st, grid, p, epi, a.pro) : launch_g4_kc<8, 2, 1>(st, grid, p, epi, a.pro);
-    case 9: return launch_g4_kc<11, 2, 1>(st, grid, p, epi, a.pro);
-    default: return seven ? launch_g4_kc<7, 2, 0>(st, grid, p, epi, a.pro) : launch_g4_kc<8, 2, 0>(st, grid, p, epi, a.pro);
+    switch (g_g4_cfg) { // (0 is the production configuration; the others are kept for tools/g4_variants.py)
+    case 1: return seven ? launch_g4_kc<7, 2, 0>(st, grid, p, epi, a.pro) : launch_g4_kc<8, 2, 0>(st, grid, p, epi, a.pro); // everything issued up front
+    case 2: return seven ? launch_g4_kc<7, 3, 1>(st, grid, p, epi, a.pro) : launch_g4_kc<8, 3, 1>(st, grid, p, epi, a.pro); // three chunks in flight
+    case 3: return launch_g4_kc<11, 2, 1>(st, grid, p, epi, a.pro);                                                          // twelve waves
+    default: return seven ? launch_g4_kc<7, 2, 1>(st, grid, p, epi, a.pro) : launch_g4_kc<8, 2, 1>(st, grid, p, epi, a.pro);
     }
 }

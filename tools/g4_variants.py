@@ -7,7 +7,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from powerserve_amd import gguf, hip, synth
 
-cfgs = [int(a) for a in sys.argv[1:]] or [0, 1, 2, 3, 4, 5, 6, 7]
+cfgs = [int(a) for a in sys.argv[1:]] or [0, 1, 2, 3, 4, 5, 6, 7]  # cfg + 100 * what-if flags
 d = os.path.join(os.environ.get("TMPDIR", "/tmp"), "ps_bench_llama-3.1-8b_Q4_K_1234")
 if not os.path.exists(os.path.join(d, ".done")):
     synth.write_model_dir(d, "llama-3.1-8b", gguf.NAME_TYPE["Q4_K"], n_ctx=4096, seed=1234)
@@ -28,7 +28,8 @@ mb = {2: 14.16, 3: 9.44, 1: 66.06, 4: 33.03, 5: 295.5, 0: 4221.4}
 names = {2: "QKV", 3: "O", 1: "gate/up", 4: "down", 5: "lm_head", 0: "all"}
 ref_ids = None
 for cfg in cfgs:
-    ctx.check(L.ps_hip_debug_set(1, cfg))
+    ctx.check(L.ps_hip_debug_set(1, cfg % 100))
+    ctx.check(L.ps_hip_debug_set(2, cfg // 100))
     line = f"cfg {cfg}:"
     for which in (2, 3, 1, 4, 5, 0):
         seq_ms, null_ms, n = C.c_double(), C.c_double(), C.c_int()
