@@ -206,7 +206,9 @@ int ps_hip_debug_timeline(ps_hip_ctx *ctx, int key, uint64_t *host_out, int n_wo
 int ps_hip_debug_set(int key, int value);
 /* bit 0: 0 = hipGraph replay of the decode step (default), 1 = eager launches (rocprofv3 needs them);
  * bit 1: 1 = run the O / gate-up / down mat-vecs of a layer as ONE chained launch (device-wide barriers from relaxed
- * atomics between the phases; needs every CU for this process; same results bit for bit) */
+ * atomics between the phases; needs every CU for this process; same results bit for bit);
+ * bit 2: 1 = single-token attention (scores, softmax, V.p) as ONE launch with a per-kv-head rendezvous instead of two
+ * launches (same results bit for bit; measured equal in time; needs every workgroup of its grid resident) */
 int ps_hip_model_set_mode(ps_hip_model *m, int mode);
 
 #ifdef __cplusplus

@@ -41,6 +41,7 @@ struct ps_hip_model {
     // arena
     float *x = nullptr, *q = nullptr, *k = nullptr, *v = nullptr, *att = nullptr, *hb = nullptr, *g1 = nullptr, *u1 = nullptr;
     unsigned *bars = nullptr; // device-wide barrier words of the chained launches, [n_layers][12*32]
+    unsigned *attn_sync = nullptr; // [32] ticket counters of the one-launch decode attention
     float *scores = nullptr, *logits = nullptr, *rope_table = nullptr;
     void *act_mem = nullptr;
     std::vector<float *> k_cache, v_cache;
@@ -148,6 +149,7 @@ static int enqueue_forward(ps_hip_model *m, int bs, bool lm_head, bool use_tree,
     aa.rope_pos = use_rope_pos ? m->rope_pos_dev : nullptr;
     aa.kv_vis = m->n_hidden ? m->kv_vis_dev : nullptr;
     aa.scale = 1.0f / sqrtf((float)f.head_size);
+    aa.sync = (m->mode & 4) ? m->attn_sync : nullptr; // mode bit 2: one-launch decode attention (measured equal to the two launches, 16.2 us; needs the GPU to itself)
 
     for (uint32_t L = 0; L < f.n_layers; L++) {
         ps_act a1 = act_for(dim);
@@ -166,8 +168,10 @@ static int enqueue_forward(ps_hip_model *m, int bs, bool lm_head, bool use_tree,
         if (mm(m, g, a1, dim, bs)) return 2;
 
         if (!fuse_rope) psl_rope_append(st, aa, bs);
-        psl_attn_scores(st, aa, bs);
-        psl_attn_softmax_pv(st, aa, bs);
+        if (!(bs == 1 && !use_tree && psl_attn_decode(st, c->n_cu, aa))) {
+            psl_attn_scores(st, aa, bs);
+            psl_attn_softmax_pv(st, aa, bs);
+        }
 
         psk_gemv_args go{};
         go.n_w = 1; go.w[0] = m->wo[L]; go.out[0] = m->x; go.ldo[0] = dim; go.residual = m->x;
@@ -247,7 +251,7 @@ int ps_hip_model_create(ps_hip_ctx *c, const ps_model_desc *d, ps_hip_model **ou
         dmalloc(m, (void **)&m->k, mb * kvd * 4) || dmalloc(m, (void **)&m->v, mb * kvd * 4) ||
         dmalloc(m, (void **)&m->att, mb * dim * 4) || dmalloc(m, (void **)&m->hb, mb * hid * 4) ||
         dmalloc(m, (void **)&m->g1, mb * hid * 4) || dmalloc(m, (void **)&m->u1, mb * hid * 4) ||
-        dmalloc(m, (void **)&m->bars, (size_t)f.n_layers * 12 * 32 * 4) ||
+        dmalloc(m, (void **)&m->bars, (size_t)f.n_layers * 12 * 32 * 4) || dmalloc(m, (void **)&m->attn_sync, 2048 * 4) ||
         dmalloc(m, (void **)&m->scores, mb * f.n_heads * nctx * 4) || dmalloc(m, (void **)&m->logits, mb * f.vocab_size * 4) ||
         dmalloc(m, (void **)&m->rope_table, nctx * f.head_size * 4) ||
         dmalloc(m, &m->act_mem, ps_act_bytes(dim > hid ? dim : hid, mb)) ||
@@ -256,6 +260,7 @@ int ps_hip_model_create(ps_hip_ctx *c, const ps_model_desc *d, ps_hip_model **ou
         dmalloc(m, (void **)&m->tree_dev, mb * mb) || dmalloc(m, (void **)&m->rope_pos_dev, mb * 4) || dmalloc(m, (void **)&m->kv_vis_dev, nctx) || dmalloc(m, (void **)&m->am_v, mb * 64 * 4) || dmalloc(m, (void **)&m->am_i, mb * 64 * 4))
         return fail();
     (void)hipMemsetAsync(m->bars, 0, (size_t)f.n_layers * 12 * 32 * 4, c->stream);
+    (void)hipMemsetAsync(m->attn_sync, 0, 2048 * 4, c->stream);
     (void)hipMemsetAsync(m->kv_vis_dev, 1, nctx, c->stream);
     m->kv_vis_host.assign(nctx, 1);
     m->k_cache.assign(L, nullptr); m->v_cache.assign(L, nullptr);
@@ -402,7 +407,10 @@ int ps_hip_model_decode_greedy(ps_hip_model *m, int32_t token, int steps, int32_
         }
     }
     PS_CHECK(c, hipMemcpyAsync(out_ids, m->ids_dev, (size_t)steps * 4, hipMemcpyDeviceToHost, c->stream));
+    unsigned stuck = 0;
+    PS_CHECK(c, hipMemcpyAsync(&stuck, m->attn_sync + 31, 4, hipMemcpyDeviceToHost, c->stream));
     PS_CHECK(c, hipStreamSynchronize(c->stream));
+    if (stuck) PS_FAIL(c, "decode_greedy: the one-launch attention timed out at its rendezvous (GPU shared or partitioned?); clear mode bit 2 for the two-launch path");
     m->position += (size_t)steps;
     return 0;
 }
@@ -499,7 +507,7 @@ int ps_hip_model_bench_gemv(ps_hip_model *m, int reps, int which, double *seq_ms
 }
 
 int ps_hip_model_set_mode(ps_hip_model *m, int mode) {
-    if (((m->mode ^ mode) & 2) && m->step_graph) { // the captured step bakes the launch plan in
+    if (((m->mode ^ mode) & 6) && m->step_graph) { // the captured step bakes the launch plan in
         (void)hipGraphExecDestroy(m->step_graph);
         m->step_graph = nullptr;
     }

@@ -36,10 +36,12 @@ struct psl_attn_args {
     const int32_t *rope_pos; // optional [bs]: RoPE position of each batch column (default: its cache slot pos0 + i)
     const uint8_t *kv_vis;   // optional [n_ctx]: 0 hides a cached slot (KVCacheInterface::mask / unmask)
     float scale;
+    unsigned *sync;          // [2048] words, zeroed once: [31] spin-timeout flag, [64 + 64 * kv head] ticket counter of the one-launch decode attention
 };
 void psl_rope_append(hipStream_t st, const psl_attn_args &a, int bs);
 void psl_attn_scores(hipStream_t st, const psl_attn_args &a, int bs);
 void psl_attn_softmax_pv(hipStream_t st, const psl_attn_args &a, int bs);
+bool psl_attn_decode(hipStream_t st, int n_cu, const psl_attn_args &a); // single token, scores + softmax + V.p in one launch; false: not covered
 size_t psl_attn_softmax_pv_lds(const psl_attn_args &a); // dynamic LDS bytes (grows with n_ctx)
 // two-stage arg-max (64 partials per row).  With state != NULL the final stage also does the greedy-decode
 // bookkeeping: token[0] = id, ids[state->n_out++] = id, state->pos0++.
