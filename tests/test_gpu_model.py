@@ -95,6 +95,37 @@ def test_chained_launch_is_bit_identical(ctx, oracle, tmp_path):
     om.close()
 
 
+def test_one_launch_attention_is_bit_identical(ctx, oracle, tmp_path):
+    """Opt-in mode bit 2: single-token attention as ONE launch (scores published write-through, per-kv-head ticket
+    rendezvous, cache-bypassing score loads) — the same ids and logits as the two-launch plan and as the oracle, eager
+    and hipGraph replay, past a few position groups so that several workgroups contribute scores."""
+    from oracle import binding as B
+    from powerserve_amd import hip, synth
+    d = str(tmp_path / "m")
+    mj = synth.write_model_dir(d, "tiny-llama", 12, n_ctx=256, seed=11)
+    cfg = B.make_config(mj["llm_config"])
+    om = oracle.model(cfg, mj["model_arch"], load_tensors(os.path.join(d, "ggml/weights.gguf")), n_threads=8)
+    prompt = np.random.default_rng(5).integers(0, cfg.vocab_size, 150)
+    want_ids, want_logits, *_ = om.generate(prompt, 32, 10, want_logits=True)
+    for mode in (4, 5):
+        gm = hip.Model(ctx, d, max_batch=32)
+        gm.set_mode(mode)
+        assert np.array_equal(gm.generate(prompt, 32, 10), want_ids), mode
+        gm.reset()
+        done = 0
+        while done < prompt.size - 1:
+            bs = min(32, prompt.size - 1 - done)
+            gm.forward(prompt[done:done + bs], np.arange(done, done + bs), lm_head=False)
+            done += bs
+        cur = int(prompt[-1])
+        for s in range(10):
+            lg, am = gm.forward([cur], [gm.position], lm_head=True)
+            assert np.array_equal(np.asarray(lg[0]).view(np.uint32), np.asarray(want_logits[s]).view(np.uint32)), (mode, s)
+            cur = int(want_ids[s])
+        gm.close()
+    om.close()
+
+
 def test_tree_mask_plumbing(ctx, tmp_path):
     """The batch forward takes an optional [bs][bs] tree mask (speculative verify; the reference's CPU
     executor ignores mask objects, executor.cpp:210-224, so there is no CPU golden for a real tree).  A tree mask that
