@@ -1,0 +1,202 @@
+// Q4_K batched mat-mul (prefill chunks, tree verify) on v_mfma_i32_16x16x32_i8 -- bit-exact with ggml_vec_dot_q4_K_q8_K.
+//
+// The AVX2 kernel (libs/ggml/src/ggml-quants.c:7809-7873) keeps, per super-block of 256 weights, ONE int32 per accumulator
+// lane u:  sumi[u] = sum over the 8 sub-blocks g of  scale[g] * dot4(q[g][4u..4u+3], y[g][4u..4u+3]),  accumulated in
+// int32 before the single  acc[u] = fma(d * y.d, (float)sumi[u], acc[u]).  Integers associate, and the 32 elements lane u
+// owns in a super-block are exactly one K = 32 contraction: for a tile of 16 weight rows x 16 activation columns and one u,
+//     D[row][col] = sum_k A[row][k] * B[k][col],   k = (g, e),  A = q4 * factor,  B = y
+// is one v_mfma_i32_16x16x32_i8.  The 6-bit scale cannot ride in an int8 operand whole (15 * 63 > 127), so it is split,
+// scale = 8 * hi + lo with 3-bit halves (q * 7 <= 105):  sumi = 8 * (A_hi . B) + (A_lo . B)  -- two MFMAs, the first result
+// shifted into the C input of the second.  Everything after sumi is the reference's fp32 arithmetic, per (row, column, u):
+// the eight acc chains, the four acc_m chains of the mins (ggml-quants.c:7831-7834), hsum_float_8.
+//
+// Operand layout (tools/micro/mfma32probe.hip): lane l supplies A[i = l % 16][k = 8 * (l / 16) ..+7] and
+// B[k = 8 * (l / 16) ..+7][j = l % 16]; result register r of lane l is D[i = 4 * (l / 16) + r][j = l % 16].  With
+// k = 8 * kb + 4 * half + e  <->  sub-block g = 2 * kb + half, element 4u + e:
+//   * A: the lane's 8 bytes come from ONE dword of the lane-major weight layout (ps_internal.h): byte 32 kb + 4u + e of
+//     the super-block holds element e of sub-block 2 kb in its low nibble and of sub-block 2 kb + 1 in its high nibble;
+//   * B: the quantizer writes a second, fragment-major copy of the Q8_K quants (ps_act::qf): per (16 columns,
+//     super-block) 4 KiB laid out [u / 2][lane][u % 2][half][4 B], so that a wave's B operands for two values of u are
+//     one fully coalesced 1 KiB load.
+// A workgroup is eight waves; a wave owns ONE 16 x 16 tile at a time (48 fp32 chains per lane) and walks K; the waves of a
+// workgroup take the eight column tiles of a 128-column block of the same 16 weight rows, so every weight byte is fetched
+// from HBM once per 128 columns (the other seven waves hit the CU's L1).  EPI 1 (SiLU(gate) * up) runs the gate tile's K
+// loop, keeps its four results, then the up tile's.
+#include "ps_gemv_dev.h"
+
+namespace {
+
+typedef int g4k_i32x4 __attribute__((ext_vector_type(4)));
+
+struct G4KMat {
+    const uint8_t *qs, *aux;
+    float *out;
+    const float *bias;
+    int64_t N, ldo;
+    int n_tiles; // N / 16
+};
+struct G4KParams {
+    G4KMat w[3];
+    int n_w, nsb, bs, n_tasks, ctw; // ctw: column tiles per workgroup (1, 2, 4 or 8); 8 / ctw row tasks per workgroup
+    const float *residual;
+    const int8_t *qf;   // fragment-major quants
+    const float *ad;    // [col][nsb]
+    const int16_t *abs16; // [col][K / 16]
+};
+
+__device__ __forceinline__ long g4k_pack(uint32_t lo, uint32_t hi) { return (long)(((unsigned long)hi << 32) | lo); }
+
+// one 16-row tile of one matrix against this wave's 16 columns: y[r] = result of row 4 * kb + r, column l % 16
+template <bool DUMMY = false>
+__device__ __forceinline__ void g4k_tile(const uint8_t *qs, const uint8_t *aux, const int tile, const int nsb, const int8_t *qf_ct,
+                                         const float *ad_col, const int16_t *bs_col, float (&y)[4]) {
+    const int lane = threadIdx.x & 63, m = lane & 15, kb = lane >> 4;
+    // A side: row m of the tile = row (m & 7) of row group 2 * tile + (m >> 3)
+    const uint8_t *qa = qs + ((size_t)(2 * tile + (m >> 3)) * nsb << 10) + (m & 7) * 128 + kb * 4;
+    const uint8_t *ha = aux + (size_t)(2 * tile + (m >> 3)) * nsb * 128 + (m & 7) * 16;
+    // D side: rows 4 kb + r of the tile: row group 2 * tile + (kb >> 1), rows (kb & 1) * 4 + r
+    const uint8_t *hd = aux + (size_t)(2 * tile + (kb >> 1)) * nsb * 128 + (kb & 1) * 64;
+    float acc[4][8], accm[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+#pragma unroll
+        for (int u = 0; u < 8; u++) acc[r][u] = 0.f;
+#pragma unroll
+        for (int v = 0; v < 4; v++) accm[r][v] = 0.f;
+    }
+    for (int sb = 0; sb < nsb; sb++) {
+        // ---- loads of this super-block
+        uint32_t wq[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) wq[u] = *(const uint32_t *)(qa + ((size_t)sb << 10) + u * 16);
+        const uint4 hA = *(const uint4 *)(ha + (size_t)sb * 128);
+        uint4 hD[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) hD[r] = *(const uint4 *)(hd + (size_t)sb * 128 + r * 16);
+        ps_u32x4 bq[4];
+#pragma unroll
+        for (int up = 0; up < 4; up++) bq[up] = *(const ps_u32x4 *)(qf_ct + ((size_t)sb << 12) + up * 1024 + lane * 16);
+        const float yd = ad_col[sb];
+        const ps_u32x4 b16a = *(const ps_u32x4 *)(bs_col + sb * 16), b16b = *(const ps_u32x4 *)(bs_col + sb * 16 + 8);
+        // ---- A operands: nibbles times the 3-bit halves of the sub-block scales 2 kb, 2 kb + 1 (get_scale_min_k4)
+        int sc0, sc1, mdum;
+        ps_scale_min_k4(2 * kb, hA.y, hA.z, hA.w, sc0, mdum);
+        ps_scale_min_k4(2 * kb + 1, hA.y, hA.z, hA.w, sc1, mdum);
+        const uint32_t f0h = (uint32_t)(sc0 >> 3) * 0x00010001u, f0l = (uint32_t)(sc0 & 7) * 0x00010001u;
+        const uint32_t f1h = (uint32_t)(sc1 >> 3) * 0x00010001u, f1l = (uint32_t)(sc1 & 7) * 0x00010001u;
+        // ---- q8 sums of 32 (q8s) and the mins of this lane's four rows
+        const uint32_t b16[8] = {b16a.x, b16a.y, b16a.z, b16a.w, b16b.x, b16b.y, b16b.z, b16b.w};
+        int q8s[8];
+#pragma unroll
+        for (int g = 0; g < 8; g++) q8s[g] = (int)(int16_t)(b16[g] & 0xffff) + (int)(int16_t)(b16[g] >> 16);
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const uint32_t lo = wq[u] & 0x0F0F0F0Fu, hi = (wq[u] >> 4) & 0x0F0F0F0Fu;
+            typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+            auto pkmul = [](uint32_t a, uint32_t f) { u16x2 va, vf; __builtin_memcpy(&va, &a, 4); __builtin_memcpy(&vf, &f, 4); va = va * vf; uint32_t o; __builtin_memcpy(&o, &va, 4); return o; };
+            const long a_hi = g4k_pack(pkmul(lo, f0h), pkmul(hi, f1h)), a_lo = g4k_pack(pkmul(lo, f0l), pkmul(hi, f1l));
+            const uint32_t b0 = (u & 1) ? bq[u >> 1].z : bq[u >> 1].x, b1 = (u & 1) ? bq[u >> 1].w : bq[u >> 1].y;
+            const long b = g4k_pack(b0, b1);
+            g4k_i32x4 c = {0, 0, 0, 0};
+            c = __builtin_amdgcn_mfma_i32_16x16x32_i8(a_hi, b, c, 0, 0, 0);
+            c = c << 3;
+            c = __builtin_amdgcn_mfma_i32_16x16x32_i8(a_lo, b, c, 0, 0, 0); // sumi[u] of rows 4 kb + r, this lane's column
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const float d = __fmul_rn(yd, ps_h2f((uint16_t)(hD[r].x & 0xffff)));
+                acc[r][u] = __fmaf_rn(d, (float)c[r], acc[r][u]);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) { // acc_m lane v: prod = mins[2v] * q8s[2v] + mins[2v+1] * q8s[2v+1]
+            const float dmin = __fmul_rn(-yd, ps_h2f((uint16_t)(hD[r].x >> 16)));
+            const uint32_t mn03 = hD[r].z & 0x3f3f3f3fu;
+            const uint32_t mn47 = ((hD[r].w >> 4) & 0x0f0f0f0fu) | (((hD[r].z >> 6) & 0x03030303u) << 4);
+#pragma unroll
+            for (int v = 0; v < 4; v++) {
+                const uint32_t mp = (v < 2) ? mn03 : mn47;
+                const int prod = __mul24(bfe8(mp, (2 * v) & 3), q8s[2 * v]) + __mul24(bfe8(mp, (2 * v + 1) & 3), q8s[2 * v + 1]);
+                accm[r][v] = __fmaf_rn(dmin, (float)prod, accm[r][v]);
+            }
+        }
+    }
+    // hsum_float_8 (ggml-quants.c:62-68) and the acc_m reduction, as row_reduce<PS_Q4_K> does with lane shifts
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        float s[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) s[k] = __fadd_rn(acc[r][k], acc[r][k + 4]);
+        float res = __fadd_rn(__fadd_rn(s[0], s[2]), __fadd_rn(s[1], s[3]));
+        const float mm = __fadd_rn(__fadd_rn(accm[r][0], accm[r][2]), __fadd_rn(accm[r][1], accm[r][3]));
+        y[r] = __fadd_rn(res, mm);
+    }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm4k_kernel(const G4KParams p) {
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int m = lane & 15, kb = lane >> 4;
+    // wave -> (row task, column tile)
+    const int ct = (int)blockIdx.y * p.ctw + (wave % p.ctw);
+    const int task = (int)blockIdx.x * (8 / p.ctw) + wave / p.ctw;
+    if (task >= p.n_tasks || ct * 16 >= p.bs) return;
+    int wi = 0, tile = task;
+    if (EPI != 1) {
+        if (p.n_w > 1 && tile >= p.w[0].n_tiles) { tile -= p.w[0].n_tiles; wi = 1; }
+        if (p.n_w > 2 && wi == 1 && tile >= p.w[1].n_tiles) { tile -= p.w[1].n_tiles; wi = 2; }
+    }
+    const G4KMat &W = wi == 0 ? p.w[0] : (wi == 1 ? p.w[1] : p.w[2]);
+    const int col = ct * 16 + m, colc = col < p.bs ? col : p.bs - 1; // (the last tile may be ragged: clamp the column metadata)
+    const int8_t *qf_ct = p.qf + ((size_t)ct * p.nsb << 12);
+    const float *ad_col = p.ad + (size_t)colc * p.nsb;
+    const int16_t *bs_col = p.abs16 + (size_t)colc * p.nsb * 16;
+    float y[4];
+    g4k_tile(W.qs, W.aux, tile, p.nsb, qf_ct, ad_col, bs_col, y);
+    if (EPI == 1) {
+        float yu[4];
+        g4k_tile(p.w[1].qs, p.w[1].aux, tile, p.nsb, qf_ct, ad_col, bs_col, yu);
+#pragma unroll
+        for (int r = 0; r < 4; r++) y[r] = ps_silu_mul(y[r], yu[r]);
+    }
+    if (col < p.bs) {
+        const int64_t row0 = (int64_t)tile * 16 + kb * 4;
+        float *o = W.out + (int64_t)col * W.ldo + row0;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            v[r] = y[r];
+            if (EPI != 1) {
+                if (W.bias) v[r] = __fadd_rn(v[r], W.bias[row0 + r]);
+                if (p.residual && wi == 0) v[r] = __fadd_rn(p.residual[(int64_t)col * W.ldo + row0 + r], v[r]);
+            }
+        }
+        *(float4 *)o = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+} // namespace
+
+// Q4_K batched mat-mul from fragment-major Q8_K activations (act.qf).  -1: not covered (the caller takes gemm8m).
+int psk_gemm4k(hipStream_t st, int n_cu, const psk_gemv_args &a, ps_act act, int64_t K, int64_t bs) {
+    static const bool off = getenv("PS_NO_GEMM4K") != nullptr; // (A/B switch for measurements)
+    if (off || a.pro != 0 || a.rope || a.n_w < 1 || !act.qf || K % 256) return -1;
+    G4KParams p{};
+    int tiles_total = 0;
+    for (int i = 0; i < a.n_w; i++) {
+        if (a.w[i]->dtype != PS_Q4_K || a.w[i]->K != K || a.w[i]->N % 16 || a.ldo[i] % 4) return -1;
+        p.w[i] = G4KMat{a.w[i]->qs, a.w[i]->aux, a.out[i], a.bias[i], a.w[i]->N, a.ldo[i], (int)(a.w[i]->N / 16)};
+        tiles_total += p.w[i].n_tiles;
+    }
+    const int epi = a.silu_pair ? 1 : 0;
+    if (epi == 1 && (a.n_w != 2 || a.w[0]->N != a.w[1]->N || a.ldo[0] != a.ldo[1])) return -1;
+    p.n_w = a.n_w; p.nsb = (int)(K / 256); p.bs = (int)bs;
+    p.n_tasks = epi == 1 ? p.w[0].n_tiles : tiles_total;
+    p.residual = a.residual; p.qf = act.qf; p.ad = act.d; p.abs16 = act.bs16;
+    const int n_ct = (int)((bs + 15) / 16);
+    p.ctw = n_ct >= 8 ? 8 : (n_ct >= 4 ? 4 : (n_ct >= 2 ? 2 : 1));
+    (void)n_cu;
+    const dim3 grid((unsigned)((p.n_tasks + 8 / p.ctw - 1) / (8 / p.ctw)), (unsigned)((n_ct + p.ctw - 1) / p.ctw));
+    if (epi == 1) hipLaunchKernelGGL(gemm4k_kernel<1>, grid, dim3(512), 0, st, p);
+    else hipLaunchKernelGGL(gemm4k_kernel<0>, grid, dim3(512), 0, st, p);
+    return 0;
+}

@@ -25,6 +25,7 @@ struct QuantArgs {
     int8_t *qs;
     float *d;
     int16_t *bs16;
+    int8_t *qf; // Q8_K batches: fragment-major copy for k_gemm4k.hip, or null
 };
 
 // MODE 1 (RMSNorm needs the whole row): one workgroup per row.
@@ -33,7 +34,8 @@ __global__ __launch_bounds__(256) void quantize_norm_kernel(QuantArgs a) {
     __shared__ double red[8];
     const int64_t row = blockIdx.x, K = a.K;
     const int64_t nblk = K / (VDT == PS_Q8_0 ? 32 : 256);
-    ps_quantize_row_wg<VDT, 1, TPW>(a.x + row * K, a.w, a.eps, K, a.qs + row * K, a.d + row * nblk, a.bs16 + row * (K / 16), red);
+    ps_quantize_row_wg<VDT, 1, TPW>(a.x + row * K, a.w, a.eps, K, a.qs + row * K, a.d + row * nblk, a.bs16 + row * (K / 16), red,
+                                    VDT == PS_Q8_K ? a.qf : nullptr, row);
 }
 // MODE 0 / 2: blocks are independent -> one wave per 256-element tile, grid (tiles/4, rows)
 template <int VDT, int MODE>
@@ -53,7 +55,8 @@ __global__ __launch_bounds__(256) void quantize_tiles_kernel(QuantArgs a) {
             v[2] = ps_silu_mul(xv.z, uv.z); v[3] = ps_silu_mul(xv.w, uv.w);
         }
     }
-    ps_quantize_tile<VDT>(v, live, e, t, a.qs + row * K, a.d + row * nblk, a.bs16 + row * (K / 16));
+    ps_quantize_tile<VDT>(v, live, e, t, a.qs + row * K, a.d + row * nblk, a.bs16 + row * (K / 16), nullptr,
+                          VDT == PS_Q8_K ? a.qf : nullptr, row, K / 256);
 }
 
 // SoA activation -> GGUF block layout (block_q8_0 34 B / block_q8_K 292 B), for parity tests of the
@@ -155,7 +158,7 @@ __global__ void repack_q6_K_kernel(const uint8_t *raw, int64_t nblk, uint8_t *ql
 
 void psk_quantize_act(hipStream_t st, int vdt, int mode, const float *x, const float *x2, const float *w, float eps,
                       int64_t K, int64_t rows, ps_act out) {
-    QuantArgs a{x, x2, w, eps, K, out.qs, out.d, out.bs16};
+    QuantArgs a{x, x2, w, eps, K, out.qs, out.d, out.bs16, (vdt == PS_Q8_K && rows >= 2 && K % 256 == 0) ? out.qf : nullptr};
     if (mode == 1) {
         dim3 g((unsigned)rows), b(256);
         const int64_t tpw = ((K + 255) / 256 + 3) / 4;

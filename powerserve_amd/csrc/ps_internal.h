@@ -53,10 +53,14 @@ struct ps_weight {
 //   qs   [rows][K] int8
 //   d    [rows][K/blk] float   (Q8_0: the fp16-rounded scale widened back to fp32; Q8_K: fp32 scale)
 //   bs16 [rows][K/16] int16    sums of 16 consecutive quants (== block_q8_K.bsums; also kept for Q8_0)
+//   qf   Q8_K only, optional: a second copy of the quants in the fragment-major order of the Q4_K batched mat-mul
+//        (k_gemm4k.hip): per (16 columns, super-block) 4 KiB  [u / 2][lane = kb * 16 + column % 16][u % 2][half][4 B]
+//        = quants 4u..4u+3 of sub-block 2 kb + half
 struct ps_act {
     int8_t *qs;
     float *d;
     int16_t *bs16;
+    int8_t *qf;
 };
 
 #define PS_CHECK(ctx, call)                                                                          \
@@ -77,7 +81,7 @@ struct ps_act {
 static inline size_t ps_act_bytes(int64_t K, int64_t rows) {
     // qs + d (worst case blk 32) + bs16, each 256-B aligned
     auto al = [](size_t x) { return (x + 255) / 256 * 256; };
-    return al((size_t)K * rows) + al((size_t)(K / 32) * rows * 4) + al((size_t)(K / 16) * rows * 2);
+    return al((size_t)K * rows) + al((size_t)(K / 32) * rows * 4) + al((size_t)(K / 16) * rows * 2) + al((size_t)K * ((rows + 15) / 16 * 16));
 }
 static inline ps_act ps_act_carve(void *base, int64_t K, int64_t rows) {
     auto al = [](size_t x) { return (x + 255) / 256 * 256; };
@@ -88,6 +92,8 @@ static inline ps_act ps_act_carve(void *base, int64_t K, int64_t rows) {
     a.d = (float *)p;
     p += al((size_t)(K / 32) * rows * 4);
     a.bs16 = (int16_t *)p;
+    p += al((size_t)(K / 16) * rows * 2);
+    a.qf = (int8_t *)p;
     return a;
 }
 
@@ -126,6 +132,7 @@ struct psk_gemv_args {
 bool psk_gemv_rope_ok(int wt, int64_t K); // the fused epilogue exists for this weight type / row length
 size_t psk_gemv_lds_col_bytes(int wt, int64_t K);
 int psk_gemm8(hipStream_t st, int n_cu, const psk_gemv_args &a, ps_act act, int64_t K, int64_t bs); // -1: not covered
+int psk_gemm4k(hipStream_t st, int n_cu, const psk_gemv_args &a, ps_act act, int64_t K, int64_t bs); // Q4_K on v_mfma_i32_16x16x32_i8 (k_gemm4k.hip); -1: not covered
 int psk_gemv_chain3(hipStream_t st, int n_cu, const psk_gemv_args a[3], unsigned *bar); // O -> gate/up -> down, one launch; -1: not covered
 int psk_gemv_max_cols(int wt, int64_t K); // widest column group one launch takes (16, 8 or 4; > 4 needs pro == 0)
 static inline int64_t ps_w_rg(int dtype) { return dtype == PS_Q4_0 ? 16 : 8; }

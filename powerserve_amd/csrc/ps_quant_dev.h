@@ -19,7 +19,8 @@ __device__ __forceinline__ float ps_silu_mul(float g, float u) {
 // quantize the 4 values of this lane (elements e..e+3 of tile t of the row); wave-collective
 template <int VDT>
 __device__ __forceinline__ void ps_quantize_tile(const float v[4], bool live, int64_t e, int64_t t, int8_t *qs, float *d,
-                                                 int16_t *bs16, int *bs32 = nullptr) { // bs32: optional int sums of 32 (two bs16)
+                                                 int16_t *bs16, int *bs32 = nullptr, // bs32: optional int sums of 32 (two bs16)
+                                                 int8_t *qf = nullptr, int64_t col = 0, int64_t nsb = 0) { // qf: fragment-major copy (ps_act::qf)
     const int lane = threadIdx.x & 63;
     int q[4];
     if (VDT == PS_Q8_0) {
@@ -53,6 +54,10 @@ __device__ __forceinline__ void ps_quantize_tile(const float v[4], bool live, in
         const uint32_t packed = (uint32_t)(q[0] & 0xff) | ((uint32_t)(q[1] & 0xff) << 8) |
                                 ((uint32_t)(q[2] & 0xff) << 16) | ((uint32_t)(q[3] & 0xff) << 24);
         *(uint32_t *)(qs + e) = packed;
+        if (qf) { // lane = (sub-block g, quad u) of super-block t: [16-column tile][t][u / 2][kb * 16 + col % 16][u % 2][half]
+            const int g = lane >> 3, u = lane & 7;
+            *(uint32_t *)(qf + ((((col >> 4) * nsb + t) << 12) + ((u >> 1) << 10) + ((((g >> 1) << 4) + (col & 15)) << 4) + ((u & 1) << 3) + ((g & 1) << 2))) = packed;
+        }
         if ((lane & 3) == 0) bs16[e / 16] = (int16_t)s16;
     }
     if (bs32) {
@@ -146,7 +151,7 @@ __device__ __forceinline__ void ps_qrow_compute(const float4 (&xv)[TPW], const f
 // Ends with __syncthreads().
 template <int VDT, int MODE, int TPW>
 __device__ __forceinline__ void ps_quantize_row_wg(const float *x, const float *w, float eps, int64_t K, int8_t *qs, float *d,
-                                                   int16_t *bs16, double *red) {
+                                                   int16_t *bs16, double *red, int8_t *qf = nullptr, int64_t col = 0) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int64_t n_tiles = (K + 255) / 256;
     for (int64_t t0 = 0; t0 < n_tiles; t0 += (int64_t)nw * TPW) { // one trip when K <= nw*TPW*256 (always, for MODE 1)
@@ -190,7 +195,7 @@ __device__ __forceinline__ void ps_quantize_row_wg(const float *x, const float *
                 v[2] = __fmul_rn(v[2], __fmul_rn(wv[i].z, scale));
                 v[3] = __fmul_rn(v[3], __fmul_rn(wv[i].w, scale));
             }
-            ps_quantize_tile<VDT>(v, live, e, t, qs, d, bs16);
+            ps_quantize_tile<VDT>(v, live, e, t, qs, d, bs16, nullptr, qf, col, K / 256);
         }
     }
     __syncthreads();
