@@ -46,8 +46,80 @@ struct G4KParams {
 
 __device__ __forceinline__ long g4k_pack(uint32_t lo, uint32_t hi) { return (long)(((unsigned long)hi << 32) | lo); }
 
-// one 16-row tile of one matrix against this wave's 16 columns: y[r] = result of row 4 * kb + r, column l % 16
-template <bool DUMMY = false>
+// the fp32 chains of one 16 x 16 tile: rows 4 kb + r of the tile, this lane's column
+struct G4KAcc {
+    float acc[4][8], accm[4][4];
+    __device__ __forceinline__ void clear() {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+#pragma unroll
+            for (int u = 0; u < 8; u++) acc[r][u] = 0.f;
+#pragma unroll
+            for (int v = 0; v < 4; v++) accm[r][v] = 0.f;
+        }
+    }
+    // hsum_float_8 (ggml-quants.c:62-68) and the acc_m reduction, as row_reduce<PS_Q4_K> does with lane shifts
+    __device__ __forceinline__ void reduce(float (&y)[4]) const {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            float s[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) s[k] = __fadd_rn(acc[r][k], acc[r][k + 4]);
+            const float res = __fadd_rn(__fadd_rn(s[0], s[2]), __fadd_rn(s[1], s[3]));
+            const float mm  = __fadd_rn(__fadd_rn(accm[r][0], accm[r][2]), __fadd_rn(accm[r][1], accm[r][3]));
+            y[r] = __fadd_rn(res, mm);
+        }
+    }
+};
+
+// one super-block of one tile: wq[u] = this lane's weight dword (row l % 16, bytes 32 kb + 4u..), hA = the header of row
+// l % 16, hD[r] = the headers of rows 4 kb + r, bq = the B fragments, yd / b16 = the column's scale and 16-sums
+__device__ __forceinline__ void g4k_superblock(G4KAcc &T, const uint32_t (&wq)[8], const uint4 hA, const uint4 (&hD)[4], const ps_u32x4 (&bq)[4],
+                                               const float yd, const ps_u32x4 b16a, const ps_u32x4 b16b, const int kb) {
+    // A operands: nibbles times the 3-bit halves of the sub-block scales 2 kb, 2 kb + 1 (get_scale_min_k4)
+    int sc0, sc1, mdum;
+    ps_scale_min_k4(2 * kb, hA.y, hA.z, hA.w, sc0, mdum);
+    ps_scale_min_k4(2 * kb + 1, hA.y, hA.z, hA.w, sc1, mdum);
+    const uint32_t f0h = (uint32_t)(sc0 >> 3) * 0x00010001u, f0l = (uint32_t)(sc0 & 7) * 0x00010001u;
+    const uint32_t f1h = (uint32_t)(sc1 >> 3) * 0x00010001u, f1l = (uint32_t)(sc1 & 7) * 0x00010001u;
+    const uint32_t b16[8] = {b16a.x, b16a.y, b16a.z, b16a.w, b16b.x, b16b.y, b16b.z, b16b.w};
+    int q8s[8]; // sums of 32 quants
+#pragma unroll
+    for (int g = 0; g < 8; g++) q8s[g] = (int)(int16_t)(b16[g] & 0xffff) + (int)(int16_t)(b16[g] >> 16);
+    float dr[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) dr[r] = __fmul_rn(yd, ps_h2f((uint16_t)(hD[r].x & 0xffff)));
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+        const uint32_t lo = wq[u] & 0x0F0F0F0Fu, hi = (wq[u] >> 4) & 0x0F0F0F0Fu;
+        typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+        auto pkmul = [](uint32_t a, uint32_t f) { u16x2 va, vf; __builtin_memcpy(&va, &a, 4); __builtin_memcpy(&vf, &f, 4); va = va * vf; uint32_t o; __builtin_memcpy(&o, &va, 4); return o; };
+        const long a_hi = g4k_pack(pkmul(lo, f0h), pkmul(hi, f1h)), a_lo = g4k_pack(pkmul(lo, f0l), pkmul(hi, f1l));
+        const uint32_t b0 = (u & 1) ? bq[u >> 1].z : bq[u >> 1].x, b1 = (u & 1) ? bq[u >> 1].w : bq[u >> 1].y;
+        const long b = g4k_pack(b0, b1);
+        g4k_i32x4 c = {0, 0, 0, 0};
+        c = __builtin_amdgcn_mfma_i32_16x16x32_i8(a_hi, b, c, 0, 0, 0);
+        c = c << 3;
+        c = __builtin_amdgcn_mfma_i32_16x16x32_i8(a_lo, b, c, 0, 0, 0); // sumi[u] of rows 4 kb + r, this lane's column
+#pragma unroll
+        for (int r = 0; r < 4; r++) T.acc[r][u] = __fmaf_rn(dr[r], (float)c[r], T.acc[r][u]);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) { // acc_m lane v: prod = mins[2v] * q8s[2v] + mins[2v+1] * q8s[2v+1]
+        const float dmin = __fmul_rn(-yd, ps_h2f((uint16_t)(hD[r].x >> 16)));
+        const uint32_t mn03 = hD[r].z & 0x3f3f3f3fu;
+        const uint32_t mn47 = ((hD[r].w >> 4) & 0x0f0f0f0fu) | (((hD[r].z >> 6) & 0x03030303u) << 4);
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+            const uint32_t mp = (v < 2) ? mn03 : mn47;
+            const int prod = __mul24(bfe8(mp, (2 * v) & 3), q8s[2 * v]) + __mul24(bfe8(mp, (2 * v + 1) & 3), q8s[2 * v + 1]);
+            T.accm[r][v] = __fmaf_rn(dmin, (float)prod, T.accm[r][v]);
+        }
+    }
+}
+
+// one 16-row tile of one matrix against this wave's 16 columns, everything straight from memory (small batches: the
+// waves of a workgroup work on different row tiles): y[r] = result of row 4 * kb + r, column l % 16
 __device__ __forceinline__ void g4k_tile(const uint8_t *qs, const uint8_t *aux, const int tile, const int nsb, const int8_t *qf_ct,
                                          const float *ad_col, const int16_t *bs_col, float (&y)[4]) {
     const int lane = threadIdx.x & 63, m = lane & 15, kb = lane >> 4;
@@ -56,16 +128,9 @@ __device__ __forceinline__ void g4k_tile(const uint8_t *qs, const uint8_t *aux, 
     const uint8_t *ha = aux + (size_t)(2 * tile + (m >> 3)) * nsb * 128 + (m & 7) * 16;
     // D side: rows 4 kb + r of the tile: row group 2 * tile + (kb >> 1), rows (kb & 1) * 4 + r
     const uint8_t *hd = aux + (size_t)(2 * tile + (kb >> 1)) * nsb * 128 + (kb & 1) * 64;
-    float acc[4][8], accm[4][4];
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-#pragma unroll
-        for (int u = 0; u < 8; u++) acc[r][u] = 0.f;
-#pragma unroll
-        for (int v = 0; v < 4; v++) accm[r][v] = 0.f;
-    }
+    G4KAcc T;
+    T.clear();
     for (int sb = 0; sb < nsb; sb++) {
-        // ---- loads of this super-block
         uint32_t wq[8];
 #pragma unroll
         for (int u = 0; u < 8; u++) wq[u] = *(const uint32_t *)(qa + ((size_t)sb << 10) + u * 16);
@@ -78,68 +143,101 @@ __device__ __forceinline__ void g4k_tile(const uint8_t *qs, const uint8_t *aux, 
         for (int up = 0; up < 4; up++) bq[up] = *(const ps_u32x4 *)(qf_ct + ((size_t)sb << 12) + up * 1024 + lane * 16);
         const float yd = ad_col[sb];
         const ps_u32x4 b16a = *(const ps_u32x4 *)(bs_col + sb * 16), b16b = *(const ps_u32x4 *)(bs_col + sb * 16 + 8);
-        // ---- A operands: nibbles times the 3-bit halves of the sub-block scales 2 kb, 2 kb + 1 (get_scale_min_k4)
-        int sc0, sc1, mdum;
-        ps_scale_min_k4(2 * kb, hA.y, hA.z, hA.w, sc0, mdum);
-        ps_scale_min_k4(2 * kb + 1, hA.y, hA.z, hA.w, sc1, mdum);
-        const uint32_t f0h = (uint32_t)(sc0 >> 3) * 0x00010001u, f0l = (uint32_t)(sc0 & 7) * 0x00010001u;
-        const uint32_t f1h = (uint32_t)(sc1 >> 3) * 0x00010001u, f1l = (uint32_t)(sc1 & 7) * 0x00010001u;
-        // ---- q8 sums of 32 (q8s) and the mins of this lane's four rows
-        const uint32_t b16[8] = {b16a.x, b16a.y, b16a.z, b16a.w, b16b.x, b16b.y, b16b.z, b16b.w};
-        int q8s[8];
-#pragma unroll
-        for (int g = 0; g < 8; g++) q8s[g] = (int)(int16_t)(b16[g] & 0xffff) + (int)(int16_t)(b16[g] >> 16);
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const uint32_t lo = wq[u] & 0x0F0F0F0Fu, hi = (wq[u] >> 4) & 0x0F0F0F0Fu;
-            typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-            auto pkmul = [](uint32_t a, uint32_t f) { u16x2 va, vf; __builtin_memcpy(&va, &a, 4); __builtin_memcpy(&vf, &f, 4); va = va * vf; uint32_t o; __builtin_memcpy(&o, &va, 4); return o; };
-            const long a_hi = g4k_pack(pkmul(lo, f0h), pkmul(hi, f1h)), a_lo = g4k_pack(pkmul(lo, f0l), pkmul(hi, f1l));
-            const uint32_t b0 = (u & 1) ? bq[u >> 1].z : bq[u >> 1].x, b1 = (u & 1) ? bq[u >> 1].w : bq[u >> 1].y;
-            const long b = g4k_pack(b0, b1);
-            g4k_i32x4 c = {0, 0, 0, 0};
-            c = __builtin_amdgcn_mfma_i32_16x16x32_i8(a_hi, b, c, 0, 0, 0);
-            c = c << 3;
-            c = __builtin_amdgcn_mfma_i32_16x16x32_i8(a_lo, b, c, 0, 0, 0); // sumi[u] of rows 4 kb + r, this lane's column
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const float d = __fmul_rn(yd, ps_h2f((uint16_t)(hD[r].x & 0xffff)));
-                acc[r][u] = __fmaf_rn(d, (float)c[r], acc[r][u]);
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < 4; r++) { // acc_m lane v: prod = mins[2v] * q8s[2v] + mins[2v+1] * q8s[2v+1]
-            const float dmin = __fmul_rn(-yd, ps_h2f((uint16_t)(hD[r].x >> 16)));
-            const uint32_t mn03 = hD[r].z & 0x3f3f3f3fu;
-            const uint32_t mn47 = ((hD[r].w >> 4) & 0x0f0f0f0fu) | (((hD[r].z >> 6) & 0x03030303u) << 4);
-#pragma unroll
-            for (int v = 0; v < 4; v++) {
-                const uint32_t mp = (v < 2) ? mn03 : mn47;
-                const int prod = __mul24(bfe8(mp, (2 * v) & 3), q8s[2 * v]) + __mul24(bfe8(mp, (2 * v + 1) & 3), q8s[2 * v + 1]);
-                accm[r][v] = __fmaf_rn(dmin, (float)prod, accm[r][v]);
-            }
-        }
+        g4k_superblock(T, wq, hA, hD, bq, yd, b16a, b16b, kb);
     }
-    // hsum_float_8 (ggml-quants.c:62-68) and the acc_m reduction, as row_reduce<PS_Q4_K> does with lane shifts
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-        float s[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) s[k] = __fadd_rn(acc[r][k], acc[r][k + 4]);
-        float res = __fadd_rn(__fadd_rn(s[0], s[2]), __fadd_rn(s[1], s[3]));
-        const float mm = __fadd_rn(__fadd_rn(accm[r][0], accm[r][2]), __fadd_rn(accm[r][1], accm[r][3]));
-        y[r] = __fadd_rn(res, mm);
-    }
+    T.reduce(y);
 }
 
-template <int EPI>
-__global__ __launch_bounds__(512) void gemm4k_kernel(const G4KParams p) {
+// 128-column blocks: all eight computing waves of a workgroup walk the same 16 weight rows.  Two things make the straight
+// version (every wave loading its own operands) slow there: the weights come from HBM (~2 us per super-block with nothing
+// but the next loads to hide behind), and the CU's address unit: a wave's eight dword loads of A touch 16 cache lines each,
+// eight waves repeat them, and the column metadata adds 48 more line look-ups per wave -- ~2200 cycles of address
+// processing per super-block step against ~800 of arithmetic.  So:
+//   * a NINTH wave touches the 18 lines of a super-block (2 KiB of quants + 2 x 128 B of headers; one dword per 128-B
+//     line) G4K_LEAD steps ahead: the weights are in the L2 when they are asked for;
+//   * the 512 computing threads fetch ONE dword each of the next super-block (coalesced, one step ahead) and park it in an
+//     LDS stage (rows padded to 144 B: a wave's A reads are at most 2-way bank conflicts); everybody reads A operands and
+//     headers from LDS behind ONE barrier per step (three stages: the one being written is never one a slow wave may
+//     still read).
+constexpr int G4K_LEAD = 10, G4K_ROW = 144, G4K_STAGE = 16 * G4K_ROW + 256;
+// stages 0 .. nsb-1: tile of (qs0, aux0); stages nsb .. n_stages-1 (EPI 1): the same tile of (qs1, aux1)
+__device__ __forceinline__ void g4k_warm_wave(const uint8_t *qs0, const uint8_t *aux0, const uint8_t *qs1, const uint8_t *aux1, const int tile,
+                                              const int nsb, const int n_stages, float *never) {
+    const int lane = threadIdx.x & 63;
+    const size_t off  = lane < 16 ? ((size_t)(2 * tile + (lane >> 3)) * nsb << 10) + (lane & 7) * 128 : (size_t)(2 * tile + (lane & 1)) * nsb * 128;
+    const size_t step = lane < 16 ? 1024 : 128;
+    const uint8_t *b0 = (lane < 16 ? qs0 : aux0) + off, *b1 = (lane < 16 ? qs1 : aux1) + off;
+    auto touch = [&](int st) -> uint32_t {
+        if (lane >= 18 || st >= n_stages) return 0u;
+        return *(const uint32_t *)(st < nsb ? b0 + (size_t)st * step : b1 + (size_t)(st - nsb) * step);
+    };
+    uint32_t sink = 0;
+    for (int st = 0; st < G4K_LEAD; st++) sink ^= touch(st);
+    __syncthreads(); // (stage 0 is parked)
+    for (int s0 = 0; s0 < n_stages; s0 += 4) { // one barrier per step, as the computing waves; four touches in flight
+        uint32_t v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) { v[k] = touch(s0 + k + G4K_LEAD); __syncthreads(); }
+#pragma unroll
+        for (int k = 0; k < 4; k++) sink ^= v[k];
+    }
+    if (sink == 0x9e3779b9u && n_stages < 0) never[0] = 0.f; // (keeps the touches alive; never true)
+}
+
+// one tile of the staged walk: `s_first` = index of its first step in the workgroup's step sequence (LDS stage = step % 3)
+__device__ __forceinline__ void g4k_tile_staged(const uint8_t *qs, const uint8_t *aux, const int tile, const int nsb, const int8_t *qf_ct,
+                                                const float *ad_col, const int16_t *bs_col, char *lds, const int s_first, const bool more,
+                                                const uint8_t *qs_next, const uint8_t *aux_next, float (&y)[4]) {
+    const int lane = threadIdx.x & 63, m = lane & 15, kb = lane >> 4, t = threadIdx.x;
+    // this thread's dword of a super-block: unit t >> 8 (row group 2 * tile + (t >> 8)), dword t & 255 = [r][u][j]
+    const size_t oq = ((size_t)(2 * tile + (t >> 8)) * nsb << 10) + (t & 255) * 4, oh = (size_t)(2 * tile + ((t >> 5) & 1)) * nsb * 128 + (t & 31) * 4;
+    const int lq = ((t >> 8) * 8 + ((t & 255) >> 5)) * G4K_ROW + (t & 31) * 4, lh = 16 * G4K_ROW + (t & 63) * 4;
+    G4KAcc T;
+    T.clear();
+    for (int sb = 0; sb < nsb; sb++) {
+        // next step's weights: one dword per thread (the first super-block of the following tile after the last one)
+        const bool last = sb + 1 == nsb;
+        const uint8_t *nqs = last ? qs_next : qs, *nax = last ? aux_next : aux;
+        const int nsbi = last ? 0 : sb + 1;
+        uint32_t nq = 0, nh = 0;
+        if (!last || more) {
+            nq = *(const uint32_t *)(nqs + oq + ((size_t)nsbi << 10));
+            if (t < 64) nh = *(const uint32_t *)(nax + oh + (size_t)nsbi * 128);
+        }
+        const char *st = lds + ((s_first + sb) % 3) * G4K_STAGE;
+        uint32_t wq[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) wq[u] = *(const uint32_t *)(st + m * G4K_ROW + u * 16 + kb * 4);
+        const uint4 hA = *(const uint4 *)(st + 16 * G4K_ROW + m * 16);
+        uint4 hD[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) hD[r] = *(const uint4 *)(st + 16 * G4K_ROW + (kb * 4 + r) * 16);
+        ps_u32x4 bq[4];
+#pragma unroll
+        for (int up = 0; up < 4; up++) bq[up] = *(const ps_u32x4 *)(qf_ct + ((size_t)sb << 12) + up * 1024 + lane * 16);
+        const float yd = ad_col[sb];
+        const ps_u32x4 b16a = *(const ps_u32x4 *)(bs_col + sb * 16), b16b = *(const ps_u32x4 *)(bs_col + sb * 16 + 8);
+        g4k_superblock(T, wq, hA, hD, bq, yd, b16a, b16b, kb);
+        if (!last || more) {
+            char *sn = lds + ((s_first + sb + 1) % 3) * G4K_STAGE;
+            *(uint32_t *)(sn + lq) = nq;
+            if (t < 64) *(uint32_t *)(sn + lh) = nh;
+        }
+        __syncthreads();
+    }
+    T.reduce(y);
+}
+
+// STAGED: 128-column blocks, nine waves: eight column tiles of ONE row task + the warm-up wave
+template <int EPI, bool STAGED>
+__global__ __launch_bounds__(STAGED ? 576 : 512) void gemm4k_kernel(const G4KParams p) {
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int m = lane & 15, kb = lane >> 4;
     // wave -> (row task, column tile)
-    const int ct = (int)blockIdx.y * p.ctw + (wave % p.ctw);
-    const int task = (int)blockIdx.x * (8 / p.ctw) + wave / p.ctw;
-    if (task >= p.n_tasks || ct * 16 >= p.bs) return;
+    const int ct = (STAGED && wave == 8) ? (int)blockIdx.y * 8 : (int)blockIdx.y * p.ctw + (wave % p.ctw);
+    const int task = STAGED ? (int)blockIdx.x : (int)blockIdx.x * (8 / p.ctw) + wave / p.ctw;
+    __shared__ __attribute__((aligned(16))) char lds[STAGED ? 3 * G4K_STAGE : 16];
+    if (!STAGED && (task >= p.n_tasks || ct * 16 >= p.bs)) return; // (STAGED: grid.x = tasks exactly; every wave stays for the barriers)
     int wi = 0, tile = task;
     if (EPI != 1) {
         if (p.n_w > 1 && tile >= p.w[0].n_tiles) { tile -= p.w[0].n_tiles; wi = 1; }
@@ -147,16 +245,38 @@ __global__ __launch_bounds__(512) void gemm4k_kernel(const G4KParams p) {
     }
     const G4KMat &W = wi == 0 ? p.w[0] : (wi == 1 ? p.w[1] : p.w[2]);
     const int col = ct * 16 + m, colc = col < p.bs ? col : p.bs - 1; // (the last tile may be ragged: clamp the column metadata)
-    const int8_t *qf_ct = p.qf + ((size_t)ct * p.nsb << 12);
+    const int ctc = ct * 16 < p.bs ? ct : (p.bs - 1) / 16; // (a wave past the batch walks the last tile's columns and stores nothing)
+    const int8_t *qf_ct = p.qf + ((size_t)ctc * p.nsb << 12);
     const float *ad_col = p.ad + (size_t)colc * p.nsb;
     const int16_t *bs_col = p.abs16 + (size_t)colc * p.nsb * 16;
     float y[4];
-    g4k_tile(W.qs, W.aux, tile, p.nsb, qf_ct, ad_col, bs_col, y);
-    if (EPI == 1) {
-        float yu[4];
-        g4k_tile(p.w[1].qs, p.w[1].aux, tile, p.nsb, qf_ct, ad_col, bs_col, yu);
+    if constexpr (STAGED) {
+        if (wave == 8) { // the warm-up wave
+            g4k_warm_wave(W.qs, W.aux, EPI == 1 ? p.w[1].qs : W.qs, EPI == 1 ? p.w[1].aux : W.aux, tile, p.nsb, EPI == 1 ? 2 * p.nsb : p.nsb, W.out);
+            return;
+        }
+        { // stage 0: the tile's first super-block
+            const int t = threadIdx.x;
+            const size_t oq = ((size_t)(2 * tile + (t >> 8)) * p.nsb << 10) + (t & 255) * 4, oh = (size_t)(2 * tile + ((t >> 5) & 1)) * p.nsb * 128 + (t & 31) * 4;
+            *(uint32_t *)(lds + ((t >> 8) * 8 + ((t & 255) >> 5)) * G4K_ROW + (t & 31) * 4) = *(const uint32_t *)(W.qs + oq);
+            if (t < 64) *(uint32_t *)(lds + 16 * G4K_ROW + t * 4) = *(const uint32_t *)(W.aux + oh);
+        }
+        __syncthreads();
+        g4k_tile_staged(W.qs, W.aux, tile, p.nsb, qf_ct, ad_col, bs_col, lds, 0, EPI == 1, p.w[1].qs, p.w[1].aux, y);
+        if (EPI == 1) {
+            float yu[4];
+            g4k_tile_staged(p.w[1].qs, p.w[1].aux, tile, p.nsb, qf_ct, ad_col, bs_col, lds, p.nsb, false, nullptr, nullptr, yu);
 #pragma unroll
-        for (int r = 0; r < 4; r++) y[r] = ps_silu_mul(y[r], yu[r]);
+            for (int r = 0; r < 4; r++) y[r] = ps_silu_mul(y[r], yu[r]);
+        }
+    } else {
+        g4k_tile(W.qs, W.aux, tile, p.nsb, qf_ct, ad_col, bs_col, y);
+        if (EPI == 1) {
+            float yu[4];
+            g4k_tile(p.w[1].qs, p.w[1].aux, tile, p.nsb, qf_ct, ad_col, bs_col, yu);
+#pragma unroll
+            for (int r = 0; r < 4; r++) y[r] = ps_silu_mul(y[r], yu[r]);
+        }
     }
     if (col < p.bs) {
         const int64_t row0 = (int64_t)tile * 16 + kb * 4;
@@ -193,10 +313,15 @@ int psk_gemm4k(hipStream_t st, int n_cu, const psk_gemv_args &a, ps_act act, int
     p.n_tasks = epi == 1 ? p.w[0].n_tiles : tiles_total;
     p.residual = a.residual; p.qf = act.qf; p.ad = act.d; p.abs16 = act.bs16;
     const int n_ct = (int)((bs + 15) / 16);
-    p.ctw = n_ct >= 8 ? 8 : (n_ct >= 4 ? 4 : (n_ct >= 2 ? 2 : 1));
+    p.ctw = (n_ct >= 8 && p.nsb % 4 == 0) ? 8 : (n_ct >= 4 ? 4 : (n_ct >= 2 ? 2 : 1)); // 8: every wave on the same rows + the warm-up wave
     (void)n_cu;
     const dim3 grid((unsigned)((p.n_tasks + 8 / p.ctw - 1) / (8 / p.ctw)), (unsigned)((n_ct + p.ctw - 1) / p.ctw));
-    if (epi == 1) hipLaunchKernelGGL(gemm4k_kernel<1>, grid, dim3(512), 0, st, p);
-    else hipLaunchKernelGGL(gemm4k_kernel<0>, grid, dim3(512), 0, st, p);
+    if (p.ctw == 8) {
+        if (epi == 1) hipLaunchKernelGGL((gemm4k_kernel<1, true>), grid, dim3(576), 0, st, p);
+        else hipLaunchKernelGGL((gemm4k_kernel<0, true>), grid, dim3(576), 0, st, p);
+    } else {
+        if (epi == 1) hipLaunchKernelGGL((gemm4k_kernel<1, false>), grid, dim3(512), 0, st, p);
+        else hipLaunchKernelGGL((gemm4k_kernel<0, false>), grid, dim3(512), 0, st, p);
+    }
     return 0;
 }
