@@ -76,10 +76,13 @@ struct G4KAcc {
 // l % 16, hD[r] = the headers of rows 4 kb + r, bq = the B fragments, yd / b16 = the column's scale and 16-sums
 __device__ __forceinline__ void g4k_superblock(G4KAcc &T, const uint32_t (&wq)[8], const uint4 hA, const uint4 (&hD)[4], const ps_u32x4 (&bq)[4],
                                                const float yd, const ps_u32x4 b16a, const ps_u32x4 b16b, const int kb) {
-    // A operands: nibbles times the 3-bit halves of the sub-block scales 2 kb, 2 kb + 1 (get_scale_min_k4)
-    int sc0, sc1, mdum;
-    ps_scale_min_k4(2 * kb, hA.y, hA.z, hA.w, sc0, mdum);
-    ps_scale_min_k4(2 * kb + 1, hA.y, hA.z, hA.w, sc1, mdum);
+    // A operands: nibbles times the 3-bit halves of the sub-block scales 2 kb, 2 kb + 1 (get_scale_min_k4, branch-free:
+    // sub-blocks 0..3 sit in the low 6 bits of scale bytes 0..3, sub-blocks 4..7 are spread over bytes 8..11 and the top
+    // bits of bytes 0..3)
+    const int is0 = 2 * kb, sh0 = 8 * (is0 & 3), sh1 = sh0 + 8;
+    const uint32_t a0 = (hA.y >> sh0) & 0xff, a1 = (hA.y >> sh1) & 0xff, c0 = (hA.w >> sh0) & 0xff, c1 = (hA.w >> sh1) & 0xff;
+    const int sc0 = kb < 2 ? (int)(a0 & 63) : (int)((c0 & 0xF) | ((a0 >> 6) << 4));
+    const int sc1 = kb < 2 ? (int)(a1 & 63) : (int)((c1 & 0xF) | ((a1 >> 6) << 4));
     const uint32_t f0h = (uint32_t)(sc0 >> 3) * 0x00010001u, f0l = (uint32_t)(sc0 & 7) * 0x00010001u;
     const uint32_t f1h = (uint32_t)(sc1 >> 3) * 0x00010001u, f1l = (uint32_t)(sc1 & 7) * 0x00010001u;
     const uint32_t b16[8] = {b16a.x, b16a.y, b16a.z, b16a.w, b16b.x, b16b.y, b16b.z, b16b.w};
@@ -89,20 +92,32 @@ __device__ __forceinline__ void g4k_superblock(G4KAcc &T, const uint32_t (&wq)[8
     float dr[4];
 #pragma unroll
     for (int r = 0; r < 4; r++) dr[r] = __fmul_rn(yd, ps_h2f((uint16_t)(hD[r].x & 0xffff)));
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    auto pkmul = [](uint32_t a, uint32_t f) { u16x2 va, vf; __builtin_memcpy(&va, &a, 4); __builtin_memcpy(&vf, &f, 4); va = va * vf; uint32_t o; __builtin_memcpy(&o, &va, 4); return o; };
+    // the MFMAs in rounds of four independent ones (the second round of a group takes the first round's results, shifted,
+    // as its C input): the matrix core's latency is covered by the other three, not by wait states
 #pragma unroll
-    for (int u = 0; u < 8; u++) {
-        const uint32_t lo = wq[u] & 0x0F0F0F0Fu, hi = (wq[u] >> 4) & 0x0F0F0F0Fu;
-        typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-        auto pkmul = [](uint32_t a, uint32_t f) { u16x2 va, vf; __builtin_memcpy(&va, &a, 4); __builtin_memcpy(&vf, &f, 4); va = va * vf; uint32_t o; __builtin_memcpy(&o, &va, 4); return o; };
-        const long a_hi = g4k_pack(pkmul(lo, f0h), pkmul(hi, f1h)), a_lo = g4k_pack(pkmul(lo, f0l), pkmul(hi, f1l));
-        const uint32_t b0 = (u & 1) ? bq[u >> 1].z : bq[u >> 1].x, b1 = (u & 1) ? bq[u >> 1].w : bq[u >> 1].y;
-        const long b = g4k_pack(b0, b1);
-        g4k_i32x4 c = {0, 0, 0, 0};
-        c = __builtin_amdgcn_mfma_i32_16x16x32_i8(a_hi, b, c, 0, 0, 0);
-        c = c << 3;
-        c = __builtin_amdgcn_mfma_i32_16x16x32_i8(a_lo, b, c, 0, 0, 0); // sumi[u] of rows 4 kb + r, this lane's column
+    for (int uh = 0; uh < 8; uh += 4) { // (four at a time: eight keep 48 more registers alive than the 168 of a nine-wave workgroup allow)
+        g4k_i32x4 cc[4];
+        long al[4], bb[4];
 #pragma unroll
-        for (int r = 0; r < 4; r++) T.acc[r][u] = __fmaf_rn(dr[r], (float)c[r], T.acc[r][u]);
+        for (int k = 0; k < 4; k++) {
+            const int u = uh + k;
+            const uint32_t lo = wq[u] & 0x0F0F0F0Fu, hi = (wq[u] >> 4) & 0x0F0F0F0Fu;
+            const long a_hi = g4k_pack(pkmul(lo, f0h), pkmul(hi, f1h));
+            al[k] = g4k_pack(pkmul(lo, f0l), pkmul(hi, f1l));
+            const uint32_t b0 = (u & 1) ? bq[u >> 1].z : bq[u >> 1].x, b1 = (u & 1) ? bq[u >> 1].w : bq[u >> 1].y;
+            bb[k] = g4k_pack(b0, b1);
+            const g4k_i32x4 z = {0, 0, 0, 0};
+            cc[k] = __builtin_amdgcn_mfma_i32_16x16x32_i8(a_hi, bb[k], z, 0, 0, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) cc[k] = __builtin_amdgcn_mfma_i32_16x16x32_i8(al[k], bb[k], cc[k] << 3, 0, 0, 0); // sumi[u] of rows 4 kb + r, this lane's column
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) T.acc[r][uh + k] = __fmaf_rn(dr[r], (float)cc[k][r], T.acc[r][uh + k]);
+        }
     }
 #pragma unroll
     for (int r = 0; r < 4; r++) { // acc_m lane v: prod = mins[2v] * q8s[2v] + mins[2v+1] * q8s[2v+1]
@@ -194,6 +209,9 @@ __device__ __forceinline__ void g4k_tile_staged(const uint8_t *qs, const uint8_t
     const int lq = ((t >> 8) * 8 + ((t & 255) >> 5)) * G4K_ROW + (t & 31) * 4, lh = 16 * G4K_ROW + (t & 63) * 4;
     G4KAcc T;
     T.clear();
+    ps_u32x4 bn[4]; // the B fragments of the next super-block (L2: a few hundred cycles -- one step ahead is enough)
+#pragma unroll
+    for (int up = 0; up < 4; up++) bn[up] = *(const ps_u32x4 *)(qf_ct + up * 1024 + lane * 16);
     for (int sb = 0; sb < nsb; sb++) {
         // next step's weights: one dword per thread (the first super-block of the following tile after the last one)
         const bool last = sb + 1 == nsb;
@@ -212,11 +230,14 @@ __device__ __forceinline__ void g4k_tile_staged(const uint8_t *qs, const uint8_t
         uint4 hD[4];
 #pragma unroll
         for (int r = 0; r < 4; r++) hD[r] = *(const uint4 *)(st + 16 * G4K_ROW + (kb * 4 + r) * 16);
-        ps_u32x4 bq[4];
-#pragma unroll
-        for (int up = 0; up < 4; up++) bq[up] = *(const ps_u32x4 *)(qf_ct + ((size_t)sb << 12) + up * 1024 + lane * 16);
+        const ps_u32x4 bq[4] = {bn[0], bn[1], bn[2], bn[3]};
         const float yd = ad_col[sb];
         const ps_u32x4 b16a = *(const ps_u32x4 *)(bs_col + sb * 16), b16b = *(const ps_u32x4 *)(bs_col + sb * 16 + 8);
+        {
+            const int nb = last ? 0 : sb + 1; // (the following tile of an EPI 1 pair meets the same columns from super-block 0)
+#pragma unroll
+            for (int up = 0; up < 4; up++) bn[up] = *(const ps_u32x4 *)(qf_ct + ((size_t)nb << 12) + up * 1024 + lane * 16);
+        }
         g4k_superblock(T, wq, hA, hD, bq, yd, b16a, b16b, kb);
         if (!last || more) {
             char *sn = lds + ((s_first + sb + 1) % 3) * G4K_STAGE;
