@@ -63,9 +63,10 @@ def ensure_model(args, rank, barrier):
     return d
 
 
-def cpu_baseline(model_dir, n_ctx, prompt, steps):
-    """CPU port (oracle/ps_oracle.c, bit-exact vs the real reference) on this host: bounded sample."""
-    from oracle import binding as B  # checker/baseline only — never on the product path
+def cpu_port(model_dir, prompt, steps):
+    """CPU port (oracle/ps_oracle.c, bit-exact vs the real reference) on this host, bounded sample: the parity checker of
+    the headline model (same GGUF weights, same short prompt as the GPU leg) and a second CPU number."""
+    from oracle import binding as B  # checker/baseline only -- never on the product path
     from powerserve_amd import gguf, synth
     mj = synth.load_model_json(model_dir)
     llm = dict(mj["llm_config"])
@@ -77,11 +78,62 @@ def cpu_baseline(model_dir, n_ctx, prompt, steps):
     nth = max(1, min(cores - 1, 48))
     m = B.Oracle().model(cfg, mj["model_arch"], tensors, n_threads=nth)
     p = np.asarray(prompt[:4], dtype=np.int32)
-    ids, _, tp, td = m.generate(p, 4, steps)
+    ids, logits, tp, td = m.generate(p, 4, steps, want_logits=True)
     m.close()
     return {"value": steps / td, "unit": "tokens/s", "cores": nth, "kind": "port",
             "sample": f"{steps} greedy decode steps after a {p.size - 1}-token prefill (n_kv<{p.size + steps}), same GGUF weights; "
-                      f"prefill {(p.size - 1) / max(tp, 1e-9):.2f} tok/s", "host_cores": cores, "ids": [int(i) for i in ids]}
+                      f"prefill {(p.size - 1) / max(tp, 1e-9):.2f} tok/s", "host_cores": cores, "ids": [int(i) for i in ids]}, p, ids, logits
+
+
+def cpu_reference(model_dir, cfg, tokens=2):
+    """The REAL reference on this host: powerserve_compute_forward_mul_mat of the vendored ggml (AVX2 vec_dot_q4_K_q8_K,
+    quantize_row_q8_K) compiled from /root/reference into oracle/_ref/libps_ref.so, called through the reference's own
+    ThreadPool over the 7 * L + 1 mat-muls of a decode token (the op that is > 90 % of the reference's decode time,
+    SURVEY.md 8a3) on the bench model's weights.  Bounded sample: `tokens` passes over all layers.  Returns None when
+    the library is not there."""
+    from oracle import binding as B  # baseline only
+    from powerserve_amd import gguf
+    if not B.have_ref():
+        return None
+    cores = os.cpu_count() or 1
+    nth = max(1, min(cores - 1, 48))
+    ref = B.Ref(n_threads=nth)
+    rd = gguf.GGUFReader(os.path.join(model_dir, "ggml", "weights.gguf"))
+    rng = np.random.default_rng(1)
+    xs = {k: rng.standard_normal(k).astype(np.float32) for k in (cfg.dim, cfg.hidden_dim)}
+    names = []
+    for L in range(cfg.n_layers):
+        names += [f"blk.{L}.{n}.weight" for n in ("attn_q", "attn_k", "attn_v", "attn_output", "ffn_gate", "ffn_up", "ffn_down")]
+    names.append("output.weight" if "output.weight" in rd.tensors else "token_embd.weight")
+    mats = []
+    for n in names:
+        ti = rd.tensors[n]
+        mats.append((ti.type, np.asarray(rd.data(n)), int(ti.ne[0]), int(ti.ne[1])))
+    nbytes = sum(m[1].nbytes for m in mats)
+    ref.mul_mat(*mats[0], xs[mats[0][2]])  # page the pool in
+    t0 = time.perf_counter()
+    for _ in range(tokens):
+        for t, w, K, N in mats:
+            ref.mul_mat(t, w, K, N, xs[K])
+    dt = (time.perf_counter() - t0) / tokens
+    ref.close()
+    return {"value": 1.0 / dt, "unit": "tokens/s", "cores": nth, "kind": "reference",
+            "sample": f"{tokens} x the {len(mats)} quantized mat-muls of one decode token ({nbytes / 1e9:.2f} GB of GGUF weights) through "
+                      f"powerserve_compute_forward_mul_mat on the reference's ThreadPool ({nth} threads; attention, norms and sampling "
+                      f"not included: an upper bound of the reference's decode rate)",
+            "host_cores": cores, "weight_GBps": nbytes / dt / 1e9}
+
+
+def gpu_short_run(model, p, ids_cpu):
+    """the GPU on the CPU leg's short prompt, teacher-forced with the CPU's ids: logits of every step"""
+    model.reset()
+    model.forward(p[:-1], np.arange(p.size - 1), lm_head=False)
+    cur, out_ids, out_logits = int(p[-1]), [], []
+    for s in range(len(ids_cpu)):
+        lg, am = model.forward([cur], [model.position], lm_head=True)
+        out_ids.append(int(am[0])); out_logits.append(np.array(lg[0]))
+        cur = int(ids_cpu[s])
+    return out_ids, out_logits
 
 
 def broadcast_prompt(dist, prompt, rank, device="cuda"):
@@ -108,8 +160,22 @@ def max_over_ranks(dist, values, device="cuda"):
     return [float(v) for v in tt]
 
 
+def relaunch_distributed(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher: re-exec under torch.distributed.run, one rank per GPU
+    (the same command line the driver uses)."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.execv(sys.executable, cmd)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        relaunch_distributed(args)  # does not return
     # the contract is ONE JSON line on stdout: libraries that chat on fd 1 (RCCL prints its library path at init) are
     # sent to stderr for the duration of the run
     sys.stdout.flush()
@@ -118,6 +184,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and not (args.gpus == 1 and world == 1):
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU")
     dist = None
     if world > 1 or args.force_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -206,9 +274,17 @@ def main():
             "roofline": rf,
         }
         if not args.no_cpu_baseline:
-            try:
-                out["cpu_baseline"] = cpu_baseline(model_dir, args.n_ctx, prompt, args.cpu_steps)
-            except Exception as e:  # the baseline must never take the GPU number down with it
+            try:  # the baselines must never take the GPU number down with them
+                port, p_short, ids_cpu, logits_cpu = cpu_port(model_dir, prompt, args.cpu_steps)
+                ids_gpu, logits_gpu = gpu_short_run(model, p_short, ids_cpu)
+                rel = max(float(np.abs(g - c).max() / max(np.abs(c).max(), 1e-30)) for g, c in zip(logits_gpu, logits_cpu))
+                out["parity"] = {"model": f"{args.preset} {args.wtype} (the bench model, all layers)", "checker": "oracle/ps_oracle.c (bit-exact vs the real reference)",
+                                 "prompt_tokens": int(p_short.size), "steps": len(ids_cpu), "ids_equal": [int(i) for i in ids_cpu] == ids_gpu,
+                                 "max_rel_logit_err": rel, "logits_bit_equal": all(np.array_equal(g.view(np.uint32), np.asarray(c, dtype=np.float32).view(np.uint32)) for g, c in zip(logits_gpu, logits_cpu))}
+                out["cpu_port"] = port
+                refb = cpu_reference(model_dir, cfg)
+                out["cpu_baseline"] = refb if refb is not None else port
+            except Exception as e:
                 out["cpu_baseline"] = {"value": None, "error": repr(e)}
     model.close()
     ctx.close()
@@ -221,14 +297,18 @@ def main():
         print(json.dumps(out), flush=True)
 
 
-def _pmc_traffic(kernel_key):
-    """HBM bytes per launch of the dominant kernel from the committed PMC pass (profiles/r01_pmc_traffic.json, produced
-    by tools/pmc_summary.py from a separate `rocprofv3 --pmc FETCH_SIZE` run of this same command; FETCH_SIZE doubled as
-    MI355X_MICROARCH.md prescribes for gfx950).  A live bench run cannot collect counters; null when absent."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+GATE_UP_KERNEL = "gemv4_kernel<8, 2, 2, 1, 1, 1>"  # <NW 8, DC 2, TPW 2, staged, EPI 1 SiLU(gate)*up, PRO 1 RMSNorm+Q8_K>
+
+
+def _pmc_traffic(kernel):
+    """HBM bytes per launch of the dominant kernel from the committed PMC pass (profiles/r02_pmc_traffic.json, produced by
+    tools/pmc_summary.py from a separate `rocprofv3 --pmc FETCH_SIZE` run of this same command; FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for gfx950).  A live bench run cannot collect counters: the record is keyed by the
+    kernel's full template name, so a kernel that has changed since the pass reports null instead of a stale number."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_traffic.json")
     try:
         with open(path) as f:
-            return json.load(f).get(kernel_key, {}).get("hbm_bytes_per_launch")
+            return json.load(f).get(kernel, {}).get("hbm_bytes_per_launch")
     except Exception:
         return None
 
@@ -239,7 +319,7 @@ def gemv_roofline(ctx, model, wbytes, gate_up_bytes, is_headline):
     The library replays that launch for every layer (each layer's own weights, so every launch streams HBM-cold bytes
     exactly like in the real step; same kernel and fused RMSNorm prologue as the decode step) between HIP events on the
     backend stream: achieved = GGUF bytes of the two matrices / average launch duration.  rocprofv3's per-kernel
-    average for gemv3_kernel<..., EPI 1, PRO 1> (profiles/) is the cross-check.  The same measurement over ALL mat-vec
+    average for that kernel (profiles/r02_decode_kernel_stats_*) is the cross-check.  The same measurement over ALL mat-vec
     launches of a token and the cost of an empty launch are reported next to it."""
     import ctypes as C
     L = ctx.L
@@ -257,9 +337,9 @@ def gemv_roofline(ctx, model, wbytes, gate_up_bytes, is_headline):
     a_ms, a_null, a_n = run(0)
     avg_us = 1e3 * g_ms / g_n
     achieved = gate_up_bytes / (avg_us * 1e-6) / 1e9
-    return {"bound": "hbm", "kernel": "gemv3_kernel<Q4_K, EPI 1 (SiLU(gate)*up), PRO 1 (RMSNorm+Q8_K)>: gate/up mat-vec, one launch per layer",
+    return {"bound": "hbm", "kernel": GATE_UP_KERNEL + ": gate/up mat-vec (Q4_K, RMSNorm + Q8_K prologue, SiLU(gate)*up epilogue), one launch per layer",
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": _pmc_traffic("gate_up") if is_headline else None,
+            "traffic": _pmc_traffic(GATE_UP_KERNEL) if is_headline else None,
             "bytes_per_launch": gate_up_bytes, "avg_launch_us": avg_us, "launches_timed": 20 * g_n,
             "empty_launch_us": 1e3 * g_null / g_n,
             "all_matvec": {"launches_per_token": a_n, "ms_per_token": a_ms, "bytes_per_token": wbytes,
