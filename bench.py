@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--model-dir", default=None)
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed/RCCL even for one rank (tests the N>1 code path)")
     ap.add_argument("--eager", action="store_true", help="eager launches instead of hipGraph replay (rocprofv3 runs)")
+    ap.add_argument("--no-graph-path", action="store_true", help="skip the Graph -> Executor -> HIPBackend::plan leg (libps_host.so)")
+    ap.add_argument("--graph-steps", type=int, default=32)
     return ap.parse_args()
 
 
@@ -122,6 +124,33 @@ def cpu_reference(model_dir, cfg, tokens=2):
                       f"powerserve_compute_forward_mul_mat on the reference's ThreadPool ({nth} threads; attention, norms and sampling "
                       f"not included: an upper bound of the reference's decode rate)",
             "host_cores": cores, "weight_GBps": nbytes / dt / 1e9}
+
+
+def graph_path(model_dir, device, args, prompt):
+    """The same workload through the reference-shaped host side (libps_host.so): every forward builds the reference's
+    op graph with the NormAttention / FFN builders, Executor::run hands it to HIPBackend::plan, which lowers the canonical
+    sequence to the fused launches.  Prefill in chunks, then single-token forwards with the logits copied to the host and
+    arg-maxed there (ModelTokenIterator's loop, src/model/model.hpp:117-184)."""
+    from powerserve_amd import host
+    hm = host.HostModel(model_dir, device, max_batch=max(args.batch, 1), n_ctx=args.n_ctx)
+    t0 = time.perf_counter()
+    done = 0
+    while done < prompt.size - 1:
+        bs = min(args.batch, prompt.size - 1 - done)
+        hm.forward(prompt[done:done + bs], np.arange(done, done + bs), lm_head=False)
+        done += bs
+    t1 = time.perf_counter()
+    cur, ids = int(prompt[-1]), []
+    for s in range(args.graph_steps):
+        lg = hm.forward([cur], [done + s], lm_head=True)
+        cur = int(np.argmax(lg[0]))
+        ids.append(cur)
+    t2 = time.perf_counter()
+    n_plans, n_low = hm.plan_stats()
+    hm.close()
+    return {"prefill_tokens_per_s": (prompt.size - 1) / (t1 - t0), "decode_tokens_per_s": args.graph_steps / (t2 - t1), "steps": args.graph_steps,
+            "graphs_planned": n_plans, "graphs_lowered": n_low, "first_ids": ids[:8],
+            "what": "Graph -> Executor::run -> HIPBackend::plan (lowered to the fused launches), logits to the host every step, eager launches"}
 
 
 def gpu_short_run(model, p, ids_cpu):
@@ -273,6 +302,12 @@ def main():
             "replicas_agree": replicas_agree, "first_ids": [int(i) for i in ids[:8]],
             "roofline": rf,
         }
+        if not args.no_graph_path and dist is None:
+            try:
+                out["graph_path"] = graph_path(model_dir, local, args, prompt)
+                out["graph_path"]["ids_equal_direct"] = out["graph_path"]["first_ids"] == ([int(i) for i in ids_w] + [int(i) for i in ids])[:8]
+            except Exception as e:
+                out["graph_path"] = {"error": repr(e)}
         if not args.no_cpu_baseline:
             try:  # the baselines must never take the GPU number down with them
                 port, p_short, ids_cpu, logits_cpu = cpu_port(model_dir, prompt, args.cpu_steps)

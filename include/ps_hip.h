@@ -169,6 +169,10 @@ int ps_hip_model_kv_move(ps_hip_model *m, size_t dst_index, size_t src_index);
  * position by n (m_kv->advance, llama_model.cpp:109). */
 int ps_hip_model_forward(ps_hip_model *m, const int32_t *tokens, int n, const int32_t *pos, const uint8_t *tree,
                          int lm_head, int32_t *argmax_host);
+/* The same launches as ps_hip_model_forward, for a graph that HIPBackend::plan lowered (src/executor/executor.cpp:47-49,79:
+ * the whole op vector goes to the backend's plan() before it runs): enqueues only -- no host sync, the KV position is left
+ * to the caller (LlamaModel::forward advances it after Executor::run, llama_model.cpp:109). */
+int ps_hip_model_forward_lowered(ps_hip_model *m, const int32_t *tokens, int n, const int32_t *pos, const uint8_t *tree, int lm_head);
 /* Token-tree forward (speculative verify / draft, src/speculative/token_tree.cpp): the n tokens are appended at the
  * cache slots kv_position .. kv_position+n-1, column i is rotated with RoPE position rope_pos[i] (its depth in the tree,
  * not its slot) and sees the cached prefix (minus slots hidden with ps_hip_model_kv_mask) plus the batch columns j with

@@ -36,9 +36,10 @@ HIPBackend::~HIPBackend() {
     if (m_model) ps_hip_model_destroy(m_model);
     if (m_ctx) ps_hip_destroy(m_ctx);
 }
-void HIPBackend::attach_model(ps_hip_model *m) {
+void HIPBackend::attach_model(ps_hip_model *m, LoweringTable table) {
     m_model = m;
     m_kv    = std::make_unique<HIPKV>(m_config, m);
+    m_table = std::move(table);
 }
 void HIPBackend::check(int rc, const char *what) const {
     if (rc != 0) POWERSERVE_ABORT(std::string(what) + ": " + ps_hip_last_error(m_ctx)); // C-ABI error -> reference abort/throw
@@ -156,10 +157,132 @@ void HIPBackend::print(const Tensor *x, size_t) const {
     check(ps_hip_memcpy_d2h(m_ctx, h.data(), x->get<HIPBuffer>().m_data, h.size() * 4), "print");
     for (float v : h) std::printf("%.6f\n", (double)v);
 }
-void HIPBackend::plan(std::vector<std::shared_ptr<OpNode>> &) {
-    // The reference sizes its CPU work buffer here (src/backend/ggml/ggml.cpp:30-109).  On the device the
-    // activation-quantization scratch lives inside the kernels' LDS; the fused lowering of the whole layer
-    // sequence is selected by the model (Model::forward) and runs through ps_hip_model_forward.
+// ---- plan(): recognise the canonical forward and lower it
+namespace {
+const void *handle_of(Node *n) { // device handle behind a graph tensor (weights: ps_weight*, F32 vectors: device float*)
+    auto *t = n->tensor();
+    return (t && t->m_data) ? t->get<HIPBuffer>().m_data : nullptr;
+}
+struct Cursor {
+    std::vector<std::shared_ptr<OpNode>> &ops;
+    size_t i = 0;
+    OpNode *take(OpType t) { return (i < ops.size() && ops[i]->op == t) ? ops[i++].get() : nullptr; }
+    bool done() const { return i == ops.size(); }
+};
+} // namespace
+
+bool HIPBackend::match_canonical(std::vector<std::shared_ptr<OpNode>> &ops, Lowered &out) const {
+    const auto &T = m_table;
+    if (!m_model || T.layers.size() != m_config.n_layers || T.layers.empty()) return false;
+    Cursor c{ops};
+    // x = get_embedding(token table, tokens)
+    OpNode *emb = c.take(OpType::GET_EMBEDDING);
+    if (!emb || handle_of(emb->prev[0]) != T.token_embd) return false;
+    const auto &tokens = emb->get_params<GetEmbeddingParams>().tokens;
+    const size_t bs = tokens.size();
+    if (bs == 0) return false;
+    Node *x = emb->next[0];
+    const std::vector<int> *pos = nullptr;
+    const CausalAttentionMask *mask = nullptr;
+    const float want_scale = 1.0f / sqrtf((float)m_config.head_size);
+    auto mat_mul = [&](const void *w, Node *act) -> Node * { // MAT_MUL(weight w, activation act) -> its output node
+        OpNode *o = c.take(OpType::MAT_MUL);
+        return (o && handle_of(o->prev[0]) == w && o->prev[1] == act) ? o->next[0] : nullptr;
+    };
+    auto rms = [&](const void *w, Node *in) -> Node * {
+        OpNode *o = c.take(OpType::RMS_NORM);
+        return (o && o->prev[0] == in && handle_of(o->prev[1]) == w && o->get_params<RMSNormParams>().eps == m_config.norm_eps) ? o->next[0] : nullptr;
+    };
+    auto add_bias = [&](Node *in, const void *b) -> Node * {
+        if (!T.bias) return in;
+        OpNode *o = c.take(OpType::ADD);
+        return (o && o->prev[0] == in && handle_of(o->prev[1]) == b) ? o->next[0] : nullptr;
+    };
+    for (size_t L = 0; L < T.layers.size(); L++) {
+        const auto &W = T.layers[L];
+        // ---- NormAttention::build
+        Node *n1 = rms(W.attn_norm, x);
+        if (!n1) return false;
+        Node *q = mat_mul(W.wq, n1); if (!q || !(q = add_bias(q, W.bq))) return false;
+        Node *k = mat_mul(W.wk, n1); if (!k || !(k = add_bias(k, W.bk))) return false;
+        Node *v = mat_mul(W.wv, n1); if (!v || !(v = add_bias(v, W.bv))) return false;
+        for (int r = 0; r < 2; r++) { // rope(q view), rope(k view): same positions, the model's rope configuration
+            OpNode *o = c.take(OpType::ROPE);
+            if (!o) return false;
+            const auto &rp = o->get_params<RopeParams>();
+            if (!pos) pos = &rp.pos;
+            if (rp.pos != *pos || rp.pos.size() != bs || rp.rope_cfg.n_dims != m_config.rope_config.n_dims || rp.rope_cfg.rope_type != m_config.rope_config.rope_type ||
+                rp.rope_cfg.freq_base != m_config.rope_config.freq_base || rp.rope_cfg.freq_scale != m_config.rope_config.freq_scale)
+                return false;
+        }
+        // KV store: transpose(v), view(k cache), copy, view(v cache), copy
+        if (!c.take(OpType::TRANSPOSE) || !c.take(OpType::VIEW) || !c.take(OpType::COPY) || !c.take(OpType::VIEW) || !c.take(OpType::COPY)) return false;
+        // scores, mask, softmax, V.p, merge heads
+        if (!c.take(OpType::PERMUTE) || !c.take(OpType::VIEW) || !c.take(OpType::MAT_MUL)) return false;
+        OpNode *gm = c.take(OpType::GET_MASK);
+        if (!gm) return false;
+        const auto &mp = gm->get_params<GetMaskParams>();
+        if (mp.pos != *pos) return false;
+        mask = &mp.mask;
+        OpNode *sm = c.take(OpType::SOFTMAX_EXT);
+        if (!sm || sm->get_params<SoftmaxExtParams>().scale != want_scale || sm->get_params<SoftmaxExtParams>().max_bias != 0.0f) return false;
+        if (!c.take(OpType::VIEW) || !c.take(OpType::MAT_MUL) || !c.take(OpType::PERMUTE)) return false;
+        OpNode *ct = c.take(OpType::CONT);
+        if (!ct) return false;
+        Node *o = mat_mul(W.wo, ct->next[0]);
+        OpNode *res = c.take(OpType::ADD);
+        if (!o || !res || res->prev[0] != x || res->prev[1] != o) return false;
+        Node *a = res->next[0];
+        // ---- FFN::build
+        Node *n2 = rms(W.ffn_norm, a);
+        if (!n2) return false;
+        Node *g = mat_mul(W.wg, n2), *u = g ? mat_mul(W.wu, n2) : nullptr;
+        OpNode *sh = c.take(OpType::SILU_HADAMARD);
+        if (!u || !sh || sh->prev[0] != g || sh->prev[1] != u) return false;
+        Node *d = mat_mul(W.wd, sh->next[0]);
+        OpNode *res2 = c.take(OpType::ADD);
+        if (!d || !res2 || res2->prev[0] != a || res2->prev[1] != d) return false;
+        x = res2->next[0];
+    }
+    out.lm_head = false;
+    out.logits  = nullptr;
+    if (!c.done()) { // final norm + lm_head (tied: the token table)
+        Node *n = rms(T.output_norm, x);
+        Node *lg = n ? mat_mul(T.output ? T.output : T.token_embd, n) : nullptr;
+        if (!lg || !c.done()) return false;
+        out.lm_head = true;
+        out.logits  = lg->tensor();
+    }
+    if (!pos) return false;
+    for (size_t i = 1; i < bs; i++) if ((*pos)[i] != (*pos)[0] + (int)i) return false; // the KV append is one contiguous block
+    out.tokens.assign(tokens.begin(), tokens.end());
+    out.pos.assign(pos->begin(), pos->end());
+    out.tree.clear();
+    if (mask && !mask->mask.empty()) {
+        out.tree.resize(bs * bs);
+        for (size_t i = 0; i < bs; i++) for (size_t j = 0; j < bs; j++) out.tree[i * bs + j] = mask->mask[i][j] ? 1 : 0;
+    }
+    return true;
+}
+
+void HIPBackend::plan(std::vector<std::shared_ptr<OpNode>> &ops) {
+    // (the reference sizes its CPU work buffer here, src/backend/ggml/ggml.cpp:30-109; on the device that scratch lives in
+    // the kernels' LDS)
+    n_plans++;
+    m_low.ok = m_fused && match_canonical(ops, m_low);
+    if (m_low.ok) n_lowered++;
+}
+
+void HIPBackend::run_lowered() {
+    POWERSERVE_ASSERT(m_low.ok);
+    check(ps_hip_model_forward_lowered(m_model, m_low.tokens.data(), (int)m_low.tokens.size(), m_low.pos.data(),
+                                       m_low.tree.empty() ? nullptr : m_low.tree.data(), m_low.lm_head ? 1 : 0), "lowered forward");
+    if (m_low.logits) { // the graph's logits tensor is the model's buffer
+        auto &t = *m_low.logits;
+        Stride st; st[0] = sizeof(float); for (size_t i = 1; i < 4; i++) st[i] = st[i - 1] * t.m_shape[i - 1];
+        t.m_data = std::make_shared<HIPBuffer>(st, (void *)ps_hip_model_logits(m_model));
+    }
+    m_low.ok = false;
 }
 
 } // namespace hip
@@ -194,11 +317,13 @@ void Executor::allocate_buffers() {
         }
     }
 }
-void Executor::plan() { m_platform.hip_backends[m_graph.m_model_id]->plan(m_graph.ops); }
+void Executor::plan() { m_platform.hip_backends[m_graph.m_model_id]->plan(m_graph.ops); m_planned = true; }
 
 void Executor::run() {
     auto &be = *m_platform.hip_backends[m_graph.m_model_id];
-    plan();
+    if (!m_planned) plan(); // (the reference plans inside run(), executor.cpp:79; a caller may plan first to learn whether buffers are needed)
+    m_planned = false;
+    if (be.lowered()) { be.run_lowered(); return; }
     for (auto &op : m_graph.ops) {
         switch (op->op) {
         case OpType::GET_EMBEDDING: be.get_embedding(op->output(), op->prev[0]->tensor(), op->get_params<GetEmbeddingParams>().tokens); break;

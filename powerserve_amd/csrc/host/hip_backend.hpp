@@ -30,6 +30,15 @@ struct HIPKV {
     auto get_cache(size_t L) -> std::pair<Tensor &, Tensor &> { return {key_tensors[L], value_tensors[L]}; }
 };
 
+// What HIPBackend::plan compares a graph's weight operands with: the device handles the attached model was created from
+// (ps_weight* for matrices, device float* for norm weights / biases), in the order NormAttention::build / FFN::build use them.
+struct LoweringTable {
+    struct Layer { const void *attn_norm, *wq, *wk, *wv, *bq, *bk, *bv, *wo, *ffn_norm, *wg, *wu, *wd; };
+    const void *token_embd = nullptr, *output = nullptr, *output_norm = nullptr;
+    std::vector<Layer> layers;
+    bool bias = false;
+};
+
 struct HIPBackend {
     ps_hip_ctx *m_ctx = nullptr;
     ps_hip_model *m_model = nullptr; // fused fast path + owner of the KV cache
@@ -40,7 +49,7 @@ struct HIPBackend {
 
     HIPBackend(const ModelConfig::LLMConfig &config, const HyperParams &hparams, int device);
     ~HIPBackend();
-    void attach_model(ps_hip_model *m); // called once the weights are uploaded
+    void attach_model(ps_hip_model *m, LoweringTable table = {}); // called once the weights are uploaded
 
     // ---- the reference's op set
     void add(const Tensor *dst, const Tensor *src0, const Tensor *src1) const;
@@ -60,7 +69,14 @@ struct HIPBackend {
     void reset_kv_batch_size(size_t batch_size) const { m_kv->reset_batch_size(batch_size); }
     void transpose(const Tensor *out, const Tensor *x) const;
     void get_mask(const Tensor *out, const std::vector<int> &pos, const CausalAttentionMask &mask) const; // executor.cpp:210-224
+    // The reference hands the whole op vector to the backend before running it (executor.cpp:47-49,79).  Here that is the
+    // fusion hook: a graph that is exactly the canonical forward of the attached model (get_embedding, L x [NormAttention,
+    // FFN] as their build() emit them, optional final norm + lm_head) is lowered to the fused launch plan
+    // (ps_hip_model_forward_lowered: 5 launches per layer for one token); anything else runs op by op.
     void plan(std::vector<std::shared_ptr<OpNode>> &ops);
+    bool lowered() const { return m_low.ok; }
+    void run_lowered();                 // Executor::run, lowered graph
+    int n_plans = 0, n_lowered = 0;     // statistics (tests, bench)
     void setup_work_data(size_t) {}
     void setup_threadpool() {}  // a generation is bracketed by these in the reference (model.hpp:145,165-168):
     void reset_threadpool();    // here: nothing to create, drain the stream at the end
@@ -72,6 +88,9 @@ struct HIPBackend {
     void arena_reserve(size_t bytes); // grows the arena (between forwards only)
 
 private:
+    struct Lowered { bool ok = false; std::vector<int32_t> tokens, pos; std::vector<uint8_t> tree; bool lm_head = false; Tensor *logits = nullptr; } m_low;
+    LoweringTable m_table;
+    bool match_canonical(std::vector<std::shared_ptr<OpNode>> &ops, Lowered &out) const;
     void check(int rc, const char *what) const;
     ps_tensor to_ps(const Tensor *t) const;
     char *m_arena = nullptr;
@@ -95,6 +114,9 @@ struct Executor { // src/executor/executor.hpp:22-45
     void allocate_buffers();
     void plan();
     void run();
+    bool lowered() const { return m_platform.hip_backends.at(m_graph.m_model_id)->lowered(); } // after plan(): no intermediate buffers needed
+private:
+    bool m_planned = false;
 };
 
 } // namespace powerserve

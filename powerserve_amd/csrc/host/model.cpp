@@ -140,7 +140,10 @@ Model::Model(const std::string &model_dir, const std::shared_ptr<ModelConfig> &c
     if (m_is_need_bias) { d.attn_q_bias = bq.data(); d.attn_k_bias = bk.data(); d.attn_v_bias = bv.data(); }
     ps_hip_model *pm = nullptr;
     if (ps_hip_model_create(be.m_ctx, &d, &pm)) POWERSERVE_ABORT(std::string("ps_hip_model_create: ") + ps_hip_last_error(be.m_ctx));
-    be.attach_model(pm);
+    hip::LoweringTable lt;
+    lt.token_embd = d.token_embd; lt.output = d.output; lt.output_norm = d.output_norm; lt.bias = m_is_need_bias;
+    for (uint32_t i = 0; i < L; i++) lt.layers.push_back({an[i], wq[i], wk[i], wv[i], bq[i], bk[i], bv[i], wo[i], fn[i], wg[i], wu[i], wd[i]});
+    be.attach_model(pm, std::move(lt));
     m_attn = std::make_shared<NormAttention>(m_config->llm, m_weights);
     m_ffn  = std::make_shared<FFN>(m_config->llm, m_weights);
 }
@@ -160,10 +163,12 @@ Model::~Model() {
 
 auto Model::forward(const std::vector<int> &tokens, const std::vector<int> &pos, const CausalAttentionMask &mask, bool lm_head) -> LogitsVector {
     POWERSERVE_ASSERT(tokens.size() == pos.size() && !tokens.empty());
-    return m_use_fused ? forward_fused(tokens, pos, mask, lm_head) : forward_graph(tokens, pos, mask, lm_head);
+    backend().m_fused = m_use_fused; // false: plan() lowers nothing, every op is its own launch (A/B, tests)
+    return forward_graph(tokens, pos, mask, lm_head);
 }
 
-// LlamaModel::forward (src/model/llama/llama_model.cpp:52-117): build the graph, allocate, run op by op.
+// LlamaModel::forward (src/model/llama/llama_model.cpp:52-117): build the graph, allocate, run -- Executor::run hands the op
+// vector to HIPBackend::plan first, which lowers the canonical sequence to the fused launches.
 auto Model::forward_graph(const std::vector<int> &tokens, const std::vector<int> &pos, const CausalAttentionMask &mask, bool lm_head) -> LogitsVector {
     auto &be = backend();
     auto &llm = m_config->llm;
@@ -183,7 +188,8 @@ auto Model::forward_graph(const std::vector<int> &tokens, const std::vector<int>
         logits = g.mat_mul(g.add_tensor(m_weights->output_weight), normed);
     }
     Executor executor(*m_platform, g);
-    executor.allocate_buffers();
+    executor.plan();
+    if (!executor.lowered()) executor.allocate_buffers(); // a lowered graph runs in the device model's own arena
     executor.run();
     be.m_kv->advance((int)bs);
     if (!lm_head) { be.sync(); return LogitsVector(); }
@@ -191,27 +197,6 @@ auto Model::forward_graph(const std::vector<int> &tokens, const std::vector<int>
     auto host = std::make_shared<CPUBuffer>(st, (size_t)llm.vocab_size * bs * 4);
     be.sync();
     if (ps_hip_memcpy_d2h(be.m_ctx, host->m_data, logits->get<HIPBuffer>().m_data, host->m_storage.size()))
-        POWERSERVE_ABORT(std::string("logits copy: ") + ps_hip_last_error(be.m_ctx));
-    return LogitsVector(host, llm.vocab_size, bs);
-}
-
-// The same forward lowered to the fused kernels (what plan() selects for the canonical layer sequence).
-auto Model::forward_fused(const std::vector<int> &tokens, const std::vector<int> &pos, const CausalAttentionMask &mask, bool lm_head) -> LogitsVector {
-    auto &be = backend();
-    auto &llm = m_config->llm;
-    const size_t bs = tokens.size();
-    std::vector<int32_t> t(tokens.begin(), tokens.end()), p(pos.begin(), pos.end());
-    std::vector<uint8_t> tree;
-    if (!mask.mask.empty()) {
-        tree.resize(bs * bs);
-        for (size_t i = 0; i < bs; i++) for (size_t j = 0; j < bs; j++) tree[i * bs + j] = mask.mask[i][j] ? 1 : 0;
-    }
-    if (ps_hip_model_forward(be.m_model, t.data(), (int)bs, p.data(), tree.empty() ? nullptr : tree.data(), lm_head ? 1 : 0, nullptr))
-        POWERSERVE_ABORT(std::string("forward: ") + ps_hip_last_error(be.m_ctx));
-    if (!lm_head) return LogitsVector();
-    Stride st = {4, 4 * (size_t)llm.vocab_size, 4 * (size_t)llm.vocab_size * bs, 4 * (size_t)llm.vocab_size * bs};
-    auto host = std::make_shared<CPUBuffer>(st, (size_t)llm.vocab_size * bs * 4);
-    if (ps_hip_memcpy_d2h(be.m_ctx, host->m_data, ps_hip_model_logits(be.m_model), host->m_storage.size()))
         POWERSERVE_ABORT(std::string("logits copy: ") + ps_hip_last_error(be.m_ctx));
     return LogitsVector(host, llm.vocab_size, bs);
 }
@@ -303,7 +288,8 @@ void *psh_model_load(const char *model_dir, int device, int max_batch, int n_ctx
     } catch (const std::exception &e) { g_err = e.what(); return nullptr; }
 }
 void psh_model_free(void *h) { delete (psh_model *)h; }
-void psh_model_set_fused(void *h, int fused) { ((psh_model *)h)->model->m_use_fused = fused != 0; }
+void psh_model_set_fused(void *h, int fused) { ((psh_model *)h)->model->m_use_fused = fused != 0; } // 0: plan() lowers nothing (A/B, tests)
+void psh_model_plan_stats(void *h, int *n_plans, int *n_lowered) { auto &be = ((psh_model *)h)->model->backend(); *n_plans = be.n_plans; *n_lowered = be.n_lowered; }
 size_t psh_model_kv_position(void *h) { auto m = (psh_model *)h; return m->platform->get_kv_position(m->model->m_config->model_id); }
 void psh_model_reset(void *h) { auto m = (psh_model *)h; m->platform->reset_kv_position(m->model->m_config->model_id); }
 uint32_t psh_model_vocab(void *h) { return ((psh_model *)h)->model->m_config->llm.vocab_size; }

@@ -55,7 +55,7 @@ struct Model {
     std::shared_ptr<FFN> m_ffn;
     std::shared_ptr<Platform> m_platform;
     bool m_is_need_bias = false; // Qwen2
-    bool m_use_fused    = true;  // fused kernels + hipGraph (HIPBackend::plan lowering); false: op-by-op graph
+    bool m_use_fused    = true;  // HIPBackend::plan lowers the canonical graph to the fused launches; false: op-by-op (A/B, tests)
 
     Model(const std::string &model_dir, const std::shared_ptr<ModelConfig> &config, const std::shared_ptr<Platform> &platform, int device,
           size_t max_batch);
@@ -78,7 +78,6 @@ private:
     std::vector<ps_weight *> m_dev_weights;
     std::vector<void *> m_dev_f32;
     auto forward_graph(const std::vector<int> &tokens, const std::vector<int> &pos, const CausalAttentionMask &mask, bool lm_head) -> LogitsVector;
-    auto forward_fused(const std::vector<int> &tokens, const std::vector<int> &pos, const CausalAttentionMask &mask, bool lm_head) -> LogitsVector;
 };
 using LlamaModel = Model;
 using Qwen2Model = Model;

@@ -319,8 +319,17 @@ int ps_hip_model_kv_move(ps_hip_model *m, size_t dst, size_t src) {
     return 0;
 }
 
+static int model_forward_impl(ps_hip_model *m, const int32_t *tokens, int n, const int32_t *pos, const uint8_t *tree, int lm_head,
+                              int32_t *argmax_host, bool advance);
 int ps_hip_model_forward(ps_hip_model *m, const int32_t *tokens, int n, const int32_t *pos, const uint8_t *tree, int lm_head,
                          int32_t *argmax_host) {
+    return model_forward_impl(m, tokens, n, pos, tree, lm_head, argmax_host, true);
+}
+int ps_hip_model_forward_lowered(ps_hip_model *m, const int32_t *tokens, int n, const int32_t *pos, const uint8_t *tree, int lm_head) {
+    return model_forward_impl(m, tokens, n, pos, tree, lm_head, nullptr, false);
+}
+static int model_forward_impl(ps_hip_model *m, const int32_t *tokens, int n, const int32_t *pos, const uint8_t *tree, int lm_head,
+                              int32_t *argmax_host, bool advance) {
     ps_hip_ctx *c = m->ctx;
     if (n <= 0 || n > m->max_batch) PS_FAIL(c, "model_forward: batch size out of range");
     for (int i = 1; i < n; i++)
@@ -335,6 +344,7 @@ int ps_hip_model_forward(ps_hip_model *m, const int32_t *tokens, int n, const in
     PS_CHECK(c, hipStreamSynchronize(c->stream)); // tokens/tree may be host temporaries
     if (int rc = enqueue_forward(m, n, lm_head != 0, tree != nullptr)) return rc;
     if (lm_head && argmax_host) PS_CHECK(c, hipMemcpyAsync(argmax_host, m->argmax_dev, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    if (!advance) return 0; // lowered graph: the executor's caller syncs when it reads the logits and advances the cache itself
     PS_CHECK(c, hipStreamSynchronize(c->stream));
     unmask_range(m, (size_t)pos[0], (size_t)n);
     m->position = (size_t)pos[0] + (size_t)n; // m_kv->advance (llama_model.cpp:109)

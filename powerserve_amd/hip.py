@@ -30,7 +30,7 @@ EXPORTS = [
     "ps_hip_get_embedding", "ps_hip_get_mask", "ps_hip_argmax", "ps_hip_model_create", "ps_hip_model_destroy",
     "ps_hip_model_kv_position", "ps_hip_model_kv_truncate", "ps_hip_model_kv_advance", "ps_hip_model_kv_rollback", "ps_hip_model_kv_move",
     "ps_hip_model_forward", "ps_hip_model_decode_greedy", "ps_hip_model_logits", "ps_hip_model_scratch", "ps_hip_model_k_cache",
-    "ps_hip_model_v_cache", "ps_hip_model_weight_bytes_per_token", "ps_hip_model_set_mode", "ps_hip_model_bench_gemv", "ps_hip_debug_timeline", "ps_hip_debug_set", "ps_hip_model_forward_tree", "ps_hip_model_kv_mask",
+    "ps_hip_model_v_cache", "ps_hip_model_weight_bytes_per_token", "ps_hip_model_set_mode", "ps_hip_model_bench_gemv", "ps_hip_debug_timeline", "ps_hip_debug_set", "ps_hip_model_forward_tree", "ps_hip_model_forward_lowered", "ps_hip_model_kv_mask",
 ]
 
 
@@ -110,6 +110,7 @@ def lib() -> C.CDLL:
         "ps_hip_model_kv_position": (sz, [vp]), "ps_hip_model_kv_truncate": (i32, [vp, sz]), "ps_hip_model_kv_advance": (i32, [vp, sz]),
         "ps_hip_model_kv_rollback": (i32, [vp, sz]), "ps_hip_model_kv_move": (i32, [vp, sz, sz]),
         "ps_hip_model_forward": (i32, [vp, vp, i32, vp, vp, i32, vp]),
+        "ps_hip_model_forward_lowered": (i32, [vp, vp, i32, vp, vp, i32]),
         "ps_hip_model_forward_tree": (i32, [vp, vp, i32, vp, vp, i32, vp, i32]), "ps_hip_model_kv_mask": (i32, [vp, sz, i32]),
         "ps_hip_model_decode_greedy": (i32, [vp, i32, i32, vp]), "ps_hip_model_logits": (vp, [vp]), "ps_hip_model_scratch": (vp, [vp, i32]),
         "ps_hip_model_k_cache": (vp, [vp, i32]), "ps_hip_model_v_cache": (vp, [vp, i32]),

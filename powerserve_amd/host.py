@@ -9,7 +9,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libps_host.so")
-EXPORTS = ["psh_last_error", "psh_model_load", "psh_model_free", "psh_model_set_fused", "psh_model_kv_position", "psh_model_reset",
+EXPORTS = ["psh_last_error", "psh_model_load", "psh_model_free", "psh_model_set_fused", "psh_model_plan_stats", "psh_model_kv_position", "psh_model_reset",
            "psh_model_vocab", "psh_model_forward", "psh_model_generate", "psh_spec_generate", "psh_draft_sample", "psh_sampler_create", "psh_sampler_free", "psh_sampler_sample",
            "psh_model_generate_sampled"]
 _LIB = None
@@ -26,6 +26,7 @@ def lib() -> C.CDLL:
         L.psh_model_load.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int]
         L.psh_model_free.argtypes = [C.c_void_p]
         L.psh_model_set_fused.argtypes = [C.c_void_p, C.c_int]
+        L.psh_model_plan_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.psh_model_kv_position.restype = C.c_size_t
         L.psh_model_kv_position.argtypes = [C.c_void_p]
         L.psh_model_reset.argtypes = [C.c_void_p]
@@ -78,6 +79,12 @@ class HostModel:
         if getattr(self, "h", None):
             self.L.psh_model_free(self.h)
             self.h = None
+
+    def plan_stats(self):
+        """(graphs handed to HIPBackend::plan, graphs it lowered to the fused launch plan)"""
+        a, b = C.c_int(), C.c_int()
+        self.L.psh_model_plan_stats(self.h, C.byref(a), C.byref(b))
+        return a.value, b.value
 
     def set_fused(self, fused: bool):
         """True: fused kernels + hipGraph (default).  False: op-by-op Graph/Executor path."""

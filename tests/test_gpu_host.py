@@ -1,6 +1,8 @@
-"""GPU: the C++ host facade (Graph -> Executor -> HIPBackend, mirror of the reference's host side).  The op-by-op
-graph path (every reference op through its own ps_hip_* entry point, built by the NormAttention/FFN builders) and
-the fused path (what plan() lowers it to) must give the SAME bits, and both must equal the CPU oracle."""
+"""GPU: the C++ host facade (Graph -> Executor -> HIPBackend, mirror of the reference's host side).  Every forward builds
+the reference's graph with the NormAttention / FFN builders and goes through Executor::run; HIPBackend::plan recognises
+the canonical op sequence and lowers it to the fused launch plan.  The lowered path and the op-by-op path (every
+reference op through its own ps_hip_* entry point; plan() lowering switched off) must give the SAME bits, and both must
+equal the CPU oracle."""
 import os
 
 import numpy as np
@@ -26,11 +28,14 @@ def test_graph_path_equals_fused_equals_oracle(oracle, tmp_path, preset, wt):
     hm = host.HostModel(d, 0, max_batch=16)
     prompt = np.random.default_rng(1).integers(0, cfg.vocab_size, 14)
     want_ids, want_logits, *_ = om.generate(prompt, 8, 10, want_logits=True)
-    # fused path through the C++ Model::generate
+    # Graph -> Executor with plan() lowering (the default), through the C++ Model::generate
     assert np.array_equal(hm.generate(prompt, 8, 10), want_ids)
+    n_plans, n_low = hm.plan_stats()
+    assert n_plans > 0 and n_low == n_plans          # every graph the builders emitted was recognised
     # op-by-op graph path: same ids, and bit-identical logits on a batched forward
     hm.set_fused(False)
     assert np.array_equal(hm.generate(prompt, 8, 10), want_ids)
+    assert hm.plan_stats()[1] == n_low               # nothing lowered with the switch off
     hm.reset(); om.reset()
     lg_graph = hm.forward(prompt[:9], np.arange(9), True)
     lg_oracle = om.forward(prompt[:9], np.arange(9), True)
@@ -38,8 +43,16 @@ def test_graph_path_equals_fused_equals_oracle(oracle, tmp_path, preset, wt):
     assert hm.position == 9
     hm.set_fused(True)
     hm.reset()
-    lg_fused = hm.forward(prompt[:9], np.arange(9), True)
+    lg_fused = hm.forward(prompt[:9], np.arange(9), True)  # lowered: one graph, fused launches
+    assert hm.plan_stats()[1] == n_low + 1
     assert np.array_equal(lg_fused.view(np.uint32), lg_graph.view(np.uint32))
+    assert hm.position == 9
+    # single-token steps through Graph -> Executor -> plan() (5 launches per layer): teacher-forced logits == oracle
+    om.reset(); om.forward(prompt[:9], np.arange(9), False)
+    for s in range(3):
+        a = hm.forward([int(prompt[9 + s])], [9 + s], True)
+        b = om.forward([int(prompt[9 + s])], [9 + s], True)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), s
     hm.close(); om.close()
 
 
