@@ -319,8 +319,6 @@ int ps_hip_rope(ps_hip_ctx *c, const ps_tensor *dst, const ps_tensor *src, const
 int ps_hip_softmax_ext(ps_hip_ctx *c, const ps_tensor *dst, const ps_tensor *src, const ps_tensor *mask, float scale, float max_bias) {
     if (max_bias != 0.0f) PS_FAIL(c, "softmax_ext: ALiBi (max_bias != 0) is not on PowerServe's path");
     if (src->ne[0] * 4 > 150 * 1024) PS_FAIL(c, "softmax_ext: row too long for the LDS-resident kernel");
-    static bool attr = false;
-    (void)attr;
     psl_softmax_ext(c->stream, dst, src, mask ? (const float *)mask->data : nullptr, scale);
     PS_CHECK(c, hipGetLastError());
     return 0;

@@ -142,6 +142,7 @@ GGUFFile::GGUFFile(const std::string &path) {
         };
         for (uint64_t i = 0; i < nkv; i++) { std::string k = r.str(); uint32_t t = r.get<uint32_t>(); skip(t, k); }
         if (kv_num.count("general.alignment")) align = (size_t)kv_num["general.alignment"];
+        if (align == 0 || (align & (align - 1))) throw std::runtime_error("gguf: general.alignment must be a power of two");
         std::vector<uint64_t> offs;
         for (uint64_t i = 0; i < nt; i++) {
             GGUFTensor t; t.name = r.str();
@@ -155,7 +156,8 @@ GGUFFile::GGUFFile(const std::string &path) {
         }
         size_t data0 = (r.p + align - 1) / align * align;
         for (size_t i = 0; i < tensors.size(); i++) {
-            if (data0 + offs[i] + tensors[i].nbytes > m_size) throw std::runtime_error("gguf: tensor data out of range: " + tensors[i].name);
+            if (data0 > m_size || offs[i] > m_size - data0 || tensors[i].nbytes > m_size - data0 - offs[i]) // (no wrap-around on hostile offsets)
+                throw std::runtime_error("gguf: tensor data out of range: " + tensors[i].name);
             tensors[i].data = (const uint8_t *)m_map + data0 + offs[i];
         }
     } catch (const std::exception &e) {

@@ -636,6 +636,7 @@ __global__ __launch_bounds__(64) void argmax_final_kernel(const float *pv, const
         if (ov > best || (ov == best && oi < idx)) { best = ov; idx = oi; }
     }
     if (lane == 0) {
+        if (idx == 0x7fffffff) idx = 0; // a row of NaNs: std::max_element (prob_array.cpp:65-67) returns the first element
         out[blockIdx.x] = idx;
         if (st) { token[0] = idx; ids[st->n_out] = idx; st->n_out += 1; st->pos0 += 1; }
     }
@@ -672,8 +673,8 @@ size_t psl_attn_softmax_pv_lds(const psl_attn_args &a) {
 }
 void psl_attn_softmax_pv(hipStream_t st, const psl_attn_args &a, int bs) {
     if (bs >= 8 && a.head_size % 16 == 0) { // prefill chunks / wide trees: soft-max in place, then V·p on the matrix cores
-        static bool attrp = false;
-        if (!attrp) { (void)hipFuncSetAttribute((const void *)attn_softmax_probs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024); attrp = true; }
+        static unsigned long long attrp = 0; // devices that have the attribute
+        if (ps_first_on_device(&attrp)) { (void)hipFuncSetAttribute((const void *)attn_softmax_probs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024); }
         const int r2p = a.n_heads / a.n_kv_heads;
         const size_t ldsp = (size_t)r2p * (((size_t)a.n_ctx + 3) & ~(size_t)3) * 4;
         hipLaunchKernelGGL(attn_softmax_probs_kernel, dim3((unsigned)a.n_kv_heads, (unsigned)bs), dim3(PV_NT), ldsp, st, a);
@@ -683,11 +684,10 @@ void psl_attn_softmax_pv(hipStream_t st, const psl_attn_args &a, int bs) {
     if (bs > 1) { // batches: one workgroup per (kv head, column pair)
         const int r2 = a.n_heads / a.n_kv_heads;
         const size_t row = ((size_t)a.n_ctx + 3) & ~(size_t)3, lds2 = 2 * r2 * row * 4, lds1 = r2 * row * 4;
-        static bool attr2 = false;
-        if (!attr2) {
+        static unsigned long long attr2 = 0; // devices that have the attribute
+        if (ps_first_on_device(&attr2)) {
             (void)hipFuncSetAttribute((const void *)attn_softmax_pv_cols_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
             (void)hipFuncSetAttribute((const void *)attn_softmax_pv_cols_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
-            attr2 = true;
         }
         // few (kv head, column pair) workgroups (tree verify, prefill tails): split the head channels over blockIdx.z
         const bool two = lds2 <= 150 * 1024;
@@ -698,8 +698,8 @@ void psl_attn_softmax_pv(hipStream_t st, const psl_attn_args &a, int bs) {
         else hipLaunchKernelGGL(attn_softmax_pv_cols_kernel<1>, dim3((unsigned)a.n_kv_heads, (unsigned)bs, nz), dim3(PV_NT), lds1, st, a);
         return;
     }
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void *)attn_softmax_pv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024); attr = true; }
+    static unsigned long long attr = 0; // devices that have the attribute
+    if (ps_first_on_device(&attr)) { (void)hipFuncSetAttribute((const void *)attn_softmax_pv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024); }
     dim3 g((unsigned)(a.head_size / 4), (unsigned)a.n_kv_heads, (unsigned)bs);
     hipLaunchKernelGGL(attn_softmax_pv_kernel, g, dim3(PV_NT), psl_attn_softmax_pv_lds(a), st, a);
 }
@@ -711,11 +711,10 @@ bool psl_attn_decode(hipStream_t st, int n_cu, const psl_attn_args &a) {
     if (gx * a.n_kv_heads > n_cu || a.n_kv_heads > 30) return false;  // every workgroup resident; ticket lines per head
     if ((a.n_ctx + 31) / 32 > DA_RMAX * gx) return false;              // position groups per workgroup
     const size_t lds = psl_attn_softmax_pv_lds(a);
-    static bool attr = false;
-    if (!attr) {
+    static unsigned long long attr = 0; // devices that have the attribute
+    if (ps_first_on_device(&attr)) {
         (void)hipFuncSetAttribute((const void *)attn_decode_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
         (void)hipFuncSetAttribute((const void *)attn_decode_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
-        attr = true;
     }
     dim3 g((unsigned)gx, (unsigned)a.n_kv_heads);
     if (a.head_size == 128) hipLaunchKernelGGL(attn_decode_kernel<4>, g, dim3(PV_NT), lds, st, a);

@@ -390,11 +390,10 @@ template <int WT, int UPW, int NW, int EPI, int PRO>
 void launch_g1(hipStream_t st, int n_cu, const GemvParams &p) {
     const int64_t n_tasks = (EPI == 1) ? p.w[0].n_groups : p.groups_total;
     const size_t smem     = (size_t)p.col_bytes;
-    static bool attr_set = false;
+    static unsigned long long attr_set = 0; // devices that have the attribute
     static int occ = 0;
-    if (!attr_set) {
+    if (ps_first_on_device(&attr_set)) {
         (void)hipFuncSetAttribute((const void *)gemv1_kernel<WT, UPW, NW, EPI, PRO>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        attr_set = true;
     }
     if (occ == 0) { // resident workgroups per CU for this instantiation (registers / LDS), queried once
         int nb = 0;
@@ -960,10 +959,9 @@ void launch_one(hipStream_t st, int n_cu, const GemvParams &p) {
     const int64_t cap     = (int64_t)n_cu * (NWV == 16 ? 1 : (smem > 40 * 1024 ? 2 : 4));
     if (grid > cap) grid = cap;
     if (grid < 1) grid = 1;
-    static bool attr_set = false;
-    if (!attr_set && smem > 48 * 1024) {
+    static unsigned long long attr_set = 0; // devices that have the attribute
+    if (ps_first_on_device(&attr_set) && smem > 48 * 1024) {
         (void)hipFuncSetAttribute((const void *)gemv_kernel<WT, BS, EPI, PRO, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
-        attr_set = true;
     }
     hipLaunchKernelGGL((gemv_kernel<WT, BS, EPI, PRO, NWV>), dim3((unsigned)grid), dim3(NWV * 64), smem, st, p);
 }
@@ -1602,10 +1600,9 @@ int psk_gemv_chain3(hipStream_t st, int n_cu, const psk_gemv_args a[3], unsigned
     }
     if (smem > 156 * 1024) return -1;
     c.bar.w = bar;
-    static bool attr = false;
-    if (!attr) {
+    static unsigned long long attr = 0; // devices that have the attribute
+    if (ps_first_on_device(&attr)) {
         (void)hipFuncSetAttribute((const void *)gemv3_chain3_kernel<PS_Q4_K, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
-        attr = true;
     }
     hipLaunchKernelGGL((gemv3_chain3_kernel<PS_Q4_K, 2, 4>), dim3((unsigned)grid), dim3(1024), smem, st, c);
     return 0;
@@ -1615,20 +1612,20 @@ int psk_gemv_chain3(hipStream_t st, int n_cu, const psk_gemv_args a[3], unsigned
 // column groups through the mat-vec).
 template <int WT, int EPI, int NWV>
 static void launch_gemm8_k(hipStream_t st, const GemvParams &p, const dim3 grid, size_t smem) {
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void *)gemm8_kernel<WT, EPI, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024); attr = true; }
+    static unsigned long long attr = 0; // devices that have the attribute
+    if (ps_first_on_device(&attr)) { (void)hipFuncSetAttribute((const void *)gemm8_kernel<WT, EPI, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024); }
     hipLaunchKernelGGL((gemm8_kernel<WT, EPI, NWV>), grid, dim3(NWV * 64), smem, st, p);
 }
 template <int EPI, int NWV, int C>
 static void launch_gemm8m_k(hipStream_t st, const GemvParams &p, const dim3 grid, size_t smem) {
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void *)gemm8m_kernel<EPI, NWV, C>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024); attr = true; }
+    static unsigned long long attr = 0; // devices that have the attribute
+    if (ps_first_on_device(&attr)) { (void)hipFuncSetAttribute((const void *)gemm8m_kernel<EPI, NWV, C>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024); }
     hipLaunchKernelGGL((gemm8m_kernel<EPI, NWV, C>), grid, dim3(NWV * 64), smem, st, p);
 }
 template <int WT, int EPI, int NWV>
 static void launch_gemm8b_k(hipStream_t st, const GemvParams &p, const dim3 grid, size_t smem) {
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void *)gemm8b_kernel<WT, EPI, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024); attr = true; }
+    static unsigned long long attr = 0; // devices that have the attribute
+    if (ps_first_on_device(&attr)) { (void)hipFuncSetAttribute((const void *)gemm8b_kernel<WT, EPI, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024); }
     hipLaunchKernelGGL((gemm8b_kernel<WT, EPI, NWV>), grid, dim3(NWV * 64), smem, st, p);
 }
 template <int WT>

@@ -384,10 +384,9 @@ __global__ __launch_bounds__((NW + 1) * 64) void gemv4_kernel(const G4Params p) 
 template <int NW, int DC, int TPW, int XW, int EPI, int PRO>
 void launch_g4(hipStream_t st, int grid, const G4Params &p) {
     const size_t smem = (size_t)p.col_bytes + (size_t)2 * NW * 4 * 64 * sizeof(float4) + (size_t)3 * (p.split_q + 1) * 8 * sizeof(float);
-    static bool attr = false;
-    if (!attr && smem > 48 * 1024) {
+    static unsigned long long attr = 0; // devices that have the attribute
+    if (ps_first_on_device(&attr) && smem > 48 * 1024) {
         (void)hipFuncSetAttribute((const void *)gemv4_kernel<NW, DC, TPW, XW, EPI, PRO>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-        attr = true;
     }
     hipLaunchKernelGGL((gemv4_kernel<NW, DC, TPW, XW, EPI, PRO>), dim3((unsigned)grid), dim3((NW + 1) * 64), smem, st, p);
 }

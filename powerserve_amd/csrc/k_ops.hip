@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256) void argmax_kernel(const float *src, int64_t n
     __syncthreads();
     if (threadIdx.x == 0) {
         for (int w = 1; w < 4; w++) if (bv[w] > best || (bv[w] == best && bi[w] < idx)) { best = bv[w]; idx = bi[w]; }
-        out[blockIdx.x] = idx;
+        out[blockIdx.x] = idx == 0x7fffffff ? 0 : idx; // a row of NaNs: std::max_element returns the first element
     }
 }
 
@@ -289,6 +289,8 @@ void psl_rope(hipStream_t st, const ps_tensor *dst, const ps_tensor *src, const 
 }
 void psl_softmax_ext(hipStream_t st, const ps_tensor *dst, const ps_tensor *src, const float *mask, float scale) {
     const int64_t rows = src->ne[1] * src->ne[2] * src->ne[3];
+    static unsigned long long attr = 0; // devices that have the attribute (rows of more than 64 KiB)
+    if (ps_first_on_device(&attr)) (void)hipFuncSetAttribute((const void *)softmax_ext_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
     hipLaunchKernelGGL(softmax_ext_kernel, dim3((unsigned)rows), dim3(256), (size_t)src->ne[0] * 4, st, tdesc(dst),
                        tdesc(src), mask, scale);
 }

@@ -221,8 +221,27 @@ extern "C" {
 int ps_hip_model_create(ps_hip_ctx *c, const ps_model_desc *d, ps_hip_model **out) {
     *out = nullptr;
     const ps_llm_config &f = d->cfg;
+    if (f.n_kv_heads == 0 || f.n_heads == 0 || f.n_layers == 0 || f.seq_len == 0) PS_FAIL(c, "model_create: zero-sized configuration");
     if (f.n_heads % f.n_kv_heads || f.head_size * f.n_heads != f.dim || f.head_size * f.n_kv_heads != f.kv_dim)
         PS_FAIL(c, "model_create: inconsistent head configuration");
+    { // the descriptor is trusted by every kernel: weight handles must exist and agree with the configuration
+        auto okw = [](const ps_weight *w, int64_t K, int64_t N) {
+            return w && w->K == K && w->N == N && w->qs && (w->dtype == PS_Q4_0 || w->dtype == PS_Q8_0 || w->dtype == PS_Q4_K || w->dtype == PS_Q6_K);
+        };
+        if (!d->token_embd || d->token_embd->K != f.dim || d->token_embd->N != f.vocab_size || !d->token_embd->qs) PS_FAIL(c, "model_create: token_embd missing or of the wrong shape");
+        if (d->output && !okw(d->output, f.dim, f.vocab_size)) PS_FAIL(c, "model_create: output.weight of the wrong shape / type");
+        if (!d->output && !okw(d->token_embd, f.dim, f.vocab_size)) PS_FAIL(c, "model_create: tied lm_head needs a quantized token_embd");
+        if (!d->output_norm || !d->attn_norm || !d->ffn_norm || !d->attn_q || !d->attn_k || !d->attn_v || !d->attn_output || !d->ffn_gate || !d->ffn_up || !d->ffn_down)
+            PS_FAIL(c, "model_create: null weight table");
+        for (uint32_t i = 0; i < f.n_layers; i++) {
+            if (!d->attn_norm[i] || !d->ffn_norm[i]) PS_FAIL(c, "model_create: null norm weights in layer " + std::to_string(i));
+            if (!okw(d->attn_q[i], f.dim, f.dim) || !okw(d->attn_k[i], f.dim, f.kv_dim) || !okw(d->attn_v[i], f.dim, f.kv_dim) || !okw(d->attn_output[i], f.dim, f.dim) ||
+                !okw(d->ffn_gate[i], f.dim, f.hidden_dim) || !okw(d->ffn_up[i], f.dim, f.hidden_dim) || !okw(d->ffn_down[i], f.hidden_dim, f.dim))
+                PS_FAIL(c, "model_create: weight of layer " + std::to_string(i) + " missing or of the wrong shape / type (model.json and weights.gguf disagree?)");
+            if (d->is_qwen2 && (!d->attn_q_bias || !d->attn_k_bias || !d->attn_v_bias || !d->attn_q_bias[i] || !d->attn_k_bias[i] || !d->attn_v_bias[i]))
+                PS_FAIL(c, "model_create: qwen2 needs the attention biases");
+        }
+    }
     if (f.head_size % 32 || f.head_size > 128) PS_FAIL(c, "model_create: head_size must be 32, 64, 96 or 128");
     if (f.n_heads / f.n_kv_heads > 8) PS_FAIL(c, "model_create: GQA ratio > 8 not supported");
     if ((int)f.rope.n_dims != (int)f.head_size) PS_FAIL(c, "model_create: rope n_dims != head_size (reference asserts the same, norm_attention.cpp:38)");
@@ -287,7 +306,15 @@ void ps_hip_model_destroy(ps_hip_model *m) {
 }
 
 size_t ps_hip_model_kv_position(const ps_hip_model *m) { return m->position; }
-int ps_hip_model_kv_truncate(ps_hip_model *m, size_t n) { if (n < m->position) m->position = n; return 0; }
+static void unmask_range(ps_hip_model *m, size_t from, size_t n);
+// slots at or behind the position are never consulted through the visibility table (the causal / tree mask governs them)
+// and KVCache::advance_tokens / append un-hides what it walks over (core/kv_cache.hpp:249-255): a rollback or truncate
+// leaves no hidden slot behind the new position, so a model that served as a speculative draft can decode again
+int ps_hip_model_kv_truncate(ps_hip_model *m, size_t n) {
+    if (n < m->position) m->position = n;
+    unmask_range(m, m->position, m->cfg.seq_len - m->position);
+    return 0;
+}
 // KVCache::advance_tokens unmasks the slots it walks over (core/kv_cache.hpp:249-255)
 static void unmask_range(ps_hip_model *m, size_t from, size_t n) {
     if (!m->n_hidden) return;
@@ -308,6 +335,7 @@ int ps_hip_model_kv_advance(ps_hip_model *m, size_t n) {
 int ps_hip_model_kv_rollback(ps_hip_model *m, size_t n) {
     if (n > m->position) { m->ctx->err = "kv_rollback: more tokens than cached"; return 2; }
     m->position -= n;
+    unmask_range(m, m->position, m->cfg.seq_len - m->position);
     return 0;
 }
 int ps_hip_model_kv_move(ps_hip_model *m, size_t dst, size_t src) {
@@ -417,9 +445,17 @@ int ps_hip_model_decode_greedy(ps_hip_model *m, int32_t token, int steps, int32_
         }
     }
     PS_CHECK(c, hipMemcpyAsync(out_ids, m->ids_dev, (size_t)steps * 4, hipMemcpyDeviceToHost, c->stream));
-    unsigned stuck = 0;
+    unsigned stuck = 0, bar_err = 0;
     PS_CHECK(c, hipMemcpyAsync(&stuck, m->attn_sync + 31, 4, hipMemcpyDeviceToHost, c->stream));
+    if (m->mode & 2) // chained launches: a device-wide barrier that gave up raises word 32 * 11 of its launch site
+        for (uint32_t L = 0; L < m->cfg.n_layers && !bar_err; L++) {
+            unsigned e = 0;
+            PS_CHECK(c, hipMemcpyAsync(&e, m->bars + (size_t)L * 12 * 32 + 32 * 11, 4, hipMemcpyDeviceToHost, c->stream));
+            PS_CHECK(c, hipStreamSynchronize(c->stream));
+            bar_err |= e;
+        }
     PS_CHECK(c, hipStreamSynchronize(c->stream));
+    if (bar_err) PS_FAIL(c, "decode_greedy: a device-wide barrier of the chained launch timed out (mode bit 1 needs every CU for this process); results are not valid");
     if (stuck) PS_FAIL(c, "decode_greedy: the one-launch attention timed out at its rendezvous (GPU shared or partitioned?); clear mode bit 2 for the two-launch path");
     m->position += (size_t)steps;
     return 0;

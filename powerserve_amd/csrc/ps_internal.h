@@ -63,6 +63,16 @@ struct ps_act {
     int8_t *qf;
 };
 
+// hipFuncSetAttribute is per device: `mask` (one static per kernel instantiation) remembers the devices that have it
+static inline bool ps_first_on_device(unsigned long long *mask) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (*mask & bit) return false;
+    *mask |= bit;
+    return true;
+}
+
 #define PS_CHECK(ctx, call)                                                                          \
     do {                                                                                             \
         hipError_t e_ = (call);                                                                      \

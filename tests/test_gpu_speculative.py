@@ -31,6 +31,15 @@ def test_speculative_output_equals_target_greedy(ctx, tmp_path, draft_seed, wt):
         assert st["tokens_per_iteration"] > 2.0, st
     # the plain path still works on the same objects afterwards (no hidden slots left behind in the visible prefix)
     assert np.array_equal(target.generate(prompt, 8, steps), want)
+    # ... and so does the DRAFT model: slots it hid while drafting lie behind its position after the roll-back
+    # (KVCache::rollback + advance/append un-hide them in the reference, core/kv_cache.hpp:249-272)
+    want_d = hip.Model(ctx, dd, max_batch=16)
+    ref_d = want_d.generate(prompt, 8, 12)
+    want_d.close()
+    assert np.array_equal(draft.generate(prompt, 8, 12), ref_d)
+    draft.reset()
+    draft.forward(prompt[:-1], np.arange(prompt.size - 1), lm_head=False)
+    assert np.array_equal(draft.decode_greedy(int(prompt[-1]), 12), ref_d)
     target.close()
     draft.close()
 
