@@ -297,6 +297,8 @@ class Ref:
         L.ref_dup.argtypes = [C.c_void_p] * 3
         L.ref_silu_hadamard.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64]
         L.ref_get_embedding.argtypes = [C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_void_p]
+        if hasattr(L, "ref_token_tree_run"):
+            L.ref_token_tree_run.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int32, C.c_int] + [C.c_void_p] * 5 + [C.c_int, C.c_void_p, C.c_void_p]
         L.ref_sampler_create.restype = C.c_void_p
         L.ref_sampler_create.argtypes = [C.c_void_p]
         L.ref_sampler_free.argtypes = [C.c_void_p]
@@ -463,3 +465,44 @@ class RefModel:
         self.r.L.ref_model_generate(self.h, _p(prompt), prompt.size, batch_size, steps, _p(toks), _p(lg), C.byref(tp),
                                     C.byref(td))
         return toks, lg, tp.value, td.value
+
+
+# ---------------------------------------------------------------- the reference's token tree on scripted models
+class SpecConfig(C.Structure):  # ref_spec_config (oracle/ref_token_tree.cpp) == psh_spec_config
+    _fields_ = [("draft_batch_size", C.c_int32), ("top_k", C.c_int32), ("max_fan_out", C.c_int32), ("early_stop", C.c_int32),
+                ("temperature", C.c_float), ("p_base", C.c_float), ("min_prob", C.c_float)]
+
+
+class Script(C.Structure):  # ref_script: the two scripted models
+    _fields_ = [("shared_seed", C.c_uint64), ("target_seed", C.c_uint64), ("draft_seed", C.c_uint64),
+                ("shared_w", C.c_float), ("target_w", C.c_float), ("draft_w", C.c_float), ("vocab", C.c_int32), ("n_ctx", C.c_int32)]
+
+
+def ref_token_tree_run(ref: "Ref", cfg: SpecConfig, script: Script, prefix, root_token: int, n_iterations: int):
+    """src/speculative/token_tree.cpp driven as SpecTokenIterator::generate_tokens drives it.  Returns a dict of arrays:
+    tokens (emitted), tree [it][bs][3] {token, position, parent}, masks [it][bs][bs], events [n][4] {model, op, a, b}."""
+    bs = cfg.draft_batch_size
+    prefix = np.ascontiguousarray(prefix, dtype=np.int32)
+    out, n_out = np.zeros(n_iterations * bs, dtype=np.int32), np.zeros(1, dtype=np.int32)
+    tree, masks = np.zeros((n_iterations, bs, 3), dtype=np.int32), np.zeros((n_iterations, bs, bs), dtype=np.uint8)
+    cap = n_iterations * bs * 16
+    events, n_ev = np.zeros((cap, 4), dtype=np.int32), np.zeros(1, dtype=np.int32)
+    rc = ref.L.ref_token_tree_run(C.addressof(cfg), C.addressof(script), prefix.ctypes.data, prefix.size, root_token, n_iterations, out.ctypes.data,
+                                  n_out.ctypes.data, tree.ctypes.data, masks.ctypes.data, events.ctypes.data, cap, n_ev.ctypes.data, None)
+    assert rc == 0 and n_ev[0] <= cap
+    return dict(tokens=out[:n_out[0]].copy(), tree=tree, masks=masks, events=events[:n_ev[0]].copy())
+
+
+def ref_gguf_write(ref: "Ref", path: str, arch: str, name: str, alignment: int, tensors):
+    """The reference's own GGUF writer (oracle/ref_gguf.cpp).  tensors: [(name, ggml type, ne tuple, uint8/float32 array)]"""
+    n = len(tensors)
+    names = (C.c_char_p * n)(*[t[0].encode() for t in tensors])
+    types = np.array([t[1] for t in tensors], dtype=np.int32)
+    ne = np.ones((n, 4), dtype=np.int64)
+    for i, t in enumerate(tensors):
+        ne[i, :len(t[2])] = t[2]
+    keep = [np.ascontiguousarray(t[3]) for t in tensors]
+    data = (C.c_void_p * n)(*[a.ctypes.data for a in keep])
+    ref.L.ref_gguf_write.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    rc = ref.L.ref_gguf_write(path.encode(), arch.encode(), name.encode(), alignment, n, names, types.ctypes.data, ne.ctypes.data, data)
+    assert rc == 0

@@ -1,99 +1,102 @@
-// Shape rules follow src/graph/graph.cpp:20-266 (e.g. mat_mul(a, b): a.shape[0] == b.shape[0], result
-// {a.shape[1], b.shape[1], b.shape[2], b.shape[3]} FP32; copy(dst, src) has dst first and no output).
 #include "graph.hpp"
 
 namespace powerserve {
 
+auto Graph::add_tensor(const Tensor &t) -> TensorNode * {
+    tensors.push_back(std::make_shared<TensorNode>(t));
+    return tensors.back().get();
+}
+auto Graph::new_tensor(DataType dt, const Shape &s) -> TensorNode * {
+    tensors.push_back(std::make_shared<TensorNode>(dt, s));
+    return tensors.back().get();
+}
+auto Graph::view_tensor(const TensorNode *t, Shape shape) -> TensorViewNode * {
+    TensorNode *v = add_tensor(*t);
+    v->m_shape  = shape;
+    v->m_data   = nullptr; // bound to the source's storage when buffers are assigned
+    v->alias_of = t;
+    return v;
+}
+
+auto Graph::emit(OpType kind, std::initializer_list<TensorNode *> inputs, TensorNode *result, OpAttr attr) -> TensorNode * {
+    auto op = std::make_shared<OpNode>(kind);
+    op->in.assign(inputs.begin(), inputs.end());
+    op->attr = std::move(attr);
+    if (result) {
+        op->out.push_back(result);
+        result->producer = op.get();
+    }
+    ops.push_back(std::move(op));
+    return result;
+}
+
+// ---- shape inference.  x keeps its shape through the elementwise / normalising ops; the rules that are not "same as
+// the first input" are spelled out where they apply.
+
 auto Graph::get_embedding(TensorNode *weight, const std::vector<int> &tokens) -> TensorNode * {
-    auto out = dup_tensor(weight);
-    out->m_dtype = DataType::FP32;
-    out->m_shape[1] = tokens.size();
-    auto op = new_op(OpType::GET_EMBEDDING);
-    op->set_inputs({weight}); op->set_outputs({out}); op->set_params(GetEmbeddingParams{tokens});
-    return out;
+    Shape rows = weight->m_shape; // one table row per token, widened to FP32
+    rows[1] = tokens.size();
+    return emit(OpType::GET_EMBEDDING, {weight}, new_tensor(DataType::FP32, rows), GetEmbeddingParams{tokens});
 }
+
 auto Graph::add(TensorNode *a, TensorNode *b) -> TensorNode * {
-    POWERSERVE_ASSERT(tensor_can_repeat(b, a));
-    auto out = dup_tensor(a);
-    auto op = new_op(OpType::ADD);
-    op->set_inputs({a, b}); op->set_outputs({out});
-    return out;
+    POWERSERVE_ASSERT(tensor_can_repeat(b, a)); // b broadcasts over a
+    return emit(OpType::ADD, {a, b}, dup_tensor(a));
 }
+
 auto Graph::mat_mul(TensorNode *a, TensorNode *b) -> TensorNode * {
+    // a: [K, M, ...] (weights / keys), b: [K, N, ...] (activations)  ->  [M, N, b.2, b.3] FP32
     POWERSERVE_ASSERT(a->m_shape[0] == b->m_shape[0]);
     POWERSERVE_ASSERT(tensor_can_mul_mat(a, b));
-    auto out = new_tensor(DataType::FP32, {a->m_shape[1], b->m_shape[1], b->m_shape[2], b->m_shape[3]});
-    auto op = new_op(OpType::MAT_MUL);
-    op->set_inputs({a, b}); op->set_outputs({out});
-    return out;
+    return emit(OpType::MAT_MUL, {a, b}, new_tensor(DataType::FP32, {a->m_shape[1], b->m_shape[1], b->m_shape[2], b->m_shape[3]}));
 }
+
 auto Graph::rms_norm(TensorNode *x, TensorNode *weight, float eps) -> TensorNode * {
-    POWERSERVE_ASSERT(weight->n_dims() == 1);
+    POWERSERVE_ASSERT(weight->n_dims() == 1 && weight->m_shape[0] == x->m_shape[0]);
     POWERSERVE_ASSERT(x->m_dtype == weight->m_dtype);
-    POWERSERVE_ASSERT(x->m_shape[0] == weight->m_shape[0]);
-    auto out = dup_tensor(x);
-    auto op = new_op(OpType::RMS_NORM);
-    op->set_inputs({x, weight}); op->set_outputs({out}); op->set_params(RMSNormParams{eps});
-    return out;
+    return emit(OpType::RMS_NORM, {x, weight}, dup_tensor(x), RMSNormParams{eps});
 }
+
 auto Graph::silu_hadamard(TensorNode *gate, TensorNode *up) -> TensorNode * {
-    POWERSERVE_ASSERT(gate->m_dtype == up->m_dtype);
-    POWERSERVE_ASSERT(gate->m_shape == up->m_shape);
-    auto out = dup_tensor(gate);
-    auto op = new_op(OpType::SILU_HADAMARD);
-    op->set_inputs({gate, up}); op->set_outputs({out});
-    return out;
+    POWERSERVE_ASSERT(gate->m_dtype == up->m_dtype && gate->m_shape == up->m_shape);
+    return emit(OpType::SILU_HADAMARD, {gate, up}, dup_tensor(gate));
 }
-void Graph::copy(TensorNode *dst, TensorNode *src) {
-    auto op = new_op(OpType::COPY);
-    op->set_inputs({dst, src}); op->set_params(CopyParams{});
-}
+
+void Graph::copy(TensorNode *dst, TensorNode *src) { emit(OpType::COPY, {dst, src}, nullptr); } // destination first, no result
+
 auto Graph::rope(TensorNode *src, const std::vector<int> &pos, const ModelConfig::LLMConfig::RopeConfig &params) -> TensorNode * {
-    auto out = dup_tensor(src);
-    auto op = new_op(OpType::ROPE);
-    op->set_inputs({src}); op->set_outputs({out}); op->set_params(RopeParams{pos, params});
-    return out;
+    return emit(OpType::ROPE, {src}, dup_tensor(src), RopeParams{pos, params});
 }
+
 auto Graph::softmax_ext(TensorNode *x, TensorNode *mask, float scale, float max_bias) -> TensorNode * {
-    auto out = dup_tensor(x);
-    auto op = new_op(OpType::SOFTMAX_EXT);
-    op->set_inputs({x, mask}); op->set_outputs({out}); op->set_params(SoftmaxExtParams{scale, max_bias});
-    return out;
+    return emit(OpType::SOFTMAX_EXT, {x, mask}, dup_tensor(x), SoftmaxExtParams{scale, max_bias});
 }
+
 auto Graph::permute(TensorNode *x, Shape axes) -> TensorViewNode * {
-    for (int i = 0; i < 4; i++) { POWERSERVE_ASSERT(axes[i] < max_n_dims); for (int j = i + 1; j < 4; j++) POWERSERVE_ASSERT(axes[i] != axes[j]); }
     Shape shape{};
-    for (int i = 0; i < 4; i++) shape[axes[i]] = x->m_shape[i];
-    auto out = view_tensor(x, shape);
-    auto op = new_op(OpType::PERMUTE);
-    op->set_inputs({x}); op->set_outputs({out}); op->set_params(PermuteParams{axes});
-    return out;
+    unsigned used = 0; // axes must be a permutation of 0..3: dimension i of x becomes dimension axes[i]
+    for (size_t i = 0; i < max_n_dims; i++) {
+        POWERSERVE_ASSERT(axes[i] < max_n_dims && !(used >> axes[i] & 1u));
+        used |= 1u << axes[i];
+        shape[axes[i]] = x->m_shape[i];
+    }
+    return emit(OpType::PERMUTE, {x}, view_tensor(x, shape), PermuteParams{axes});
 }
-auto Graph::cont(TensorNode *x, Shape shape) -> TensorNode * {
-    auto out = new_tensor(x->m_dtype, shape);
-    auto op = new_op(OpType::CONT);
-    op->set_inputs({x}); op->set_outputs({out}); op->set_params(ContParams{});
-    return out;
-}
+
+auto Graph::cont(TensorNode *x, Shape shape) -> TensorNode * { return emit(OpType::CONT, {x}, new_tensor(x->m_dtype, shape)); }
+
 auto Graph::view(const TensorNode *x, Shape shape, Shape stride, size_t offset) -> TensorViewNode * {
-    auto out = view_tensor(x, shape);
-    auto op = new_op(OpType::VIEW);
-    op->set_inputs({}); op->set_outputs({out}); op->set_params(ViewParams{stride, offset});
-    return out;
+    return emit(OpType::VIEW, {}, view_tensor(x, shape), ViewParams{stride, offset}); // x is reached through alias_of
 }
+
 auto Graph::get_mask(const CausalAttentionMask &mask, Shape shape, const std::vector<int> &pos) -> TensorNode * {
-    auto out = new_tensor(DataType::FP32, shape);
-    auto op = new_op(OpType::GET_MASK);
-    op->set_outputs({out}); op->set_params(GetMaskParams{mask, pos});
-    return out;
+    return emit(OpType::GET_MASK, {}, new_tensor(DataType::FP32, shape), GetMaskParams{&mask, pos});
 }
+
 auto Graph::transpose(TensorNode *x) -> TensorViewNode * {
-    auto shape = x->m_shape;
+    Shape shape = x->m_shape;
     std::swap(shape[0], shape[1]);
-    auto out = view_tensor(x, shape);
-    auto op = new_op(OpType::TRANSPOSE);
-    op->set_inputs({x}); op->set_outputs({out});
-    return out;
+    return emit(OpType::TRANSPOSE, {x}, view_tensor(x, shape));
 }
 
 } // namespace powerserve

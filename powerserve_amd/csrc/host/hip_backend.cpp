@@ -159,8 +159,7 @@ void HIPBackend::print(const Tensor *x, size_t) const {
 }
 // ---- plan(): recognise the canonical forward and lower it
 namespace {
-const void *handle_of(Node *n) { // device handle behind a graph tensor (weights: ps_weight*, F32 vectors: device float*)
-    auto *t = n->tensor();
+const void *handle_of(const TensorNode *t) { // device handle behind a graph tensor (weights: ps_weight*, F32 vectors: device float*)
     return (t && t->m_data) ? t->get<HIPBuffer>().m_data : nullptr;
 }
 struct Cursor {
@@ -177,35 +176,35 @@ bool HIPBackend::match_canonical(std::vector<std::shared_ptr<OpNode>> &ops, Lowe
     Cursor c{ops};
     // x = get_embedding(token table, tokens)
     OpNode *emb = c.take(OpType::GET_EMBEDDING);
-    if (!emb || handle_of(emb->prev[0]) != T.token_embd) return false;
+    if (!emb || handle_of(emb->in[0]) != T.token_embd) return false;
     const auto &tokens = emb->get_params<GetEmbeddingParams>().tokens;
     const size_t bs = tokens.size();
     if (bs == 0) return false;
-    Node *x = emb->next[0];
+    TensorNode *x = emb->out[0];
     const std::vector<int> *pos = nullptr;
     const CausalAttentionMask *mask = nullptr;
     const float want_scale = 1.0f / sqrtf((float)m_config.head_size);
-    auto mat_mul = [&](const void *w, Node *act) -> Node * { // MAT_MUL(weight w, activation act) -> its output node
+    auto mat_mul = [&](const void *w, TensorNode *act) -> TensorNode * { // MAT_MUL(weight w, activation act) -> its output node
         OpNode *o = c.take(OpType::MAT_MUL);
-        return (o && handle_of(o->prev[0]) == w && o->prev[1] == act) ? o->next[0] : nullptr;
+        return (o && handle_of(o->in[0]) == w && o->in[1] == act) ? o->out[0] : nullptr;
     };
-    auto rms = [&](const void *w, Node *in) -> Node * {
+    auto rms = [&](const void *w, TensorNode *in) -> TensorNode * {
         OpNode *o = c.take(OpType::RMS_NORM);
-        return (o && o->prev[0] == in && handle_of(o->prev[1]) == w && o->get_params<RMSNormParams>().eps == m_config.norm_eps) ? o->next[0] : nullptr;
+        return (o && o->in[0] == in && handle_of(o->in[1]) == w && o->get_params<RMSNormParams>().eps == m_config.norm_eps) ? o->out[0] : nullptr;
     };
-    auto add_bias = [&](Node *in, const void *b) -> Node * {
+    auto add_bias = [&](TensorNode *in, const void *b) -> TensorNode * {
         if (!T.bias) return in;
         OpNode *o = c.take(OpType::ADD);
-        return (o && o->prev[0] == in && handle_of(o->prev[1]) == b) ? o->next[0] : nullptr;
+        return (o && o->in[0] == in && handle_of(o->in[1]) == b) ? o->out[0] : nullptr;
     };
     for (size_t L = 0; L < T.layers.size(); L++) {
         const auto &W = T.layers[L];
         // ---- NormAttention::build
-        Node *n1 = rms(W.attn_norm, x);
+        TensorNode *n1 = rms(W.attn_norm, x);
         if (!n1) return false;
-        Node *q = mat_mul(W.wq, n1); if (!q || !(q = add_bias(q, W.bq))) return false;
-        Node *k = mat_mul(W.wk, n1); if (!k || !(k = add_bias(k, W.bk))) return false;
-        Node *v = mat_mul(W.wv, n1); if (!v || !(v = add_bias(v, W.bv))) return false;
+        TensorNode *q = mat_mul(W.wq, n1); if (!q || !(q = add_bias(q, W.bq))) return false;
+        TensorNode *k = mat_mul(W.wk, n1); if (!k || !(k = add_bias(k, W.bk))) return false;
+        TensorNode *v = mat_mul(W.wv, n1); if (!v || !(v = add_bias(v, W.bv))) return false;
         for (int r = 0; r < 2; r++) { // rope(q view), rope(k view): same positions, the model's rope configuration
             OpNode *o = c.take(OpType::ROPE);
             if (!o) return false;
@@ -223,35 +222,35 @@ bool HIPBackend::match_canonical(std::vector<std::shared_ptr<OpNode>> &ops, Lowe
         if (!gm) return false;
         const auto &mp = gm->get_params<GetMaskParams>();
         if (mp.pos != *pos) return false;
-        mask = &mp.mask;
+        mask = mp.mask;
         OpNode *sm = c.take(OpType::SOFTMAX_EXT);
         if (!sm || sm->get_params<SoftmaxExtParams>().scale != want_scale || sm->get_params<SoftmaxExtParams>().max_bias != 0.0f) return false;
         if (!c.take(OpType::VIEW) || !c.take(OpType::MAT_MUL) || !c.take(OpType::PERMUTE)) return false;
         OpNode *ct = c.take(OpType::CONT);
         if (!ct) return false;
-        Node *o = mat_mul(W.wo, ct->next[0]);
+        TensorNode *o = mat_mul(W.wo, ct->out[0]);
         OpNode *res = c.take(OpType::ADD);
-        if (!o || !res || res->prev[0] != x || res->prev[1] != o) return false;
-        Node *a = res->next[0];
+        if (!o || !res || res->in[0] != x || res->in[1] != o) return false;
+        TensorNode *a = res->out[0];
         // ---- FFN::build
-        Node *n2 = rms(W.ffn_norm, a);
+        TensorNode *n2 = rms(W.ffn_norm, a);
         if (!n2) return false;
-        Node *g = mat_mul(W.wg, n2), *u = g ? mat_mul(W.wu, n2) : nullptr;
+        TensorNode *g = mat_mul(W.wg, n2), *u = g ? mat_mul(W.wu, n2) : nullptr;
         OpNode *sh = c.take(OpType::SILU_HADAMARD);
-        if (!u || !sh || sh->prev[0] != g || sh->prev[1] != u) return false;
-        Node *d = mat_mul(W.wd, sh->next[0]);
+        if (!u || !sh || sh->in[0] != g || sh->in[1] != u) return false;
+        TensorNode *d = mat_mul(W.wd, sh->out[0]);
         OpNode *res2 = c.take(OpType::ADD);
-        if (!d || !res2 || res2->prev[0] != a || res2->prev[1] != d) return false;
-        x = res2->next[0];
+        if (!d || !res2 || res2->in[0] != a || res2->in[1] != d) return false;
+        x = res2->out[0];
     }
     out.lm_head = false;
     out.logits  = nullptr;
     if (!c.done()) { // final norm + lm_head (tied: the token table)
-        Node *n = rms(T.output_norm, x);
-        Node *lg = n ? mat_mul(T.output ? T.output : T.token_embd, n) : nullptr;
+        TensorNode *n = rms(T.output_norm, x);
+        TensorNode *lg = n ? mat_mul(T.output ? T.output : T.token_embd, n) : nullptr;
         if (!lg || !c.done()) return false;
         out.lm_head = true;
-        out.logits  = lg->tensor();
+        out.logits  = lg;
     }
     if (!pos) return false;
     for (size_t i = 1; i < bs; i++) if ((*pos)[i] != (*pos)[0] + (int)i) return false; // the KV append is one contiguous block
@@ -297,7 +296,7 @@ void Executor::allocate_buffers() {
     auto cstride = [](const Tensor &t, size_t es) { Stride s; s[0] = es; for (size_t i = 1; i < 4; i++) s[i] = s[i - 1] * t.m_shape[i - 1]; return s; };
     size_t need = 0;
     for (auto &t : m_graph.tensors)
-        if (!t->m_data && t->type != NodeType::TENSOR_VIEW) need += (t->n_elements() * (t->m_dtype == DataType::INT64 ? 8 : 4) + 255) / 256 * 256;
+        if (!t->m_data && !t->is_view()) need += (t->n_elements() * (t->m_dtype == DataType::INT64 ? 8 : 4) + 255) / 256 * 256;
     be.arena_reset();
     be.arena_reserve(need + 4096); // one device allocation at most (grown geometrically), not one malloc per intermediate
     for (auto &t : m_graph.tensors) {
@@ -308,10 +307,9 @@ void Executor::allocate_buffers() {
         case DataType::INT64: es = 8; break;
         default: POWERSERVE_ABORT("could not allocate buffer for data type");
         }
-        if (t->type == NodeType::TENSOR_VIEW) {
-            auto *v = static_cast<TensorViewNode *>(t.get());
-            POWERSERVE_ASSERT(v->parent->m_data != nullptr, "parent buffer is nullptr");
-            t->m_data = std::make_shared<HIPBuffer>(cstride(*t, es), v->parent->get<HIPBuffer>().m_data);
+        if (t->is_view()) {
+            POWERSERVE_ASSERT(t->alias_of->m_data != nullptr, "a view was created before its source had storage");
+            t->m_data = std::make_shared<HIPBuffer>(cstride(*t, es), t->alias_of->get<HIPBuffer>().m_data);
         } else {
             t->m_data = std::make_shared<HIPBuffer>(cstride(*t, es), be.arena_alloc(t->n_elements() * es));
         }
@@ -326,25 +324,25 @@ void Executor::run() {
     if (be.lowered()) { be.run_lowered(); return; }
     for (auto &op : m_graph.ops) {
         switch (op->op) {
-        case OpType::GET_EMBEDDING: be.get_embedding(op->output(), op->prev[0]->tensor(), op->get_params<GetEmbeddingParams>().tokens); break;
-        case OpType::ADD: be.add(op->output(), op->prev[0]->tensor(), op->prev[1]->tensor()); break;
-        case OpType::MAT_MUL: be.matmul(op->output(), op->prev[0]->tensor(), op->prev[1]->tensor()); break;
-        case OpType::RMS_NORM: be.rmsnorm(op->output(), op->prev[0]->tensor(), op->prev[1]->tensor(), op->get_params<RMSNormParams>().eps); break;
-        case OpType::SILU_HADAMARD: be.silu_hadamard(op->output(), op->prev[0]->tensor(), op->prev[1]->tensor()); break;
-        case OpType::ROPE: { auto &p = op->get_params<RopeParams>(); be.rope(op->next[0]->tensor(), op->prev[0]->tensor(), p.pos, p.rope_cfg); } break;
-        case OpType::SOFTMAX: be.softmax(op->output(), op->prev[0]->tensor()); break;
-        case OpType::COPY: be.copy(op->prev[0]->tensor(), op->prev[1]->tensor()); break;
-        case OpType::PRINT: be.print(op->prev[0]->tensor(), op->get_params<PrintParams>().size); break;
-        case OpType::PERMUTE: be.permute(op->output(), op->prev[0]->tensor(), op->get_params<PermuteParams>().axes); break;
-        case OpType::CONT: be.cont(op->output(), op->prev[0]->tensor()); break;
+        case OpType::GET_EMBEDDING: be.get_embedding(op->output(), op->in[0], op->get_params<GetEmbeddingParams>().tokens); break;
+        case OpType::ADD: be.add(op->output(), op->in[0], op->in[1]); break;
+        case OpType::MAT_MUL: be.matmul(op->output(), op->in[0], op->in[1]); break;
+        case OpType::RMS_NORM: be.rmsnorm(op->output(), op->in[0], op->in[1], op->get_params<RMSNormParams>().eps); break;
+        case OpType::SILU_HADAMARD: be.silu_hadamard(op->output(), op->in[0], op->in[1]); break;
+        case OpType::ROPE: { auto &p = op->get_params<RopeParams>(); be.rope(op->out[0], op->in[0], p.pos, p.rope_cfg); } break;
+        case OpType::SOFTMAX: be.softmax(op->output(), op->in[0]); break;
+        case OpType::COPY: be.copy(op->in[0], op->in[1]); break;
+        case OpType::PRINT: be.print(op->in[0], op->get_params<PrintParams>().size); break;
+        case OpType::PERMUTE: be.permute(op->output(), op->in[0], op->get_params<PermuteParams>().axes); break;
+        case OpType::CONT: be.cont(op->output(), op->in[0]); break;
         case OpType::VIEW: { // executed in the executor, like the reference (executor.cpp:194-199)
             auto out = op->output(); auto &p = op->get_params<ViewParams>();
             out->get<HIPBuffer>().m_stride = p.stride;
             out->get<HIPBuffer>().m_data   = (char *)out->get<HIPBuffer>().m_data + p.offset;
         } break;
-        case OpType::SOFTMAX_EXT: { auto &p = op->get_params<SoftmaxExtParams>(); be.softmax_ext(op->output(), op->prev[0]->tensor(), op->prev[1]->tensor(), p.scale, p.max_bias); } break;
-        case OpType::GET_MASK: { auto &p = op->get_params<GetMaskParams>(); be.get_mask(op->output(), p.pos, p.mask); } break;
-        case OpType::TRANSPOSE: be.transpose(op->output(), op->prev[0]->tensor()); break;
+        case OpType::SOFTMAX_EXT: { auto &p = op->get_params<SoftmaxExtParams>(); be.softmax_ext(op->output(), op->in[0], op->in[1], p.scale, p.max_bias); } break;
+        case OpType::GET_MASK: { auto &p = op->get_params<GetMaskParams>(); be.get_mask(op->output(), p.pos, *p.mask); } break;
+        case OpType::TRANSPOSE: be.transpose(op->output(), op->in[0]); break;
         default: POWERSERVE_ABORT("Unknown OpType: " + std::to_string((int)op->op));
         }
     }

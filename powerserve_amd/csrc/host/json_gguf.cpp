@@ -171,3 +171,30 @@ const GGUFTensor *GGUFFile::find(const std::string &name) const {
 }
 
 } // namespace powerserve
+
+// ---------------------------------------------------------------- C driver API: what the reader saw in a file
+extern "C" {
+void psh_set_error(const char *msg);
+// One line per item into buf: "T <name> <type> <nbytes> <fnv1a-64 of the data, hex> <ne...>" per tensor (file order),
+// "S <key> <value>" / "N <key> <value %.17g>" per scalar metadata key.  Returns the length needed (> cap: truncated), -1 on error.
+int64_t psh_gguf_summary(const char *path, char *buf, size_t cap) {
+    try {
+        powerserve::GGUFFile f(path);
+        std::string out;
+        char line[512];
+        for (const auto &t : f.tensors) {
+            uint64_t h = 0xcbf29ce484222325ull;
+            const uint8_t *p = (const uint8_t *)t.data;
+            for (size_t i = 0; i < t.nbytes; i++) { h ^= p[i]; h *= 0x100000001b3ull; }
+            snprintf(line, sizeof line, "T %s %d %zu %016llx", t.name.c_str(), t.type, t.nbytes, (unsigned long long)h);
+            out += line;
+            for (int64_t d : t.ne) out += " " + std::to_string(d);
+            out += "\n";
+        }
+        for (const auto &kv : f.kv_str) out += "S " + kv.first + " " + kv.second + "\n";
+        for (const auto &kv : f.kv_num) { snprintf(line, sizeof line, "N %s %.17g\n", kv.first.c_str(), kv.second); out += line; }
+        if (cap) { const size_t n = std::min(cap - 1, out.size()); memcpy(buf, out.data(), n); buf[n] = 0; }
+        return (int64_t)out.size() + 1;
+    } catch (const std::exception &e) { psh_set_error(e.what()); return -1; }
+}
+}

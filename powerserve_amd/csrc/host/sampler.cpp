@@ -2,160 +2,172 @@
 
 #include <algorithm>
 #include <cmath>
-#include <unordered_map>
 
 namespace powerserve {
 
-ProbArray::ProbArray(std::span<const float> logits) {
-    m_probs.resize(logits.size());
-    for (size_t i = 0; i < logits.size(); i++) m_probs[i] = {logits[i], (Token)i};
+ProbArray::ProbArray(std::span<const float> logits) : m_probs(logits.size()) {
+    Token id = 0;
+    for (auto &c : m_probs) { c.prob = logits[(size_t)id]; c.token = id++; }
+}
+
+void ProbArray::sort_descending(size_t first_n) {
+    if (m_is_sorted) return;
+    first_n = std::min(first_n, size());
+    // (partial_sort over the full length is the library's heap sort; the reference sorts fully with std::sort only in
+    //  softmax, see there)
+    std::partial_sort(m_probs.begin(), m_probs.begin() + first_n, m_probs.end(), std::greater<ProbIndex>());
+    m_is_sorted = true;
 }
 
 void ProbArray::normalize() {
     if (m_is_normalized) return;
-    double sum = 0.;
-    for (const auto &p : m_probs) sum += p.prob;
-    for (auto &p : m_probs) p.prob /= sum; // (float /= double: divided in double, rounded once)
+    double total = 0.;
+    for (const ProbIndex &c : m_probs) total += c.prob;
+    for (ProbIndex &c : m_probs) c.prob = (float)((double)c.prob / total);
     m_is_normalized = true;
 }
 
 void ProbArray::softmax() {
-    POWERSERVE_ASSERT(m_probs.size() > 0);
-    if (!m_is_sorted) {
-        std::sort(m_probs.begin(), m_probs.end(), std::greater());
+    POWERSERVE_ASSERT(!m_probs.empty());
+    if (!m_is_sorted) { // full order, std::sort as in prob_array.cpp:40 (tie order is the algorithm's)
+        std::sort(m_probs.begin(), m_probs.end(), std::greater<ProbIndex>());
         m_is_sorted = true;
     }
-    const float max_prob = m_probs[0].prob;
-    double exp_prob_sum  = 0; // smallest to largest
-    for (auto it = m_probs.rbegin(); it != m_probs.rend(); ++it) {
-        it->prob = std::exp(it->prob - max_prob);
-        exp_prob_sum += it->prob;
+    const float top = m_probs.front().prob;
+    double total = 0.; // accumulated from the small end
+    for (size_t i = size(); i-- > 0;) {
+        const float e = std::exp(m_probs[i].prob - top);
+        m_probs[i].prob = e;
+        total += e;
     }
-    for (auto &p : m_probs) p.prob /= exp_prob_sum;
+    for (ProbIndex &c : m_probs) c.prob = (float)((double)c.prob / total);
     m_is_normalized = true;
 }
 
-ProbIndex &ProbArray::greedy_sample() { return *std::max_element(m_probs.begin(), m_probs.end()); }
+ProbIndex &ProbArray::greedy_sample() {
+    size_t best = 0;
+    for (size_t i = 1; i < size(); i++)
+        if (m_probs[best].prob < m_probs[i].prob) best = i; // first of equals wins
+    return m_probs[best];
+}
 
-void TemperatureSampler::apply(ProbArray &probs) {
-    POWERSERVE_ASSERT(m_temperature > 0);
-    if (m_temperature != 1) {
-        for (auto &p : probs.m_probs) p.prob /= m_temperature;
-        probs.m_is_normalized = false;
+namespace stage {
+
+void top_k(ProbArray &c, size_t k) {
+    POWERSERVE_ASSERT(k > 0);
+    k = std::min(k, c.size());
+    c.sort_descending(k);
+    if (k < c.size()) {
+        c.resize(k);
+        c.m_is_normalized = false;
     }
 }
 
-void TopKSampler::apply(ProbArray &probs) {
-    POWERSERVE_ASSERT(m_topk > 0);
-    const size_t k = std::min(m_topk, probs.m_probs.size());
-    if (!probs.m_is_sorted) {
-        std::partial_sort(probs.m_probs.begin(), probs.m_probs.begin() + k, probs.m_probs.end(), std::greater<ProbIndex>{});
-        probs.m_is_sorted = true;
-    }
-    if (k != probs.m_probs.size()) probs.m_is_normalized = false;
-    probs.m_probs.resize(k);
+void temperature(ProbArray &c, float t) {
+    POWERSERVE_ASSERT(t > 0);
+    if (t == 1) return;
+    for (ProbIndex &x : c.m_probs) x.prob /= t;
+    c.m_is_normalized = false;
 }
 
-void TopPSampler::apply(ProbArray &probs) {
-    if (m_topp >= 1.0f) return;
-    POWERSERVE_ASSERT(probs.m_is_normalized);
-    POWERSERVE_ASSERT(probs.m_is_sorted);
-    float cum_sum   = 0.0f;
-    size_t last_idx = probs.m_probs.size();
-    for (size_t i = 0; i < probs.m_probs.size(); ++i) {
-        cum_sum += probs.m_probs[i].prob;
-        if (cum_sum >= m_topp && i + 1 >= m_min_keep) { last_idx = i + 1; break; }
+void top_p(ProbArray &c, float p, size_t min_keep) {
+    if (p >= 1.0f) return;
+    POWERSERVE_ASSERT(c.m_is_normalized && c.m_is_sorted);
+    float mass  = 0.0f;
+    size_t keep = 0;
+    while (keep < c.size()) {
+        mass += c[keep++].prob;
+        if (mass >= p && keep >= min_keep) break;
     }
-    if (last_idx != probs.m_probs.size()) probs.m_is_normalized = false;
-    probs.m_probs.resize(last_idx);
+    if (keep < c.size()) {
+        c.resize(keep);
+        c.m_is_normalized = false;
+    }
 }
 
-RepeatPenaltySampler::RepeatPenaltySampler(int32_t vocab_size, Token special_eos_id, Token linefeed_id, int32_t penalty_last_n, float penalty_repeat,
-                                           float penalty_freq, float penalty_present, bool penalize_nl, bool ignore_eos)
-    : m_vocab_size(vocab_size), m_special_eos_id(special_eos_id), m_linefeed_id(linefeed_id), m_penalty_last_n(penalty_last_n),
-      m_penalty_repeat(penalty_repeat), m_penalty_freq(penalty_freq), m_penalty_present(penalty_present), m_penalize_nl(penalize_nl),
-      m_ignore_eos(ignore_eos) {
-    if (linefeed_id == null_token) m_penalize_nl = true;
-    if (special_eos_id == null_token) m_ignore_eos = false;
-    // as in the reference the history starts as penalty_last_n entries of token 0 and only ever grows at the back, and the
-    // window that is counted is its FIRST penalty_last_n entries (sampler.hpp:109-110, sampler.cpp:142-144)
-    m_prev.resize(m_penalty_last_n);
+void draw(ProbArray &c, std::mt19937 &engine) {
+    const ProbIndex chosen = c.stochastic_sample(engine);
+    c.resize(1);
+    c[0] = {1.0f, chosen.token};
+    c.m_is_sorted = c.m_is_normalized = true;
 }
 
-void RepeatPenaltySampler::apply(ProbArray &probs) {
-    auto find = [&](Token t) -> int64_t { // candidates not yet sorted / truncated: the token sits at its own index
-        if (t >= 0 && probs.m_probs.size() > (size_t)t && probs.m_probs[t].token == t) return t;
-        for (size_t i = 0; i < probs.m_probs.size(); ++i)
-            if (probs.m_probs[i].token == t) return (int64_t)i;
-        return -1;
-    };
-    if (m_ignore_eos) {
-        const int64_t i = find(m_special_eos_id);
-        if (i >= 0) probs.m_probs[i].prob = -INFINITY;
-    }
-    if (m_penalty_last_n == 0 || (m_penalty_repeat == 1.0f && m_penalty_freq == 0.0f && m_penalty_present == 0.0f)) return;
-    int64_t nl_idx = -1;
-    float nl_logit = -INFINITY;
-    if (!m_penalize_nl) {
-        POWERSERVE_ASSERT(m_linefeed_id >= 0);
-        nl_idx = find(m_linefeed_id);
-        if (nl_idx >= 0) nl_logit = probs.m_probs[nl_idx].prob;
-    }
-    std::unordered_map<Token, int> token_count;
-    for (int i = 0; i < std::min<int>(m_penalty_last_n, (int)m_prev.size()); ++i) token_count[m_prev[i]]++;
-    for (auto &p : probs.m_probs) {
-        const auto it = token_count.find(p.token);
-        if (it == token_count.end()) continue;
-        const int count = it->second;
-        if (p.prob <= 0) p.prob *= m_penalty_repeat; // multiply negative logits, divide positive ones
-        else p.prob /= m_penalty_repeat;
-        p.prob -= float(count) * m_penalty_freq + float(count > 0) * m_penalty_present;
-    }
-    probs.m_is_sorted = false;
-    if (!m_penalize_nl && nl_idx >= 0) probs.m_probs[nl_idx].prob = nl_logit;
+RepeatPenalty::RepeatPenalty(const SamplerConfig &cfg, Token eos_id, Token linefeed_id)
+    : eos(eos_id), linefeed(linefeed_id), last_n(cfg.penalty_last_n), repeat(cfg.penalty_repeat), freq(cfg.penalty_freq),
+      present(cfg.penalty_present), spare_linefeed(!cfg.penalize_nl && linefeed_id != none), ban_eos(cfg.ignore_eos && eos_id != none),
+      history((size_t)std::max(cfg.penalty_last_n, 0), 0) {}
+
+// position of `t` in the list: its own index while nothing has reordered the list yet, otherwise searched for
+static ProbIndex *locate(ProbArray &c, Token t) {
+    if (t >= 0 && (size_t)t < c.size() && c[(size_t)t].token == t) return &c[(size_t)t];
+    for (ProbIndex &x : c.m_probs)
+        if (x.token == t) return &x;
+    return nullptr;
 }
 
-void RepeatPenaltySampler::accept(Token token) {
-    if (m_penalty_last_n > 0) m_prev.push_back(token);
-}
-
-void StochasticSampler::apply(ProbArray &probs) {
-    probs[0] = probs.stochastic_sample(m_random_state);
-    probs.resize(1);
-    probs[0].prob         = 1.0f;
-    probs.m_is_sorted     = true;
-    probs.m_is_normalized = true;
-}
-
-void SamplerChain::build_from_config(const SamplerConfig &config, int32_t n_vocabs, Token special_eos_id, Token linefeed_id) {
-    uint64_t seed = config.seed;
-    if (seed == (uint64_t)-1) {
-        std::random_device rd;
-        seed = rd();
+void RepeatPenalty::apply(ProbArray &c) const {
+    if (ban_eos)
+        if (ProbIndex *e = locate(c, eos)) e->prob = -INFINITY;
+    if (!active()) return;
+    ProbIndex *nl        = spare_linefeed ? locate(c, linefeed) : nullptr;
+    const float nl_logit = nl ? nl->prob : 0.f;
+    // occurrences inside the window, dense over the token ids that can appear in the list
+    const size_t window = std::min((size_t)last_n, history.size());
+    Token hi = -1;
+    for (size_t i = 0; i < window; i++) hi = std::max(hi, history[i]);
+    std::vector<int> seen((size_t)(hi + 1), 0);
+    for (size_t i = 0; i < window; i++)
+        if (history[i] >= 0) seen[(size_t)history[i]]++;
+    for (ProbIndex &x : c.m_probs) {
+        const int n = (x.token >= 0 && x.token <= hi) ? seen[(size_t)x.token] : 0;
+        if (n == 0) continue;
+        // a positive logit is divided, a non-positive one multiplied, so the token always becomes less likely
+        x.prob = x.prob > 0 ? x.prob / repeat : x.prob * repeat;
+        x.prob -= float(n) * freq + 1.0f * present;
     }
-    m_seed = seed;
-    append<RepeatPenaltySampler>(n_vocabs, special_eos_id, linefeed_id, config.penalty_last_n, config.penalty_repeat, config.penalty_freq,
-                                 config.penalty_present, config.penalize_nl, config.ignore_eos);
-    append<TopKSampler>(config.top_k);
-    append<TemperatureSampler>(config.temperature);
-    append<SoftmaxSampler>();
-    append<TopPSampler>(config.top_p);
-    append<NormalizeSampler>();
-    append<StochasticSampler>(seed);
+    c.m_is_sorted = false;
+    if (nl) nl->prob = nl_logit;
+}
+
+} // namespace stage
+
+void SamplerChain::append(std::shared_ptr<Sampler> s) {
+    m_plugins.push_back(s);
+    m_stages.push_back([s](ProbArray &c) { s->apply(c); });
+}
+
+void SamplerChain::build_from_config(const SamplerConfig &config, int32_t, Token special_eos_id, Token linefeed_id) {
+    m_seed = config.seed;
+    if (m_seed == (uint64_t)-1) m_seed = std::random_device{}();
+    m_engine.seed((std::mt19937::result_type)m_seed);
+    m_penalty = stage::RepeatPenalty(config, special_eos_id, linefeed_id);
+    const float t = config.temperature, p = config.top_p;
+    const size_t k = config.top_k;
+    m_stages.clear();
+    append([this](ProbArray &c) { m_penalty.apply(c); });
+    append([k](ProbArray &c) { stage::top_k(c, k); });
+    append([t](ProbArray &c) { stage::temperature(c, t); });
+    append(stage::softmax);
+    append([p](ProbArray &c) { stage::top_p(c, p); });
+    append(stage::normalize);
+    append([this](ProbArray &c) { stage::draw(c, m_engine); });
 }
 
 void SamplerChain::apply(ProbArray &probs) {
-    for (auto &s : m_samplers) s->apply(probs);
+    for (const Stage &s : m_stages) s(probs);
 }
+
 void SamplerChain::accept(Token token) {
-    for (auto &s : m_samplers) s->accept(token);
+    m_penalty.accept(token);
+    for (auto &s : m_plugins) s->accept(token);
 }
+
 Token SamplerChain::sample(std::span<const float> logits) {
-    ProbArray probs(logits);
-    apply(probs);
-    const Token next = probs[0].token;
-    accept(next);
-    return next;
+    ProbArray candidates(logits);
+    apply(candidates);
+    const Token chosen = candidates[0].token;
+    accept(chosen);
+    return chosen;
 }
 
 } // namespace powerserve

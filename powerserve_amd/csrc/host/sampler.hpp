@@ -1,16 +1,17 @@
-// Sampler chain, host side — mirrors
-//   ProbIndex / ProbArray          src/sampler/prob_array.hpp:24-82, prob_array.cpp:21-67
-//   Temperature / Softmax / Normalize / TopK / TopP / RepeatPenalty / Stochastic samplers
-//                                  src/sampler/sampler.hpp:26-127, sampler.cpp:19-186
-//   SamplerChain::build_from_config src/sampler/sampler_chain.cpp:19-51 (order: repeat penalty, top-k, temperature,
-//                                  softmax, top-p, normalize, stochastic)
-//   HyperParams::SamplerConfig     src/core/config.hpp:34-47
-// Logits come from the backend (ps_hip_model_logits); this is plain host arithmetic on at most vocab_size floats per
-// token, kept bit-compatible with the reference (same float / double mix, same std::mt19937 + discrete_distribution).
+// Token sampling on the host.  What has to agree with the reference (pinned token for token by
+// tests/test_sampler_vs_ref.py against the reference's own classes in oracle/_ref):
+//   candidate list + its two invariants        src/sampler/prob_array.hpp:24-82, prob_array.cpp:21-67
+//   the arithmetic of each stage               src/sampler/sampler.cpp:19-186
+//   stage order of a configured chain          src/sampler/sampler_chain.cpp:19-51
+//   configuration fields and defaults          src/core/config.hpp:34-47
+// How it is organised here: a chain is a flat list of stage closures over one candidate list; the stages themselves are
+// free functions in namespace `stage` (usable on their own — the token tree's draft sampler is three of them), the only
+// stateful pieces (repeat-penalty history, the random engine) are owned by the chain.  `Sampler` stays as the plug-in
+// interface (apply / accept) so a caller can still splice its own stage into a chain.
 #pragma once
 #include "core.hpp"
 
-#include <deque>
+#include <functional>
 #include <memory>
 #include <random>
 #include <span>
@@ -25,26 +26,29 @@ struct ProbIndex {
     bool operator>(const ProbIndex &o) const { return prob > o.prob; }
 };
 
+// Candidates of one sampling step.  `m_is_sorted`: descending by prob; `m_is_normalized`: probs sum to one.
 struct ProbArray {
     std::vector<ProbIndex> m_probs;
-    bool m_is_sorted     = false; // descending
-    bool m_is_normalized = false; // sums to 1
+    bool m_is_sorted     = false;
+    bool m_is_normalized = false;
     explicit ProbArray(std::span<const float> logits);
     ProbIndex &operator[](size_t i) { return m_probs[i]; }
+    size_t size() const { return m_probs.size(); }
+    void resize(size_t n) { m_probs.resize(n); }
+    void sort_descending(size_t first_n); // only the leading first_n entries are put in order
     void normalize();
     void softmax();
-    void resize(size_t n) { m_probs.resize(n); }
-    template <typename RandomEngine> ProbIndex &stochastic_sample(RandomEngine &&gen) {
-        POWERSERVE_ASSERT(m_is_normalized);
-        // weight i is evaluated at x = i + 0.5 (discrete_distribution(count, xmin, xmax, unary_op))
-        const size_t index = std::discrete_distribution<size_t>(m_probs.size(), 0, m_probs.size(), [&](double x) { return m_probs[(size_t)x].prob; })(gen);
-        return m_probs[index];
-    }
     ProbIndex &greedy_sample();
+    template <typename Engine> ProbIndex &stochastic_sample(Engine &&gen) {
+        POWERSERVE_ASSERT(m_is_normalized);
+        // discrete_distribution(count, xmin, xmax, op) evaluates op at the bucket centres i + 0.5
+        std::discrete_distribution<size_t> pick(size(), 0, size(), [this](double x) { return m_probs[(size_t)x].prob; });
+        return m_probs[pick(gen)];
+    }
 };
 
 struct SamplerConfig {
-    uint64_t seed     = (uint64_t)-1; // -1: random_device
+    uint64_t seed     = (uint64_t)-1; // -1: take one from std::random_device
     float temperature = 0.80f;
     float top_p       = 0.95f;
     size_t top_k      = 40;
@@ -57,62 +61,57 @@ struct SamplerConfig {
     bool ignore_eos       = false;
 };
 
-struct Sampler {
+namespace stage {
+void top_k(ProbArray &c, size_t k);
+void temperature(ProbArray &c, float t);
+inline void softmax(ProbArray &c) { c.softmax(); }
+void top_p(ProbArray &c, float p, size_t min_keep = 1);
+inline void normalize(ProbArray &c) { c.normalize(); }
+void draw(ProbArray &c, std::mt19937 &engine); // collapses the list to the drawn candidate
+
+// Logit penalties for recently seen tokens.  Reference behaviour kept as is: the history starts as `last_n` zeros and is
+// appended to, and the window that gets counted is its first `last_n` entries.
+struct RepeatPenalty {
+    static constexpr Token none = -1;
+    Token eos = none, linefeed = none;
+    int last_n = 0;
+    float repeat = 1.f, freq = 0.f, present = 0.f;
+    bool spare_linefeed = false, ban_eos = false;
+    std::vector<Token> history;
+    RepeatPenalty() = default;
+    RepeatPenalty(const SamplerConfig &cfg, Token eos_id, Token linefeed_id);
+    void apply(ProbArray &c) const;
+    void accept(Token t) { if (last_n > 0) history.push_back(t); }
+    bool active() const { return last_n != 0 && !(repeat == 1.0f && freq == 0.0f && present == 0.0f); }
+};
+} // namespace stage
+
+struct Sampler { // plug-in interface
     virtual ~Sampler() = default;
     virtual void apply(ProbArray &probs) = 0;
     virtual void accept(Token) {}
 };
-struct TemperatureSampler final : Sampler {
-    float m_temperature;
-    explicit TemperatureSampler(float t) : m_temperature(t) {}
-    void apply(ProbArray &probs) override;
-};
-struct SoftmaxSampler final : Sampler { void apply(ProbArray &probs) override { probs.softmax(); } };
-struct NormalizeSampler final : Sampler { void apply(ProbArray &probs) override { probs.normalize(); } };
-struct TopKSampler final : Sampler {
-    size_t m_topk;
-    explicit TopKSampler(size_t k) : m_topk(k) {}
-    void apply(ProbArray &probs) override;
-};
-struct TopPSampler final : Sampler {
-    float m_topp;
-    size_t m_min_keep;
-    explicit TopPSampler(float p, size_t min_keep = 1) : m_topp(p), m_min_keep(min_keep) {}
-    void apply(ProbArray &probs) override;
-};
-struct RepeatPenaltySampler final : Sampler {
-    static constexpr Token null_token = -1;
-    int32_t m_vocab_size;
-    Token m_special_eos_id, m_linefeed_id;
-    int32_t m_penalty_last_n;
-    float m_penalty_repeat, m_penalty_freq, m_penalty_present;
-    bool m_penalize_nl, m_ignore_eos;
-    std::deque<Token> m_prev;
-    RepeatPenaltySampler(int32_t vocab_size, Token special_eos_id, Token linefeed_id, int32_t penalty_last_n, float penalty_repeat, float penalty_freq,
-                         float penalty_present, bool penalize_nl, bool ignore_eos);
-    void apply(ProbArray &probs) override;
-    void accept(Token token) override;
-};
-struct StochasticSampler final : Sampler {
-    std::mt19937 m_random_state;
-    explicit StochasticSampler(uint64_t seed) : m_random_state(seed) {}
-    void apply(ProbArray &probs) override;
-};
 
 struct SamplerChain final : Sampler {
+    using Stage = std::function<void(ProbArray &)>;
     SamplerChain() = default;
-    // the two vocabulary facts the reference takes from its Tokenizer (sampler_chain.cpp:34-36)
+    SamplerChain(const SamplerChain &) = delete; // the configured stages refer to the chain's own state
+    SamplerChain &operator=(const SamplerChain &) = delete;
+    // n_vocabs / special_eos_id / linefeed_id are the vocabulary facts the reference reads from its Tokenizer
     SamplerChain(const SamplerConfig &config, int32_t n_vocabs, Token special_eos_id, Token linefeed_id) { build_from_config(config, n_vocabs, special_eos_id, linefeed_id); }
-    template <typename S, typename... Args> void append(Args &&...args) { m_samplers.emplace_back(std::make_unique<S>(std::forward<Args>(args)...)); }
     void build_from_config(const SamplerConfig &config, int32_t n_vocabs, Token special_eos_id, Token linefeed_id);
+    void append(Stage s) { m_stages.push_back(std::move(s)); }
+    void append(std::shared_ptr<Sampler> s); // a user stage: apply in place, accept forwarded
     void apply(ProbArray &probs) override;
     void accept(Token token) override;
-    // apply + take probs[0] + accept: one sampling step as ModelTokenIterator::decode does (model.hpp:170-183)
-    Token sample(std::span<const float> logits);
+    Token sample(std::span<const float> logits); // apply, take candidate 0, accept it
     uint64_t m_seed = 0;
 
 private:
-    std::vector<std::unique_ptr<Sampler>> m_samplers;
+    std::vector<Stage> m_stages;
+    std::vector<std::shared_ptr<Sampler>> m_plugins;
+    stage::RepeatPenalty m_penalty;
+    std::mt19937 m_engine;
 };
 
 } // namespace powerserve

@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libps_host.so")
 EXPORTS = ["psh_last_error", "psh_model_load", "psh_model_free", "psh_model_set_fused", "psh_model_plan_stats", "psh_model_kv_position", "psh_model_reset",
            "psh_model_vocab", "psh_model_forward", "psh_model_generate", "psh_spec_generate", "psh_draft_sample", "psh_sampler_create", "psh_sampler_free", "psh_sampler_sample",
-           "psh_model_generate_sampled"]
+           "psh_model_generate_sampled", "psh_token_tree_run", "psh_gguf_summary"]
 _LIB = None
 
 
@@ -42,6 +42,9 @@ def lib() -> C.CDLL:
         L.psh_sampler_sample.restype = C.c_int32
         L.psh_sampler_sample.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.psh_model_generate_sampled.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.psh_token_tree_run.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int] + [C.c_void_p] * 5
+        L.psh_gguf_summary.restype = C.c_int64
+        L.psh_gguf_summary.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t]
         _LIB = L
     return _LIB
 
@@ -114,6 +117,30 @@ class HostModel:
         return out
 
 
+def gguf_summary(path: str):
+    """What the C++ GGUF reader (csrc/host/json_gguf.cpp) sees in a file: (tensors, strings, numbers) with
+    tensors = [(name, type, nbytes, fnv1a-64 hex of the data, ne tuple)] in file order."""
+    L = lib()
+    need = L.psh_gguf_summary(path.encode(), None, 0)
+    if need < 0:
+        raise HostError(L.psh_last_error().decode())
+    buf = C.create_string_buffer(need)
+    L.psh_gguf_summary(path.encode(), buf, need)
+    tensors, strings, numbers = [], {}, {}
+    for line in buf.value.decode().splitlines():
+        kind, rest = line[0], line[2:]
+        if kind == "T":
+            name, t, nb, h, *ne = rest.split(" ")
+            tensors.append((name, int(t), int(nb), h, tuple(int(x) for x in ne)))
+        else:
+            k, _, v = rest.partition(" ")
+            if kind == "S":
+                strings[k] = v
+            else:
+                numbers[k] = float(v)
+    return tensors, strings, numbers
+
+
 def draft_sample(logits, top_k: int = 15, temperature: float = 1.5):
     """TopK -> Temperature -> Softmax of the C++ mirror (csrc/host/speculative.cpp): (tokens, probs) sorted by probability."""
     L = lib()
@@ -135,6 +162,75 @@ def spec_generate(target: HostModel, draft: HostModel, prompt, batch_size: int, 
         raise HostError(L.psh_last_error().decode())
     keys = ("n_draft_times", "n_draft_tokens", "n_accepted_tokens", "n_iterations", "n_generated_tokens")
     return out, {k: int(v) for k, v in zip(keys, st)}
+
+
+class SpecConfig(C.Structure):
+    """psh_spec_config: plain-C view of SpeculativeConfig (csrc/host/speculative.hpp); defaults = the reference's."""
+    _fields_ = [("draft_batch_size", C.c_int32), ("top_k", C.c_int32), ("max_fan_out", C.c_int32), ("early_stop", C.c_int32),
+                ("temperature", C.c_float), ("p_base", C.c_float), ("min_prob", C.c_float)]
+
+    @classmethod
+    def make(cls, draft_batch_size=12, top_k=15, max_fan_out=3, early_stop=True, temperature=1.5, p_base=0.9, min_prob=0.2):
+        return cls(draft_batch_size, top_k, max_fan_out, int(early_stop), temperature, p_base, min_prob)
+
+
+class SpecBackendCallbacks(C.Structure):
+    """psh_spec_backend: the seven calls the token tree makes on a model, as C function pointers."""
+    KV_POSITION = C.CFUNCTYPE(C.c_int64, C.c_void_p)
+    FORWARD_ONE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_float))
+    FORWARD_TREE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int32), C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_uint8), C.POINTER(C.c_int32))
+    KV_MASK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_int32)
+    KV_MOVE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_int64)
+    KV_N = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64)
+    _fields_ = [("user", C.c_void_p), ("kv_position", KV_POSITION), ("forward_one", FORWARD_ONE), ("forward_tree", FORWARD_TREE),
+                ("kv_mask", KV_MASK), ("kv_move", KV_MOVE), ("kv_advance", KV_N), ("kv_rollback", KV_N), ("vocab_size", C.c_int32)]
+
+    @classmethod
+    def wrap(cls, model):
+        """`model`: any object with kv_position(), forward_one(token, position, want_logits) -> logits | None,
+        forward_tree(tokens, positions, mask[n][n]) -> argmax[n], kv_mask(slot, visible), kv_move(dst, src), kv_advance(n),
+        kv_rollback(n) and a vocab_size attribute.  An exception in a callback is reported as a failed call."""
+        def guard(fn, bad=1):
+            def run(*a):
+                try:
+                    r = fn(*a)
+                    return 0 if r is None else r
+                except Exception:  # noqa: BLE001 — must not propagate through the C frame
+                    import traceback
+                    traceback.print_exc()
+                    return bad
+            return run
+
+        def fwd1(_, tok, pos, out):
+            lg = model.forward_one(int(tok), int(pos), bool(out))
+            if out:
+                C.memmove(out, np.ascontiguousarray(lg, dtype=np.float32).ctypes.data, model.vocab_size * 4)
+
+        def fwdt(_, toks, n, poss, mask, am):
+            t, p = np.ctypeslib.as_array(toks, (n,)).copy(), np.ctypeslib.as_array(poss, (n,)).copy()
+            mk = np.ctypeslib.as_array(mask, (n, n)).copy()
+            np.ctypeslib.as_array(am, (n,))[:] = np.asarray(model.forward_tree(t, p, mk), dtype=np.int32)
+
+        cb = cls(None, cls.KV_POSITION(guard(lambda _: int(model.kv_position()), -1)), cls.FORWARD_ONE(guard(fwd1)), cls.FORWARD_TREE(guard(fwdt)),
+                 cls.KV_MASK(guard(lambda _, s, v: model.kv_mask(int(s), bool(v)))), cls.KV_MOVE(guard(lambda _, d, s: model.kv_move(int(d), int(s)))),
+                 cls.KV_N(guard(lambda _, n: model.kv_advance(int(n)))), cls.KV_N(guard(lambda _, n: model.kv_rollback(int(n)))), int(model.vocab_size))
+        return cb
+
+
+def token_tree_run(target, draft, cfg: SpecConfig, root_token: int, n_iterations: int):
+    """TokenTree (csrc/host/speculative.cpp) over two caller-supplied models (see SpecBackendCallbacks.wrap):
+    n_iterations rounds of draft / tree forward / verify.  Returns (emitted tokens, trees, stats) where trees[it] is an
+    int32 array [n_nodes][6] of {token, position, parent, cache_index, accepted, depth}."""
+    L = lib()
+    tcb, dcb = SpecBackendCallbacks.wrap(target), SpecBackendCallbacks.wrap(draft)
+    bs = cfg.draft_batch_size
+    out, n_out = np.zeros(n_iterations * bs, dtype=np.int32), np.zeros(1, dtype=np.int32)
+    tree, n_nodes, st = np.zeros((n_iterations, bs, 6), dtype=np.int32), np.zeros(n_iterations, dtype=np.int32), np.zeros(5, dtype=np.uint64)
+    if L.psh_token_tree_run(C.addressof(tcb), C.addressof(dcb), C.addressof(cfg), root_token, n_iterations, out.ctypes.data, n_out.ctypes.data,
+                            tree.ctypes.data, n_nodes.ctypes.data, st.ctypes.data):
+        raise HostError(L.psh_last_error().decode())
+    keys = ("n_draft_times", "n_draft_tokens", "n_accepted_tokens", "n_iterations", "n_generated_tokens")
+    return out[:n_out[0]].copy(), [tree[i, :n_nodes[i]].copy() for i in range(n_iterations)], {k: int(v) for k, v in zip(keys, st)}
 
 
 class Sampler:

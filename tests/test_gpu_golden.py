@@ -9,7 +9,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
-T = {"Q4_0": 2, "Q8_0": 8, "Q4_K": 12}
+T = {"Q4_0": 2, "Q8_0": 8, "Q4_K": 12, "Q6_K": 14}
 
 
 def test_act_quant_golden(ctx):
@@ -25,11 +25,14 @@ def test_act_quant_golden(ctx):
             assert np.array_equal(out.numpy(), g[f"{key}_{K}"])
 
 
-def test_mul_mat_golden(ctx):
-    g = np.load(os.path.join(GOLD, "mul_mat.npz"))
+@pytest.mark.parametrize("name,count", [("mul_mat", 12), ("mul_mat_wide", 11)])
+def test_mul_mat_golden(ctx, name, count):
+    """ps_hip_mul_mat against the real reference's outputs, Q6_K included.  `mul_mat_wide` holds the shapes that reach
+    gemv4 (one column, K % 1024 == 0), gemm4k (MFMA, full / ragged / small batches) and the Q6_K kernels beyond a few rows."""
+    g = np.load(os.path.join(GOLD, name + ".npz"))
     n = 0
     for key in g.files:
-        if not key.startswith("y_") or "Q6_K" in key:
+        if not key.startswith("y_"):
             continue
         _, a, b, K, N, bs = key.split("_")
         t, K, N = T[a + "_" + b], int(K), int(N)
@@ -40,7 +43,7 @@ def test_mul_mat_golden(ctx):
         assert np.array_equal(dy.numpy().view(np.uint32), g[key].view(np.uint32)), key
         W.free()
         n += 1
-    assert n == 9
+    assert n == count
 
 
 def _sha(path):

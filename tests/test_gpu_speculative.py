@@ -11,37 +11,54 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("draft_seed,wt", [(77, 12), (5, 12), (5, 8)])
-def test_speculative_output_equals_target_greedy(ctx, tmp_path, draft_seed, wt):
-    from powerserve_amd import hip, speculative, synth
+def teacher_forced_gaps(model, prompt, emitted):
+    """Feed `emitted` back through SINGLE-token forwards: per step (top logit - logit of the emitted token, logit std)."""
+    model.reset()
+    model.forward(prompt[:-1], np.arange(len(prompt) - 1), lm_head=False)
+    cur, gaps, stds = int(prompt[-1]), [], []
+    for t in emitted:
+        lg = model.forward([cur], [model.position], lm_head=True)[0]
+        gaps.append(float(lg.max() - lg[int(t)]))
+        stds.append(float(lg.std()))
+        cur = int(t)
+    return np.array(gaps), np.array(stds)
+
+
+@pytest.mark.parametrize("draft,draft_seed,wt", [("small-llama-hs128", 77, 12), ("small-llama-hs128", 5, 12), ("small-llama-hs128", 5, 8),
+                                               ("small-llama-draft", 9, 12), ("small-llama-draft", 9, 2)])
+def test_speculative_output_follows_target_greedy(tmp_path, draft, draft_seed, wt):
+    """BASELINE config #4 in miniature (target + smaller draft of a DIFFERENT shape, and same-shape pairs): the output of
+    SpeculativeModel::generate (csrc/host/speculative.cpp) is the target's own greedy output.  Where the two differ the
+    documented bound must hold (KV entries of accepted nodes come from the tree batch, whose softmax
+    row split differs from single-token decode, as in the reference): every emitted token lies within 0.25 sigma of the
+    single-token arg-max under teacher forcing — and on these models, whose margins are healthy, the ids are equal."""
+    from powerserve_amd import host, synth
     td, dd = str(tmp_path / "t"), str(tmp_path / "d")
-    synth.write_model_dir(td, "small-llama-hs128", wt, n_ctx=160, seed=5)
-    synth.write_model_dir(dd, "small-llama-hs128", wt, n_ctx=160, seed=draft_seed)
-    target = hip.Model(ctx, td, max_batch=16)
-    draft = hip.Model(ctx, dd, max_batch=16)
-    prompt = np.random.default_rng(11).integers(0, target.cfg.vocab_size, 13)
+    synth.write_model_dir(td, "small-llama-hs128", wt if draft == "small-llama-hs128" else 12, n_ctx=160, seed=5)
+    synth.write_model_dir(dd, draft, wt, n_ctx=160, seed=draft_seed)
+    target, dm = host.HostModel(td, max_batch=16), host.HostModel(dd, max_batch=16)
+    prompt = np.random.default_rng(11).integers(0, target.vocab, 13)
     steps = 40
     want = target.generate(prompt, 8, steps)
-    spec = speculative.SpeculativeModel(target, draft, speculative.SpeculativeConfig(draft_batch_size=12))
-    got = spec.generate(prompt, steps, batch_size=8)
+    got, st = host.spec_generate(target, dm, prompt, 8, steps)
+    gaps, stds = teacher_forced_gaps(target, prompt, got)
+    assert (gaps <= 0.25 * stds).all(), (gaps.max(), stds.mean())
     assert np.array_equal(got, want), (got, want)
-    st = spec.stat()
-    assert st["n_generated_tokens"] >= steps
-    if draft_seed == 5:  # the target drafts for itself: greedy children are accepted, several tokens per iteration
-        assert st["tokens_per_iteration"] > 2.0, st
+    assert st["n_generated_tokens"] >= steps and st["n_iterations"] > 0
+    if draft == "small-llama-hs128" and draft_seed == 5:  # the target drafts for itself: several tokens per iteration
+        assert st["n_generated_tokens"] / st["n_iterations"] > 2.0, st
+    else:                                                  # unrelated draft: catch-up forwards, branch switches, KV moves
+        assert st["n_draft_times"] > st["n_iterations"]
     # the plain path still works on the same objects afterwards (no hidden slots left behind in the visible prefix)
     assert np.array_equal(target.generate(prompt, 8, steps), want)
     # ... and so does the DRAFT model: slots it hid while drafting lie behind its position after the roll-back
     # (KVCache::rollback + advance/append un-hide them in the reference, core/kv_cache.hpp:249-272)
-    want_d = hip.Model(ctx, dd, max_batch=16)
-    ref_d = want_d.generate(prompt, 8, 12)
-    want_d.close()
-    assert np.array_equal(draft.generate(prompt, 8, 12), ref_d)
-    draft.reset()
-    draft.forward(prompt[:-1], np.arange(prompt.size - 1), lm_head=False)
-    assert np.array_equal(draft.decode_greedy(int(prompt[-1]), 12), ref_d)
+    fresh = host.HostModel(dd, max_batch=16)
+    ref_d = fresh.generate(prompt, 8, 12)
+    fresh.close()
+    assert np.array_equal(dm.generate(prompt, 8, 12), ref_d)
     target.close()
-    draft.close()
+    dm.close()
 
 
 def test_tree_forward_positions_and_masks(ctx, tmp_path):
@@ -86,33 +103,3 @@ def test_tree_forward_positions_and_masks(ctx, tmp_path):
     assert not np.array_equal(base, hid)
     assert np.array_equal(base.view(np.uint32), back.view(np.uint32))
     gm.close()
-
-
-@pytest.mark.parametrize("draft_seed", [77, 5])
-def test_cpp_speculative_mirror(tmp_path, draft_seed):
-    """The C++ host mirror (csrc/host/speculative.cpp: TokenTree / SpeculativeModel over the C-ABI) produces the target's
-    greedy output, and the same statistics as the Python mirror on the same pair of models."""
-    from powerserve_amd import hip, host, speculative, synth
-    td, dd = str(tmp_path / "t"), str(tmp_path / "d")
-    synth.write_model_dir(td, "small-llama-hs128", 12, n_ctx=160, seed=5)
-    synth.write_model_dir(dd, "small-llama-hs128", 12, n_ctx=160, seed=draft_seed)
-    prompt = np.random.default_rng(11).integers(0, 1024, 13)
-    steps = 40
-    target, draft = host.HostModel(td, max_batch=16), host.HostModel(dd, max_batch=16)
-    want = target.generate(prompt, 8, steps)
-    got, st = host.spec_generate(target, draft, prompt, 8, steps)
-    assert np.array_equal(got, want), (got, want)
-    assert st["n_generated_tokens"] >= steps and st["n_iterations"] > 0
-    assert np.array_equal(target.generate(prompt, 8, steps), want)  # nothing hidden is left behind
-    target.close()
-    draft.close()
-    c = hip.Ctx(0)
-    pt, pd = hip.Model(c, td, max_batch=16), hip.Model(c, dd, max_batch=16)
-    spec = speculative.SpeculativeModel(pt, pd)
-    assert np.array_equal(spec.generate(prompt, steps, batch_size=8), want)
-    ps = spec.stat()
-    # same trees up to last-ulp differences of the two softmax implementations: iteration counts agree closely
-    assert abs(st["n_iterations"] - ps["n_iterations"]) <= 2, (st, ps)
-    pt.close()
-    pd.close()
-    c.close()

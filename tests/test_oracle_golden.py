@@ -25,8 +25,9 @@ def test_act_quant_bit_exact(oracle):
                 assert np.array_equal(oracle.from_float(15, x[i]), g[f"q8_K_{K}"][i])
 
 
-def test_mul_mat_bit_exact(oracle):
-    g = np.load(os.path.join(GOLD, "mul_mat.npz"))
+@pytest.mark.parametrize("name,count", [("mul_mat", 12), ("mul_mat_wide", 11)])
+def test_mul_mat_bit_exact(oracle, name, count):
+    g = np.load(os.path.join(GOLD, name + ".npz"))
     n = 0
     for key in g.files:
         if not key.startswith("y_"):
@@ -36,7 +37,7 @@ def test_mul_mat_bit_exact(oracle):
         y = oracle.mul_mat(t, g["w_" + key[2:]], int(K), int(N), g["x_" + key[2:]])
         assert np.array_equal(bits(y), bits(g[key])), key
         n += 1
-    assert n == 12
+    assert n == count
 
 
 def test_ops_bit_exact(oracle):

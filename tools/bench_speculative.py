@@ -9,7 +9,7 @@ usage: bench_speculative.py [--steps N] [--prompt-len P] [--self-draft] [--wtype
 import argparse, json, os, sys, tempfile, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from powerserve_amd import gguf, hip, speculative, synth
+from powerserve_amd import gguf, host, synth
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=64)
@@ -30,19 +30,14 @@ def model_dir(preset, wt, seed):
         open(os.path.join(d, ".done"), "w").write("ok")
     return d
 
-ctx = hip.Ctx(0)
-target = hip.Model(ctx, model_dir(a.target, a.wtype, 1234), max_batch=128, n_ctx=a.n_ctx)
-draft = target if a.self_draft else hip.Model(ctx, model_dir(a.draft, a.draft_wtype, 99), max_batch=128, n_ctx=a.n_ctx)
-if a.self_draft:  # a second instance of the same weights: the draft needs its own KV cache
-    draft = hip.Model(ctx, model_dir(a.target, a.wtype, 1234), max_batch=128, n_ctx=a.n_ctx)
-prompt = np.random.default_rng(42).integers(0, target.cfg.vocab_size, a.prompt_len).astype(np.int32)
+target = host.HostModel(model_dir(a.target, a.wtype, 1234), max_batch=128, n_ctx=a.n_ctx)
+# --self-draft: a second instance of the same weights (the draft needs its own KV cache)
+draft = host.HostModel(model_dir(a.target, a.wtype, 1234) if a.self_draft else model_dir(a.draft, a.draft_wtype, 99), max_batch=128, n_ctx=a.n_ctx)
+prompt = np.random.default_rng(42).integers(0, target.vocab, a.prompt_len).astype(np.int32)
 
-t0 = time.perf_counter(); want = target.generate(prompt, 128, a.steps); ctx.sync(); t_plain = time.perf_counter() - t0
-spec = speculative.SpeculativeModel(target, draft)
-spec.generate(prompt, 8, batch_size=128)  # warm-up (one-time kernel attribute calls)
-spec.token_tree.stat = {k: 0 for k in spec.token_tree.stat}
-t0 = time.perf_counter(); got = spec.generate(prompt, a.steps, batch_size=128); ctx.sync(); t_spec = time.perf_counter() - t0
-st = spec.stat()
+t0 = time.perf_counter(); want = target.generate(prompt, 128, a.steps); t_plain = time.perf_counter() - t0
+host.spec_generate(target, draft, prompt, 128, 8)  # warm-up (one-time kernel attribute calls)
+t0 = time.perf_counter(); got, st = host.spec_generate(target, draft, prompt, 128, a.steps); t_spec = time.perf_counter() - t0
 # How far from the plain path's greedy choice is every emitted token?  Teacher-force the speculative output through
 # single-token forwards: gap = (top logit) - (logit of the token the speculative run emitted next); 0 where they agree.
 target.reset()
@@ -51,11 +46,14 @@ while done < a.prompt_len - 1:
     bs = min(128, a.prompt_len - 1 - done); target.forward(prompt[done:done + bs], np.arange(done, done + bs), lm_head=False); done += bs
 cur, gaps, stds = int(prompt[-1]), [], []
 for i in range(a.steps):
-    lg, _ = target.forward([cur], [target.position], lm_head=True)
+    lg = target.forward([cur], [target.position], lm_head=True)
     gaps.append(float(lg[0].max() - lg[0][int(got[i])])); stds.append(float(lg[0].std()))
     cur = int(got[i])
+it = max(st["n_iterations"], 1)
 print(json.dumps({"config": f"{a.target} {a.wtype} target + {'itself' if a.self_draft else a.draft + ' ' + a.draft_wtype} draft, tree of 12, prompt {a.prompt_len}, {a.steps} tokens",
-                  "matching_prefix": int(np.argmax(np.append(got != want, True))), "max_logit_gap_vs_single_token_greedy": max(gaps), "n_tokens_with_gap": int(sum(g > 0 for g in gaps)), "logit_std": float(np.mean(stds)), "tokens": int(a.steps), "speculative_s_incl_prefill": t_spec, "plain_greedy_s_incl_prefill": t_plain,
-                  "tokens_per_iteration": st["tokens_per_iteration"], "draft_forwards_per_iteration": st["draft_forwards_per_iteration"],
-                  "accept_ratio": st["accept_ratio"], "iterations": st["n_iterations"],
-                  "ms_per_iteration": 1e3 * t_spec / max(st["n_iterations"], 1)}))
+                  "matching_prefix": int(np.argmax(np.append(got != want, True))), "max_logit_gap_vs_single_token_greedy": max(gaps),
+                  "max_gap_in_sigma": float(max(g / s for g, s in zip(gaps, stds))), "n_tokens_with_gap": int(sum(g > 0 for g in gaps)), "logit_std": float(np.mean(stds)),
+                  "tokens": int(a.steps), "speculative_s_incl_prefill": t_spec, "plain_greedy_s_incl_prefill": t_plain,
+                  "tokens_per_iteration": st["n_generated_tokens"] / it, "draft_forwards_per_iteration": st["n_draft_times"] / it,
+                  "accept_ratio": st["n_accepted_tokens"] / max(st["n_draft_tokens"], 1), "iterations": st["n_iterations"],
+                  "ms_per_iteration": 1e3 * t_spec / it}))
