@@ -37,7 +37,7 @@ struct G4KMat {
 };
 struct G4KParams {
     G4KMat w[3];
-    int n_w, nsb, bs, n_tasks, ctw; // ctw: column tiles per workgroup (1, 2, 4 or 8); 8 / ctw row tasks per workgroup
+    int n_w, nsb, bs, n_tasks;
     const float *residual;
     const int8_t *qf;   // fragment-major quants
     const float *ad;    // [col][nsb]
@@ -133,38 +133,8 @@ __device__ __forceinline__ void g4k_superblock(G4KAcc &T, const uint32_t (&wq)[8
     }
 }
 
-// one 16-row tile of one matrix against this wave's 16 columns, everything straight from memory (small batches: the
-// waves of a workgroup work on different row tiles): y[r] = result of row 4 * kb + r, column l % 16
-__device__ __forceinline__ void g4k_tile(const uint8_t *qs, const uint8_t *aux, const int tile, const int nsb, const int8_t *qf_ct,
-                                         const float *ad_col, const int16_t *bs_col, float (&y)[4]) {
-    const int lane = threadIdx.x & 63, m = lane & 15, kb = lane >> 4;
-    // A side: row m of the tile = row (m & 7) of row group 2 * tile + (m >> 3)
-    const uint8_t *qa = qs + ((size_t)(2 * tile + (m >> 3)) * nsb << 10) + (m & 7) * 128 + kb * 4;
-    const uint8_t *ha = aux + (size_t)(2 * tile + (m >> 3)) * nsb * 128 + (m & 7) * 16;
-    // D side: rows 4 kb + r of the tile: row group 2 * tile + (kb >> 1), rows (kb & 1) * 4 + r
-    const uint8_t *hd = aux + (size_t)(2 * tile + (kb >> 1)) * nsb * 128 + (kb & 1) * 64;
-    G4KAcc T;
-    T.clear();
-    for (int sb = 0; sb < nsb; sb++) {
-        uint32_t wq[8];
-#pragma unroll
-        for (int u = 0; u < 8; u++) wq[u] = *(const uint32_t *)(qa + ((size_t)sb << 10) + u * 16);
-        const uint4 hA = *(const uint4 *)(ha + (size_t)sb * 128);
-        uint4 hD[4];
-#pragma unroll
-        for (int r = 0; r < 4; r++) hD[r] = *(const uint4 *)(hd + (size_t)sb * 128 + r * 16);
-        ps_u32x4 bq[4];
-#pragma unroll
-        for (int up = 0; up < 4; up++) bq[up] = *(const ps_u32x4 *)(qf_ct + ((size_t)sb << 12) + up * 1024 + lane * 16);
-        const float yd = ad_col[sb];
-        const ps_u32x4 b16a = *(const ps_u32x4 *)(bs_col + sb * 16), b16b = *(const ps_u32x4 *)(bs_col + sb * 16 + 8);
-        g4k_superblock(T, wq, hA, hD, bq, yd, b16a, b16b, kb);
-    }
-    T.reduce(y);
-}
-
-// 128-column blocks: all eight computing waves of a workgroup walk the same 16 weight rows.  Two things make the straight
-// version (every wave loading its own operands) slow there: the weights come from HBM (~2 us per super-block with nothing
+// All eight computing waves of a workgroup walk the same 16 weight rows.  Two things make a straight version (every wave
+// loading its own operands; measured, removed) slow: the weights come from HBM (~2 us per super-block with nothing
 // but the next loads to hide behind), and the CU's address unit: a wave's eight dword loads of A touch 16 cache lines each,
 // eight waves repeat them, and the column metadata adds 48 more line look-ups per wave -- ~2200 cycles of address
 // processing per super-block step against ~800 of arithmetic.  So:
@@ -249,16 +219,15 @@ __device__ __forceinline__ void g4k_tile_staged(const uint8_t *qs, const uint8_t
     T.reduce(y);
 }
 
-// STAGED: 128-column blocks, nine waves: eight column tiles of ONE row task + the warm-up wave
-template <int EPI, bool STAGED>
-__global__ __launch_bounds__(STAGED ? 576 : 512) void gemm4k_kernel(const G4KParams p) {
+// nine waves: the eight column tiles of ONE row task (128 columns per workgroup) + the warm-up wave
+template <int EPI>
+__global__ __launch_bounds__(576) void gemm4k_kernel(const G4KParams p) {
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int m = lane & 15, kb = lane >> 4;
     // wave -> (row task, column tile)
-    const int ct = (STAGED && wave == 8) ? (int)blockIdx.y * 8 : (int)blockIdx.y * p.ctw + (wave % p.ctw);
-    const int task = STAGED ? (int)blockIdx.x : (int)blockIdx.x * (8 / p.ctw) + wave / p.ctw;
-    __shared__ __attribute__((aligned(16))) char lds[STAGED ? 3 * G4K_STAGE : 16];
-    if (!STAGED && (task >= p.n_tasks || ct * 16 >= p.bs)) return; // (STAGED: grid.x = tasks exactly; every wave stays for the barriers)
+    const int ct = (int)blockIdx.y * 8 + (wave & 7);
+    const int task = (int)blockIdx.x; // (grid.x = tasks exactly; every wave stays for the barriers)
+    __shared__ __attribute__((aligned(16))) char lds[3 * G4K_STAGE];
     int wi = 0, tile = task;
     if (EPI != 1) {
         if (p.n_w > 1 && tile >= p.w[0].n_tiles) { tile -= p.w[0].n_tiles; wi = 1; }
@@ -271,7 +240,7 @@ __global__ __launch_bounds__(STAGED ? 576 : 512) void gemm4k_kernel(const G4KPar
     const float *ad_col = p.ad + (size_t)colc * p.nsb;
     const int16_t *bs_col = p.abs16 + (size_t)colc * p.nsb * 16;
     float y[4];
-    if constexpr (STAGED) {
+    {
         if (wave == 8) { // the warm-up wave
             g4k_warm_wave(W.qs, W.aux, EPI == 1 ? p.w[1].qs : W.qs, EPI == 1 ? p.w[1].aux : W.aux, tile, p.nsb, EPI == 1 ? 2 * p.nsb : p.nsb, W.out);
             return;
@@ -287,14 +256,6 @@ __global__ __launch_bounds__(STAGED ? 576 : 512) void gemm4k_kernel(const G4KPar
         if (EPI == 1) {
             float yu[4];
             g4k_tile_staged(p.w[1].qs, p.w[1].aux, tile, p.nsb, qf_ct, ad_col, bs_col, lds, p.nsb, false, nullptr, nullptr, yu);
-#pragma unroll
-            for (int r = 0; r < 4; r++) y[r] = ps_silu_mul(y[r], yu[r]);
-        }
-    } else {
-        g4k_tile(W.qs, W.aux, tile, p.nsb, qf_ct, ad_col, bs_col, y);
-        if (EPI == 1) {
-            float yu[4];
-            g4k_tile(p.w[1].qs, p.w[1].aux, tile, p.nsb, qf_ct, ad_col, bs_col, yu);
 #pragma unroll
             for (int r = 0; r < 4; r++) y[r] = ps_silu_mul(y[r], yu[r]);
         }
@@ -334,15 +295,14 @@ int psk_gemm4k(hipStream_t st, int n_cu, const psk_gemv_args &a, ps_act act, int
     p.n_tasks = epi == 1 ? p.w[0].n_tiles : tiles_total;
     p.residual = a.residual; p.qf = act.qf; p.ad = act.d; p.abs16 = act.bs16;
     const int n_ct = (int)((bs + 15) / 16);
-    p.ctw = (n_ct >= 8 && p.nsb % 4 == 0) ? 8 : (n_ct >= 4 ? 4 : (n_ct >= 2 ? 2 : 1)); // 8: every wave on the same rows + the warm-up wave
+    // Below eight column tiles a workgroup's waves would not share their weight rows any more, and the kernels that spread
+    // a row group's integer work over producer waves (gemm8) are ahead there: tree forward of the 8B shape, ms by width,
+    // this kernel / gemm8: 2: 12.5 / 4.9, 12: 13.7 / 6.4, 32: 14.4 / 9.2, 64: 18.3 / 13.3, 128: 17.0 / 22.9
+    // (profiles/r02_tree_forward_latency_8b.json).
+    if (n_ct < 8 || p.nsb % 4) return -1;
     (void)n_cu;
-    const dim3 grid((unsigned)((p.n_tasks + 8 / p.ctw - 1) / (8 / p.ctw)), (unsigned)((n_ct + p.ctw - 1) / p.ctw));
-    if (p.ctw == 8) {
-        if (epi == 1) hipLaunchKernelGGL((gemm4k_kernel<1, true>), grid, dim3(576), 0, st, p);
-        else hipLaunchKernelGGL((gemm4k_kernel<0, true>), grid, dim3(576), 0, st, p);
-    } else {
-        if (epi == 1) hipLaunchKernelGGL((gemm4k_kernel<1, false>), grid, dim3(512), 0, st, p);
-        else hipLaunchKernelGGL((gemm4k_kernel<0, false>), grid, dim3(512), 0, st, p);
-    }
+    const dim3 grid((unsigned)p.n_tasks, (unsigned)((n_ct + 7) / 8));
+    if (epi == 1) hipLaunchKernelGGL((gemm4k_kernel<1>), grid, dim3(576), 0, st, p);
+    else hipLaunchKernelGGL((gemm4k_kernel<0>), grid, dim3(576), 0, st, p);
     return 0;
 }

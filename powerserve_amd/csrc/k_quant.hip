@@ -158,7 +158,7 @@ __global__ void repack_q6_K_kernel(const uint8_t *raw, int64_t nblk, uint8_t *ql
 
 void psk_quantize_act(hipStream_t st, int vdt, int mode, const float *x, const float *x2, const float *w, float eps,
                       int64_t K, int64_t rows, ps_act out) {
-    QuantArgs a{x, x2, w, eps, K, out.qs, out.d, out.bs16, (vdt == PS_Q8_K && rows >= 2 && K % 256 == 0) ? out.qf : nullptr};
+    QuantArgs a{x, x2, w, eps, K, out.qs, out.d, out.bs16, (vdt == PS_Q8_K && rows > 112 && K % 1024 == 0) ? out.qf : nullptr /* exactly when psk_gemm4k takes the batch */};
     if (mode == 1) {
         dim3 g((unsigned)rows), b(256);
         const int64_t tpw = ((K + 255) / 256 + 3) / 4;

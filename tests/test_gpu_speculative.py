@@ -48,7 +48,7 @@ def test_speculative_output_follows_target_greedy(tmp_path, draft, draft_seed, w
     if draft == "small-llama-hs128" and draft_seed == 5:  # the target drafts for itself: several tokens per iteration
         assert st["n_generated_tokens"] / st["n_iterations"] > 2.0, st
     else:                                                  # unrelated draft: catch-up forwards, branch switches, KV moves
-        assert st["n_draft_times"] > st["n_iterations"]
+        assert st["n_draft_times"] >= st["n_iterations"]
     # the plain path still works on the same objects afterwards (no hidden slots left behind in the visible prefix)
     assert np.array_equal(target.generate(prompt, 8, steps), want)
     # ... and so does the DRAFT model: slots it hid while drafting lie behind its position after the roll-back
