@@ -189,16 +189,19 @@ def max_over_ranks(dist, values, device="cuda"):
     return [float(v) for v in tt]
 
 
+def distributed_command(n_gpus, port, argv):
+    """the launcher command line for N ranks on this node — the one the driver uses"""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
 def relaunch_distributed(args):
-    """`python bench.py --gpus N` with N > 1 and no launcher: re-exec under torch.distributed.run, one rank per GPU
-    (the same command line the driver uses)."""
+    """`python bench.py --gpus N` with N > 1 and no launcher: re-exec under torch.distributed.run, one rank per GPU."""
     import socket
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    os.execv(sys.executable, cmd)
+    os.execv(sys.executable, distributed_command(args.gpus, port, sys.argv[1:]))
 
 
 def main():

@@ -64,3 +64,19 @@ def test_broadcast_gather_max():
 def test_divergent_replica_is_detected():
     out = _run(diverge=True)
     assert all(not agree for _, _, agree, _, _ in out)
+
+
+def test_self_launch_command_and_world_check(tmp_path):
+    """`python bench.py --gpus N` without a launcher re-executes itself under torch.distributed.run with one rank per GPU
+    on 127.0.0.1 (the driver's command line); started under a launcher whose world size disagrees with --gpus it refuses."""
+    import subprocess
+    sys.path.insert(0, ROOT)
+    import bench
+    cmd = bench.distributed_command(4, 29511, ["--gpus", "4", "--steps", "3"])
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29511"
+    assert cmd[-5:] == [os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "3"]
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in (r.stderr + r.stdout)
