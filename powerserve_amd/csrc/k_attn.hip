@@ -66,6 +66,9 @@ __global__ __launch_bounds__(256) void attn_scores_kernel(psl_attn_args a) {
     const int n_kv = a.state->pos0 + a.state->bs;
     const int j0 = blockIdx.x * 32;
     if (j0 >= n_kv) return;
+    const int wg = blockIdx.y * gridDim.x + blockIdx.x; // timeline (tools/gpu_attn_timeline.py, key 40)
+    unsigned long long *const dbg = (a.dbg && wg < 1024 && threadIdx.x == 0 && blockIdx.z == 0) ? a.dbg + (size_t)wg * 64 : nullptr;
+    if (dbg) { dbg[0] = __builtin_amdgcn_s_memtime(); dbg[29] = __builtin_amdgcn_s_memrealtime(); }
     const float *qb = a.q + (int64_t)i * dim + (int64_t)kvh * r2 * hs;
     float *sb       = a.scores + ((int64_t)i * a.n_heads + (int64_t)kvh * r2) * a.n_ctx;
     float qf[R2MAX][NV];
@@ -81,6 +84,7 @@ __global__ __launch_bounds__(256) void attn_scores_kernel(psl_attn_args a) {
 #pragma unroll
         for (int m = 0; m < NV; m++) kf[rd][m] = kr[m * 32 + c];
     }
+    if (dbg) dbg[1] = __builtin_amdgcn_s_memtime(); // loads issued
 #pragma unroll
     for (int rd = 0; rd < 4; rd++) {
         const int j     = j0 + rd * 8 + hw;
@@ -93,9 +97,11 @@ __global__ __launch_bounds__(256) void attn_scores_kernel(psl_attn_args a) {
                 for (int m = 0; m < NV; m++) s = __fmaf_rn(kf[rd][m], qf[g][m], s); // sum = x*y + sum, x = K row (src0)
                 s = reduce_f32x8x4(s);
                 if (live && c == 0) sb[(int64_t)g * a.n_ctx + j] = s;
+                if (dbg && rd == 0 && g == 0 && s != 12345.678f) dbg[2] = __builtin_amdgcn_s_memtime(); // q and the first K round have landed
             }
         }
     }
+    if (dbg) { dbg[3] = __builtin_amdgcn_s_memtime(); dbg[30] = __builtin_amdgcn_s_memrealtime(); }
 }
 
 // Batches: the same scores on the matrix cores, still bit-exact.  v_mfma_f32_16x16x4_f32 is a k-ordered f32 fma chain
@@ -178,7 +184,9 @@ constexpr int PV_LPT  = (4 * PV_TILE / 4 + PV_NT - 1) / PV_NT; // float4 V loads
 // caller's next __syncthreads().
 template <bool COH = false>
 __device__ __forceinline__ void attn_softmax_rows(const psl_attn_args &a, const int i, const int kvh, const int r2, const int pos0, const int bs,
-                                                  const int n_kv, float *pl, float (*redf)[PV_NW], double (*redd)[PV_NW], float *invs) {
+                                                  const int n_kv, float *pl, float (*redf)[PV_NW], double (*redd)[PV_NW], float *invs,
+                                                  unsigned long long *dbg = nullptr) {
+    auto mark = [&](int k) { if (dbg) dbg[k] = __builtin_amdgcn_s_memtime(); };
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n8 = n_kv & ~7, n_kv4 = (n_kv + 3) & ~3;
     // ---- phase 1a: scores -> masked, scaled logits in LDS; row maxima
@@ -217,7 +225,9 @@ __device__ __forceinline__ void attn_softmax_rows(const psl_attn_args &a, const 
     for (int g = 0; g < R2MAX; g++) {
         if (g < r2) { const float m = wave_max_dpp(rmax[g]); if (lane == 0) redf[g][wave] = m; }
     }
+    mark(2); // scores landed, logits in LDS
     __syncthreads();
+    mark(3);
     // ---- phase 1b: e_j = exp(x_j - max), row sums.  r2 | 16: wave w works on row w % r2 with 16/r2 - 1 others,
     //      else one wave per row
     const bool split = (PV_NW % r2) == 0;
@@ -247,7 +257,9 @@ __device__ __forceinline__ void attn_softmax_rows(const psl_attn_args &a, const 
             if (lane == 0) redd[g][sub] = sw;
         }
     }
+    mark(4);
     __syncthreads();
+    mark(5);
     if (threadIdx.x < r2) {
         double t = 0.0;
         for (int w = 0; w < wpr; w++) t += redd[threadIdx.x][w];
@@ -272,6 +284,10 @@ __global__ __launch_bounds__(PV_NT) void attn_softmax_pv_kernel(psl_attn_args a)
     __shared__ float redf[R2MAX][PV_NW];
     __shared__ double redd[R2MAX][PV_NW];
     __shared__ float invs[R2MAX];
+    const int wg = blockIdx.y * gridDim.x + blockIdx.x; // timeline (tools/gpu_attn_timeline.py, key 41)
+    unsigned long long *const dbg = (a.dbg && wg < 1024 && threadIdx.x == 0 && blockIdx.z == 0) ? a.dbg + (size_t)wg * 64 : nullptr;
+    auto mark = [&](int k) { if (dbg) dbg[k] = __builtin_amdgcn_s_memtime(); };
+    if (dbg) { dbg[0] = __builtin_amdgcn_s_memtime(); dbg[29] = __builtin_amdgcn_s_memrealtime(); }
 
     // ---- V tile loads (registers -> LDS), one tile ahead of the chains
     const float *vbase = a.v_cache + ((int64_t)kvh * hs + blockIdx.x * 4) * a.n_ctx;
@@ -293,10 +309,13 @@ __global__ __launch_bounds__(PV_NT) void attn_softmax_pv_kernel(psl_attn_args a)
         }
     };
     load_tile(0);
-
-    attn_softmax_rows(a, i, kvh, r2, pos0, bs, n_kv, pl, redf, redd, invs);
+    mark(1);
+    attn_softmax_rows(a, i, kvh, r2, pos0, bs, n_kv, pl, redf, redd, invs, dbg);
+    mark(6);
     store_tile();
+    mark(7);
     __syncthreads();
+    mark(8);
 
     // ---- phase 2: V·p.  thread: chain c = tid & 31, channel dl = (tid >> 5) & 3, head g = tid >> 7
     const int c = threadIdx.x & 31, dl = (threadIdx.x >> 5) & 3, g = threadIdx.x >> 7;
@@ -330,7 +349,9 @@ __global__ __launch_bounds__(PV_NT) void attn_softmax_pv_kernel(psl_attn_args a)
             }
         }
     }
+    mark(9);
     if (live && c == 0) a.att[(int64_t)i * dim + ((int64_t)kvh * r2 + g) * hs + blockIdx.x * 4 + dl] = out;
+    if (dbg) { dbg[10] = __builtin_amdgcn_s_memtime(); dbg[30] = __builtin_amdgcn_s_memrealtime(); }
 }
 
 // ---------------------------------------------------------------- single token: scores + softmax + V·p in ONE launch

@@ -169,8 +169,11 @@ static int enqueue_forward(ps_hip_model *m, int bs, bool lm_head, bool use_tree,
 
         if (!fuse_rope) psl_rope_append(st, aa, bs);
         if (!(bs == 1 && !use_tree && psl_attn_decode(st, c->n_cu, aa))) {
+            aa.dbg = bs == 1 ? psk_gemv_dbg_buf(10, 0) : nullptr; // timeline key 40
             psl_attn_scores(st, aa, bs);
+            aa.dbg = bs == 1 ? psk_gemv_dbg_buf(10, 1) : nullptr; // timeline key 41
             psl_attn_softmax_pv(st, aa, bs);
+            aa.dbg = nullptr;
         }
 
         psk_gemv_args go{};

@@ -36,6 +36,7 @@ struct psl_attn_args {
     const int32_t *rope_pos; // optional [bs]: RoPE position of each batch column (default: its cache slot pos0 + i)
     const uint8_t *kv_vis;   // optional [n_ctx]: 0 hides a cached slot (KVCacheInterface::mask / unmask)
     float scale;
+    unsigned long long *dbg; // timeline buffer of the single-token kernels (ps_hip_debug_timeline keys 40 / 41), or null
     unsigned *sync;          // [2048] words, zeroed once: [31] spin-timeout flag, [64 + 64 * kv head] ticket counter of the one-launch decode attention
 };
 void psl_rope_append(hipStream_t st, const psl_attn_args &a, int bs);
