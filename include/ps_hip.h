@@ -40,7 +40,7 @@ extern "C" {
 
 #define PS_HIP_ABI_VERSION 1
 
-/* ggml_type values (libs/ggml/include/ggml.h:361-398); Q4_K/Q6_K extend PowerServe's DataType enum
+/* ggml_type values (libs/ggml/include/ggml.h:361-398); Q4_K/Q5_K/Q6_K extend PowerServe's DataType enum
  * (core/data_type.hpp:24-35) which stops at Q8_0. */
 enum ps_dtype {
     PS_F32  = 0,
@@ -48,6 +48,7 @@ enum ps_dtype {
     PS_Q4_0 = 2,
     PS_Q8_0 = 8,
     PS_Q4_K = 12,
+    PS_Q5_K = 13,
     PS_Q6_K = 14,
     PS_Q8_K = 15,
     PS_I32  = 26,

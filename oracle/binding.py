@@ -19,8 +19,8 @@ ORACLE_SO = os.path.join(HERE, "libps_oracle.so")
 REF_SO = os.path.join(HERE, "_ref", "libps_ref.so")
 
 # ggml_type values (libs/ggml/include/ggml.h:361-398)
-F32, F16, Q4_0, Q8_0, Q4_K, Q6_K, Q8_K, I32 = 0, 1, 2, 8, 12, 14, 15, 26
-TYPE_NAMES = {F32: "F32", F16: "F16", Q4_0: "Q4_0", Q8_0: "Q8_0", Q4_K: "Q4_K", Q6_K: "Q6_K", Q8_K: "Q8_K"}
+F32, F16, Q4_0, Q8_0, Q4_K, Q5_K, Q6_K, Q8_K, I32 = 0, 1, 2, 8, 12, 13, 14, 15, 26
+TYPE_NAMES = {F32: "F32", F16: "F16", Q4_0: "Q4_0", Q8_0: "Q8_0", Q4_K: "Q4_K", Q5_K: "Q5_K", Q6_K: "Q6_K", Q8_K: "Q8_K"}
 
 
 def build(ref: bool = True) -> None:

@@ -31,12 +31,13 @@
 #define QK_K 256
 
 /* ------------------------------------------------------------------ block layouts
- * libs/ggml/src/ggml-common.h:158-162 (q4_0), :200-204 (q8_0), :296-310 (q4_K), :335-340 (q6_K),
+ * libs/ggml/src/ggml-common.h:158-162 (q4_0), :200-204 (q8_0), :296-310 (q4_K), :317-328 (q5_K), :335-340 (q6_K),
  * :344-348 (q8_K). */
 #pragma pack(push, 1)
 typedef struct { uint16_t d; uint8_t qs[16]; } blk_q4_0;                               /* 18 B */
 typedef struct { uint16_t d; int8_t qs[32]; } blk_q8_0;                                /* 34 B */
 typedef struct { uint16_t d, dmin; uint8_t scales[12]; uint8_t qs[128]; } blk_q4_K;    /* 144 B */
+typedef struct { uint16_t d, dmin; uint8_t scales[12]; uint8_t qh[32]; uint8_t qs[128]; } blk_q5_K; /* 176 B */
 typedef struct { uint8_t ql[128]; uint8_t qh[64]; int8_t scales[16]; uint16_t d; } blk_q6_K; /* 210 B */
 typedef struct { float d; int8_t qs[256]; int16_t bsums[16]; } blk_q8_K;               /* 292 B */
 #pragma pack(pop)
@@ -82,7 +83,7 @@ size_t pso_type_size(int t) {
     switch (t) {
     case PSO_F32: return 4; case PSO_F16: return 2; case PSO_I32: return 4;
     case PSO_Q4_0: return sizeof(blk_q4_0); case PSO_Q8_0: return sizeof(blk_q8_0);
-    case PSO_Q4_K: return sizeof(blk_q4_K); case PSO_Q6_K: return sizeof(blk_q6_K);
+    case PSO_Q4_K: return sizeof(blk_q4_K); case PSO_Q5_K: return sizeof(blk_q5_K); case PSO_Q6_K: return sizeof(blk_q6_K);
     case PSO_Q8_K: return sizeof(blk_q8_K);
     }
     return 0;
@@ -90,16 +91,16 @@ size_t pso_type_size(int t) {
 int64_t pso_blck_size(int t) {
     switch (t) {
     case PSO_Q4_0: case PSO_Q8_0: return QK;
-    case PSO_Q4_K: case PSO_Q6_K: case PSO_Q8_K: return QK_K;
+    case PSO_Q4_K: case PSO_Q5_K: case PSO_Q6_K: case PSO_Q8_K: return QK_K;
     }
     return 1;
 }
 size_t pso_row_size(int t, int64_t k) { return pso_type_size(t) * (size_t)(k / pso_blck_size(t)); }
-/* vec_dot_type: Q4_0,Q8_0 -> Q8_0 (ggml.c:734-748,814-830); Q4_K,Q6_K -> Q8_K (:865-900); F32 -> F32 */
+/* vec_dot_type: Q4_0,Q8_0 -> Q8_0 (ggml.c:734-748,814-830); Q4_K,Q5_K,Q6_K -> Q8_K (:865-900); F32 -> F32 */
 int pso_vec_dot_type(int t) {
     switch (t) {
     case PSO_Q4_0: case PSO_Q8_0: return PSO_Q8_0;
-    case PSO_Q4_K: case PSO_Q6_K: return PSO_Q8_K;
+    case PSO_Q4_K: case PSO_Q5_K: case PSO_Q6_K: return PSO_Q8_K;
     }
     return t;
 }
@@ -194,6 +195,20 @@ void pso_dequantize_row(int type, const void *vx, float *y, int64_t k) {
                 q += 32; is += 2;
             }
         }
+    } else if (type == PSO_Q5_K) { /* dequantize_row_q5_K (ggml-quants.c:2777-2802) */
+        const blk_q5_K *x = vx;
+        for (int64_t i = 0; i < k / QK_K; i++) {
+            const uint8_t *ql = x[i].qs, *qh = x[i].qh;
+            const float d = pso_fp16_to_fp32(x[i].d), min = pso_fp16_to_fp32(x[i].dmin);
+            int is = 0; uint8_t sc, m, u1 = 1, u2 = 2;
+            for (int j = 0; j < QK_K; j += 64) {
+                get_scale_min_k4(is + 0, x[i].scales, &sc, &m); const float d1 = d * sc, m1 = min * m;
+                get_scale_min_k4(is + 1, x[i].scales, &sc, &m); const float d2 = d * sc, m2 = min * m;
+                for (int l = 0; l < 32; ++l) *y++ = d1 * ((ql[l] & 0xF) + (qh[l] & u1 ? 16 : 0)) - m1;
+                for (int l = 0; l < 32; ++l) *y++ = d2 * ((ql[l] >> 4) + (qh[l] & u2 ? 16 : 0)) - m2;
+                ql += 32; is += 2; u1 <<= 2; u2 <<= 2;
+            }
+        }
     } else if (type == PSO_Q6_K) { /* dequantize_row_q6_K (ggml-quants.c:2991-3020) */
         const blk_q6_K *x = vx;
         for (int64_t i = 0; i < k / QK_K; i++) {
@@ -282,6 +297,40 @@ static float dot_q4_K_q8_K(int64_t n, const void *vx, const void *vy) {
     return hsum8(acc) + (m0 + m1);
 }
 
+/* ggml_vec_dot_q5_K_q8_K, AVX2 branch (ggml-quants.c:8382-8459).  The integer part is as in q4_K with the fifth bit of
+ * sub-vector b taken from bit b of qh; the mins are NOT kept in vector lanes here but in a scalar,
+ *     summs += dmin * hsum(madd(mins, q8s))                                                   (:8411)
+ * a float multiply followed by a float add in the C source.  Whether a compiler fuses the two is its fp-contraction
+ * setting; the reference library this oracle is pinned to (oracle/_ref) is built with -ffp-contract=off, as is this file:
+ * two roundings. */
+static float dot_q5_K_q8_K(int64_t n, const void *vx, const void *vy) {
+    const blk_q5_K *x = vx; const blk_q8_K *y = vy; float acc[8] = {0}; float summs = 0.f;
+    for (int64_t i = 0; i < n / QK_K; ++i) {
+        const float d = y[i].d * pso_fp16_to_fp32(x[i].d);
+        const float dmin = -y[i].d * pso_fp16_to_fp32(x[i].dmin);
+        uint8_t sc[8], mn[8];
+        for (int j = 0; j < 8; j++) get_scale_min_k4(j, x[i].scales, &sc[j], &mn[j]);
+        int hsum = 0; /* madd of the mins with the pairwise sums of bsums, then both hadds: one int32 */
+        for (int t = 0; t < 8; t++) hsum += mn[t] * (int16_t)(y[i].bsums[2 * t] + y[i].bsums[2 * t + 1]);
+        summs += dmin * (float)hsum;
+        int sumi[8] = {0};
+        const uint8_t *q5 = x[i].qs, *qh = x[i].qh; const int8_t *q8 = y[i].qs;
+        for (int j = 0; j < QK_K / 64; ++j) {
+            for (int u = 0; u < 8; u++) {
+                int l = 0, h = 0;
+                for (int e = 4 * u; e < 4 * u + 4; e++) {
+                    l += ((q5[e] & 0xF) + (((qh[e] >> (2 * j)) & 1) << 4)) * q8[e];
+                    h += ((q5[e] >> 4) + (((qh[e] >> (2 * j + 1)) & 1) << 4)) * q8[32 + e];
+                }
+                sumi[u] += sc[2 * j] * l + sc[2 * j + 1] * h;
+            }
+            q5 += 32; q8 += 64;
+        }
+        for (int u = 0; u < 8; u++) acc[u] = fmaf(d, (float)sumi[u], acc[u]);
+    }
+    return hsum8(acc) + summs;
+}
+
 /* ggml_vec_dot_q6_K_q8_K, AVX2 branch (ggml-quants.c:9040-9115) */
 static float dot_q6_K_q8_K(int64_t n, const void *vx, const void *vy) {
     const blk_q6_K *x = vx; const blk_q8_K *y = vy; float acc[8] = {0};
@@ -330,6 +379,7 @@ float pso_vec_dot(int type, int64_t n, const void *vx, const void *vy) {
     case PSO_Q4_0: return dot_q4_0_q8_0(n, vx, vy);
     case PSO_Q8_0: return dot_q8_0_q8_0(n, vx, vy);
     case PSO_Q4_K: return dot_q4_K_q8_K(n, vx, vy);
+    case PSO_Q5_K: return dot_q5_K_q8_K(n, vx, vy);
     case PSO_Q6_K: return dot_q6_K_q8_K(n, vx, vy);
     case PSO_F32: return pso_vec_dot_f32(n, vx, vy);
     }

@@ -20,6 +20,7 @@ enum pso_type {
     PSO_Q4_0 = 2,
     PSO_Q8_0 = 8,
     PSO_Q4_K = 12,
+    PSO_Q5_K = 13,
     PSO_Q6_K = 14,
     PSO_Q8_K = 15,
     PSO_I32  = 26,

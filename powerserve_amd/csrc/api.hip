@@ -41,7 +41,8 @@ void ps_rope_table_host(const ps_rope_params *rp, int64_t ne0, const int32_t *po
     }
 }
 
-static inline bool is_quant(int t) { return t == PS_Q4_0 || t == PS_Q8_0 || t == PS_Q4_K || t == PS_Q6_K; }
+static inline bool is_quant(int t) { return t == PS_Q4_0 || t == PS_Q8_0 || t == PS_Q4_K || t == PS_Q5_K || t == PS_Q6_K; }
+static inline bool is_row_wave(int t) { return t == PS_Q5_K || t == PS_Q6_K; } // one wave per weight row (k_gemv6.hip)
 
 extern "C" {
 
@@ -147,6 +148,7 @@ size_t ps_hip_row_size(int t, int64_t k) {
     case PS_Q4_0: return (size_t)(k / 32) * 18;
     case PS_Q8_0: return (size_t)(k / 32) * 34;
     case PS_Q4_K: return (size_t)(k / 256) * 144;
+    case PS_Q5_K: return (size_t)(k / 256) * 176;
     case PS_Q6_K: return (size_t)(k / 256) * 210;
     case PS_Q8_K: return (size_t)(k / 256) * 292;
     }
@@ -155,7 +157,7 @@ size_t ps_hip_row_size(int t, int64_t k) {
 int ps_hip_vec_dot_type(int t) {
     switch (t) {
     case PS_Q4_0: case PS_Q8_0: return PS_Q8_0;
-    case PS_Q4_K: case PS_Q6_K: return PS_Q8_K;
+    case PS_Q4_K: case PS_Q5_K: case PS_Q6_K: return PS_Q8_K;
     }
     return t;
 }
@@ -164,7 +166,7 @@ int ps_hip_vec_dot_type(int t) {
 int ps_hip_weight_upload(ps_hip_ctx *c, int dtype, const void *host, int64_t K, int64_t N, ps_weight **out) {
     *out = nullptr;
     if (!(is_quant(dtype) || dtype == PS_F32)) PS_FAIL(c, "weight_upload: unsupported dtype");
-    const int64_t blk = (dtype == PS_Q4_K || dtype == PS_Q6_K) ? 256 : (dtype == PS_F32 ? 1 : 32);
+    const int64_t blk = (dtype == PS_Q4_K || dtype == PS_Q5_K || dtype == PS_Q6_K) ? 256 : (dtype == PS_F32 ? 1 : 32);
     if (K % blk) PS_FAIL(c, "weight_upload: K is not a multiple of the block size");
     PS_CHECK(c, hipSetDevice(c->device));
     auto w        = new ps_weight();
@@ -190,6 +192,7 @@ int ps_hip_weight_upload(ps_hip_ctx *c, int dtype, const void *host, int64_t K, 
         aux_b = (size_t)(ng * nu) * (size_t)rg * (dtype == PS_Q4_K ? 16 : 8);
     }
     if (dtype == PS_Q6_K) { qs_b = (size_t)N * K / 2; qh_b = (size_t)N * K / 4; sc_b = (size_t)N * K / 16; aux_b = (size_t)N * (K / 256) * 2; }
+    if (dtype == PS_Q5_K) { qs_b = (size_t)N * K / 2; qh_b = (size_t)N * K / 8; sc_b = (size_t)N * (K / 256) * 16; aux_b = 0; }
     bool ok = hipMalloc((void **)&w->qs, qs_b + 64) == hipSuccess && hipMalloc((void **)&w->aux, aux_b + 64) == hipSuccess;
     if (ok && qh_b) ok = hipMalloc((void **)&w->qh, qh_b + 64) == hipSuccess && hipMalloc((void **)&w->sc, sc_b + 64) == hipSuccess;
     if (!ok) { (void)hipFree(tmp); return fail("weight_upload: hipMalloc(planes)"); }
@@ -260,10 +263,10 @@ int ps_hip_mul_mat(ps_hip_ctx *c, const ps_tensor *dst, const ps_tensor *src0, c
         const int vdt = ps_hip_vec_dot_type(w->dtype);
         if (ensure(c, &c->act_buf, &c->act_cap, ps_act_bytes(K, bs))) return 1;
         ps_act a = ps_act_carve(c->act_buf, K, bs);
-        if (w->dtype == PS_Q6_K) { // one wave per row (k_gemv6.hip)
+        if (is_row_wave(w->dtype)) { // one wave per row (k_gemv6.hip)
             psk_quantize_act(c->stream, vdt, 0, (const float *)src1->data, nullptr, nullptr, 0.f, K, bs, a);
             psk_gemv6_args g6{w, (float *)dst->data, w->N, nullptr, nullptr};
-            if (int rc = psk_gemv6(c->stream, c->n_cu, g6, a, K, bs)) { c->err = "mul_mat: Q6_K launch rc=" + std::to_string(rc); return 2; }
+            if (int rc = psk_gemv6(c->stream, c->n_cu, g6, a, K, bs)) { c->err = "mul_mat: Q5_K / Q6_K launch rc=" + std::to_string(rc); return 2; }
             PS_CHECK(c, hipGetLastError());
             return 0;
         }

@@ -1,7 +1,7 @@
 // Host-side core types of the MI355X backend, mirroring PowerServe's src/core (same names, same meaning) so
 // that graph-builder code written against the reference compiles against this tree:
 //   Tensor / Shape / Stride      src/core/tensor.hpp:27-91, src/core/typedefs.hpp:27-29
-//   DataType (+ GGML_Q4_K/Q6_K)  src/core/data_type.hpp:24-35  (the reference stops at Q8_0 and aborts on K-quants)
+//   DataType (+ GGML_Q4_K/Q5_K/Q6_K)  src/core/data_type.hpp:24-35  (the reference stops at Q8_0 and aborts on K-quants)
 //   BaseBuffer / HIPBuffer       src/core/buffer.hpp:21-26, src/backend/cpu_buffer.hpp:23-64 (stride in BYTES)
 //   ModelConfig / HyperParams    src/core/config.hpp:33-147
 //   POWERSERVE_ASSERT / ABORT    src/core/logger.hpp:56-82 (log + abort, or throw under POWERSERVE_EXCEPTION_ABORT)
@@ -41,13 +41,13 @@ using Shape  = std::array<size_t, max_n_dims>;
 using Stride = std::array<size_t, max_n_dims>;
 
 // values chosen so that static_cast<int> is NOT the ggml enum: use to_ps_dtype()/from ggml for the C-ABI
-enum class DataType { UNKNOWN, FP32, FP16, INT32, INT64, GGML_Q4_0, GGML_Q8_0, GGML_Q4_K, GGML_Q6_K, COUNT };
+enum class DataType { UNKNOWN, FP32, FP16, INT32, INT64, GGML_Q4_0, GGML_Q8_0, GGML_Q4_K, GGML_Q5_K, GGML_Q6_K, COUNT };
 
 // ggml_type values used by the C-ABI (include/ps_hip.h)
 inline int to_ggml_type(DataType t) {
     switch (t) {
     case DataType::FP32: return 0; case DataType::FP16: return 1; case DataType::GGML_Q4_0: return 2;
-    case DataType::GGML_Q8_0: return 8; case DataType::GGML_Q4_K: return 12; case DataType::GGML_Q6_K: return 14;
+    case DataType::GGML_Q8_0: return 8; case DataType::GGML_Q4_K: return 12; case DataType::GGML_Q5_K: return 13; case DataType::GGML_Q6_K: return 14;
     case DataType::INT32: return 26; case DataType::INT64: return 27;
     default: POWERSERVE_ABORT("unsupported data type");
     }
@@ -55,7 +55,7 @@ inline int to_ggml_type(DataType t) {
 inline DataType from_ggml_type(int t) {
     switch (t) {
     case 0: return DataType::FP32; case 1: return DataType::FP16; case 2: return DataType::GGML_Q4_0;
-    case 8: return DataType::GGML_Q8_0; case 12: return DataType::GGML_Q4_K; case 14: return DataType::GGML_Q6_K;
+    case 8: return DataType::GGML_Q8_0; case 12: return DataType::GGML_Q4_K; case 13: return DataType::GGML_Q5_K; case 14: return DataType::GGML_Q6_K;
     case 26: return DataType::INT32; case 27: return DataType::INT64;
     default: POWERSERVE_ABORT("unsupported ggml data type " + std::to_string(t));
     }
@@ -63,14 +63,14 @@ inline DataType from_ggml_type(int t) {
 inline size_t get_type_size(DataType t) {
     switch (t) {
     case DataType::FP32: case DataType::INT32: return 4; case DataType::FP16: return 2; case DataType::INT64: return 8;
-    case DataType::GGML_Q4_0: return 18; case DataType::GGML_Q8_0: return 34; case DataType::GGML_Q4_K: return 144; case DataType::GGML_Q6_K: return 210;
+    case DataType::GGML_Q4_0: return 18; case DataType::GGML_Q8_0: return 34; case DataType::GGML_Q4_K: return 144; case DataType::GGML_Q5_K: return 176; case DataType::GGML_Q6_K: return 210;
     default: POWERSERVE_ABORT("get_type_size");
     }
 }
 inline size_t get_block_size(DataType t) {
     switch (t) {
     case DataType::GGML_Q4_0: case DataType::GGML_Q8_0: return 32;
-    case DataType::GGML_Q4_K: case DataType::GGML_Q6_K: return 256;
+    case DataType::GGML_Q4_K: case DataType::GGML_Q5_K: case DataType::GGML_Q6_K: return 256;
     default: return 1;
     }
 }

@@ -1,4 +1,4 @@
-// Q6_K weights x Q8_K activations: y[c][row] = ggml_vec_dot_q6_K_q8_K(K, W[row], act[c])  
+// Q6_K and Q5_K weights x Q8_K activations: y[c][row] = ggml_vec_dot_q{6,5}_K_q8_K(K, W[row], act[c])  
 //
 // Reference numerics (AVX2 branch, libs/ggml/src/ggml-quants.c:9040-9115):
 // per super-block of 256 weights an EXACT int32 vector sumi[8] is formed (lane u owns weights 4u..4u+3 of each of the
@@ -118,10 +118,124 @@ __global__ __launch_bounds__(256) void gemv6_kernel(Gemv6Params p) {
     }
 }
 
+// ---------------------------------------------------------------- Q5_K (ggml-quants.c:8382-8459, AVX2 branch)
+// Same wave mapping and the same integer/fp32 split as Q6_K: lane (sbl, u) forms the exact int32
+//   sumi[u] = sum over the 8 sub-vectors j of  scale[j] * dot4(q5[j][4u..4u+3], y[j][4u..4u+3]),   q5 = low nibble + 16 * (bit j of qh),
+// and acc[u] = fma(d_w * d_act, (float)sumi[u], acc[u]) is walked in super-block order.  The mins do not ride in vector
+// lanes in this kernel of the reference but in ONE scalar,  summs += dmin * (float)hsum(mins . bsums)  — a multiply and an
+// add (two roundings: the reference build this backend is pinned to has fp-contraction off) — so a
+// third value per super-block joins the two that are broadcast for the chain.  Result: hsum_float_8(acc) + summs.
+struct Gemv5Params {
+    const uint8_t *qs, *qh;
+    const uint4 *hdr;     // [N][K/256] {d | dmin << 16, scales[12]}
+    int64_t K, N;
+    int nsb;
+    const int8_t *aq;     // [bs][K]
+    const float *ad;      // [bs][K/256]
+    const int16_t *abs16; // [bs][K/16]
+    float *out;
+    int64_t ldo;
+    const float *bias;
+    const float *residual;
+    int nc;
+};
+
+template <int BS>
+__global__ __launch_bounds__(256) void gemv5_kernel(Gemv5Params p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sbl = lane >> 3, u = lane & 7;
+    const int nsb = p.nsb, nit = (nsb + 7) >> 3;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < p.N; row += (int64_t)gridDim.x * 4) {
+        float acc[BS], summs[BS];
+#pragma unroll
+        for (int c = 0; c < BS; c++) { acc[c] = 0.f; summs[c] = 0.f; }
+        const int64_t rb = row * nsb;
+        for (int it = 0; it < nit; it++) {
+            const int sb0 = it * 8, sbr = sb0 + sbl;
+            const int sb = sbr < nsb ? sbr : nsb - 1; // lanes past the row end re-read the last block; never chained
+            const uint4 Q = ld_stream16(p.qs + (rb + sb) * 128 + u * 16);
+            const uint32_t H = *(const uint32_t *)(p.qh + (rb + sb) * 32 + u * 4);
+            const uint4 hd = p.hdr[rb + sb];
+            const float dw = ps_h2f((uint16_t)(hd.x & 0xffff)), dmw = ps_h2f((uint16_t)(hd.x >> 16));
+            // 5-bit weights of this lane: q[j] = elements 4u..4u+3 of sub-vector j, one per byte
+            const uint32_t Qw[4] = {Q.x, Q.y, Q.z, Q.w};
+            uint32_t q[8];
+            int scl[8], mnl[8];
+#pragma unroll
+            for (int jj = 0; jj < 4; jj++) {
+                q[2 * jj]     = (Qw[jj] & 0x0F0F0F0Fu) | (((H >> (2 * jj)) & 0x01010101u) << 4);
+                q[2 * jj + 1] = ((Qw[jj] >> 4) & 0x0F0F0F0Fu) | (((H >> (2 * jj + 1)) & 0x01010101u) << 4);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; j++) ps_scale_min_k4(j, hd.y, hd.z, hd.w, scl[j], mnl[j]);
+            const int nlive = nsb - sb0 < 8 ? nsb - sb0 : 8; // wave-uniform
+#pragma unroll
+            for (int c = 0; c < BS; c++) {
+                const int cc = c < p.nc ? c : p.nc - 1;
+                const int8_t *a = p.aq + (int64_t)cc * p.K + (int64_t)sb * 256 + 4 * u;
+                int sumi = 0;
+#pragma unroll
+                for (int j = 0; j < 8; j++) sumi += scl[j] * dot4((int)q[j], *(const int *)(a + j * 32), 0);
+                // mins . (bsums[2j] + bsums[2j+1]): every lane of the super-block forms the same int32
+                const int16_t *bs = p.abs16 + ((int64_t)cc * nsb + sb) * 16;
+                int hsum = 0;
+#pragma unroll
+                for (int j = 0; j < 8; j++) hsum += mnl[j] * (int)(int16_t)(bs[2 * j] + bs[2 * j + 1]);
+                const float yd = p.ad[(int64_t)cc * nsb + sb];
+                const float dd = __fmul_rn(yd, dw);                                  // y[i].d * GGML_FP16_TO_FP32(x[i].d)
+                const float mm = __fmul_rn(__fmul_rn(-yd, dmw), (float)hsum);        // dmin * hsum, dmin = -y[i].d * fp16(x[i].dmin)
+                const float t  = (float)sumi;
+                float ds[8], ts[8], ms[8]; // all lane broadcasts in flight, then the chains in super-block order
+#pragma unroll
+                for (int s = 0; s < 8; s++) { ds[s] = __shfl(dd, s * 8 + u, 64); ts[s] = __shfl(t, s * 8 + u, 64); ms[s] = __shfl(mm, s * 8 + u, 64); }
+                float ac = acc[c], sm = summs[c];
+#pragma unroll
+                for (int s = 0; s < 8; s++)
+                    if (s < nlive) { ac = __fmaf_rn(ds[s], ts[s], ac); sm = __fadd_rn(sm, ms[s]); }
+                acc[c] = ac; summs[c] = sm;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < BS; c++) { // hsum_float_8 (ggml-quants.c:62-68), then + summs
+            float v = acc[c];
+            v = __fadd_rn(v, dpp_f<0x104>(v));
+            v = __fadd_rn(v, dpp_f<0x102>(v));
+            v = __fadd_rn(v, dpp_f<0x101>(v));
+            v = __fadd_rn(v, summs[c]);
+            if (lane == 0 && c < p.nc) {
+                if (p.bias) v = __fadd_rn(v, p.bias[row]);
+                if (p.residual) v = __fadd_rn(p.residual[(int64_t)c * p.ldo + row], v);
+                p.out[(int64_t)c * p.ldo + row] = v;
+            }
+        }
+    }
+}
+
+int launch_gemv5(hipStream_t st, int n_cu, const psk_gemv6_args &a, ps_act act, int64_t K, int64_t bs) {
+    const ps_weight *w = a.w;
+    Gemv5Params p{};
+    p.qs = w->qs; p.qh = w->qh; p.hdr = (const uint4 *)w->sc;
+    p.K = K; p.N = w->N; p.nsb = (int)(K / 256);
+    p.ldo = a.ldo; p.bias = a.bias;
+    const int64_t nwg = (w->N + 3) / 4;
+    const unsigned grid = (unsigned)(nwg < (int64_t)n_cu * 16 ? nwg : (int64_t)n_cu * 16);
+    for (int64_t c0 = 0; c0 < bs; c0 += 8) {
+        const int nc = (int)(bs - c0 < 8 ? bs - c0 : 8);
+        p.aq = act.qs + c0 * K; p.ad = act.d + c0 * (K / 256); p.abs16 = act.bs16 + c0 * (K / 16);
+        p.out = a.out + c0 * a.ldo; p.residual = a.residual ? a.residual + c0 * a.ldo : nullptr; p.nc = nc;
+        if (nc == 1) hipLaunchKernelGGL(gemv5_kernel<1>, dim3(grid), dim3(256), 0, st, p);
+        else if (nc == 2) hipLaunchKernelGGL(gemv5_kernel<2>, dim3(grid), dim3(256), 0, st, p);
+        else if (nc <= 4) hipLaunchKernelGGL(gemv5_kernel<4>, dim3(grid), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL(gemv5_kernel<8>, dim3(grid), dim3(256), 0, st, p);
+    }
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
 } // namespace
 
 int psk_gemv6(hipStream_t st, int n_cu, const psk_gemv6_args &a, ps_act act, int64_t K, int64_t bs) {
     const ps_weight *w = a.w;
+    if (w->dtype == PS_Q5_K && w->K == K && K % 256 == 0) return launch_gemv5(st, n_cu, a, act, K, bs);
     if (w->dtype != PS_Q6_K || w->K != K || K % 256) return 4;
     Gemv6Params p{};
     p.ql = w->qs; p.qh = w->qh; p.sc = w->sc; p.d = (const uint16_t *)w->aux;

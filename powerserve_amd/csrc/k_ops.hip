@@ -209,6 +209,15 @@ __global__ void get_rows_kernel(WView w, const int32_t *tokens, int n, float *ou
             const int q = (l < 32) ? (bv & 0xF) : (bv >> 4);
             const float d = ps_h2f((uint16_t)(h.x & 0xffff)), mn = ps_h2f((uint16_t)(h.x >> 16));
             v = __fsub_rn(__fmul_rn(__fmul_rn(d, (float)sc), (float)q), __fmul_rn(mn, (float)m));
+        } else if (w.dtype == PS_Q5_K) { // dequantize_row_q5_K (ggml-quants.c:2777-2802): d1 * (q + 16 h) - m1
+            const int64_t sb = e / 256; const int r = (int)(e % 256), j = r / 32, l = r % 32, u5 = l >> 2;
+            const uint4 h = ((const uint4 *)w.sc)[row * (K / 256) + sb];
+            int sc, m; ps_scale_min_k4(j, h.y, h.z, h.w, sc, m);
+            const uint8_t bv = w.qs[row * (K / 2) + sb * 128 + (u5 * 4 + (j >> 1)) * 4 + (l & 3)];
+            const int hb = (w.qh[row * (K / 8) + sb * 32 + u5 * 4 + (l & 3)] >> j) & 1;
+            const int q = ((j & 1) ? (bv >> 4) : (bv & 0xF)) + 16 * hb;
+            const float d = ps_h2f((uint16_t)(h.x & 0xffff)), mn = ps_h2f((uint16_t)(h.x >> 16));
+            v = __fsub_rn(__fmul_rn(__fmul_rn(d, (float)sc), (float)q), __fmul_rn(mn, (float)m));
         } else { // Q6_K
             const int64_t sb = e / 256; const int r = (int)(e % 256), half = r / 128, rr = r % 128, sub = rr / 32, l = rr % 32;
             const uint8_t *ql = w.qs + row * (K / 2) + sb * 128; // lane-major inside the super-block (ps_internal.h)

@@ -154,6 +154,20 @@ __global__ void repack_q6_K_kernel(const uint8_t *raw, int64_t nblk, uint8_t *ql
     else ((uint16_t *)d)[b] = v;
 }
 
+__global__ void repack_q5_K_kernel(const uint8_t *raw, int64_t nblk, uint8_t *qs, uint8_t *qh, uint8_t *sc) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; // dword index, 44 per 176-byte block
+    if (i >= nblk * 44) return;
+    const int64_t b  = i / 44;
+    const int p      = (int)(i % 44);
+    const uint32_t v = ((const uint32_t *)raw)[i];
+    if (p < 4) ((uint32_t *)sc)[b * 4 + p] = v;        // {d, dmin}, scales[12]
+    else if (p < 12) ((uint32_t *)qh)[b * 8 + (p - 4)] = v; // qh dword u = bytes 4u..
+    else { // qs dword (jj * 8 + u) = bytes 32 jj + 4u.. -> lane-major dword u * 4 + jj
+        const int q = p - 12, jj = q >> 3, u = q & 7;
+        ((uint32_t *)qs)[b * 32 + u * 4 + jj] = v;
+    }
+}
+
 } // namespace
 
 void psk_quantize_act(hipStream_t st, int vdt, int mode, const float *x, const float *x2, const float *w, float eps,
@@ -197,6 +211,9 @@ void psk_repack_weight(hipStream_t st, int dtype, const uint8_t *raw, int64_t K,
     } else if (dtype == PS_Q4_K) {
         const int64_t nsb = K / 256, ng = (N + 7) / 8, n = ng * nsb * 256;
         hipLaunchKernelGGL(repack_q4_K_kernel, dim3((unsigned)((n + T - 1) / T)), dim3(T), 0, st, raw, N, nsb, (uint32_t *)w->qs, (uint4 *)w->aux);
+    } else if (dtype == PS_Q5_K) {
+        const int64_t nb = N * (K / 256);
+        hipLaunchKernelGGL(repack_q5_K_kernel, dim3((unsigned)((nb * 44 + T - 1) / T)), dim3(T), 0, st, raw, nb, w->qs, w->qh, w->sc);
     } else if (dtype == PS_Q6_K) {
         const int64_t nb = N * (K / 256);
         hipLaunchKernelGGL(repack_q6_K_kernel, dim3((unsigned)((nb * 105 + T - 1) / T)), dim3(T), 0, st, raw, nb, w->qs,

@@ -79,10 +79,10 @@ static int mm_each(ps_hip_model *m, psk_gemv_args &g, ps_act act, int64_t K, int
         s.n_w = 1; s.w[0] = g.w[i]; s.out[0] = g.silu_pair ? tmp[i] : g.out[i]; s.bias[0] = g.bias[i];
         s.ldo[0] = g.ldo[i]; s.residual = (i == 0 && !g.silu_pair) ? g.residual : nullptr;
         s.pro = g.pro; s.pro_x = g.pro_x; s.pro_norm_w = g.pro_norm_w; s.pro_eps = g.pro_eps;
-        if (g.w[i]->dtype == PS_Q6_K) {
+        if (g.w[i]->dtype == PS_Q6_K || g.w[i]->dtype == PS_Q5_K) {
             if (g.pro) psk_quantize_act(c->stream, PS_Q8_K, g.pro == 1 ? 1 : 0, g.pro_x, nullptr, g.pro_norm_w, g.pro_eps, K, bs, act);
             psk_gemv6_args a6{g.w[i], s.out[0], s.ldo[0], s.bias[0], s.residual};
-            if (int rc = psk_gemv6(c->stream, c->n_cu, a6, act, K, bs)) { c->err = "Q6_K mat-vec launch rc=" + std::to_string(rc); return 2; }
+            if (int rc = psk_gemv6(c->stream, c->n_cu, a6, act, K, bs)) { c->err = "Q5_K / Q6_K mat-vec launch rc=" + std::to_string(rc); return 2; }
         } else if (mm(m, s, act, K, bs)) {
             return 2;
         }
@@ -93,7 +93,7 @@ static int mm_each(ps_hip_model *m, psk_gemv_args &g, ps_act act, int64_t K, int
 
 static int mm(ps_hip_model *m, psk_gemv_args &g, ps_act act, int64_t K, int64_t bs) {
     ps_hip_ctx *c = m->ctx;
-    bool each = g.w[0]->dtype == PS_Q6_K;
+    bool each = g.w[0]->dtype == PS_Q6_K || g.w[0]->dtype == PS_Q5_K;
     for (int i = 1; i < g.n_w; i++) each = each || g.w[i]->dtype != g.w[0]->dtype;
     if (each) return mm_each(m, g, act, K, bs);
     const int vdt = ps_hip_vec_dot_type(g.w[0]->dtype);
@@ -229,7 +229,7 @@ int ps_hip_model_create(ps_hip_ctx *c, const ps_model_desc *d, ps_hip_model **ou
         PS_FAIL(c, "model_create: inconsistent head configuration");
     { // the descriptor is trusted by every kernel: weight handles must exist and agree with the configuration
         auto okw = [](const ps_weight *w, int64_t K, int64_t N) {
-            return w && w->K == K && w->N == N && w->qs && (w->dtype == PS_Q4_0 || w->dtype == PS_Q8_0 || w->dtype == PS_Q4_K || w->dtype == PS_Q6_K);
+            return w && w->K == K && w->N == N && w->qs && (w->dtype == PS_Q4_0 || w->dtype == PS_Q8_0 || w->dtype == PS_Q4_K || w->dtype == PS_Q5_K || w->dtype == PS_Q6_K);
         };
         if (!d->token_embd || d->token_embd->K != f.dim || d->token_embd->N != f.vocab_size || !d->token_embd->qs) PS_FAIL(c, "model_create: token_embd missing or of the wrong shape");
         if (d->output && !okw(d->output, f.dim, f.vocab_size)) PS_FAIL(c, "model_create: output.weight of the wrong shape / type");

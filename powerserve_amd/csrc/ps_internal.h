@@ -38,6 +38,9 @@ struct ps_hip_ctx {
 //   Q6_K : planes per row, lane-major inside a super-block (k_gemv6.hip: one wave per row, lane = (sb % 8, u)):
 //          qs [N][K/256][u=0..7][16 B] = ql bytes {4u.., 32+4u.., 64+4u.., 96+4u..}   qh [N][K/256][u][8 B] = qh bytes
 //          {4u.., 32+4u..}   sc [N][K/16] int8   aux [N][K/256] fp16 d
+//   Q5_K : the same per-row planes: qs [N][K/256][u][16 B] = qs bytes {4u.., 32+4u.., 64+4u.., 96+4u..} (byte 32 jj + e:
+//          element e of sub-vector 2 jj in the low nibble, of 2 jj + 1 in the high one)   qh [N][K/256][u][4 B] = qh bytes 4u..
+//          (bit b = fifth bit of sub-vector b)   sc [N][K/256] 16 B = {d, dmin, scales[12]}
 //   F32  : qs [N][K] float
 struct ps_weight {
     int dtype;
@@ -147,7 +150,7 @@ int psk_gemv_chain3(hipStream_t st, int n_cu, const psk_gemv_args a[3], unsigned
 int psk_gemv_max_cols(int wt, int64_t K); // widest column group one launch takes (16, 8 or 4; > 4 needs pro == 0)
 static inline int64_t ps_w_rg(int dtype) { return dtype == PS_Q4_0 ? 16 : 8; }
 static inline int64_t ps_w_unit(int dtype) { return dtype == PS_Q4_K ? 256 : 128; }
-// Q6_K x Q8_K (k_gemv6.hip): one matrix, any number of columns (groups of 8 inside); act must be quantized (Q8_K)
+// Q6_K / Q5_K x Q8_K (k_gemv6.hip): one matrix, any number of columns (groups of 8 inside); act must be quantized (Q8_K)
 struct psk_gemv6_args {
     const ps_weight *w;
     float *out;            // [bs][ldo]

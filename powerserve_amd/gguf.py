@@ -17,10 +17,10 @@ GGUF_VERSION = 3
 ALIGNMENT = 32
 
 # ggml_type values (libs/ggml/include/ggml.h:361-398)
-F32, F16, Q4_0, Q8_0, Q4_K, Q6_K, Q8_K, I32 = 0, 1, 2, 8, 12, 14, 15, 26
-TYPE_NAME = {F32: "F32", F16: "F16", Q4_0: "Q4_0", Q8_0: "Q8_0", Q4_K: "Q4_K", Q6_K: "Q6_K"}
+F32, F16, Q4_0, Q8_0, Q4_K, Q5_K, Q6_K, Q8_K, I32 = 0, 1, 2, 8, 12, 13, 14, 15, 26
+TYPE_NAME = {F32: "F32", F16: "F16", Q4_0: "Q4_0", Q8_0: "Q8_0", Q4_K: "Q4_K", Q5_K: "Q5_K", Q6_K: "Q6_K"}
 NAME_TYPE = {v: k for k, v in TYPE_NAME.items()}
-BLOCK = {F32: (1, 4), F16: (1, 2), Q4_0: (32, 18), Q8_0: (32, 34), Q4_K: (256, 144), Q6_K: (256, 210), I32: (1, 4)}
+BLOCK = {F32: (1, 4), F16: (1, 2), Q4_0: (32, 18), Q8_0: (32, 34), Q4_K: (256, 144), Q5_K: (256, 176), Q6_K: (256, 210), I32: (1, 4)}
 
 # gguf_type enum
 _U8, _I8, _U16, _I16, _U32, _I32, _F32, _BOOL, _STR, _ARR, _U64, _I64, _F64 = range(13)

@@ -17,8 +17,8 @@ from . import gguf
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libps_hip.so")
 
-F32, F16, Q4_0, Q8_0, Q4_K, Q6_K, Q8_K, I32 = 0, 1, 2, 8, 12, 14, 15, 26
-QUANT = (Q4_0, Q8_0, Q4_K, Q6_K)
+F32, F16, Q4_0, Q8_0, Q4_K, Q5_K, Q6_K, Q8_K, I32 = 0, 1, 2, 8, 12, 13, 14, 15, 26
+QUANT = (Q4_0, Q8_0, Q4_K, Q5_K, Q6_K)
 
 EXPORTS = [
     "ps_hip_abi_version", "ps_hip_device_count", "ps_hip_create", "ps_hip_destroy", "ps_hip_last_error",
@@ -241,7 +241,7 @@ class Weight:
 
     def tensor(self) -> PSTensor:
         rs = self.ctx.L.ps_hip_row_size(self.dtype, self.K)
-        ts = {F32: 4, Q4_0: 18, Q8_0: 34, Q4_K: 144, Q6_K: 210}[self.dtype]
+        ts = {F32: 4, Q4_0: 18, Q8_0: 34, Q4_K: 144, Q5_K: 176, Q6_K: 210}[self.dtype]
         return PSTensor(self.dtype, 0, (C.c_int64 * 4)(self.K, self.N, 1, 1), (C.c_uint64 * 4)(ts, rs, rs * self.N, rs * self.N),
                         self.h)
 

@@ -16,7 +16,7 @@ import os
 import numpy as np
 
 from . import gguf
-from .gguf import F32, Q4_0, Q4_K, Q6_K, Q8_0
+from .gguf import F32, Q4_0, Q4_K, Q5_K, Q6_K, Q8_0
 
 # SURVEY.md §8 shape table (public HF configs)
 PRESETS = {
@@ -76,6 +76,17 @@ def random_blocks(rng: np.random.Generator, t: int, n_rows: int, k: int, std: fl
         s[:, 4:8] = m[:, 0:4] | ((m[:, 4:8] >> 4) << 6)
         s[:, 8:12] = (sc[:, 4:8] & 0xF) | ((m[:, 4:8] & 0xF) << 4)
         out[:, 16:] = rng.integers(0, 256, (nb, 128), dtype=np.uint8)
+    elif t == Q5_K:  # w = d*sc*q - dmin*m, q~U[0,31]: std 9.23; dmin = 16d, m = round(15.5*sc/16) -> ~zero-mean
+        sc = rng.integers(8, 64, (nb, 8), dtype=np.uint8)
+        m = np.minimum(63, np.rint(15.5 * sc / 16.0)).astype(np.uint8)
+        d = std / (36.0 * 9.23) * jit
+        out[:, 0:2] = _f16(d).reshape(-1, 1).view(np.uint8)
+        out[:, 2:4] = _f16(16.0 * d).reshape(-1, 1).view(np.uint8)
+        s = out[:, 4:16]
+        s[:, 0:4] = sc[:, 0:4] | ((sc[:, 4:8] >> 4) << 6)
+        s[:, 4:8] = m[:, 0:4] | ((m[:, 4:8] >> 4) << 6)
+        s[:, 8:12] = (sc[:, 4:8] & 0xF) | ((m[:, 4:8] & 0xF) << 4)
+        out[:, 16:] = rng.integers(0, 256, (nb, 160), dtype=np.uint8)  # qh[32] + qs[128]
     elif t == Q6_K:  # w = d*sc*(q-32), q~U[0,63]: std 18.5
         out[:, 0:192] = rng.integers(0, 256, (nb, 192), dtype=np.uint8)
         out[:, 192:208] = rng.integers(-64, 64, (nb, 16), dtype=np.int8).view(np.uint8)
@@ -85,6 +96,7 @@ def random_blocks(rng: np.random.Generator, t: int, n_rows: int, k: int, std: fl
     return out.reshape(-1)
 
 
+Q5_K_M = 1017  # pseudo type: llama.cpp's "Q5_K_M" recipe, Q5_K with Q6_K for the same sensitive tensors
 Q4_K_M = 1015  # pseudo type: the per-tensor mix llama.cpp's "Q4_K_M" file type uses (Q4_K with Q6_K for the sensitive tensors)
 
 
@@ -95,9 +107,9 @@ def _more_bits(i: int, n: int) -> bool:  # llama.cpp use_more_bits(i_layer, n_la
 def tensor_plan(cfg: dict, arch: str, wtype: int, tied: bool, embd_type: int | None = None):
     """[(name, type, ne)] in file order."""
     dim, hid, L, kvd, vocab = cfg["embed_dim"], cfg["ffn_dim"], cfg["n_layers"], cfg["kv_dim"], cfg["vocab_size"]
-    mix = wtype == Q4_K_M
+    mix = wtype in (Q4_K_M, Q5_K_M)
     if mix:
-        wtype = Q4_K
+        wtype = Q4_K if wtype == Q4_K_M else Q5_K
     et = (Q6_K if (mix and tied) else wtype) if embd_type is None else embd_type
     plan = [("token_embd.weight", et, (dim, vocab))]
     for i in range(L):
@@ -123,7 +135,7 @@ def write_model_dir(out_dir: str, preset: str, wtype: int, n_ctx: int, seed: int
     tied = PRESETS[preset][10]
     cfg = llm_config(preset, n_ctx)
     os.makedirs(os.path.join(out_dir, "ggml"), exist_ok=True)
-    mj = {"version": 1, "model_arch": arch, "model_id": model_id or f"{preset}-{'Q4_K_M' if wtype == Q4_K_M else gguf.TYPE_NAME[wtype]}",
+    mj = {"version": 1, "model_arch": arch, "model_id": model_id or f"{preset}-{'Q4_K_M' if wtype == Q4_K_M else ('Q5_K_M' if wtype == Q5_K_M else gguf.TYPE_NAME[wtype])}",
           "llm_config": cfg}
     with open(os.path.join(out_dir, "model.json"), "w") as f:
         json.dump(mj, f, indent=1)

@@ -9,7 +9,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
-T = {"Q4_0": 2, "Q8_0": 8, "Q4_K": 12, "Q6_K": 14}
+T = {"Q4_0": 2, "Q8_0": 8, "Q4_K": 12, "Q5_K": 13, "Q6_K": 14}
 
 
 def test_act_quant_golden(ctx):
@@ -25,7 +25,7 @@ def test_act_quant_golden(ctx):
             assert np.array_equal(out.numpy(), g[f"{key}_{K}"])
 
 
-@pytest.mark.parametrize("name,count", [("mul_mat", 12), ("mul_mat_wide", 13)])
+@pytest.mark.parametrize("name,count", [("mul_mat", 12), ("mul_mat_wide", 16)])
 def test_mul_mat_golden(ctx, name, count):
     """ps_hip_mul_mat against the real reference's outputs, Q6_K included.  `mul_mat_wide` holds the shapes that reach
     gemv4 (one column, K % 1024 == 0), gemm4k (MFMA, full / ragged / small batches) and the Q6_K kernels beyond a few rows."""

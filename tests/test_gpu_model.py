@@ -24,7 +24,8 @@ def load_tensors(path):
 
 CASES = [("tiny-llama", 2), ("tiny-llama", 8), ("tiny-llama", 12), ("tiny-qwen2", 8), ("tiny-qwen2", 2),
          ("small-llama", 2), ("small-llama-hs128", 12),
-         ("small-llama-hs128", 14), ("small-llama-hs128", 1015), ("tiny-llama", 1015)]  # 14: pure Q6_K; 1015: synth.Q4_K_M mix
+         ("small-llama-hs128", 14), ("small-llama-hs128", 1015), ("tiny-llama", 1015),  # 14: pure Q6_K; 1015: synth.Q4_K_M mix
+         ("small-llama-hs128", 13), ("tiny-llama", 1017)]                                # 13: pure Q5_K; 1017: synth.Q5_K_M mix
 
 
 @pytest.mark.parametrize("preset,wt", CASES)

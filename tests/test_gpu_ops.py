@@ -44,12 +44,12 @@ def test_quantize_act_bit_exact(ctx, oracle, hip, K, vdt):
         assert np.array_equal(got[r], want), f"row {r}: {np.flatnonzero(got[r] != want)[:8]}"
 
 
-@pytest.mark.parametrize("wt", [2, 8, 12, 14])
+@pytest.mark.parametrize("wt", [2, 8, 12, 13, 14])
 @pytest.mark.parametrize("K,N", [(256, 64), (512, 96), (896, 130), (2048, 256), (2816, 37), (4096, 128), (4864, 64), (14336, 32)])
 @pytest.mark.parametrize("bs", [1, 2, 5])
 def test_mul_mat_quant(ctx, oracle, hip, wt, K, N, bs):
     from powerserve_amd import synth
-    if wt in (12, 14) and K % 256:
+    if wt in (12, 13, 14) and K % 256:
         pytest.skip("K-quants need K % 256 == 0")
     rng = np.random.default_rng(wt * 1000 + K + N + bs)
     w = synth.random_blocks(rng, wt, N, K)
@@ -64,7 +64,7 @@ def test_mul_mat_quant(ctx, oracle, hip, wt, K, N, bs):
     W.free()
 
 
-@pytest.mark.parametrize("wt", [2, 8, 12, 14])
+@pytest.mark.parametrize("wt", [2, 8, 12, 13, 14])
 @pytest.mark.parametrize("K,N", [(4096, 14001), (2048, 9000), (14336, 7001)])
 def test_mul_mat_quant_many_row_groups(ctx, oracle, hip, wt, K, N):
     """More row groups than resident workgroups: every workgroup streams several groups (uneven split, partial
@@ -83,13 +83,13 @@ def test_mul_mat_quant_many_row_groups(ctx, oracle, hip, wt, K, N):
     W.free()
 
 
-@pytest.mark.parametrize("wt", [12, 8, 2, 14])
+@pytest.mark.parametrize("wt", [12, 8, 2, 14, 13])
 @pytest.mark.parametrize("K,N,bs", [(4096, 520, 128), (2048, 96, 21), (14336, 72, 12), (256, 64, 9), (896, 40, 7)])
 def test_mul_mat_batched(ctx, oracle, hip, wt, K, N, bs):
     """Prefill / tree-verify batches: activations quantized once, 8 columns per workgroup, ragged last column group and
     a partial last row group; every column keeps the reference's accumulation order."""
     from powerserve_amd import synth
-    if wt in (12, 14) and K % 256:
+    if wt in (12, 13, 14) and K % 256:
         pytest.skip("K-quants need K % 256 == 0")
     rng = np.random.default_rng(K + N + bs + wt)
     w = synth.random_blocks(rng, wt, N, K)
@@ -197,7 +197,7 @@ def test_add_dup_silu(ctx, oracle, hip):
     assert np.array_equal(ddst.numpy(), src.transpose(1, 0, 2).reshape(bs, nh * hs))
 
 
-@pytest.mark.parametrize("wt", [0, 2, 8, 12, 14])
+@pytest.mark.parametrize("wt", [0, 2, 8, 12, 13, 14])
 def test_get_embedding(ctx, oracle, hip, wt):
     from powerserve_amd import synth
     rng = np.random.default_rng(wt)

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
-T = {"Q4_0": 2, "Q8_0": 8, "Q4_K": 12, "Q6_K": 14}
+T = {"Q4_0": 2, "Q8_0": 8, "Q4_K": 12, "Q5_K": 13, "Q6_K": 14}
 
 
 def bits(a):
@@ -25,7 +25,7 @@ def test_act_quant_bit_exact(oracle):
                 assert np.array_equal(oracle.from_float(15, x[i]), g[f"q8_K_{K}"][i])
 
 
-@pytest.mark.parametrize("name,count", [("mul_mat", 12), ("mul_mat_wide", 13)])
+@pytest.mark.parametrize("name,count", [("mul_mat", 12), ("mul_mat_wide", 16)])
 def test_mul_mat_bit_exact(oracle, name, count):
     g = np.load(os.path.join(GOLD, name + ".npz"))
     n = 0

@@ -1,4 +1,4 @@
-"""CPU, dev container only: restatement vs the live reference library (oracle/_ref), randomized, incl. Q4_K/Q6_K
+"""CPU, dev container only: restatement vs the live reference library (oracle/_ref), randomized, incl. Q4_K/Q5_K/Q6_K
 which the reference can only run at op level (its loader aborts on K-quants).  Skipped where _ref is absent."""
 import numpy as np
 import pytest
@@ -8,7 +8,7 @@ def bits(a):
     return np.ascontiguousarray(a).view(np.uint32)
 
 
-@pytest.mark.parametrize("t", [2, 8, 12, 14])
+@pytest.mark.parametrize("t", [2, 8, 12, 13, 14])
 @pytest.mark.parametrize("K,N,bs", [(256, 40, 1), (1024, 24, 5), (4096, 16, 2)])
 def test_mul_mat(oracle, ref, t, K, N, bs):
     from powerserve_amd import synth
