@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--model-dir", default=None)
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed/RCCL even for one rank (tests the N>1 code path)")
     ap.add_argument("--eager", action="store_true", help="eager launches instead of hipGraph replay (rocprofv3 runs)")
+    ap.add_argument("--no-kv-f16", action="store_true", help="skip the fp16-KV decode mode leg")
     ap.add_argument("--no-graph-path", action="store_true", help="skip the Graph -> Executor -> HIPBackend::plan leg (libps_host.so)")
     ap.add_argument("--graph-steps", type=int, default=32)
     return ap.parse_args()
@@ -151,6 +152,45 @@ def graph_path(model_dir, device, args, prompt):
     return {"prefill_tokens_per_s": (prompt.size - 1) / (t1 - t0), "decode_tokens_per_s": args.graph_steps / (t2 - t1), "steps": args.graph_steps,
             "graphs_planned": n_plans, "graphs_lowered": n_low, "first_ids": ids[:8],
             "what": "Graph -> Executor::run -> HIPBackend::plan (lowered to the fused launches), logits to the host every step, eager launches"}
+
+
+def fp16_kv_leg(ctx, model, args, prompt, ids_parity):
+    """SURVEY 8 f4, reported next to the headline and never mixed into it: the same prefill + decode with the fp16-KV
+    decode mode on (ps_hip_model_set_mode bit 3: fp16 mirrors of K and V, split-KV online soft-max for the single-token
+    attention).  NOT bit-exact: the ids are compared with the parity run's, and the logits of the first decode step."""
+    model.reset()
+    model.set_mode((1 if args.eager else 0) | 8)
+    done = 0
+    while done < prompt.size - 1:
+        bs = min(args.batch, prompt.size - 1 - done)
+        model.forward(prompt[done:done + bs], np.arange(done, done + bs), lm_head=False)
+        done += bs
+    lg16, _ = model.forward([int(prompt[-1])], [model.position], lm_head=True)
+    model.ctx.check(model.ctx.L.ps_hip_model_kv_rollback(model.h, 1))
+    cur = int(prompt[-1])
+    ids_w = model.decode_greedy(cur, args.warmup) if args.warmup > 0 else np.zeros(0, np.int32)
+    if ids_w.size:
+        cur = int(ids_w[-1])
+    ctx.sync()
+    t0 = time.perf_counter()
+    ids = model.decode_greedy(cur, args.steps)
+    ctx.sync()
+    dt = time.perf_counter() - t0
+    both = np.concatenate([ids_w, ids])
+    n_same = int(np.argmax(np.append(both != ids_parity[:both.size], True)))
+    # parity logits of the same step
+    model.reset()
+    model.set_mode(1 if args.eager else 0)
+    done = 0
+    while done < prompt.size - 1:
+        bs = min(args.batch, prompt.size - 1 - done)
+        model.forward(prompt[done:done + bs], np.arange(done, done + bs), lm_head=False)
+        done += bs
+    lg32, _ = model.forward([int(prompt[-1])], [model.position], lm_head=True)
+    rel = float(np.abs(lg16 - lg32).max() / np.abs(lg32).max())
+    return {"decode_tokens_per_s": args.steps / dt, "ms_per_step": 1e3 * dt / args.steps, "ids_matching_prefix_vs_parity": n_same, "ids_compared": int(both.size),
+            "first_step_logits_max_abs_err_over_max_abs": rel, "first_step_argmax_equal": bool(np.argmax(lg16) == np.argmax(lg32)),
+            "note": "fp16 K/V mirrors + split-KV online soft-max for single-token attention only; prefill reads the FP32 cache; not bit-exact by design"}
 
 
 def gpu_short_run(model, p, ids_cpu):
@@ -305,6 +345,11 @@ def main():
             "replicas_agree": replicas_agree, "first_ids": [int(i) for i in ids[:8]],
             "roofline": rf,
         }
+        if not args.no_kv_f16 and dist is None:
+            try:
+                out["fp16_kv_mode"] = fp16_kv_leg(ctx, model, args, prompt, np.concatenate([ids_w, ids]))
+            except Exception as e:  # noqa: BLE001 — a failing side leg must not take the headline line with it
+                out["fp16_kv_mode"] = {"error": repr(e)}
         if not args.no_graph_path and dist is None:
             try:
                 out["graph_path"] = graph_path(model_dir, local, args, prompt)

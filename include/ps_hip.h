@@ -213,7 +213,10 @@ int ps_hip_debug_set(int key, int value);
  * bit 1: 1 = run the O / gate-up / down mat-vecs of a layer as ONE chained launch (device-wide barriers from relaxed
  * atomics between the phases; needs every CU for this process; same results bit for bit);
  * bit 2: 1 = single-token attention (scores, softmax, V.p) as ONE launch with a per-kv-head rendezvous instead of two
- * launches (same results bit for bit; measured equal in time; needs every workgroup of its grid resident) */
+ * launches (same results bit for bit; measured equal in time; needs every workgroup of its grid resident);
+ * bit 3: 1 = fp16-KV decode mode — NOT bit-exact: K and V are mirrored in fp16 as they are appended and the
+ * single-token attention reads only the mirrors (half the KV bytes) with a split-KV online soft-max; prefill, batches and
+ * tree verify keep reading the FP32 caches.  Must be switched on while the cache is empty (position 0). */
 int ps_hip_model_set_mode(ps_hip_model *m, int mode);
 
 #ifdef __cplusplus

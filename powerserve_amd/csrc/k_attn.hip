@@ -41,16 +41,23 @@ __global__ void rope_append_kernel(psl_attn_args a, int bs) {
             const int rp = a.rope_pos ? a.rope_pos[i] : p;      // RoPE position
             const float *src = isq ? a.q + (int64_t)i * dim + h * hs : a.k + (int64_t)i * kvd + h * hs;
             float *dst = isq ? a.q + (int64_t)i * dim + h * hs : a.k_cache + (int64_t)p * kvd + h * hs;
-            if (i0 >= a.n_dims) { dst[i0] = src[i0]; dst[i0 + 1] = src[i0 + 1]; continue; }
+            if (i0 >= a.n_dims) {
+                dst[i0] = src[i0]; dst[i0 + 1] = src[i0 + 1];
+                if (!isq && a.k16) { a.k16[(int64_t)p * kvd + h * hs + i0] = (_Float16)src[i0]; a.k16[(int64_t)p * kvd + h * hs + i0 + 1] = (_Float16)src[i0 + 1]; }
+                continue;
+            }
             const float c = a.rope_table[(int64_t)rp * hs + i0], s = a.rope_table[(int64_t)rp * hs + i0 + 1];
             const int ia = a.neox ? pi : i0, ib = a.neox ? pi + half : i0 + 1;
             const float x0 = src[ia], x1 = src[ib];
-            dst[ia] = __fsub_rn(__fmul_rn(x0, c), __fmul_rn(x1, s));
-            dst[ib] = __fadd_rn(__fmul_rn(x0, s), __fmul_rn(x1, c));
+            const float ra = __fsub_rn(__fmul_rn(x0, c), __fmul_rn(x1, s)), rb = __fadd_rn(__fmul_rn(x0, s), __fmul_rn(x1, c));
+            dst[ia] = ra;
+            dst[ib] = rb;
+            if (!isq && a.k16) { a.k16[(int64_t)p * kvd + h * hs + ia] = (_Float16)ra; a.k16[(int64_t)p * kvd + h * hs + ib] = (_Float16)rb; }
         } else {
             const int64_t oo = o - nq - nk;
             const int d = (int)(oo % kvd), i = (int)(oo / kvd);
             a.v_cache[(int64_t)d * a.n_ctx + pos0 + i] = a.v[(int64_t)i * kvd + d];
+            if (a.v16) a.v16[(int64_t)(pos0 + i) * kvd + d] = (_Float16)a.v[(int64_t)i * kvd + d];
         }
     }
 }
@@ -621,6 +628,118 @@ __global__ __launch_bounds__(512, 1) void attn_pv_mfma_kernel(psl_attn_args a) {
         *(float4 *)(a.att + (int64_t)i * dim + ((int64_t)kvh * r2 + g) * hs + d0 + 4 * m) = make_float4(res[0], res[1], res[2], res[3]);
 }
 
+// ---------------------------------------------------------------- fp16-KV decode mode: NOT bit-exact
+// ps_hip_model_set_mode bit 3.  The FP32 caches stay the source of truth (prefill, batches, tree verify and every parity
+// path read them); K and V are mirrored in fp16, both [n_ctx][kv_dim], and ONLY the single-token attention reads the
+// mirrors: half the KV bytes, and — freed from the reference's summation order — a split-KV online soft-max:
+//   attn_flash16_kernel   grid (FL_SPLITS, n_kv_heads), 512 threads.  A workgroup takes a contiguous chunk of <= 128
+//                         cached positions of one kv head.  Scores: lane = (position, q head of the group), K row as 16 B
+//                         loads (the lanes of a position share it), q in registers as fp16 pairs, v_dot2_f32_f16 with fp32
+//                         accumulation.  Then per q head one wave: chunk max, p = exp(s - max), chunk sum, and
+//                         o[d] = sum_j p_j V[j][d] with lane = channel pair (coalesced V rows).  Writes (o, max, sum).
+//   attn_flash16_combine_kernel   one workgroup per q head merges the FL_SPLITS partials the usual way.
+// Differences from the parity path: fp16 rounding of K, V and q; exp via __expf; fp32 sums in split order.
+constexpr int FL_SPLITS = 32, FL_NT = 512;
+typedef _Float16 fl_h2 __attribute__((ext_vector_type(2)));
+template <int HS> // head_size: 64 or 128
+__global__ __launch_bounds__(FL_NT) void attn_flash16_kernel(psl_attn_args a) {
+    constexpr int NP = HS / 2;          // fp16 pairs per row
+    __shared__ float sc[R2MAX][128];    // scaled, masked scores of the chunk
+    const int kvd = a.n_kv_heads * HS, r2 = a.n_heads / a.n_kv_heads;
+    const int split = blockIdx.x, kvh = blockIdx.y;
+    const int n_kv = a.state->pos0 + 1;
+    const int chunk = (n_kv + FL_SPLITS - 1) / FL_SPLITS; // <= 128 for n_ctx <= 4096
+    const int j0 = split * chunk, j1 = min(j0 + chunk, n_kv), nj = max(j1 - j0, 0);
+    // ---- q of the r2 heads as fp16 pairs, through LDS (one conversion per workgroup)
+    __shared__ fl_h2 qs[R2MAX][NP];
+    for (int t = threadIdx.x; t < r2 * NP; t += FL_NT) {
+        const float2 qv = *(const float2 *)(a.q + (int64_t)kvh * r2 * HS + 2 * t);
+        fl_h2 h; h.x = (_Float16)qv.x; h.y = (_Float16)qv.y;
+        qs[t / NP][t % NP] = h;
+    }
+    __syncthreads();
+    // ---- scores: thread = (position jl, head g)
+    {
+        const int g = threadIdx.x % r2, jl = threadIdx.x / r2; // r2 in {1, 2, 4, 8}: 512 / r2 >= 64 positions per pass
+        fl_h2 qh[NP];
+#pragma unroll
+        for (int d = 0; d < NP / 4; d++) {
+            const uint4 qq = *(const uint4 *)&qs[g][4 * d];
+            __builtin_memcpy(&qh[4 * d], &qq.x, 4); __builtin_memcpy(&qh[4 * d + 1], &qq.y, 4); __builtin_memcpy(&qh[4 * d + 2], &qq.z, 4); __builtin_memcpy(&qh[4 * d + 3], &qq.w, 4);
+        }
+        for (int jb = 0; jb < nj; jb += FL_NT / r2) {
+            const int j = j0 + min(jb + jl, nj - 1); // (clamped: every lane loads a valid row, only live ones store)
+            const uint4 *kr = (const uint4 *)(a.k16 + (int64_t)j * kvd + kvh * HS);
+            uint4 kq[NP / 4];
+#pragma unroll
+            for (int d = 0; d < NP / 4; d++) kq[d] = kr[d];
+            float s = 0.f;
+#pragma unroll
+            for (int d = 0; d < NP / 4; d++) {
+                fl_h2 k0, k1, k2, k3;
+                __builtin_memcpy(&k0, &kq[d].x, 4); __builtin_memcpy(&k1, &kq[d].y, 4); __builtin_memcpy(&k2, &kq[d].z, 4); __builtin_memcpy(&k3, &kq[d].w, 4);
+                s = __builtin_amdgcn_fdot2(k0, qh[4 * d], s, false);
+                s = __builtin_amdgcn_fdot2(k1, qh[4 * d + 1], s, false);
+                s = __builtin_amdgcn_fdot2(k2, qh[4 * d + 2], s, false);
+                s = __builtin_amdgcn_fdot2(k3, qh[4 * d + 3], s, false);
+            }
+            if (jb + jl < nj) {
+                const bool ok = a.kv_vis ? (j >= n_kv - 1 || a.kv_vis[j] != 0) : true;
+                sc[g][jb + jl] = ok ? s * a.scale : -INFINITY;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- per head: wave g (r2 <= 8 waves)
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (wave >= r2) return;
+    const int g = wave, h = kvh * r2 + g;
+    float *out = a.part + ((int64_t)h * FL_SPLITS + split) * (HS + 2);
+    float s0 = lane < nj ? sc[g][lane] : -INFINITY, s1 = lane + 64 < nj ? sc[g][lane + 64] : -INFINITY;
+    const float m = wave_max_dpp(fmaxf(s0, s1));
+    const float p0 = (lane < nj && m > -INFINITY) ? __expf(s0 - m) : 0.f, p1 = (lane + 64 < nj && m > -INFINITY) ? __expf(s1 - m) : 0.f;
+    float l = p0 + p1;
+    l += dpp_f<0xB1>(l); l += dpp_f<0x4E>(l); l += dpp_f<0x141>(l); l += dpp_f<0x140>(l);
+    l = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(l), 0)) + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(l), 16)) +
+        __int_as_float(__builtin_amdgcn_readlane(__float_as_int(l), 32)) + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(l), 48));
+    // o: lane owns channels (2 lane, 2 lane + 1) [HS = 128] or lanes < 32 own them [HS = 64]
+    float o0 = 0.f, o1 = 0.f;
+    const bool own = 2 * lane < HS;
+    const _Float16 *vb = a.v16 + (int64_t)j0 * kvd + kvh * HS + 2 * (own ? lane : 0);
+    for (int jb = 0; jb < nj; jb += 16) { // sixteen V rows in flight at a time (lanes past the chunk carry p = 0)
+        fl_h2 vv[16];
+#pragma unroll
+        for (int t = 0; t < 16; t++) __builtin_memcpy(&vv[t], vb + (int64_t)min(jb + t, nj - 1) * kvd, 4);
+#pragma unroll
+        for (int t = 0; t < 16; t++) {
+            const int jl = jb + t; // uniform
+            const float pj = jl < 64 ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p0), jl & 63)) : __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p1), jl & 63));
+            o0 = fmaf(pj, (float)vv[t].x, o0);
+            o1 = fmaf(pj, (float)vv[t].y, o1);
+        }
+    }
+    if (own) { out[2 * lane] = o0; out[2 * lane + 1] = o1; }
+    if (lane == 0) { out[HS] = m; out[HS + 1] = l; }
+}
+
+template <int HS>
+__global__ __launch_bounds__(HS) void attn_flash16_combine_kernel(psl_attn_args a) {
+    const int h = blockIdx.x, d = threadIdx.x;
+    const float *pp = a.part + (int64_t)h * FL_SPLITS * (HS + 2);
+    float M = -INFINITY;
+#pragma unroll
+    for (int s = 0; s < FL_SPLITS; s++) M = fmaxf(M, pp[s * (HS + 2) + HS]);
+    float L = 0.f, o = 0.f;
+#pragma unroll
+    for (int s = 0; s < FL_SPLITS; s++) {
+        const float ms = pp[s * (HS + 2) + HS];
+        const float w = ms > -INFINITY ? __expf(ms - M) : 0.f;
+        L = fmaf(w, pp[s * (HS + 2) + HS + 1], L);
+        o = fmaf(w, pp[s * (HS + 2) + d], o);
+    }
+    a.att[(int64_t)h * HS + d] = o / L;
+}
+
 // ---------------------------------------------------------------- arg-max, first maximum (prob_array.cpp:65-67)
 constexpr int AM_PARTS = 64;
 __global__ __launch_bounds__(256) void argmax_partial_kernel(const float *src, int64_t n, float *pv, int *pi) {
@@ -723,6 +842,21 @@ void psl_attn_softmax_pv(hipStream_t st, const psl_attn_args &a, int bs) {
     if (ps_first_on_device(&attr)) { (void)hipFuncSetAttribute((const void *)attn_softmax_pv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024); }
     dim3 g((unsigned)(a.head_size / 4), (unsigned)a.n_kv_heads, (unsigned)bs);
     hipLaunchKernelGGL(attn_softmax_pv_kernel, g, dim3(PV_NT), psl_attn_softmax_pv_lds(a), st, a);
+}
+
+bool psl_attn_decode_f16(hipStream_t st, const psl_attn_args &a) {
+    if (!a.k16 || !a.v16 || !a.part || a.tree || a.n_ctx > 128 * FL_SPLITS) return false;
+    const int r2 = a.n_heads / a.n_kv_heads;
+    if ((r2 != 1 && r2 != 2 && r2 != 4 && r2 != 8) || (a.head_size != 128 && a.head_size != 64)) return false;
+    const dim3 g(FL_SPLITS, (unsigned)a.n_kv_heads);
+    if (a.head_size == 128) {
+        hipLaunchKernelGGL(attn_flash16_kernel<128>, g, dim3(FL_NT), 0, st, a);
+        hipLaunchKernelGGL(attn_flash16_combine_kernel<128>, dim3((unsigned)a.n_heads), dim3(128), 0, st, a);
+    } else {
+        hipLaunchKernelGGL(attn_flash16_kernel<64>, g, dim3(FL_NT), 0, st, a);
+        hipLaunchKernelGGL(attn_flash16_combine_kernel<64>, dim3((unsigned)a.n_heads), dim3(64), 0, st, a);
+    }
+    return true;
 }
 
 // single token, one launch (attn_decode_kernel); false: not covered, the caller launches scores + softmax/V·p

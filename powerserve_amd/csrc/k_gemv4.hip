@@ -317,6 +317,7 @@ __global__ __launch_bounds__((NW + 1) * 64) void gemv4_kernel(const G4Params p) 
                 if (u == 0 && row < Nw) {
                     if (wi == 2) {
                         R.v_cache[row * R.n_ctx + kv_pos] = v;
+                        if (R.v16) R.v16[(int64_t)kv_pos * R.kv_dim + row] = (_Float16)v;
                     } else {
                         const int e = (int)(row % R.head_size);
                         float res = v;
@@ -325,7 +326,7 @@ __global__ __launch_bounds__((NW + 1) * 64) void gemv4_kernel(const G4Params p) 
                             const float x0 = (e & 1) ? vp : v, x1 = (e & 1) ? v : vp;
                             res = (e & 1) ? __fadd_rn(__fmul_rn(x0, sn), __fmul_rn(x1, c)) : __fsub_rn(__fmul_rn(x0, c), __fmul_rn(x1, sn));
                         }
-                        if (wi == 0) o[row] = res; else R.k_cache[(int64_t)kv_pos * R.kv_dim + row] = res;
+                        if (wi == 0) o[row] = res; else { R.k_cache[(int64_t)kv_pos * R.kv_dim + row] = res; if (R.k16) R.k16[(int64_t)kv_pos * R.kv_dim + row] = (_Float16)res; }
                     }
                 }
             } else if (u == 0 && row < Nw) {

@@ -21,11 +21,12 @@ __global__ void set_state_kernel(ps_step_state *s, int pos0, int bs, int n_out) 
     s->pos0 = pos0; s->bs = bs; s->n_out = n_out;
 }
 __global__ void null_kernel(int *p) { if (p && threadIdx.x == 12345) *p = 0; }
-__global__ void kv_move_kernel(float *k, float *v, int kvd, int n_ctx, int dst, int src) {
+__global__ void kv_move_kernel(float *k, float *v, _Float16 *k16, _Float16 *v16, int kvd, int n_ctx, int dst, int src) {
     const int d = blockIdx.x * blockDim.x + threadIdx.x;
     if (d >= kvd) return;
     k[(int64_t)dst * kvd + d]   = k[(int64_t)src * kvd + d];
     v[(int64_t)d * n_ctx + dst] = v[(int64_t)d * n_ctx + src];
+    if (k16) { k16[(int64_t)dst * kvd + d] = k16[(int64_t)src * kvd + d]; v16[(int64_t)dst * kvd + d] = v16[(int64_t)src * kvd + d]; }
 }
 } // namespace
 
@@ -45,6 +46,8 @@ struct ps_hip_model {
     float *scores = nullptr, *logits = nullptr, *rope_table = nullptr;
     void *act_mem = nullptr;
     std::vector<float *> k_cache, v_cache;
+    std::vector<_Float16 *> k16, v16; // fp16 mirrors, both [n_ctx][kv_dim]: allocated when mode bit 3 is first set
+    float *attn_part = nullptr;       // split-KV partials of the fp16 decode attention
     ps_step_state *state = nullptr;
     int32_t *tokens_dev = nullptr, *argmax_dev = nullptr, *ids_dev = nullptr;
     float *am_v = nullptr;
@@ -161,14 +164,18 @@ static int enqueue_forward(ps_hip_model *m, int bs, bool lm_head, bool use_tree,
         if (m->qwen2) { g.bias[0] = m->bq[L]; g.bias[1] = m->bk[L]; g.bias[2] = m->bv[L]; }
         g.pro = 1; g.pro_x = m->x; g.pro_norm_w = m->attn_norm[L]; g.pro_eps = f.norm_eps; // RMSNorm + quantize in the prologue
         aa.k_cache = m->k_cache[L]; aa.v_cache = m->v_cache[L];
+        const bool kv16 = (m->mode & 8) && !m->k16.empty();
+        aa.k16 = kv16 ? m->k16[L] : nullptr; aa.v16 = kv16 ? m->v16[L] : nullptr; aa.part = m->attn_part;
         // single token, adjacent-pair RoPE: rotation and the KV append ride in the mat-vec epilogue
         const bool fuse_rope = bs == 1 && !aa.neox && psk_gemv_rope_ok(m->wq[L]->dtype, dim) && m->wk[L]->dtype == m->wq[L]->dtype && m->wv[L]->dtype == m->wq[L]->dtype;
-        psk_rope_kv rk{m->state, m->rope_table, aa.k_cache, aa.v_cache, (int)f.head_size, (int)f.rope.n_dims, (int)f.seq_len, (int)kvd, aa.rope_pos};
+        psk_rope_kv rk{m->state, m->rope_table, aa.k_cache, aa.v_cache, (int)f.head_size, (int)f.rope.n_dims, (int)f.seq_len, (int)kvd, aa.rope_pos, aa.k16, aa.v16};
         if (fuse_rope) g.rope = &rk;
         if (mm(m, g, a1, dim, bs)) return 2;
 
         if (!fuse_rope) psl_rope_append(st, aa, bs);
-        if (!(bs == 1 && !use_tree && psl_attn_decode(st, c->n_cu, aa))) {
+        if (bs == 1 && !use_tree && kv16 && psl_attn_decode_f16(st, aa)) {
+            // fp16-KV decode mode (not bit-exact): split-KV online soft-max over the fp16 mirrors
+        } else if (!(bs == 1 && !use_tree && psl_attn_decode(st, c->n_cu, aa))) {
             aa.dbg = bs == 1 ? psk_gemv_dbg_buf(10, 0) : nullptr; // timeline key 40
             psl_attn_scores(st, aa, bs);
             aa.dbg = bs == 1 ? psk_gemv_dbg_buf(10, 1) : nullptr; // timeline key 41
@@ -346,7 +353,7 @@ int ps_hip_model_kv_move(ps_hip_model *m, size_t dst, size_t src) {
     if (dst >= m->cfg.seq_len || src >= m->cfg.seq_len) { m->ctx->err = "kv_move: index out of range"; return 2; }
     for (uint32_t L = 0; L < m->cfg.n_layers; L++)
         hipLaunchKernelGGL(kv_move_kernel, dim3((m->cfg.kv_dim + 255) / 256), dim3(256), 0, m->ctx->stream, m->k_cache[L],
-                           m->v_cache[L], (int)m->cfg.kv_dim, (int)m->cfg.seq_len, (int)dst, (int)src);
+                           m->v_cache[L], m->k16.empty() ? nullptr : m->k16[L], m->v16.empty() ? nullptr : m->v16[L], (int)m->cfg.kv_dim, (int)m->cfg.seq_len, (int)dst, (int)src);
     return 0;
 }
 
@@ -556,7 +563,19 @@ int ps_hip_model_bench_gemv(ps_hip_model *m, int reps, int which, double *seq_ms
 }
 
 int ps_hip_model_set_mode(ps_hip_model *m, int mode) {
-    if (((m->mode ^ mode) & 6) && m->step_graph) { // the captured step bakes the launch plan in
+    if ((mode & 8) && m->k16.empty()) { // fp16 mirrors of the caches: filled from now on, so the cache must be empty
+        if (m->position != 0) { m->ctx->err = "set_mode: the fp16-KV decode mode must be switched on while the cache is empty"; return 2; }
+        const size_t n = (size_t)m->cfg.seq_len * m->cfg.kv_dim * 2;
+        m->k16.assign(m->cfg.n_layers, nullptr); m->v16.assign(m->cfg.n_layers, nullptr);
+        for (uint32_t i = 0; i < m->cfg.n_layers; i++) {
+            if (dmalloc(m, (void **)&m->k16[i], n) || dmalloc(m, (void **)&m->v16[i], n)) { m->k16.clear(); m->v16.clear(); return 2; }
+            (void)hipMemsetAsync(m->k16[i], 0, n, m->ctx->stream);
+            (void)hipMemsetAsync(m->v16[i], 0, n, m->ctx->stream);
+        }
+        if (dmalloc(m, (void **)&m->attn_part, (size_t)m->cfg.n_heads * 32 * (m->cfg.head_size + 2) * 4)) return 2;
+    }
+    if ((mode & 8) && !(m->mode & 8) && m->position != 0) { m->ctx->err = "set_mode: the fp16-KV decode mode must be switched on while the cache is empty"; return 2; }
+    if (((m->mode ^ mode) & 14) && m->step_graph) { // the captured step bakes the launch plan in
         (void)hipGraphExecDestroy(m->step_graph);
         m->step_graph = nullptr;
     }

@@ -124,6 +124,7 @@ struct psk_rope_kv {
     float *k_cache, *v_cache;          // [n_ctx][kv_dim], [kv_dim][n_ctx]
     int head_size, n_dims, n_ctx, kv_dim;
     const int32_t *rope_pos;           // optional: RoPE position of the token (default: its cache slot)
+    _Float16 *k16, *v16;               // optional fp16 mirrors, both [n_ctx][kv_dim] (fp16-KV decode mode, k_attn.hip)
 };
 struct psk_gemv_args {
     int n_w;                 // 1..3 matrices sharing the activation

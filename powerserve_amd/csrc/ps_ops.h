@@ -36,12 +36,15 @@ struct psl_attn_args {
     const int32_t *rope_pos; // optional [bs]: RoPE position of each batch column (default: its cache slot pos0 + i)
     const uint8_t *kv_vis;   // optional [n_ctx]: 0 hides a cached slot (KVCacheInterface::mask / unmask)
     float scale;
+    _Float16 *k16, *v16;     // optional fp16 mirrors of the caches, both [n_ctx][kv_dim] (fp16-KV decode mode: ps_hip_model_set_mode bit 3)
+    float *part;             // [n_heads][FL_SPLITS][head_size + 2] partial (o, m, l) of the split-KV decode attention
     unsigned long long *dbg; // timeline buffer of the single-token kernels (ps_hip_debug_timeline keys 40 / 41), or null
     unsigned *sync;          // [2048] words, zeroed once: [31] spin-timeout flag, [64 + 64 * kv head] ticket counter of the one-launch decode attention
 };
 void psl_rope_append(hipStream_t st, const psl_attn_args &a, int bs);
 void psl_attn_scores(hipStream_t st, const psl_attn_args &a, int bs);
 void psl_attn_softmax_pv(hipStream_t st, const psl_attn_args &a, int bs);
+bool psl_attn_decode_f16(hipStream_t st, const psl_attn_args &a); // single token over the fp16 mirrors: split-KV online soft-max + combine (NOT bit-exact); false: not covered
 bool psl_attn_decode(hipStream_t st, int n_cu, const psl_attn_args &a); // single token, scores + softmax + V.p in one launch; false: not covered
 size_t psl_attn_softmax_pv_lds(const psl_attn_args &a); // dynamic LDS bytes (grows with n_ctx)
 // two-stage arg-max (64 partials per row).  With state != NULL the final stage also does the greedy-decode
