@@ -130,11 +130,16 @@ __global__ __launch_bounds__((NW + 1) * 64) void gemv4_kernel(const G4Params p) 
             while (un >= tot) { un -= tot; t++; }
             tS[d] = t; uS[d] = un;
         }
-        ps_u32x4 q[DC][UPW], h[DC][UPW];
-        const uint32_t lane16 = (uint32_t)lane * 16u, raux = (uint32_t)r * 16u;
+        // Ring of weight chunks in registers: per chunk and lane four 16-byte quant loads and ONE 16-byte header load — the
+        // 4 x 128 B of a slot's headers are contiguous, lane l < 32 fetches piece l, and the wave hands them round through
+        // 512 B of LDS when the chunk is produced (a header register per unit and lane made the ring 32 registers per chunk:
+        // three chunks did not fit under the 168-register cap of a nine-wave workgroup)
+        ps_u32x4 q[DC][UPW], h[DC];
+        __shared__ ps_u32x4 hscr[NW][32];
+        const uint32_t lane16 = (uint32_t)lane * 16u;
         // loads are UNCONDITIONAL (a slot past the range re-reads the workgroup's first unit) so that the compiler counts
         // vmcnt exactly and a chunk is consumed while the next ones are in flight
-        auto issue = [&](ps_u32x4 (&q)[UPW], ps_u32x4 (&h)[UPW], int tl, int un) {
+        auto issue = [&](ps_u32x4 (&q)[UPW], ps_u32x4 &h, int tl, int un) {
             const bool live = tl < nt;
             int grp = t0 + (live ? tl : 0), ul = live ? un : 0;
             const uint8_t *qb = p.w[0].qs, *ab = p.w[0].aux;
@@ -147,16 +152,18 @@ __global__ __launch_bounds__((NW + 1) * 64) void gemv4_kernel(const G4Params p) 
             const uint32_t idx = (uint32_t)(grp * n_units + ul);
             const uint8_t *qg = qb + ((uint64_t)idx << 10), *ag = ab + ((uint64_t)idx << 7);
             // a dead slot costs one cache line: every lane asks for the same 16 bytes of the workgroup's first unit
-            const uint32_t lo = live ? lane16 : 0u, ro = live ? raux : 0u, st = live ? 1u : 0u;
+            const uint32_t lo = live ? lane16 : 0u, st = live ? 1u : 0u;
 #pragma unroll
-            for (int i = 0; i < UPW; i++) {
-                q[i] = __builtin_nontemporal_load((const ps_u32x4 *)(qg + i * (1024 * st) + lo));
-                h[i] = *(const ps_u32x4 *)(ag + i * (128 * st) + ro);
-            }
+            for (int i = 0; i < UPW; i++) q[i] = __builtin_nontemporal_load((const ps_u32x4 *)(qg + i * (1024 * st) + lo));
+            h = *(const ps_u32x4 *)(ag + (live ? (uint32_t)(lane & 31) * 16u : 0u));
         };
-        auto produce = [&](const ps_u32x4 (&q)[UPW], const ps_u32x4 (&h)[UPW], int tl, int un, int buf) {
+        auto produce = [&](const ps_u32x4 (&q)[UPW], const ps_u32x4 &hc, int tl, int un, int buf) {
             if (tl >= nt) return; // wave-uniform: nothing of this chunk belongs to the wave
             const int ul = (EPI == 1 && un >= n_units) ? un - n_units : un;
+            if (lane < 32) hscr[wave][lane] = hc;
+            ps_u32x4 h[UPW]; // header of (unit i, this lane's row r)
+#pragma unroll
+            for (int i = 0; i < UPW; i++) h[i] = hscr[wave][i * 8 + r];
 #pragma unroll
             for (int i = 0; i < UPW; i++) {
                 const int2 rc  = unit_rec<WT>(make_uint4(q[i].x, q[i].y, q[i].z, q[i].w), make_uint4(h[i].x, h[i].y, h[i].z, h[i].w), ul + i, u, A);
@@ -454,6 +461,7 @@ int psk_gemv4(hipStream_t st, int n_cu, const psk_gemv_args &a, ps_act act, int6
     case 1: return seven ? launch_g4_kc<7, 2, 0>(st, grid, p, epi, a.pro) : launch_g4_kc<8, 2, 0>(st, grid, p, epi, a.pro); // everything issued up front
     case 2: return seven ? launch_g4_kc<7, 3, 1>(st, grid, p, epi, a.pro) : launch_g4_kc<8, 3, 1>(st, grid, p, epi, a.pro); // three chunks in flight
     case 3: return launch_g4_kc<11, 2, 1>(st, grid, p, epi, a.pro);                                                          // twelve waves
+    case 4: return seven ? launch_g4_kc<7, 4, 1>(st, grid, p, epi, a.pro) : launch_g4_kc<8, 4, 1>(st, grid, p, epi, a.pro); // four chunks in flight
     default: return seven ? launch_g4_kc<7, 2, 1>(st, grid, p, epi, a.pro) : launch_g4_kc<8, 2, 1>(st, grid, p, epi, a.pro);
     }
 }
