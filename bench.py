@@ -380,7 +380,7 @@ def main():
         print(json.dumps(out), flush=True)
 
 
-GATE_UP_KERNEL = "gemv4_kernel<8, 2, 2, 1, 1, 1>"  # <NW 8, DC 2, TPW 2, staged, EPI 1 SiLU(gate)*up, PRO 1 RMSNorm+Q8_K>
+GATE_UP_KERNEL = "gemv4_kernel<8, 2, 2, 2, 1, 1>"  # <NW 8, DC 2, TPW 2, staged, EPI 1 SiLU(gate)*up, PRO 1 RMSNorm+Q8_K>
 
 
 def _pmc_traffic(kernel):

@@ -139,7 +139,7 @@ __global__ __launch_bounds__((NW + 1) * 64) void gemv4_kernel(const G4Params p) 
         const uint32_t lane16 = (uint32_t)lane * 16u;
         // loads are UNCONDITIONAL (a slot past the range re-reads the workgroup's first unit) so that the compiler counts
         // vmcnt exactly and a chunk is consumed while the next ones are in flight
-        auto issue = [&](ps_u32x4 (&q)[UPW], ps_u32x4 &h, int tl, int un) {
+        auto issue = [&](ps_u32x4 (&q)[UPW], ps_u32x4 &h, int tl, int un, int i_lo = 0, int i_hi = UPW) { // units [i_lo, i_hi) of the slot; the header piece rides with unit 0
             const bool live = tl < nt;
             int grp = t0 + (live ? tl : 0), ul = live ? un : 0;
             const uint8_t *qb = p.w[0].qs, *ab = p.w[0].aux;
@@ -154,18 +154,21 @@ __global__ __launch_bounds__((NW + 1) * 64) void gemv4_kernel(const G4Params p) 
             // a dead slot costs one cache line: every lane asks for the same 16 bytes of the workgroup's first unit
             const uint32_t lo = live ? lane16 : 0u, st = live ? 1u : 0u;
 #pragma unroll
-            for (int i = 0; i < UPW; i++) q[i] = __builtin_nontemporal_load((const ps_u32x4 *)(qg + i * (1024 * st) + lo));
-            h = *(const ps_u32x4 *)(ag + (live ? (uint32_t)(lane & 31) * 16u : 0u));
+            for (int i = 0; i < UPW; i++)
+                if (i >= i_lo && i < i_hi) q[i] = __builtin_nontemporal_load((const ps_u32x4 *)(qg + i * (1024 * st) + lo));
+            if (i_lo == 0) h = *(const ps_u32x4 *)(ag + (live ? (uint32_t)(lane & 31) * 16u : 0u));
         };
-        auto produce = [&](const ps_u32x4 (&q)[UPW], const ps_u32x4 &hc, int tl, int un, int buf) {
+        auto produce = [&](const ps_u32x4 (&q)[UPW], const ps_u32x4 &hc, int tl, int un, int buf, int i_lo = 0, int i_hi = UPW) {
             if (tl >= nt) return; // wave-uniform: nothing of this chunk belongs to the wave
             const int ul = (EPI == 1 && un >= n_units) ? un - n_units : un;
-            if (lane < 32) hscr[wave][lane] = hc;
+            if (i_lo == 0 && lane < 32) hscr[wave][lane] = hc;
             ps_u32x4 h[UPW]; // header of (unit i, this lane's row r)
 #pragma unroll
-            for (int i = 0; i < UPW; i++) h[i] = hscr[wave][i * 8 + r];
+            for (int i = 0; i < UPW; i++)
+                if (i >= i_lo && i < i_hi) h[i] = hscr[wave][i * 8 + r];
 #pragma unroll
             for (int i = 0; i < UPW; i++) {
+                if (i < i_lo || i >= i_hi) continue;
                 const int2 rc  = unit_rec<WT>(make_uint4(q[i].x, q[i].y, q[i].z, q[i].w), make_uint4(h[i].x, h[i].y, h[i].z, h[i].w), ul + i, u, A);
                 const float yd = A.d[ul + i];
                 const float d    = __fmul_rn(yd, ps_h2f((uint16_t)(h[i].x & 0xffff)));
@@ -178,7 +181,10 @@ __global__ __launch_bounds__((NW + 1) * 64) void gemv4_kernel(const G4Params p) 
             tl += step_t; un += step_u;
             if (un >= tot) { un -= tot; tl++; }
         };
-        // XW (staged issue): only chunk 0 goes out before the prologue.  The CU's vector-memory queue is served in order at
+        // XW (staged issue): only chunk 0 goes out before the prologue.  XW 1: chunk 1 at the sum-of-squares barrier, XW 2 (production):
+        // chunk 1 behind the quantizer as well — at the barrier the CU's queue still holds every wave's chunk 0, the waves
+        // stalled ~0.9 us IN that issue, on the critical path of the prologue (activation in LDS after 3.1 instead of 4.0 us;
+        // gate/up 17.3 -> 16.1 us).  XW 3 adds the split issue of the steady state (no gain, kept for the sweep).  The CU's vector-memory queue is served in order at
         // 64 B per clock and a wave whose requests do not fit stalls IN the issue: with two chunks (16 KiB + headers per
         // wave) up front the waves spent 1.2 us issuing before they could look at the activation row, and the slowest
         // reached the sum-of-squares barrier 1 us after the first.  The later chunks follow behind the prologue's barriers.
@@ -215,7 +221,7 @@ __global__ __launch_bounds__((NW + 1) * 64) void gemv4_kernel(const G4Params p) 
                 if (lane == 0) red[wave] = ss;
                 __syncthreads();
                 pmark(25);
-                if (STAGED && DC > 1) issue(q[1], h[1], tS[1], uS[1]);
+                if (STAGED && XW == 1 && DC > 1) issue(q[1], h[1], tS[1], uS[1]); // (XW 2, 3: after the quantizer instead, with the others)
                 double tot_ss = 0.0;
 #pragma unroll
                 for (int i = 0; i <= NW; i++) tot_ss += red[i];
@@ -239,7 +245,7 @@ __global__ __launch_bounds__((NW + 1) * 64) void gemv4_kernel(const G4Params p) 
             pmark(27);
             if (STAGED) {
 #pragma unroll
-                for (int d = (PRO == 1 ? 2 : 1); d < DC; d++) issue(q[d], h[d], tS[d], uS[d]);
+                for (int d = ((PRO == 1 && XW == 1) ? 2 : 1); d < DC; d++) issue(q[d], h[d], tS[d], uS[d]);
             }
             __syncthreads();
         }
@@ -248,10 +254,23 @@ __global__ __launch_bounds__((NW + 1) * 64) void gemv4_kernel(const G4Params p) 
         for (int it = 0; it < n_iters; it++) {
 #pragma unroll
             for (int d = 0; d < DC; d++) {
-                produce(q[d], h[d], tS[d], uS[d], (it * DC + d) & 1);
-                mark(); // 3, 6, ...: chunk produced
-                advance(tS[d], uS[d]);
-                issue(q[d], h[d], tS[d], uS[d]);
+                if constexpr (XW == 3) {
+                    // split issue: the registers of a slot's first two units are free once those units are produced, so
+                    // their next loads go out half a chunk earlier (more bytes in flight while this chunk is being produced,
+                    // without a deeper ring)
+                    const int tl_now = tS[d], un_now = uS[d];
+                    advance(tS[d], uS[d]);
+                    produce(q[d], h[d], tl_now, un_now, (it * DC + d) & 1, 0, 2);
+                    issue(q[d], h[d], tS[d], uS[d], 0, 2);
+                    produce(q[d], h[d], tl_now, un_now, (it * DC + d) & 1, 2, 4);
+                    mark(); // 3, 6, ...: chunk produced
+                    issue(q[d], h[d], tS[d], uS[d], 2, 4);
+                } else {
+                    produce(q[d], h[d], tS[d], uS[d], (it * DC + d) & 1);
+                    mark(); // 3, 6, ...: chunk produced
+                    advance(tS[d], uS[d]);
+                    issue(q[d], h[d], tS[d], uS[d]);
+                }
                 mark(); // 4, 7, ...: next loads issued
                 __syncthreads();
                 mark(); // 5, 8, ...: barrier passed
@@ -461,7 +480,10 @@ int psk_gemv4(hipStream_t st, int n_cu, const psk_gemv_args &a, ps_act act, int6
     case 1: return seven ? launch_g4_kc<7, 2, 0>(st, grid, p, epi, a.pro) : launch_g4_kc<8, 2, 0>(st, grid, p, epi, a.pro); // everything issued up front
     case 2: return seven ? launch_g4_kc<7, 3, 1>(st, grid, p, epi, a.pro) : launch_g4_kc<8, 3, 1>(st, grid, p, epi, a.pro); // three chunks in flight
     case 3: return launch_g4_kc<11, 2, 1>(st, grid, p, epi, a.pro);                                                          // twelve waves
+    case 7: return seven ? launch_g4_kc<7, 2, 3>(st, grid, p, epi, a.pro) : launch_g4_kc<8, 2, 3>(st, grid, p, epi, a.pro); // + split issue
+    case 6: return seven ? launch_g4_kc<7, 3, 2>(st, grid, p, epi, a.pro) : launch_g4_kc<8, 3, 2>(st, grid, p, epi, a.pro);
     case 4: return seven ? launch_g4_kc<7, 4, 1>(st, grid, p, epi, a.pro) : launch_g4_kc<8, 4, 1>(st, grid, p, epi, a.pro); // four chunks in flight
-    default: return seven ? launch_g4_kc<7, 2, 1>(st, grid, p, epi, a.pro) : launch_g4_kc<8, 2, 1>(st, grid, p, epi, a.pro);
+    case 8: return seven ? launch_g4_kc<7, 2, 1>(st, grid, p, epi, a.pro) : launch_g4_kc<8, 2, 1>(st, grid, p, epi, a.pro); // chunk 1 at the sum-of-squares barrier (round-2 default until the timeline showed the stall)
+    default: return seven ? launch_g4_kc<7, 2, 2>(st, grid, p, epi, a.pro) : launch_g4_kc<8, 2, 2>(st, grid, p, epi, a.pro);
     }
 }
