@@ -29,27 +29,28 @@ __device__ __forceinline__ float g4_silu_mul(float g, float u, const uint64_t *t
 // prologue's version of ps_quantize_tile: every tile is full (K % 256 == 0), no 16-sums, and the scale / 32-sums are
 // written by every lane of their group (same value, same address) instead of behind exec-mask branches -- the prologue is
 // issue-bound on a single wave per tile, so instructions are what it costs.
-__device__ __forceinline__ void g4_quantize_tile(const float v[4], const int e, const int t, int8_t *qs, float *d, int *bs32) {
+__device__ __forceinline__ void g4_quantize_tile(const float v[4], const int e, const int t, int8_t *qs, float *d, int *bs32, const bool live = true) {
+    // straight-line on purpose (no branch on the all-zero tile, `live` guards only the stores): a wave quantizes several
+    // independent tiles back to back and the scheduler can only interleave their dependent chains inside one basic block
     int q[4];
     const float am   = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
     const float amax = wave_max_dpp(am); // max is order-independent: exact
-    float dd = 0.f;
-    if (amax == 0.f) { // wave-uniform
-        q[0] = q[1] = q[2] = q[3] = 0;
-    } else { // the first element (index order) with the largest |x| decides the sign of iscale
-        const unsigned long long hits = __ballot(am == amax);
-        const float mine = fabsf(v[0]) == amax ? v[0] : fabsf(v[1]) == amax ? v[1] : fabsf(v[2]) == amax ? v[2] : v[3];
-        const float mx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine), __ffsll((long long)hits) - 1));
-        const float iscale = __fdiv_rn(-127.f, mx);
+    // the first element (index order) with the largest |x| decides the sign of iscale
+    const unsigned long long hits = __ballot(am == amax);
+    const float mine = fabsf(v[0]) == amax ? v[0] : fabsf(v[1]) == amax ? v[1] : fabsf(v[2]) == amax ? v[2] : v[3];
+    const float mx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine), __ffsll((long long)hits) - 1));
+    const bool zero = amax == 0.f; // (an all-zero tile: quants 0, d 0 — quantize_row_q8_K's early-out)
+    const float iscale = zero ? 0.f : __fdiv_rn(-127.f, mx);
 #pragma unroll
-        for (int i = 0; i < 4; i++) q[i] = min(127, __float2int_rn(__fmul_rn(iscale, v[i])));
-        dd = __fdiv_rn(1.0f, iscale);
-    }
+    for (int i = 0; i < 4; i++) q[i] = min(127, __float2int_rn(__fmul_rn(iscale, v[i])));
+    const float dd = zero ? 0.f : __fdiv_rn(1.0f, iscale);
     int s = q[0] + q[1] + q[2] + q[3];
     s += dpp_i<0xB1>(s); s += dpp_i<0x4E>(s); s += dpp_i<0x141>(s); // all 8 lanes of a 32-element group hold its sum
-    *(uint32_t *)(qs + e) = (uint32_t)(q[0] & 0xff) | ((uint32_t)(q[1] & 0xff) << 8) | ((uint32_t)(q[2] & 0xff) << 16) | ((uint32_t)(q[3] & 0xff) << 24);
-    d[t] = dd;
-    bs32[e >> 5] = s;
+    if (live) {
+        *(uint32_t *)(qs + e) = (uint32_t)(q[0] & 0xff) | ((uint32_t)(q[1] & 0xff) << 8) | ((uint32_t)(q[2] & 0xff) << 16) | ((uint32_t)(q[3] & 0xff) << 24);
+        d[t] = dd;
+        bs32[e >> 5] = s;
+    }
 }
 
 struct G4Mat {
@@ -232,7 +233,7 @@ __global__ __launch_bounds__((NW + 1) * 64) void gemv4_kernel(const G4Params p) 
 #pragma unroll
             for (int i = 0; i < TPW; i++) {
                 const int t = wave + i * NW;
-                if (t >= n_units) continue; // wave-uniform (n_units tiles of 256)
+                const bool live = t < n_units; // wave-uniform (n_units tiles of 256); a dead tile runs on zeros and stores nothing
                 float v[4] = {xv[i].x, xv[i].y, xv[i].z, xv[i].w};
                 if (PRO == 1) {
                     v[0] = __fmul_rn(v[0], __fmul_rn(wv[i].x, scale));
@@ -240,7 +241,7 @@ __global__ __launch_bounds__((NW + 1) * 64) void gemv4_kernel(const G4Params p) 
                     v[2] = __fmul_rn(v[2], __fmul_rn(wv[i].z, scale));
                     v[3] = __fmul_rn(v[3], __fmul_rn(wv[i].w, scale));
                 }
-                g4_quantize_tile(v, t * 256 + lane * 4, t, lq, ld, lb);
+                g4_quantize_tile(v, t * 256 + lane * 4, t, lq, ld, lb, live);
             }
             pmark(27);
             if (STAGED) {

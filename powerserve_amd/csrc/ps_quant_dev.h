@@ -79,8 +79,17 @@ __device__ __forceinline__ void ps_qrow_load(const float *x, const float *w, int
     for (int i = 0; i < TPW; i++) {
         const int64_t t = wave < nw ? wave + (int64_t)i * nw : n_tiles, e = t * 256 + lane * 4;
         const bool in = t < n_tiles && e < K;
-        xv[i] = in ? *(const float4 *)(x + e) : make_float4(0.f, 0.f, 0.f, 0.f);
-        wv[i] = (MODE == 1 && in) ? *(const float4 *)(w + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+        // never a branch around a load (hipcc waits vmcnt(0) behind one): an out-of-range slot re-reads the row's first 16
+        // bytes and is zeroed by a select
+        const int64_t ec = in ? e : 0;
+        const float4 xl = *(const float4 *)(x + ec);
+        xv[i] = in ? xl : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (MODE == 1) {
+            const float4 wl = *(const float4 *)(w + ec);
+            wv[i] = in ? wl : make_float4(0.f, 0.f, 0.f, 0.f);
+        } else {
+            wv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
     }
 }
 // the same tile map, activation only, fetched with cache-bypassing (agent-scope relaxed atomic) 64-bit loads: the row was
