@@ -133,6 +133,11 @@ __device__ __forceinline__ void g4k_superblock(G4KAcc &T, const uint32_t (&wq)[8
     }
 }
 
+// (Measured and not kept, round 2: preparing the MFMA A operands and the decoded mins / scales ONCE per workgroup, by the
+// staging threads, and parking those in LDS instead of the raw dwords halves the VALU work of a wave's step (375 -> ~185
+// instructions) but costs registers the nine-wave workgroup does not have (spills whose reloads queue behind the prefetch
+// loads: 5.3 k tok/s) and, with the spills removed for the experiment by dropping the mins chains, gains only 12 %
+// (7.95 k vs 7.1 k tok/s): the step is not VALU-bound alone.)
 // All eight computing waves of a workgroup walk the same 16 weight rows.  Two things make a straight version (every wave
 // loading its own operands; measured, removed) slow: the weights come from HBM (~2 us per super-block with nothing
 // but the next loads to hide behind), and the CU's address unit: a wave's eight dword loads of A touch 16 cache lines each,
