@@ -16,6 +16,7 @@
 #include "ps_gemv_dev.h"
 
 namespace {
+constexpr int G4_PAIR = 0; // units of a chunk the scheduler may interleave (0: one at a time)
 
 // silu_hadamard (src/backend/ggml/ggml.cpp:115-129) with glibc's expf table read from LDS: a table lookup in global /
 // constant memory is a vector-memory round trip (> 1 us behind the weight stream) on the chain wave's critical path
@@ -175,7 +176,7 @@ __global__ __launch_bounds__((NW + 1) * 64) void gemv4_kernel(const G4Params p) 
                 const float d    = __fmul_rn(yd, ps_h2f((uint16_t)(h[i].x & 0xffff)));
                 const float dmin = __fmul_rn(-yd, ps_h2f((uint16_t)(h[i].x >> 16)));
                 recs[(buf * UPB + wave * UPW + i) * 64 + lane] = make_float4(d, (float)rc.x, dmin, (float)rc.y); // (lanes u >= 4: .w is not a product, their acc_m is never read)
-                __builtin_amdgcn_sched_barrier(0); // one unit at a time: interleaving four of them costs registers, hides nothing
+                if (G4_PAIR == 0 || (i & 1)) __builtin_amdgcn_sched_barrier(0); // one unit (G4_PAIR: two) at a time: interleaving four of them costs registers, hides nothing
             }
         };
         auto advance = [&](int &tl, int &un) {
