@@ -47,8 +47,9 @@ __device__ __forceinline__ void g4_quantize_tile(const float v[4], const int e, 
     const float dd = zero ? 0.f : __fdiv_rn(1.0f, iscale);
     int s = q[0] + q[1] + q[2] + q[3];
     s += dpp_i<0xB1>(s); s += dpp_i<0x4E>(s); s += dpp_i<0x141>(s); // all 8 lanes of a 32-element group hold its sum
-    if (live) {
-        *(uint32_t *)(qs + e) = (uint32_t)(q[0] & 0xff) | ((uint32_t)(q[1] & 0xff) << 8) | ((uint32_t)(q[2] & 0xff) << 16) | ((uint32_t)(q[3] & 0xff) << 24);
+    if (live) { // quad-major inside the tile (unit_rec<.., QT>): dword (e / 4) % 64 = g * 8 + u goes to u * 8 + g
+        const int dw = (e >> 2) & 63, eq = (e & ~255) + (((dw & 7) << 3) | (dw >> 3)) * 4;
+        *(uint32_t *)(qs + eq) = (uint32_t)(q[0] & 0xff) | ((uint32_t)(q[1] & 0xff) << 8) | ((uint32_t)(q[2] & 0xff) << 16) | ((uint32_t)(q[3] & 0xff) << 24);
         d[t] = dd;
         bs32[e >> 5] = s;
     }
@@ -171,7 +172,7 @@ __global__ __launch_bounds__((NW + 1) * 64) void gemv4_kernel(const G4Params p) 
 #pragma unroll
             for (int i = 0; i < UPW; i++) {
                 if (i < i_lo || i >= i_hi) continue;
-                const int2 rc  = unit_rec<WT>(make_uint4(q[i].x, q[i].y, q[i].z, q[i].w), make_uint4(h[i].x, h[i].y, h[i].z, h[i].w), ul + i, u, A);
+                const int2 rc  = unit_rec<WT, true>(make_uint4(q[i].x, q[i].y, q[i].z, q[i].w), make_uint4(h[i].x, h[i].y, h[i].z, h[i].w), ul + i, u, A);
                 const float yd = A.d[ul + i];
                 const float d    = __fmul_rn(yd, ps_h2f((uint16_t)(h[i].x & 0xffff)));
                 const float dmin = __fmul_rn(-yd, ps_h2f((uint16_t)(h[i].x >> 16)));
@@ -199,7 +200,10 @@ __global__ __launch_bounds__((NW + 1) * 64) void gemv4_kernel(const G4Params p) 
         mark(); // 1: loads issued
         // 3. activation -> LDS (the chain wave joins the barriers)
         if (PRO == 0) {
-            for (int i = threadIdx.x * 16; i < K; i += NW * 64 * 16) *(int4 *)(lq + i) = *(const int4 *)(p.aq + i);
+            for (int i = threadIdx.x; i < K / 4; i += NW * 64) { // (quad-major tiles, as the quantizer writes them)
+                const int dw = i & 63;
+                ((int *)lq)[(i & ~63) + (((dw & 7) << 3) | (dw >> 3))] = ((const int *)p.aq)[i];
+            }
             for (int i = threadIdx.x; i < n_units; i += NW * 64) ld[i] = p.ad[i];
             for (int i = threadIdx.x; i < nb32; i += NW * 64) lb[i] = (int)p.abs16[2 * i] + (int)p.abs16[2 * i + 1];
             __syncthreads();

@@ -106,7 +106,10 @@ template <int WT> struct RecOf { using T = int4; };
 template <> struct RecOf<PS_Q4_K> { using T = int2; };
 
 // Q4_K record: {s, u < 4 ? prod : d|dmin}: the four acc_m lanes need prod, the other four carry the fp16 pair
-template <int WT>
+// QT (Q4_K, k_gemv4.hip): the quants of a 256-element tile are stored quad-major in LDS — dword u * 8 + g instead of
+// g * 8 + u (g = sub-block, u = AVX lane) — so that lane u fetches its eight dwords with two ds_read_b128 instead of
+// eight ds_read_b32
+template <int WT, bool QT = false>
 __device__ __forceinline__ typename RecOf<WT>::T unit_rec(const uint4 q, const uint4 h, const int unit, const int u, const LAct a) {
     constexpr uint32_t M = 0x0F0F0F0Fu;
     const uint32_t wq[4] = {q.x, q.y, q.z, q.w};
@@ -118,10 +121,18 @@ __device__ __forceinline__ typename RecOf<WT>::T unit_rec(const uint4 q, const u
         const int base = unit * 64 + u;
         int s = 0;
         int ylv[4], yhv[4]; // every LDS read of the unit first: one wait instead of one per 64-element group
-#pragma unroll
-        for (int j = 0; j < 4; j++) { ylv[j] = a.q32[base + j * 16]; yhv[j] = a.q32[base + j * 16 + 8]; }
         const int v = u & 3;
-        const int bsa = a.bs32[unit * 8 + 2 * v], bsb = a.bs32[unit * 8 + 2 * v + 1];
+        int bsa, bsb;
+        if constexpr (QT) {
+            const int4 y0 = *(const int4 *)(a.q32 + unit * 64 + u * 8), y1 = *(const int4 *)(a.q32 + unit * 64 + u * 8 + 4);
+            ylv[0] = y0.x; yhv[0] = y0.y; ylv[1] = y0.z; yhv[1] = y0.w; ylv[2] = y1.x; yhv[2] = y1.y; ylv[3] = y1.z; yhv[3] = y1.w;
+            const int2 bs = *(const int2 *)(a.bs32 + unit * 8 + 2 * v);
+            bsa = bs.x; bsb = bs.y;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++) { ylv[j] = a.q32[base + j * 16]; yhv[j] = a.q32[base + j * 16 + 8]; }
+            bsa = a.bs32[unit * 8 + 2 * v]; bsb = a.bs32[unit * 8 + 2 * v + 1];
+        }
         int dlo[4], dhi[4]; // the eight quad dots as plain v_dot4 (no zeroed accumulators)
         dot4x4(dlo, (int)(wq[0] & M), (int)(wq[1] & M), (int)(wq[2] & M), (int)(wq[3] & M), ylv[0], ylv[1], ylv[2], ylv[3]);
         dot4x4(dhi, (int)((wq[0] >> 4) & M), (int)((wq[1] >> 4) & M), (int)((wq[2] >> 4) & M), (int)((wq[3] >> 4) & M), yhv[0], yhv[1], yhv[2], yhv[3]);
