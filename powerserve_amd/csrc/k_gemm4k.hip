@@ -40,8 +40,7 @@ struct G4KParams {
     int n_w, nsb, bs, n_tasks;
     const float *residual;
     const int8_t *qf;   // fragment-major quants
-    const float *ad;    // [col][nsb]
-    const int16_t *abs16; // [col][K / 16]
+    const uint8_t *mf;  // tile-major column metadata (ps_act::mf)
 };
 
 __device__ __forceinline__ long g4k_pack(uint32_t lo, uint32_t hi) { return (long)(((unsigned long)hi << 32) | lo); }
@@ -176,7 +175,7 @@ __device__ __forceinline__ void g4k_warm_wave(const uint8_t *qs0, const uint8_t 
 
 // one tile of the staged walk: `s_first` = index of its first step in the workgroup's step sequence (LDS stage = step % 3)
 __device__ __forceinline__ void g4k_tile_staged(const uint8_t *qs, const uint8_t *aux, const int tile, const int nsb, const int8_t *qf_ct,
-                                                const float *ad_col, const int16_t *bs_col, char *lds, const int s_first, const bool more,
+                                                const uint8_t *mf_ct, const int mc, char *lds, const int s_first, const bool more,
                                                 const uint8_t *qs_next, const uint8_t *aux_next, float (&y)[4]) {
     const int lane = threadIdx.x & 63, m = lane & 15, kb = lane >> 4, t = threadIdx.x;
     // this thread's dword of a super-block: unit t >> 8 (row group 2 * tile + (t >> 8)), dword t & 255 = [r][u][j]
@@ -206,8 +205,9 @@ __device__ __forceinline__ void g4k_tile_staged(const uint8_t *qs, const uint8_t
 #pragma unroll
         for (int r = 0; r < 4; r++) hD[r] = *(const uint4 *)(st + 16 * G4K_ROW + (kb * 4 + r) * 16);
         const ps_u32x4 bq[4] = {bn[0], bn[1], bn[2], bn[3]};
-        const float yd = ad_col[sb];
-        const ps_u32x4 b16a = *(const ps_u32x4 *)(bs_col + sb * 16), b16b = *(const ps_u32x4 *)(bs_col + sb * 16 + 8);
+        const uint8_t *mfs = mf_ct + (size_t)sb * 576; // the (column tile, super-block) block: d[16], then bsums[16][16]
+        const float yd = *(const float *)(mfs + mc * 4);
+        const ps_u32x4 b16a = *(const ps_u32x4 *)(mfs + 64 + mc * 32), b16b = *(const ps_u32x4 *)(mfs + 64 + mc * 32 + 16);
         {
             const int nb = last ? 0 : sb + 1; // (the following tile of an EPI 1 pair meets the same columns from super-block 0)
 #pragma unroll
@@ -242,8 +242,8 @@ __global__ __launch_bounds__(576) void gemm4k_kernel(const G4KParams p) {
     const int col = ct * 16 + m, colc = col < p.bs ? col : p.bs - 1; // (the last tile may be ragged: clamp the column metadata)
     const int ctc = ct * 16 < p.bs ? ct : (p.bs - 1) / 16; // (a wave past the batch walks the last tile's columns and stores nothing)
     const int8_t *qf_ct = p.qf + ((size_t)ctc * p.nsb << 12);
-    const float *ad_col = p.ad + (size_t)colc * p.nsb;
-    const int16_t *bs_col = p.abs16 + (size_t)colc * p.nsb * 16;
+    const uint8_t *mf_ct = p.mf + (size_t)ctc * p.nsb * 576;
+    const int mc = colc & 15;
     float y[4];
     {
         if (wave == 8) { // the warm-up wave
@@ -257,10 +257,10 @@ __global__ __launch_bounds__(576) void gemm4k_kernel(const G4KParams p) {
             if (t < 64) *(uint32_t *)(lds + 16 * G4K_ROW + t * 4) = *(const uint32_t *)(W.aux + oh);
         }
         __syncthreads();
-        g4k_tile_staged(W.qs, W.aux, tile, p.nsb, qf_ct, ad_col, bs_col, lds, 0, EPI == 1, p.w[1].qs, p.w[1].aux, y);
+        g4k_tile_staged(W.qs, W.aux, tile, p.nsb, qf_ct, mf_ct, mc, lds, 0, EPI == 1, p.w[1].qs, p.w[1].aux, y);
         if (EPI == 1) {
             float yu[4];
-            g4k_tile_staged(p.w[1].qs, p.w[1].aux, tile, p.nsb, qf_ct, ad_col, bs_col, lds, p.nsb, false, nullptr, nullptr, yu);
+            g4k_tile_staged(p.w[1].qs, p.w[1].aux, tile, p.nsb, qf_ct, mf_ct, mc, lds, p.nsb, false, nullptr, nullptr, yu);
 #pragma unroll
             for (int r = 0; r < 4; r++) y[r] = ps_silu_mul(y[r], yu[r]);
         }
@@ -298,7 +298,7 @@ int psk_gemm4k(hipStream_t st, int n_cu, const psk_gemv_args &a, ps_act act, int
     if (epi == 1 && (a.n_w != 2 || a.w[0]->N != a.w[1]->N || a.ldo[0] != a.ldo[1])) return -1;
     p.n_w = a.n_w; p.nsb = (int)(K / 256); p.bs = (int)bs;
     p.n_tasks = epi == 1 ? p.w[0].n_tiles : tiles_total;
-    p.residual = a.residual; p.qf = act.qf; p.ad = act.d; p.abs16 = act.bs16;
+    p.residual = a.residual; p.qf = act.qf; p.mf = act.mf;
     const int n_ct = (int)((bs + 15) / 16);
     // Below eight column tiles a workgroup's waves would not share their weight rows any more, and the kernels that spread
     // a row group's integer work over producer waves (gemm8) are ahead there: tree forward of the 8B shape, ms by width,

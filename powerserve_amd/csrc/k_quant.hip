@@ -26,6 +26,7 @@ struct QuantArgs {
     float *d;
     int16_t *bs16;
     int8_t *qf; // Q8_K batches: fragment-major copy for k_gemm4k.hip, or null
+    uint8_t *mf; // ... and the tile-major copy of the column metadata (ps_act::mf), with qf
 };
 
 // MODE 1 (RMSNorm needs the whole row): one workgroup per row.
@@ -35,7 +36,7 @@ __global__ __launch_bounds__(256) void quantize_norm_kernel(QuantArgs a) {
     const int64_t row = blockIdx.x, K = a.K;
     const int64_t nblk = K / (VDT == PS_Q8_0 ? 32 : 256);
     ps_quantize_row_wg<VDT, 1, TPW>(a.x + row * K, a.w, a.eps, K, a.qs + row * K, a.d + row * nblk, a.bs16 + row * (K / 16), red,
-                                    VDT == PS_Q8_K ? a.qf : nullptr, row);
+                                    VDT == PS_Q8_K ? a.qf : nullptr, row, VDT == PS_Q8_K ? a.mf : nullptr);
 }
 // MODE 0 / 2: blocks are independent -> one wave per 256-element tile, grid (tiles/4, rows)
 template <int VDT, int MODE>
@@ -56,7 +57,7 @@ __global__ __launch_bounds__(256) void quantize_tiles_kernel(QuantArgs a) {
         }
     }
     ps_quantize_tile<VDT>(v, live, e, t, a.qs + row * K, a.d + row * nblk, a.bs16 + row * (K / 16), nullptr,
-                          VDT == PS_Q8_K ? a.qf : nullptr, row, K / 256);
+                          VDT == PS_Q8_K ? a.qf : nullptr, row, K / 256, VDT == PS_Q8_K ? a.mf : nullptr);
 }
 
 // SoA activation -> GGUF block layout (block_q8_0 34 B / block_q8_K 292 B), for parity tests of the
@@ -172,7 +173,8 @@ __global__ void repack_q5_K_kernel(const uint8_t *raw, int64_t nblk, uint8_t *qs
 
 void psk_quantize_act(hipStream_t st, int vdt, int mode, const float *x, const float *x2, const float *w, float eps,
                       int64_t K, int64_t rows, ps_act out) {
-    QuantArgs a{x, x2, w, eps, K, out.qs, out.d, out.bs16, (vdt == PS_Q8_K && rows > 112 && K % 1024 == 0) ? out.qf : nullptr /* exactly when psk_gemm4k takes the batch */};
+    const bool frag = vdt == PS_Q8_K && rows > 112 && K % 1024 == 0; // exactly when psk_gemm4k takes the batch
+    QuantArgs a{x, x2, w, eps, K, out.qs, out.d, out.bs16, frag ? out.qf : nullptr, frag ? out.mf : nullptr};
     if (mode == 1) {
         dim3 g((unsigned)rows), b(256);
         const int64_t tpw = ((K + 255) / 256 + 3) / 4;

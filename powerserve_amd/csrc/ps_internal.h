@@ -64,6 +64,8 @@ struct ps_act {
     float *d;
     int16_t *bs16;
     int8_t *qf;
+    uint8_t *mf; // with qf: the column metadata tile-major, per (16 columns, super-block) 576 B = d[16] (fp32) then bsums[16][16]
+                 // (int16): a wave of the Q4_K batched mat-mul reads its 16 columns' scale and sums from 5 cache lines, not 48
 };
 
 // hipFuncSetAttribute is per device: `mask` (one static per kernel instantiation) remembers the devices that have it
@@ -94,7 +96,7 @@ static inline bool ps_first_on_device(unsigned long long *mask) {
 static inline size_t ps_act_bytes(int64_t K, int64_t rows) {
     // qs + d (worst case blk 32) + bs16, each 256-B aligned
     auto al = [](size_t x) { return (x + 255) / 256 * 256; };
-    return al((size_t)K * rows) + al((size_t)(K / 32) * rows * 4) + al((size_t)(K / 16) * rows * 2) + al((size_t)K * ((rows + 15) / 16 * 16));
+    return al((size_t)K * rows) + al((size_t)(K / 32) * rows * 4) + al((size_t)(K / 16) * rows * 2) + al((size_t)K * ((rows + 15) / 16 * 16)) + al((size_t)((rows + 15) / 16) * (K / 256 + 1) * 576);
 }
 static inline ps_act ps_act_carve(void *base, int64_t K, int64_t rows) {
     auto al = [](size_t x) { return (x + 255) / 256 * 256; };
@@ -107,6 +109,8 @@ static inline ps_act ps_act_carve(void *base, int64_t K, int64_t rows) {
     a.bs16 = (int16_t *)p;
     p += al((size_t)(K / 16) * rows * 2);
     a.qf = (int8_t *)p;
+    p += al((size_t)K * ((rows + 15) / 16 * 16));
+    a.mf = (uint8_t *)p;
     return a;
 }
 

@@ -20,7 +20,8 @@ __device__ __forceinline__ float ps_silu_mul(float g, float u) {
 template <int VDT>
 __device__ __forceinline__ void ps_quantize_tile(const float v[4], bool live, int64_t e, int64_t t, int8_t *qs, float *d,
                                                  int16_t *bs16, int *bs32 = nullptr, // bs32: optional int sums of 32 (two bs16)
-                                                 int8_t *qf = nullptr, int64_t col = 0, int64_t nsb = 0) { // qf: fragment-major copy (ps_act::qf)
+                                                 int8_t *qf = nullptr, int64_t col = 0, int64_t nsb = 0, // qf: fragment-major copy (ps_act::qf)
+                                                 uint8_t *mf = nullptr) { // mf: tile-major copy of the column metadata (ps_act::mf)
     const int lane = threadIdx.x & 63;
     int q[4];
     if (VDT == PS_Q8_0) {
@@ -39,14 +40,18 @@ __device__ __forceinline__ void ps_quantize_tile(const float v[4], bool live, in
         const unsigned long long hits = __ballot(am == amax);
         if (amax == 0.f) {
             q[0] = q[1] = q[2] = q[3] = 0;
-            if (live && lane == 0) d[t] = 0.f;
+            if (live && lane == 0) { d[t] = 0.f; if (mf) *(float *)(mf + ((col >> 4) * nsb + t) * 576 + (col & 15) * 4) = 0.f; }
         } else {
             const float mine = fabsf(v[0]) == amax ? v[0] : fabsf(v[1]) == amax ? v[1] : fabsf(v[2]) == amax ? v[2] : v[3];
             const float mx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine), __ffsll((long long)hits) - 1));
             const float iscale = __fdiv_rn(-127.f, mx);
 #pragma unroll
             for (int i = 0; i < 4; i++) q[i] = min(127, __float2int_rn(__fmul_rn(iscale, v[i])));
-            if (live && lane == 0) d[t] = __fdiv_rn(1.0f, iscale);
+            if (live && lane == 0) {
+                const float dd = __fdiv_rn(1.0f, iscale);
+                d[t] = dd;
+                if (mf) *(float *)(mf + ((col >> 4) * nsb + t) * 576 + (col & 15) * 4) = dd;
+            }
         }
     }
     const int s16 = group4_sum_i_dpp(q[0] + q[1] + q[2] + q[3]);
@@ -58,7 +63,10 @@ __device__ __forceinline__ void ps_quantize_tile(const float v[4], bool live, in
             const int g = lane >> 3, u = lane & 7;
             *(uint32_t *)(qf + ((((col >> 4) * nsb + t) << 12) + ((u >> 1) << 10) + ((((g >> 1) << 4) + (col & 15)) << 4) + ((u & 1) << 3) + ((g & 1) << 2))) = packed;
         }
-        if ((lane & 3) == 0) bs16[e / 16] = (int16_t)s16;
+        if ((lane & 3) == 0) {
+            bs16[e / 16] = (int16_t)s16;
+            if (VDT == PS_Q8_K && mf) *(int16_t *)(mf + ((col >> 4) * nsb + t) * 576 + 64 + (col & 15) * 32 + (lane >> 2) * 2) = (int16_t)s16;
+        }
     }
     if (bs32) {
         const int s32 = s16 + dpp_i<0x104>(s16); // lane & 7 == 0: + the next four lanes' 16-sum
@@ -160,7 +168,7 @@ __device__ __forceinline__ void ps_qrow_compute(const float4 (&xv)[TPW], const f
 // Ends with __syncthreads().
 template <int VDT, int MODE, int TPW>
 __device__ __forceinline__ void ps_quantize_row_wg(const float *x, const float *w, float eps, int64_t K, int8_t *qs, float *d,
-                                                   int16_t *bs16, double *red, int8_t *qf = nullptr, int64_t col = 0) {
+                                                   int16_t *bs16, double *red, int8_t *qf = nullptr, int64_t col = 0, uint8_t *mf = nullptr) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int64_t n_tiles = (K + 255) / 256;
     for (int64_t t0 = 0; t0 < n_tiles; t0 += (int64_t)nw * TPW) { // one trip when K <= nw*TPW*256 (always, for MODE 1)
@@ -204,7 +212,7 @@ __device__ __forceinline__ void ps_quantize_row_wg(const float *x, const float *
                 v[2] = __fmul_rn(v[2], __fmul_rn(wv[i].z, scale));
                 v[3] = __fmul_rn(v[3], __fmul_rn(wv[i].w, scale));
             }
-            ps_quantize_tile<VDT>(v, live, e, t, qs, d, bs16, nullptr, qf, col, K / 256);
+            ps_quantize_tile<VDT>(v, live, e, t, qs, d, bs16, nullptr, qf, col, K / 256, mf);
         }
     }
     __syncthreads();
