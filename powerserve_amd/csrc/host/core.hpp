@@ -121,9 +121,34 @@ inline bool tensor_can_repeat(const Tensor *t0, const Tensor *t1) {
            t1->m_shape[3] % t0->m_shape[3] == 0;
 }
 
-struct HyperParams {
-    size_t n_threads  = 4;   // unused on the GPU (kept for config compatibility)
+struct SamplerConfig { // HyperParams::SamplerConfig, src/core/config.hpp:34-47
+    uint64_t seed     = (uint64_t)-1; // -1: take one from std::random_device
+    float temperature = 0.80f;
+    float top_p       = 0.95f;
+    size_t top_k      = 40;
+    size_t min_keep   = 0;
+    int penalty_last_n    = 64;
+    float penalty_repeat  = 1.00f;
+    float penalty_freq    = 0.00f;
+    float penalty_present = 0.00f;
+    bool penalize_nl      = false;
+    bool ignore_eos       = false;
+};
+
+struct HyperParams { // hparams.json (src/core/config.cpp:30-67): every key optional, defaults as the reference's
+    SamplerConfig sampler_config;
+    size_t n_threads  = 4;   // unused on the GPU (kept for config compatibility; clamped to the host's cores like the reference)
     size_t batch_size = 128; // prefill chunk
+    HyperParams() = default;
+    explicit HyperParams(const std::string &params_file);
+};
+
+// workspace.json (src/core/config.cpp:121-152, key names config.hpp:24-26): which hparams file, main and draft model directories,
+// all relative to the work folder
+struct Config {
+    HyperParams hyper_params;
+    std::string main_model_dir, draft_model_dir;
+    Config(const std::string &work_folder, const std::string &workspace_config_path);
 };
 
 struct ModelConfig {

@@ -3,7 +3,10 @@
 #include <cctype>
 #include <cstring>
 #include <fcntl.h>
+#include <algorithm>
+#include <filesystem>
 #include <fstream>
+#include <thread>
 #include <sstream>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -73,6 +76,49 @@ JsonValue JsonValue::parse_file(const std::string &path) {
     std::string s = ss.str();
     JP p{s};
     return p.val();
+}
+
+HyperParams::HyperParams(const std::string &params_file) {
+    try {
+        const JsonValue j = JsonValue::parse_file(params_file);
+        auto num = [](const JsonValue &o, const char *k, double dflt) { return o.contains(k) ? o.at(k).num : dflt; };
+        auto flag = [](const JsonValue &o, const char *k, bool dflt) { return o.contains(k) ? (o.at(k).kind == JsonValue::BOOL ? o.at(k).b : o.at(k).num != 0) : dflt; };
+        n_threads  = (size_t)num(j, "n_threads", (double)n_threads);
+        batch_size = (size_t)num(j, "batch_size", (double)batch_size);
+        const unsigned hw = std::thread::hardware_concurrency();
+        if (hw != 0) n_threads = std::min<size_t>(n_threads, hw);
+        if (j.contains("sampler") && j.at("sampler").kind == JsonValue::OBJ && !j.at("sampler").obj.empty()) {
+            const JsonValue &s = j.at("sampler");
+            auto &c = sampler_config;
+            if (s.contains("seed")) c.seed = s.at("seed").num < 0 ? (uint64_t)(int64_t)s.at("seed").num : (uint64_t)s.at("seed").num;
+            c.temperature = (float)num(s, "temperature", c.temperature);
+            c.top_p = (float)num(s, "top_p", c.top_p);
+            c.top_k = (size_t)num(s, "top_k", (double)c.top_k);
+            c.min_keep = (size_t)num(s, "min_keep", (double)c.min_keep);
+            c.penalty_last_n = (int)num(s, "penalty_last_n", c.penalty_last_n);
+            c.penalty_repeat = (float)num(s, "penalty_repeat", c.penalty_repeat);
+            c.penalty_freq = (float)num(s, "penalty_freq", c.penalty_freq);
+            c.penalty_present = (float)num(s, "penalty_present", c.penalty_present);
+            c.penalize_nl = flag(s, "penalize_nl", c.penalize_nl);
+            c.ignore_eos = flag(s, "ignore_eos", c.ignore_eos);
+        }
+    } catch (const std::exception &e) {
+        POWERSERVE_ABORT("failed parsing hyper param config file " + params_file + ": " + e.what());
+    }
+}
+
+Config::Config(const std::string &work_folder, const std::string &workspace_config_path) {
+    struct stat st;
+    if (stat(work_folder.c_str(), &st) != 0 || !S_ISDIR(st.st_mode)) POWERSERVE_ABORT("work folder " + work_folder + " is not a directory");
+    try {
+        const JsonValue j = JsonValue::parse_file(workspace_config_path);
+        auto join = [&](const std::string &rel) { return (std::filesystem::path(work_folder) / rel).string(); };
+        if (j.contains("hparams_config")) hyper_params = HyperParams(join(j.at("hparams_config").str));
+        if (j.contains("model_main")) main_model_dir = join(j.at("model_main").str);
+        if (j.contains("model_draft")) draft_model_dir = join(j.at("model_draft").str);
+    } catch (const std::exception &e) {
+        POWERSERVE_ABORT("failed parsing artifact config file " + workspace_config_path + ": " + e.what());
+    }
 }
 
 ModelConfig::ModelConfig(const std::string &path) {
@@ -193,6 +239,24 @@ int64_t psh_gguf_summary(const char *path, char *buf, size_t cap) {
         }
         for (const auto &kv : f.kv_str) out += "S " + kv.first + " " + kv.second + "\n";
         for (const auto &kv : f.kv_num) { snprintf(line, sizeof line, "N %s %.17g\n", kv.first.c_str(), kv.second); out += line; }
+        if (cap) { const size_t n = std::min(cap - 1, out.size()); memcpy(buf, out.data(), n); buf[n] = 0; }
+        return (int64_t)out.size() + 1;
+    } catch (const std::exception &e) { psh_set_error(e.what()); return -1; }
+}
+}
+
+extern "C" {
+// "key=value" lines of what Config(work_folder, work_folder/workspace.json) parsed; returns the length needed, -1 on error
+int64_t psh_config_summary(const char *work_folder, char *buf, size_t cap) {
+    try {
+        const std::string wf(work_folder);
+        powerserve::Config c(wf, (std::filesystem::path(wf) / "workspace.json").string());
+        const auto &h = c.hyper_params; const auto &s = h.sampler_config;
+        char line[1024];
+        snprintf(line, sizeof line, "n_threads=%zu\nbatch_size=%zu\nseed=%llu\ntemperature=%.9g\ntop_p=%.9g\ntop_k=%zu\nmin_keep=%zu\npenalty_last_n=%d\npenalty_repeat=%.9g\n"
+                 "penalty_freq=%.9g\npenalty_present=%.9g\npenalize_nl=%d\nignore_eos=%d\n", h.n_threads, h.batch_size, (unsigned long long)s.seed, (double)s.temperature,
+                 (double)s.top_p, s.top_k, s.min_keep, s.penalty_last_n, (double)s.penalty_repeat, (double)s.penalty_freq, (double)s.penalty_present, (int)s.penalize_nl, (int)s.ignore_eos);
+        const std::string out = std::string(line) + "model_main=" + c.main_model_dir + "\nmodel_draft=" + c.draft_model_dir + "\n";
         if (cap) { const size_t n = std::min(cap - 1, out.size()); memcpy(buf, out.data(), n); buf[n] = 0; }
         return (int64_t)out.size() + 1;
     } catch (const std::exception &e) { psh_set_error(e.what()); return -1; }

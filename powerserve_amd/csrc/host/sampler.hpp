@@ -47,20 +47,6 @@ struct ProbArray {
     }
 };
 
-struct SamplerConfig {
-    uint64_t seed     = (uint64_t)-1; // -1: take one from std::random_device
-    float temperature = 0.80f;
-    float top_p       = 0.95f;
-    size_t top_k      = 40;
-    size_t min_keep   = 0;
-    int penalty_last_n    = 64;
-    float penalty_repeat  = 1.00f;
-    float penalty_freq    = 0.00f;
-    float penalty_present = 0.00f;
-    bool penalize_nl      = false;
-    bool ignore_eos       = false;
-};
-
 namespace stage {
 void top_k(ProbArray &c, size_t k);
 void temperature(ProbArray &c, float t);

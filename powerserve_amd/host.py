@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libps_host.so")
 EXPORTS = ["psh_last_error", "psh_model_load", "psh_model_free", "psh_model_set_fused", "psh_model_plan_stats", "psh_model_kv_position", "psh_model_reset",
            "psh_model_vocab", "psh_model_forward", "psh_model_generate", "psh_spec_generate", "psh_draft_sample", "psh_sampler_create", "psh_sampler_free", "psh_sampler_sample",
-           "psh_model_generate_sampled", "psh_token_tree_run", "psh_gguf_summary"]
+           "psh_model_generate_sampled", "psh_token_tree_run", "psh_gguf_summary", "psh_config_summary"]
 _LIB = None
 
 
@@ -43,6 +43,8 @@ def lib() -> C.CDLL:
         L.psh_sampler_sample.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.psh_model_generate_sampled.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.psh_token_tree_run.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int] + [C.c_void_p] * 5
+        L.psh_config_summary.restype = C.c_int64
+        L.psh_config_summary.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t]
         L.psh_gguf_summary.restype = C.c_int64
         L.psh_gguf_summary.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t]
         _LIB = L
@@ -115,6 +117,18 @@ class HostModel:
         if self.L.psh_model_generate(self.h, p.ctypes.data, p.size, batch_size, steps, out.ctypes.data):
             raise HostError(self.L.psh_last_error().decode())
         return out
+
+
+def config_summary(work_folder: str) -> dict:
+    """Config(work_folder, work_folder/workspace.json) of the C++ host (csrc/host/json_gguf.cpp): hparams incl. the sampler
+    section, main / draft model directories — as a dict of strings."""
+    L = lib()
+    need = L.psh_config_summary(work_folder.encode(), None, 0)
+    if need < 0:
+        raise HostError(L.psh_last_error().decode())
+    buf = C.create_string_buffer(need)
+    L.psh_config_summary(work_folder.encode(), buf, need)
+    return dict(line.split("=", 1) for line in buf.value.decode().splitlines())
 
 
 def gguf_summary(path: str):
@@ -264,3 +278,35 @@ def generate_sampled(model: HostModel, prompt, batch_size: int, steps: int, cfg:
     if L.psh_model_generate_sampled(model.h, p.ctypes.data, p.size, batch_size, steps, C.byref(cfg), out.ctypes.data):
         raise HostError(L.psh_last_error().decode())
     return out
+
+
+class Workspace:
+    """A PowerServe work folder (workspace.json -> hparams file, main and optional draft model directories;
+    src/core/config.cpp:121-152) opened on the HIP backend: what `powerserve-run --work-folder` sets up, ids in / ids out.
+    generate(): speculative (greedy, token tree) when a draft model is configured, otherwise through the sampler chain
+    the hparams describe (top_k = 1 is plain greedy)."""
+
+    def __init__(self, work_folder: str, device: int = 0, n_ctx: int = 0):
+        self.config = config_summary(work_folder)
+        if not self.config["model_main"]:
+            raise HostError("workspace.json names no model_main")
+        self.batch_size = int(self.config["batch_size"])
+        self.main = HostModel(self.config["model_main"], device, max_batch=self.batch_size, n_ctx=n_ctx)
+        self.draft = HostModel(self.config["model_draft"], device, max_batch=self.batch_size, n_ctx=n_ctx) if self.config["model_draft"] else None
+
+    def sampler_cfg(self, special_eos_id: int = -1, linefeed_id: int = -1) -> SamplerCfg:
+        c = self.config
+        return SamplerCfg.make(self.main.vocab, seed=int(c["seed"]), temperature=float(c["temperature"]), top_p=float(c["top_p"]), top_k=int(c["top_k"]),
+                               penalty_last_n=int(c["penalty_last_n"]), penalty_repeat=float(c["penalty_repeat"]), penalty_freq=float(c["penalty_freq"]),
+                               penalty_present=float(c["penalty_present"]), penalize_nl=c["penalize_nl"] == "1", ignore_eos=c["ignore_eos"] == "1",
+                               special_eos_id=special_eos_id, linefeed_id=linefeed_id)
+
+    def generate(self, prompt, steps: int):
+        if self.draft is not None:
+            return spec_generate(self.main, self.draft, prompt, self.batch_size, steps)[0]
+        return generate_sampled(self.main, prompt, self.batch_size, steps, self.sampler_cfg())
+
+    def close(self):
+        self.main.close()
+        if self.draft is not None:
+            self.draft.close()

@@ -104,3 +104,25 @@ def test_sampled_generation_matches_reference_pipeline(oracle, ref, tmp_path, kw
     g1 = host.generate_sampled(hm, prompt, 8, steps, host.SamplerCfg.make(cfg.vocab_size, top_k=1))
     assert np.array_equal(g1, hm.generate(prompt, 8, steps))
     hm.close(); om.close()
+
+
+def test_workspace_folder(tmp_path):
+    """workspace.json -> hparams + main / draft model directories (src/core/config.cpp:121-152), opened on the HIP backend:
+    greedy hparams (top_k 1) reproduce Model::generate; with a draft model configured the output is still the target's."""
+    import json
+    from powerserve_amd import host, synth
+    wf = tmp_path / "work"
+    synth.write_model_dir(str(wf / "main"), "small-llama-hs128", 12, n_ctx=128, seed=3)
+    synth.write_model_dir(str(wf / "draft"), "small-llama-draft", 2, n_ctx=128, seed=4)
+    (wf / "hparams.json").write_text(json.dumps({"batch_size": 16, "sampler": {"top_k": 1, "seed": 5}}))
+    (wf / "workspace.json").write_text(json.dumps({"hparams_config": "hparams.json", "model_main": "main"}))
+    prompt = np.random.default_rng(0).integers(0, 1024, 19)
+    ws = host.Workspace(str(wf))
+    assert ws.batch_size == 16 and ws.draft is None
+    want = ws.main.generate(prompt, 16, 12)
+    assert np.array_equal(ws.generate(prompt, 12), want)
+    ws.close()
+    (wf / "workspace.json").write_text(json.dumps({"hparams_config": "hparams.json", "model_main": "main", "model_draft": "draft"}))
+    ws = host.Workspace(str(wf))
+    assert np.array_equal(ws.generate(prompt, 12), want)
+    ws.close()
