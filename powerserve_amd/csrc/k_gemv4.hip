@@ -55,6 +55,46 @@ __device__ __forceinline__ void g4_quantize_tile(const float v[4], const int e, 
     }
 }
 
+// A row's header of one super-block, expanded ONCE per chunk (by the lane that loaded it) into what the eight lanes of the
+// row need for each unit, so that they do not all unpack the same 6-bit fields again (the producers are VALU-bound:
+// ~62 instructions per unit and lane, a third of them header work).  64 bytes in LDS:
+//   [0..15]  sc16[j] = {scale[2j], scale[2j+1]} as int16 pairs (the v_dot2_i32_i16 operand)
+//   [16..47] mins as int32 pairs {min[2v], min[2v+1]}, v = 0..3 (lane u takes pair u & 3)
+//   [48..55] d, dmin as fp32
+constexpr int G4_HX = 64;
+__device__ __forceinline__ void g4_expand_header(const ps_u32x4 hc, char *dst) {
+    const uint32_t sc03 = hc.y & 0x3f3f3f3fu, sc47 = (hc.w & 0x0f0f0f0fu) | (((hc.y >> 6) & 0x03030303u) << 4);
+    const uint32_t mn03 = hc.z & 0x3f3f3f3fu, mn47 = ((hc.w >> 4) & 0x0f0f0f0fu) | (((hc.z >> 6) & 0x03030303u) << 4);
+    *(uint4 *)dst = make_uint4(__builtin_amdgcn_perm(0u, sc03, 0x0c010c00u), __builtin_amdgcn_perm(0u, sc03, 0x0c030c02u),
+                               __builtin_amdgcn_perm(0u, sc47, 0x0c010c00u), __builtin_amdgcn_perm(0u, sc47, 0x0c030c02u));
+    *(uint4 *)(dst + 16) = make_uint4(mn03 & 0xff, (mn03 >> 8) & 0xff, (mn03 >> 16) & 0xff, mn03 >> 24);
+    *(uint4 *)(dst + 32) = make_uint4(mn47 & 0xff, (mn47 >> 8) & 0xff, (mn47 >> 16) & 0xff, mn47 >> 24);
+    *(float2 *)(dst + 48) = make_float2(ps_h2f((uint16_t)(hc.x & 0xffff)), ps_h2f((uint16_t)(hc.x >> 16)));
+}
+// one unit against the activation column (unit_rec<PS_Q4_K, QT> of ps_gemv_dev.h with the header work taken out):
+// returns the record {d * yd, (float)sumi, -dmin * yd, (float)(mins . bsums)}
+__device__ __forceinline__ float4 g4_unit(const ps_u32x4 q, const char *hx, const int unit, const int u, const LAct a) {
+    constexpr uint32_t M = 0x0F0F0F0Fu;
+    const uint32_t wq[4] = {q.x, q.y, q.z, q.w};
+    const int v = u & 3;
+    const int4 y0 = *(const int4 *)(a.q32 + unit * 64 + u * 8), y1 = *(const int4 *)(a.q32 + unit * 64 + u * 8 + 4);
+    const int2 bs = *(const int2 *)(a.bs32 + unit * 8 + 2 * v);
+    const uint4 sc16 = *(const uint4 *)hx;
+    const int2 mp = *(const int2 *)(hx + 16 + v * 8);
+    const float2 dd = *(const float2 *)(hx + 48);
+    const float yd = a.d[unit];
+    int dlo[4], dhi[4]; // the eight quad dots as plain v_dot4 (no zeroed accumulators)
+    dot4x4(dlo, (int)(wq[0] & M), (int)(wq[1] & M), (int)(wq[2] & M), (int)(wq[3] & M), y0.x, y0.z, y1.x, y1.z);
+    dot4x4(dhi, (int)((wq[0] >> 4) & M), (int)((wq[1] >> 4) & M), (int)((wq[2] >> 4) & M), (int)((wq[3] >> 4) & M), y0.y, y0.w, y1.y, y1.w);
+    const uint32_t scv[4] = {sc16.x, sc16.y, sc16.z, sc16.w};
+    int s = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) // |dot4| <= 4*15*127 fits int16: {dl, dh} meet their scale pair in one v_dot2_i32_i16 (exact)
+        s = dot2_i16(__builtin_amdgcn_perm((uint32_t)dhi[j], (uint32_t)dlo[j], 0x05040100u), scv[j], s);
+    const int pr = __mul24(mp.x, bs.x) + __mul24(mp.y, bs.y);
+    return make_float4(__fmul_rn(yd, dd.x), (float)s, __fmul_rn(-yd, dd.y), (float)pr);
+}
+
 struct G4Mat {
     const uint8_t *qs, *aux;
     float *out;
@@ -138,7 +178,7 @@ __global__ __launch_bounds__((NW + 1) * 64) void gemv4_kernel(const G4Params p) 
         // 512 B of LDS when the chunk is produced (a header register per unit and lane made the ring 32 registers per chunk:
         // three chunks did not fit under the 168-register cap of a nine-wave workgroup)
         ps_u32x4 q[DC][UPW], h[DC];
-        __shared__ ps_u32x4 hscr[NW][32];
+        __shared__ __attribute__((aligned(16))) char hscr[NW][32 * G4_HX];
         const uint32_t lane16 = (uint32_t)lane * 16u;
         // loads are UNCONDITIONAL (a slot past the range re-reads the workgroup's first unit) so that the compiler counts
         // vmcnt exactly and a chunk is consumed while the next ones are in flight
@@ -164,19 +204,11 @@ __global__ __launch_bounds__((NW + 1) * 64) void gemv4_kernel(const G4Params p) 
         auto produce = [&](const ps_u32x4 (&q)[UPW], const ps_u32x4 &hc, int tl, int un, int buf, int i_lo = 0, int i_hi = UPW) {
             if (tl >= nt) return; // wave-uniform: nothing of this chunk belongs to the wave
             const int ul = (EPI == 1 && un >= n_units) ? un - n_units : un;
-            if (i_lo == 0 && lane < 32) hscr[wave][lane] = hc;
-            ps_u32x4 h[UPW]; // header of (unit i, this lane's row r)
-#pragma unroll
-            for (int i = 0; i < UPW; i++)
-                if (i >= i_lo && i < i_hi) h[i] = hscr[wave][i * 8 + r];
+            if (i_lo == 0 && lane < 32) g4_expand_header(hc, hscr[wave] + lane * G4_HX); // lane l loaded the header of (unit l >> 3, row l & 7)
 #pragma unroll
             for (int i = 0; i < UPW; i++) {
                 if (i < i_lo || i >= i_hi) continue;
-                const int2 rc  = unit_rec<WT, true>(make_uint4(q[i].x, q[i].y, q[i].z, q[i].w), make_uint4(h[i].x, h[i].y, h[i].z, h[i].w), ul + i, u, A);
-                const float yd = A.d[ul + i];
-                const float d    = __fmul_rn(yd, ps_h2f((uint16_t)(h[i].x & 0xffff)));
-                const float dmin = __fmul_rn(-yd, ps_h2f((uint16_t)(h[i].x >> 16)));
-                recs[(buf * UPB + wave * UPW + i) * 64 + lane] = make_float4(d, (float)rc.x, dmin, (float)rc.y); // (lanes u >= 4: .w is not a product, their acc_m is never read)
+                recs[(buf * UPB + wave * UPW + i) * 64 + lane] = g4_unit(q[i], hscr[wave] + (i * 8 + r) * G4_HX, ul + i, u, A); // (lanes u >= 4: .w is not a product, their acc_m is never read)
                 if (G4_PAIR == 0 || (i & 1)) __builtin_amdgcn_sched_barrier(0); // one unit (G4_PAIR: two) at a time: interleaving four of them costs registers, hides nothing
             }
         };
@@ -486,10 +518,18 @@ int psk_gemv4(hipStream_t st, int n_cu, const psk_gemv_args &a, ps_act act, int6
     case 1: return seven ? launch_g4_kc<7, 2, 0>(st, grid, p, epi, a.pro) : launch_g4_kc<8, 2, 0>(st, grid, p, epi, a.pro); // everything issued up front
     case 2: return seven ? launch_g4_kc<7, 3, 1>(st, grid, p, epi, a.pro) : launch_g4_kc<8, 3, 1>(st, grid, p, epi, a.pro); // three chunks in flight
     case 3: return launch_g4_kc<11, 2, 1>(st, grid, p, epi, a.pro);                                                          // twelve waves
+    case 12: return launch_g4_kc<10, 2, 2>(st, grid, p, epi, a.pro);
+    case 13: return launch_g4_kc<11, 2, 2>(st, grid, p, epi, a.pro);
+    case 14: return launch_g4_kc<12, 2, 2>(st, grid, p, epi, a.pro);
     case 7: return seven ? launch_g4_kc<7, 2, 3>(st, grid, p, epi, a.pro) : launch_g4_kc<8, 2, 3>(st, grid, p, epi, a.pro); // + split issue
     case 6: return seven ? launch_g4_kc<7, 3, 2>(st, grid, p, epi, a.pro) : launch_g4_kc<8, 3, 2>(st, grid, p, epi, a.pro);
     case 4: return seven ? launch_g4_kc<7, 4, 1>(st, grid, p, epi, a.pro) : launch_g4_kc<8, 4, 1>(st, grid, p, epi, a.pro); // four chunks in flight
     case 8: return seven ? launch_g4_kc<7, 2, 1>(st, grid, p, epi, a.pro) : launch_g4_kc<8, 2, 1>(st, grid, p, epi, a.pro); // chunk 1 at the sum-of-squares barrier (round-2 default until the timeline showed the stall)
-    default: return seven ? launch_g4_kc<7, 2, 2>(st, grid, p, epi, a.pro) : launch_g4_kc<8, 2, 2>(st, grid, p, epi, a.pro);
+    default:
+        // eleven producers where the stream per workgroup is long and there is one matrix (down: K = 14336; lm_head: 63 row
+        // groups per workgroup): 45 KB per chunk in flight instead of 29-37 (down 12.2 -> 11.6 us, lm_head 54.5 -> 51 us);
+        // the short launches and gate/up measured slower with them (QKV 7.5 -> 9.1 us: prologue and boundary of 768 threads)
+        if (epi == 0 && a.n_w == 1 && (seven || p.split_q >= 32)) return launch_g4_kc<11, 2, 2>(st, grid, p, epi, a.pro);
+        return seven ? launch_g4_kc<7, 2, 2>(st, grid, p, epi, a.pro) : launch_g4_kc<8, 2, 2>(st, grid, p, epi, a.pro);
     }
 }
