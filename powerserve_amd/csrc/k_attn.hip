@@ -792,15 +792,18 @@ void psl_rope_append(hipStream_t st, const psl_attn_args &a, int bs) {
 }
 
 void psl_attn_scores(hipStream_t st, const psl_attn_args &a, int bs) {
+    // workgroups past pos0 + bs exit at once, but a grid sized for n_ctx still costs its dispatch (2048 empty workgroups of the
+    // batch kernel: 36 us per call whatever n_kv is) — so eager forwards size the grid with the host's copy of the position
+    const int nk = a.n_kv_host > 0 && a.n_kv_host < a.n_ctx ? a.n_kv_host : a.n_ctx;
     if (bs >= 8) { // batches: matrix cores (exact f32 chains), one wave per 16 positions
-        dim3 gm((unsigned)((a.n_ctx + 63) / 64), (unsigned)a.n_kv_heads, (unsigned)SCM_Z);
+        dim3 gm((unsigned)((nk + 63) / 64), (unsigned)a.n_kv_heads, (unsigned)SCM_Z);
         if (a.head_size == 128) hipLaunchKernelGGL(attn_scores_mfma_kernel<4>, gm, dim3(256), 0, st, a);
         else if (a.head_size == 64) hipLaunchKernelGGL(attn_scores_mfma_kernel<2>, gm, dim3(256), 0, st, a);
         else if (a.head_size == 32) hipLaunchKernelGGL(attn_scores_mfma_kernel<1>, gm, dim3(256), 0, st, a);
         else hipLaunchKernelGGL(attn_scores_mfma_kernel<3>, gm, dim3(256), 0, st, a);
         return;
     }
-    dim3 g((unsigned)((a.n_ctx + 31) / 32), (unsigned)a.n_kv_heads, (unsigned)bs);
+    dim3 g((unsigned)((nk + 31) / 32), (unsigned)a.n_kv_heads, (unsigned)bs);
     if (a.head_size == 128) hipLaunchKernelGGL(attn_scores_kernel<4>, g, dim3(256), 0, st, a);
     else if (a.head_size == 64) hipLaunchKernelGGL(attn_scores_kernel<2>, g, dim3(256), 0, st, a);
     else if (a.head_size == 32) hipLaunchKernelGGL(attn_scores_kernel<1>, g, dim3(256), 0, st, a);

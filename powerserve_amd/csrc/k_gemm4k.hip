@@ -73,7 +73,8 @@ struct G4KAcc {
 
 // one super-block of one tile: wq[u] = this lane's weight dword (row l % 16, bytes 32 kb + 4u..), hA = the header of row
 // l % 16, hD[r] = the headers of rows 4 kb + r, bq = the B fragments, yd / b16 = the column's scale and 16-sums
-__device__ __forceinline__ void g4k_superblock(G4KAcc &T, const uint32_t (&wq)[8], const uint4 hA, const uint4 (&hD)[4], const ps_u32x4 (&bq)[4],
+template <int EXP>
+__device__ __forceinline__ void g4k_superblock(G4KAcc &T, const uint32_t (&wq)[8], const uint4 hA, const uint32_t (&hD)[4], const ps_u32x4 (&bq)[4],
                                                const float yd, const ps_u32x4 b16a, const ps_u32x4 b16b, const int kb) {
     // A operands: nibbles times the 3-bit halves of the sub-block scales 2 kb, 2 kb + 1 (get_scale_min_k4, branch-free:
     // sub-blocks 0..3 sit in the low 6 bits of scale bytes 0..3, sub-blocks 4..7 are spread over bytes 8..11 and the top
@@ -84,13 +85,9 @@ __device__ __forceinline__ void g4k_superblock(G4KAcc &T, const uint32_t (&wq)[8
     const int sc1 = kb < 2 ? (int)(a1 & 63) : (int)((c1 & 0xF) | ((a1 >> 6) << 4));
     const uint32_t f0h = (uint32_t)(sc0 >> 3) * 0x00010001u, f0l = (uint32_t)(sc0 & 7) * 0x00010001u;
     const uint32_t f1h = (uint32_t)(sc1 >> 3) * 0x00010001u, f1l = (uint32_t)(sc1 & 7) * 0x00010001u;
-    const uint32_t b16[8] = {b16a.x, b16a.y, b16a.z, b16a.w, b16b.x, b16b.y, b16b.z, b16b.w};
-    int q8s[8]; // sums of 32 quants
-#pragma unroll
-    for (int g = 0; g < 8; g++) q8s[g] = (int)(int16_t)(b16[g] & 0xffff) + (int)(int16_t)(b16[g] >> 16);
     float dr[4];
 #pragma unroll
-    for (int r = 0; r < 4; r++) dr[r] = __fmul_rn(yd, ps_h2f((uint16_t)(hD[r].x & 0xffff)));
+    for (int r = 0; r < 4; r++) dr[r] = __fmul_rn(yd, ps_h2f((uint16_t)(hD[r] & 0xffff)));
     typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
     auto pkmul = [](uint32_t a, uint32_t f) { u16x2 va, vf; __builtin_memcpy(&va, &a, 4); __builtin_memcpy(&vf, &f, 4); va = va * vf; uint32_t o; __builtin_memcpy(&o, &va, 4); return o; };
     // the MFMAs in rounds of four independent ones (the second round of a group takes the first round's results, shifted,
@@ -103,31 +100,67 @@ __device__ __forceinline__ void g4k_superblock(G4KAcc &T, const uint32_t (&wq)[8
         for (int k = 0; k < 4; k++) {
             const int u = uh + k;
             const uint32_t lo = wq[u] & 0x0F0F0F0Fu, hi = (wq[u] >> 4) & 0x0F0F0F0Fu;
-            const long a_hi = g4k_pack(pkmul(lo, f0h), pkmul(hi, f1h));
-            al[k] = g4k_pack(pkmul(lo, f0l), pkmul(hi, f1l));
+            const long a_hi = (EXP & 8) ? g4k_pack(lo, hi) : g4k_pack(pkmul(lo, f0h), pkmul(hi, f1h));
+            al[k] = (EXP & 8) ? g4k_pack(hi ^ f0l, lo ^ f1l) : g4k_pack(pkmul(lo, f0l), pkmul(hi, f1l));
             const uint32_t b0 = (u & 1) ? bq[u >> 1].z : bq[u >> 1].x, b1 = (u & 1) ? bq[u >> 1].w : bq[u >> 1].y;
             bb[k] = g4k_pack(b0, b1);
             const g4k_i32x4 z = {0, 0, 0, 0};
-            cc[k] = __builtin_amdgcn_mfma_i32_16x16x32_i8(a_hi, bb[k], z, 0, 0, 0);
+            if (EXP & 32) { cc[k] = z; cc[k][0] = (int)a_hi ^ (int)bb[k]; cc[k][1] = (int)(a_hi >> 32); }
+            else cc[k] = __builtin_amdgcn_mfma_i32_16x16x32_i8(a_hi, bb[k], z, 0, 0, 0);
         }
 #pragma unroll
-        for (int k = 0; k < 4; k++) cc[k] = __builtin_amdgcn_mfma_i32_16x16x32_i8(al[k], bb[k], cc[k] << 3, 0, 0, 0); // sumi[u] of rows 4 kb + r, this lane's column
+        for (int k = 0; k < 4; k++) {
+            if (EXP & 32) { cc[k] = cc[k] << 3; cc[k][2] ^= (int)al[k]; cc[k][3] ^= (int)(al[k] >> 32); }
+            else cc[k] = __builtin_amdgcn_mfma_i32_16x16x32_i8(al[k], bb[k], cc[k] << 3, 0, 0, 0); // sumi[u] of rows 4 kb + r, this lane's column
+        }
+        if (EXP & 1) {
+            const g4k_i32x4 x = (cc[0] ^ cc[1]) ^ (cc[2] ^ cc[3]);
+#pragma unroll
+            for (int r = 0; r < 4; r++) T.acc[r][uh] = __int_as_float(__float_as_int(T.acc[r][uh]) ^ x[r]);
+        } else {
 #pragma unroll
         for (int k = 0; k < 4; k++) {
 #pragma unroll
             for (int r = 0; r < 4; r++) T.acc[r][uh + k] = __fmaf_rn(dr[r], (float)cc[k][r], T.acc[r][uh + k]);
         }
+        }
     }
+    if (!(EXP & 2)) {
+        // acc_m lane v: prod = mins[2v] * q8s[2v] + mins[2v+1] * q8s[2v+1] -- a K = 4 contraction over the four 16-sums of
+        // sub-blocks 2v, 2v + 1 (q8s = the sum of two).  Every factor is an integer fp16 holds exactly (mins <= 63,
+        // |16-sum| <= 2032) and every partial sum is below 2^24, so v_mfma_f32_16x16x16_f16 returns (float)prod itself:
+        // the lanes of k-group 0 supply A[row l % 16] = (m[2v], m[2v], m[2v+1], m[2v+1]), the others zeros; B is the
+        // column's fp16 16-sums as the quantizer stored them.
+        typedef _Float16 g4k_h2 __attribute__((ext_vector_type(2)));
+        typedef _Float16 g4k_h4 __attribute__((ext_vector_type(4)));
+        typedef float g4k_f4 __attribute__((ext_vector_type(4)));
+        const uint32_t lm = kb == 0 ? 0xffffffffu : 0u;
+        const uint32_t mn03 = hA.z & 0x3f3f3f3fu & lm;
+        const uint32_t mn47 = (((hA.w >> 4) & 0x0f0f0f0fu) | (((hA.z >> 6) & 0x03030303u) << 4)) & lm;
+        float dmin[4];
 #pragma unroll
-    for (int r = 0; r < 4; r++) { // acc_m lane v: prod = mins[2v] * q8s[2v] + mins[2v+1] * q8s[2v+1]
-        const float dmin = __fmul_rn(-yd, ps_h2f((uint16_t)(hD[r].x >> 16)));
-        const uint32_t mn03 = hD[r].z & 0x3f3f3f3fu;
-        const uint32_t mn47 = ((hD[r].w >> 4) & 0x0f0f0f0fu) | (((hD[r].z >> 6) & 0x03030303u) << 4);
+        for (int r = 0; r < 4; r++) dmin[r] = __fmul_rn(-yd, ps_h2f((uint16_t)(hD[r] >> 16)));
 #pragma unroll
         for (int v = 0; v < 4; v++) {
             const uint32_t mp = (v < 2) ? mn03 : mn47;
-            const int prod = __mul24(bfe8(mp, (2 * v) & 3), q8s[2 * v]) + __mul24(bfe8(mp, (2 * v + 1) & 3), q8s[2 * v + 1]);
-            T.accm[r][v] = __fmaf_rn(dmin, (float)prod, T.accm[r][v]);
+            const int e = (2 * v) & 3;
+            // bytes (m, 0x64, m, 0x64) = the fp16 pair (1024 + m, 1024 + m); minus 1024 is exact
+            const uint32_t p0 = __builtin_amdgcn_perm(0x64646464u, mp, 0x04000400u | (uint32_t)(e * 0x00010001u));
+            const uint32_t p1 = __builtin_amdgcn_perm(0x64646464u, mp, 0x04000400u | (uint32_t)((e + 1) * 0x00010001u));
+            g4k_h2 h0, h1;
+            __builtin_memcpy(&h0, &p0, 4); __builtin_memcpy(&h1, &p1, 4);
+            const g4k_h2 k1024 = {(_Float16)1024.f, (_Float16)1024.f};
+            h0 = h0 - k1024; h1 = h1 - k1024;
+            const g4k_h4 am = {h0[0], h0[1], h1[0], h1[1]};
+            const uint32_t bx = v == 0 ? b16a.x : v == 1 ? b16a.z : v == 2 ? b16b.x : b16b.z;
+            const uint32_t by = v == 0 ? b16a.y : v == 1 ? b16a.w : v == 2 ? b16b.y : b16b.w;
+            g4k_h2 g0, g1;
+            __builtin_memcpy(&g0, &bx, 4); __builtin_memcpy(&g1, &by, 4);
+            const g4k_h4 bm = {g0[0], g0[1], g1[0], g1[1]};
+            const g4k_f4 zf = {0.f, 0.f, 0.f, 0.f};
+            const g4k_f4 pr = __builtin_amdgcn_mfma_f32_16x16x16f16(am, bm, zf, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; r++) T.accm[r][v] = __fmaf_rn(dmin[r], pr[r], T.accm[r][v]);
         }
     }
 }
@@ -150,6 +183,7 @@ __device__ __forceinline__ void g4k_superblock(G4KAcc &T, const uint32_t (&wq)[8
 //     still read).
 constexpr int G4K_LEAD = 10, G4K_ROW = 144, G4K_STAGE = 16 * G4K_ROW + 256;
 // stages 0 .. nsb-1: tile of (qs0, aux0); stages nsb .. n_stages-1 (EPI 1): the same tile of (qs1, aux1)
+template <int EXP>
 __device__ __forceinline__ void g4k_warm_wave(const uint8_t *qs0, const uint8_t *aux0, const uint8_t *qs1, const uint8_t *aux1, const int tile,
                                               const int nsb, const int n_stages, float *never) {
     const int lane = threadIdx.x & 63;
@@ -162,6 +196,7 @@ __device__ __forceinline__ void g4k_warm_wave(const uint8_t *qs0, const uint8_t 
     };
     uint32_t sink = 0;
     for (int st = 0; st < G4K_LEAD; st++) sink ^= touch(st);
+    if (EXP & 16) { for (int st = G4K_LEAD; st < n_stages; st++) sink ^= touch(st); if (sink == 0x9e3779b9u && n_stages < 0) never[0] = 0.f; return; }
     __syncthreads(); // (stage 0 is parked)
     for (int s0 = 0; s0 < n_stages; s0 += 4) { // one barrier per step, as the computing waves; four touches in flight
         uint32_t v[4];
@@ -174,6 +209,7 @@ __device__ __forceinline__ void g4k_warm_wave(const uint8_t *qs0, const uint8_t 
 }
 
 // one tile of the staged walk: `s_first` = index of its first step in the workgroup's step sequence (LDS stage = step % 3)
+template <int EXP>
 __device__ __forceinline__ void g4k_tile_staged(const uint8_t *qs, const uint8_t *aux, const int tile, const int nsb, const int8_t *qf_ct,
                                                 const uint8_t *mf_ct, const int mc, char *lds, const int s_first, const bool more,
                                                 const uint8_t *qs_next, const uint8_t *aux_next, float (&y)[4]) {
@@ -201,31 +237,31 @@ __device__ __forceinline__ void g4k_tile_staged(const uint8_t *qs, const uint8_t
 #pragma unroll
         for (int u = 0; u < 8; u++) wq[u] = *(const uint32_t *)(st + m * G4K_ROW + u * 16 + kb * 4);
         const uint4 hA = *(const uint4 *)(st + 16 * G4K_ROW + m * 16);
-        uint4 hD[4];
+        uint32_t hD[4]; // (d, dmin) of the result rows 4 kb + r
 #pragma unroll
-        for (int r = 0; r < 4; r++) hD[r] = *(const uint4 *)(st + 16 * G4K_ROW + (kb * 4 + r) * 16);
+        for (int r = 0; r < 4; r++) hD[r] = *(const uint32_t *)(st + 16 * G4K_ROW + (kb * 4 + r) * 16);
         const ps_u32x4 bq[4] = {bn[0], bn[1], bn[2], bn[3]};
         const uint8_t *mfs = mf_ct + (size_t)sb * 576; // the (column tile, super-block) block: d[16], then bsums[16][16]
         const float yd = *(const float *)(mfs + mc * 4);
         const ps_u32x4 b16a = *(const ps_u32x4 *)(mfs + 64 + mc * 32), b16b = *(const ps_u32x4 *)(mfs + 64 + mc * 32 + 16);
-        {
+        if (!(EXP & 4)) {
             const int nb = last ? 0 : sb + 1; // (the following tile of an EPI 1 pair meets the same columns from super-block 0)
 #pragma unroll
             for (int up = 0; up < 4; up++) bn[up] = *(const ps_u32x4 *)(qf_ct + ((size_t)nb << 12) + up * 1024 + lane * 16);
         }
-        g4k_superblock(T, wq, hA, hD, bq, yd, b16a, b16b, kb);
-        if (!last || more) {
+        g4k_superblock<EXP>(T, wq, hA, hD, bq, yd, b16a, b16b, kb);
+        if (!(EXP & 16) && (!last || more)) {
             char *sn = lds + ((s_first + sb + 1) % 3) * G4K_STAGE;
             *(uint32_t *)(sn + lq) = nq;
             if (t < 64) *(uint32_t *)(sn + lh) = nh;
         }
-        __syncthreads();
+        if (!(EXP & 16)) __syncthreads();
     }
     T.reduce(y);
 }
 
 // nine waves: the eight column tiles of ONE row task (128 columns per workgroup) + the warm-up wave
-template <int EPI>
+template <int EPI, int EXP>
 __global__ __launch_bounds__(576) void gemm4k_kernel(const G4KParams p) {
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int m = lane & 15, kb = lane >> 4;
@@ -247,7 +283,7 @@ __global__ __launch_bounds__(576) void gemm4k_kernel(const G4KParams p) {
     float y[4];
     {
         if (wave == 8) { // the warm-up wave
-            g4k_warm_wave(W.qs, W.aux, EPI == 1 ? p.w[1].qs : W.qs, EPI == 1 ? p.w[1].aux : W.aux, tile, p.nsb, EPI == 1 ? 2 * p.nsb : p.nsb, W.out);
+            g4k_warm_wave<EXP>(W.qs, W.aux, EPI == 1 ? p.w[1].qs : W.qs, EPI == 1 ? p.w[1].aux : W.aux, tile, p.nsb, EPI == 1 ? 2 * p.nsb : p.nsb, W.out);
             return;
         }
         { // stage 0: the tile's first super-block
@@ -257,10 +293,10 @@ __global__ __launch_bounds__(576) void gemm4k_kernel(const G4KParams p) {
             if (t < 64) *(uint32_t *)(lds + 16 * G4K_ROW + t * 4) = *(const uint32_t *)(W.aux + oh);
         }
         __syncthreads();
-        g4k_tile_staged(W.qs, W.aux, tile, p.nsb, qf_ct, mf_ct, mc, lds, 0, EPI == 1, p.w[1].qs, p.w[1].aux, y);
+        g4k_tile_staged<EXP>(W.qs, W.aux, tile, p.nsb, qf_ct, mf_ct, mc, lds, 0, EPI == 1, p.w[1].qs, p.w[1].aux, y);
         if (EPI == 1) {
             float yu[4];
-            g4k_tile_staged(p.w[1].qs, p.w[1].aux, tile, p.nsb, qf_ct, mf_ct, mc, lds, p.nsb, false, nullptr, nullptr, yu);
+            g4k_tile_staged<EXP>(p.w[1].qs, p.w[1].aux, tile, p.nsb, qf_ct, mf_ct, mc, lds, p.nsb, false, nullptr, nullptr, yu);
 #pragma unroll
             for (int r = 0; r < 4; r++) y[r] = ps_silu_mul(y[r], yu[r]);
         }
@@ -307,7 +343,8 @@ int psk_gemm4k(hipStream_t st, int n_cu, const psk_gemv_args &a, ps_act act, int
     if (n_ct < 8 || p.nsb % 4) return -1;
     (void)n_cu;
     const dim3 grid((unsigned)p.n_tasks, (unsigned)((n_ct + 7) / 8));
-    if (epi == 1) hipLaunchKernelGGL((gemm4k_kernel<1>), grid, dim3(576), 0, st, p);
-    else hipLaunchKernelGGL((gemm4k_kernel<0>), grid, dim3(576), 0, st, p);
+    extern int g_g4_flags;
+#define G4K_L(E) case E: if (epi == 1) hipLaunchKernelGGL((gemm4k_kernel<1, E>), grid, dim3(576), 0, st, p); else hipLaunchKernelGGL((gemm4k_kernel<0, E>), grid, dim3(576), 0, st, p); break;
+    switch (g_g4_flags) { G4K_L(1) G4K_L(2) G4K_L(3) G4K_L(4) G4K_L(8) G4K_L(16) G4K_L(32) G4K_L(11) G4K_L(15) G4K_L(31) G4K_L(63) default: G4K_L(0) }
     return 0;
 }

@@ -43,6 +43,7 @@ struct ps_hip_model {
     float *x = nullptr, *q = nullptr, *k = nullptr, *v = nullptr, *att = nullptr, *hb = nullptr, *g1 = nullptr, *u1 = nullptr;
     unsigned *bars = nullptr; // device-wide barrier words of the chained launches, [n_layers][12*32]
     unsigned *attn_sync = nullptr; // [32] ticket counters of the one-launch decode attention
+    int n_kv_host = 0;             // pos0 + bs of the forward being enqueued eagerly (0 while a graph is captured / replayed)
     float *scores = nullptr, *logits = nullptr, *rope_table = nullptr;
     void *act_mem = nullptr;
     std::vector<float *> k_cache, v_cache;
@@ -152,6 +153,7 @@ static int enqueue_forward(ps_hip_model *m, int bs, bool lm_head, bool use_tree,
     aa.rope_pos = use_rope_pos ? m->rope_pos_dev : nullptr;
     aa.kv_vis = m->n_hidden ? m->kv_vis_dev : nullptr;
     aa.scale = 1.0f / sqrtf((float)f.head_size);
+    aa.n_kv_host = m->n_kv_host;
     aa.sync = (m->mode & 4) ? m->attn_sync : nullptr; // mode bit 2: one-launch decode attention (measured equal to the two launches, 16.2 us; needs the GPU to itself)
 
     for (uint32_t L = 0; L < f.n_layers; L++) {
@@ -380,7 +382,10 @@ static int model_forward_impl(ps_hip_model *m, const int32_t *tokens, int n, con
     if (tree) PS_CHECK(c, hipMemcpyAsync(m->tree_dev, tree, (size_t)n * n, hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(1), 0, c->stream, m->state, pos[0], n, 0);
     PS_CHECK(c, hipStreamSynchronize(c->stream)); // tokens/tree may be host temporaries
-    if (int rc = enqueue_forward(m, n, lm_head != 0, tree != nullptr)) return rc;
+    m->n_kv_host = pos[0] + n;
+    const int rc_fw = enqueue_forward(m, n, lm_head != 0, tree != nullptr);
+    m->n_kv_host = 0;
+    if (rc_fw) return rc_fw;
     if (lm_head && argmax_host) PS_CHECK(c, hipMemcpyAsync(argmax_host, m->argmax_dev, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
     if (!advance) return 0; // lowered graph: the executor's caller syncs when it reads the logits and advances the cache itself
     PS_CHECK(c, hipStreamSynchronize(c->stream));
@@ -404,7 +409,10 @@ int ps_hip_model_forward_tree(ps_hip_model *m, const int32_t *tokens, int n, con
     if (tree) PS_CHECK(c, hipMemcpyAsync(m->tree_dev, tree, (size_t)n * n, hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(1), 0, c->stream, m->state, (int)m->position, n, 0);
     PS_CHECK(c, hipStreamSynchronize(c->stream));
-    if (int rc = enqueue_forward(m, n, lm_head != 0, tree != nullptr, false, true)) return rc;
+    m->n_kv_host = (int)m->position + n;
+    const int rc_fw = enqueue_forward(m, n, lm_head != 0, tree != nullptr, false, true);
+    m->n_kv_host = 0;
+    if (rc_fw) return rc_fw;
     if (lm_head && argmax_host) PS_CHECK(c, hipMemcpyAsync(argmax_host, m->argmax_dev, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
     PS_CHECK(c, hipStreamSynchronize(c->stream));
     if (advance) { unmask_range(m, m->position, (size_t)n); m->position += (size_t)n; }

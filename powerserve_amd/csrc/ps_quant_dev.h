@@ -65,7 +65,7 @@ __device__ __forceinline__ void ps_quantize_tile(const float v[4], bool live, in
         }
         if ((lane & 3) == 0) {
             bs16[e / 16] = (int16_t)s16;
-            if (VDT == PS_Q8_K && mf) *(int16_t *)(mf + ((col >> 4) * nsb + t) * 576 + 64 + (col & 15) * 32 + (lane >> 2) * 2) = (int16_t)s16;
+            if (VDT == PS_Q8_K && mf) *(_Float16 *)(mf + ((col >> 4) * nsb + t) * 576 + 64 + (col & 15) * 32 + (lane >> 2) * 2) = (_Float16)(float)s16; // |s16| <= 16 * 127: exact in fp16
         }
     }
     if (bs32) {
