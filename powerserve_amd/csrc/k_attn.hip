@@ -119,57 +119,110 @@ __global__ __launch_bounds__(256) void attn_scores_kernel(psl_attn_args a) {
 // at all; a K row is fetched once per 16 positions and meets every column of the batch.
 // grid (ceil(n_ctx / 64), n_kv_heads, SCM_Z): one wave per 16 positions, the column tiles split over blockIdx.z.
 typedef float ps_f32x4 __attribute__((ext_vector_type(4)));
-constexpr int SCM_Z = 4;
+constexpr int SCM_Z = 8;
+// Operands go through LDS: a lane's operand run is 128 B of one row, and fetched directly a wave instruction touches 64
+// cache lines for 1 KiB (the CU's address unit, not the matrix core, set the time).  So a wave fetches its 16 K rows with
+// row-coalesced instructions into its own LDS block once, the workgroup fetches each 16-column block of q once for its
+// four waves (double-buffered, one barrier per column tile), and the operand registers are read back from rows padded by
+// 16 B (conflict-free b128 reads).
 template <int NV>
 __global__ __launch_bounds__(256, 2) void attn_scores_mfma_kernel(psl_attn_args a) {
-    const int hs = NV * 32, dim = a.n_heads * hs, kvd = a.n_kv_heads * hs, r2 = a.n_heads / a.n_kv_heads;
+    constexpr int hs = NV * 32, RS = hs + 4, SEGS = hs / 4, NSK = 16 * SEGS / 64, NSQ = (16 * SEGS + 255) / 256; // float4 segments per lane: K block / q block
+    const int dim = a.n_heads * hs, kvd = a.n_kv_heads * hs, r2 = a.n_heads / a.n_kv_heads;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int kvh = blockIdx.y, bs = a.state->bs, n_kv = a.state->pos0 + bs;
+    if ((int)blockIdx.x * 64 >= n_kv) return; // (the whole workgroup)
     const int j0 = ((int)blockIdx.x * 4 + wave) * 16;
-    if (j0 >= n_kv) return;
+    const bool live = j0 < n_kv; // (a wave past the end still helps fetching q and keeps the barriers)
+    __shared__ __attribute__((aligned(16))) float kl[4][16 * RS];
+    __shared__ __attribute__((aligned(16))) float ql[2][16 * RS];
     const int rl = lane & 15, m = lane >> 4; // A: row rl (position), k = m;  B: k = m, column rl
+    const int N = bs * r2, n_tiles = (N + 15) / 16;
+    float4 sq0, sq1; // (named, not an array: the array went to scratch)
+    auto q_fetch1 = [&](int tile, int k) -> float4 { // (segment indices past the block are clamped here and not parked)
+        const int sidx = min((int)threadIdx.x + k * 256, 16 * SEGS - 1), row = sidx / SEGS, sg = sidx - row * SEGS;
+        const int n = min(tile * 16 + row, N - 1), i = n / r2, g = n - i * r2;
+        return *(const float4 *)(a.q + (int64_t)i * dim + (int64_t)(kvh * r2 + g) * hs + sg * 4);
+    };
+    auto q_fetch = [&](int tile) { sq0 = q_fetch1(tile, 0); if (NSQ > 1) sq1 = q_fetch1(tile, 1); };
+    auto q_park1 = [&](float *buf, int k, const float4 v) {
+        const int sidx = (int)threadIdx.x + k * 256, row = sidx / SEGS, sg = sidx - row * SEGS;
+        if (sidx < 16 * SEGS) *(float4 *)(buf + row * RS + sg * 4) = v;
+    };
+    auto q_park = [&](float *buf) { q_park1(buf, 0, sq0); if (NSQ > 1) q_park1(buf, 1, sq1); };
+    static_assert(NSQ <= 2, "q block: at most two segments per thread");
+    // ---- this wave's K block, then the first q block
+    {
+        float4 sk[NSK];
+#pragma unroll
+        for (int k = 0; k < NSK; k++) {
+            const int sidx = lane + k * 64, row = sidx / SEGS, sg = sidx - row * SEGS;
+            sk[k] = *(const float4 *)(a.k_cache + (int64_t)min(j0 + row, n_kv - 1) * kvd + kvh * hs + sg * 4);
+        }
+        q_fetch((int)blockIdx.z < n_tiles ? (int)blockIdx.z : 0);
+#pragma unroll
+        for (int k = 0; k < NSK; k++) {
+            const int sidx = lane + k * 64, row = sidx / SEGS, sg = sidx - row * SEGS;
+            *(float4 *)(&kl[wave][row * RS + sg * 4]) = sk[k];
+        }
+        q_park(ql[0]);
+    }
+    __syncthreads();
     // A operand of chain c: K[j0 + rl][32 m + c]
     float ka[32];
-    {
-        const float *kr = a.k_cache + (int64_t)min(j0 + rl, n_kv - 1) * kvd + kvh * hs + 32 * m;
 #pragma unroll
-        for (int q4 = 0; q4 < 8; q4++) {
-            const float4 t = (m < NV) ? *(const float4 *)(kr + 4 * q4) : make_float4(0.f, 0.f, 0.f, 0.f);
-            ka[4 * q4] = t.x; ka[4 * q4 + 1] = t.y; ka[4 * q4 + 2] = t.z; ka[4 * q4 + 3] = t.w;
-        }
+    for (int q4 = 0; q4 < 8; q4++) {
+        const float4 t = (m < NV) ? *(const float4 *)(&kl[wave][rl * RS + 32 * (m < NV ? m : 0) + 4 * q4]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        ka[4 * q4] = t.x; ka[4 * q4 + 1] = t.y; ka[4 * q4 + 2] = t.z; ka[4 * q4 + 3] = t.w;
     }
-    const int N = bs * r2, n_tiles = (N + 15) / 16;
     const ps_f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    for (int tile = blockIdx.z; tile < n_tiles; tile += SCM_Z) {
-        const int n = min(tile * 16 + rl, N - 1), i = n / r2, g = n - i * r2;
-        float qb[32]; // B operand of chain c: q[i][kvh * r2 + g][32 m + c]
-        {
-            const float *qr = a.q + (int64_t)i * dim + (int64_t)(kvh * r2 + g) * hs + 32 * m;
+    int cur = 0;
+    for (int tile = blockIdx.z; tile < n_tiles; tile += SCM_Z, cur ^= 1) {
+        const bool more = tile + SCM_Z < n_tiles;
+        q_fetch(more ? tile + SCM_Z : tile); // (the next block: one column tile of matrix work to hide behind)
+        if (live) {
+            const int n = min(tile * 16 + rl, N - 1), i = n / r2, g = n - i * r2;
+            float qb[32]; // B operand of chain c: q[i][kvh * r2 + g][32 m + c]
 #pragma unroll
             for (int q4 = 0; q4 < 8; q4++) {
-                const float4 t = (m < NV) ? *(const float4 *)(qr + 4 * q4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const float4 t = (m < NV) ? *(const float4 *)(&ql[cur][rl * RS + 32 * (m < NV ? m : 0) + 4 * q4]) : make_float4(0.f, 0.f, 0.f, 0.f);
                 qb[4 * q4] = t.x; qb[4 * q4 + 1] = t.y; qb[4 * q4 + 2] = t.z; qb[4 * q4 + 3] = t.w;
             }
-        }
-        auto chain = [&](int c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(ka[c], qb[c], zero, 0, 0, 0); }; // sum = x*y + sum, x = K row
-        ps_f32x4 t3[4];
+            auto chain = [&](int c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(ka[c], qb[c], zero, 0, 0, 0); }; // sum = x*y + sum, x = K row
+            // GGML_F32x8_REDUCE: (c, c+16), then (.., c+8), then (.., c+4); the two hadds below.  Eight products at a time
+            // (all 32 at once cost 128 accumulator registers), and the next eight are issued BEFORE the adds of the
+            // current eight: the matrix core works while the vector unit folds.
+            ps_f32x4 t3[4], pr[2][8];
+            auto issue = [&](ps_f32x4 (&d)[8], int c) {
 #pragma unroll
-        for (int c = 0; c < 4; c++) { // GGML_F32x8_REDUCE: (c, c+16), then (.., c+8), then (.., c+4); the two hadds below
-            const ps_f32x4 ta = chain(c) + chain(c + 16), tb = chain(c + 8) + chain(c + 24);
-            const ps_f32x4 tc = chain(c + 4) + chain(c + 20), td = chain(c + 12) + chain(c + 28);
-            t3[c] = (ta + tb) + (tc + td);
-            __builtin_amdgcn_sched_barrier(0); // eight products at a time (all 32 at once cost 128 accumulator registers)
-        }
-        const ps_f32x4 res = (t3[0] + t3[1]) + (t3[2] + t3[3]);
-        // D: column = lane & 15 (the (i, g) pair), rows 4 * (lane >> 4) + r (positions)
-        if (tile * 16 + rl < N) {
-            float *sb = a.scores + ((int64_t)i * a.n_heads + (int64_t)kvh * r2 + g) * a.n_ctx;
-            const int jb = j0 + 4 * m;
-            if (jb + 3 < n_kv) *(float4 *)(sb + jb) = make_float4(res[0], res[1], res[2], res[3]);
-            else
+                for (int k = 0; k < 8; k++) d[k] = chain(c + 4 * k); // c, c+4, ..., c+28
+            };
+            auto fold = [&](const ps_f32x4 (&d)[8]) { // d[k] = chain(c + 4k)
+                const ps_f32x4 ta = d[0] + d[4], tb = d[2] + d[6]; // (c, c+16), (c+8, c+24)
+                const ps_f32x4 tc = d[1] + d[5], td = d[3] + d[7]; // (c+4, c+20), (c+12, c+28)
+                return (ta + tb) + (tc + td);
+            };
+            issue(pr[0], 0);
 #pragma unroll
-                for (int r = 0; r < 4; r++) if (jb + r < n_kv) sb[jb + r] = res[r];
+            for (int c = 0; c < 4; c++) {
+                if (c < 3) issue(pr[(c + 1) & 1], c + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                t3[c] = fold(pr[c & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const ps_f32x4 res = (t3[0] + t3[1]) + (t3[2] + t3[3]);
+            // D: column = lane & 15 (the (i, g) pair), rows 4 * (lane >> 4) + r (positions)
+            if (tile * 16 + rl < N) {
+                float *sb = a.scores + ((int64_t)i * a.n_heads + (int64_t)kvh * r2 + g) * a.n_ctx;
+                const int jb = j0 + 4 * m;
+                if (jb + 3 < n_kv) *(float4 *)(sb + jb) = make_float4(res[0], res[1], res[2], res[3]);
+                else
+#pragma unroll
+                    for (int r = 0; r < 4; r++) if (jb + r < n_kv) sb[jb + r] = res[r];
+            }
         }
+        q_park(ql[cur ^ 1]);
+        __syncthreads();
     }
 }
 
@@ -586,6 +639,83 @@ __global__ __launch_bounds__(PV_NT) void attn_softmax_probs_kernel(psl_attn_args
     }
 }
 
+// (1'), n_kv <= 4096: one WAVE per score row (column i, head h), the row in registers -- no LDS, no barrier.  Lane l holds the
+// float4 of elements 4 (64 k + l) ..+3, so a group of 8 of the reference's vector loop (ggml.c:2831-2866) is the lane pair
+// (2p, 2p + 1) and its in-group sum tree ((v4 + v0) + (v6 + v2)) + ((v5 + v1) + (v7 + v3)) is one neighbour exchange; the
+// n_kv % 8 leftovers take libm's expf on lanes of their own.  grid ceil(bs * n_heads / 4), four rows per workgroup.
+constexpr int SMW_MAXQ = 16; // float4 per lane: n_kv <= 64 * 4 * 16
+__global__ __launch_bounds__(256) void attn_softmax_probs_wave_kernel(psl_attn_args a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int bs = a.state->bs, pos0 = a.state->pos0, n_kv = pos0 + bs, n8 = n_kv & ~7;
+    const int row = (int)blockIdx.x * 4 + wave;
+    if (row >= bs * a.n_heads) return;
+    const int i = row / a.n_heads;
+    float *sr = a.scores + (int64_t)row * a.n_ctx;
+    const int nq = (n_kv + 255) >> 8; // float4 trips
+    float4 v[SMW_MAXQ];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < SMW_MAXQ; k++) {
+        if (k < nq) {
+            const int j = (k * 64 + lane) * 4;
+            const float4 t = j < n_kv ? *(const float4 *)(sr + j) : make_float4(0.f, 0.f, 0.f, 0.f); // (rows are n_ctx long: the float4 stays inside)
+            float e[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int jj = j + r;
+                bool ok = false;
+                if (jj < n_kv) ok = (jj < pos0) ? (a.kv_vis ? a.kv_vis[jj] != 0 : true) : (a.tree ? a.tree[i * bs + (jj - pos0)] != 0 : (jj - pos0) <= i);
+                float x = __fmul_rn(e[r], a.scale);
+                x = __fadd_rn(x, ok ? 0.f : -INFINITY);
+                e[r] = jj < n_kv ? x : -INFINITY;
+                mx = fmaxf(mx, e[r]);
+            }
+            v[k] = make_float4(e[0], e[1], e[2], e[3]);
+        }
+    }
+    mx = wave_max_dpp(mx);
+    mx = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(mx)));
+    double rs = 0.0;
+#pragma unroll
+    for (int k = 0; k < SMW_MAXQ; k++) {
+        if (k < nq) {
+            const int j = (k * 64 + lane) * 4;
+            float4 e;
+            e.x = ps_v_expf(__fsub_rn(v[k].x, mx)); e.y = ps_v_expf(__fsub_rn(v[k].y, mx));
+            e.z = ps_v_expf(__fsub_rn(v[k].z, mx)); e.w = ps_v_expf(__fsub_rn(v[k].w, mx));
+            v[k] = e;
+            // the neighbour's half of the group of 8 (quad_perm [1, 0, 3, 2])
+            const float a0 = __fadd_rn(dpp_f<0xB1>(e.x), e.x), a1 = __fadd_rn(dpp_f<0xB1>(e.y), e.y);
+            const float a2 = __fadd_rn(dpp_f<0xB1>(e.z), e.z), a3 = __fadd_rn(dpp_f<0xB1>(e.w), e.w);
+            const float gs = __fadd_rn(__fadd_rn(a0, a2), __fadd_rn(a1, a3));
+            if (!(lane & 1) && j + 8 <= n8) rs += (double)gs;
+        }
+    }
+    // leftovers n8 .. n_kv - 1: lane t takes element n8 + t
+    float et = 0.f;
+    const int jt = n8 + lane;
+    if (jt < n_kv) {
+        const bool ok = (jt < pos0) ? (a.kv_vis ? a.kv_vis[jt] != 0 : true) : (a.tree ? a.tree[i * bs + (jt - pos0)] != 0 : (jt - pos0) <= i);
+        float x = __fmul_rn(sr[jt], a.scale);
+        x = __fadd_rn(x, ok ? 0.f : -INFINITY);
+        et = ps_expf_glibc(__fsub_rn(x, mx));
+        rs += (double)et;
+    }
+    const double tot = wave_sum_d_dpp(rs);
+    float inv = (float)(1.0 / tot);
+    inv = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(inv)));
+#pragma unroll
+    for (int k = 0; k < SMW_MAXQ; k++) {
+        if (k < nq) {
+            const int j = (k * 64 + lane) * 4;
+            const float4 e = v[k];
+            const float4 pq = make_float4(__fmul_rn(e.x, inv), __fmul_rn(e.y, inv), __fmul_rn(e.z, inv), __fmul_rn(e.w, inv));
+            if (j + 4 <= n8) *(float4 *)(sr + j) = pq; // (n8 is a multiple of 4: a float4 is wholly inside or wholly leftovers)
+        }
+    }
+    if (jt < n_kv) sr[jt] = __fmul_rn(et, inv);
+}
+
 __global__ __launch_bounds__(512, 1) void attn_pv_mfma_kernel(psl_attn_args a) {
     const int hs = a.head_size, dim = a.n_heads * hs, r2 = a.n_heads / a.n_kv_heads;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -620,6 +750,98 @@ __global__ __launch_bounds__(512, 1) void attn_pv_mfma_kernel(psl_attn_args a) {
     // D: column = lane & 15 (the (i, g) pair), rows d0 + 4 * (lane >> 4) + r.  Leftovers: sumf += x[j] * y[j], in order
     const float *vl = a.v_cache + ((int64_t)kvh * hs + d0 + 4 * m) * a.n_ctx;
     for (int jj = np; jj < n_kv; jj++) {
+        const float pj = pr[jj];
+#pragma unroll
+        for (int r = 0; r < 4; r++) res[r] = __fadd_rn(res[r], __fmul_rn(vl[(int64_t)r * a.n_ctx + jj], pj));
+    }
+    if ((int)blockIdx.x * 16 + rl < N)
+        *(float4 *)(a.att + (int64_t)i * dim + ((int64_t)kvh * r2 + g) * hs + d0 + 4 * m) = make_float4(res[0], res[1], res[2], res[3]);
+}
+
+// The same contraction with its operands staged through LDS (head sizes 128 and 64).  The kernel above has every lane
+// fetch its own 128-B run of V and of p as eight 16-B loads: a wave instruction touches 64 cache lines for 1 KiB, and the
+// CU's address unit, not the matrix core, sets the time (86 us at n_kv = 2048).  Here a wave fetches the 16 x 128 block of
+// its V rows with eight row-coalesced instructions (two 512-B rows each), the workgroup fetches the 16 x 128 block of
+// probabilities once for all its waves, both are parked in LDS (rows padded to 132 floats: the b128 operand reads are
+// conflict-free) one 128-position step ahead, and positions past the last full block of 32 are parked as zeros.
+constexpr int PVM_RS = 132;
+template <int NW> // waves per workgroup = head_size / 16
+__global__ __launch_bounds__(NW * 64, 1) void attn_pv_mfma_lds_kernel(psl_attn_args a) {
+    extern __shared__ __attribute__((aligned(16))) float pvs[]; // [2][(NW + 1) * 16][PVM_RS]: the waves' V rows, then the 16 probability rows
+    constexpr int hs = NW * 16, NT = NW * 64, ROWS = (NW + 1) * 16, NPS = 512 / NT; // NPS: probability segments per thread
+    const int dim = a.n_heads * hs, r2 = a.n_heads / a.n_kv_heads;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int kvh = blockIdx.y, bs = a.state->bs, n_kv = a.state->pos0 + bs, np = n_kv & ~31, nblk = np >> 5, n_it = (nblk + 3) >> 2;
+    const int rl = lane & 15, m = lane >> 4;
+    const int N = bs * r2, n = min((int)blockIdx.x * 16 + rl, N - 1), i = n / r2, g = n - i * r2;
+    const int d0 = wave * 16;
+    // staging roles.  V: instruction k covers rows 2k, 2k + 1 of the wave's 16, 32 lanes x 16 B per row
+    const int vrow = lane >> 5, seg = lane & 31;
+    const float *vg = a.v_cache + ((int64_t)kvh * hs + d0 + vrow) * a.n_ctx + seg * 4;
+    const float *pg[NPS];
+    int prow[NPS];
+#pragma unroll
+    for (int k = 0; k < NPS; k++) {
+        const int sidx = (int)threadIdx.x + k * NT; // segment sidx: row sidx >> 5, 16-B segment sidx & 31
+        prow[k] = sidx >> 5;
+        const int nn = min((int)blockIdx.x * 16 + prow[k], N - 1), ii = nn / r2, gg = nn - ii * r2;
+        pg[k] = a.scores + ((int64_t)ii * a.n_heads + (int64_t)kvh * r2 + gg) * a.n_ctx + (sidx & 31) * 4;
+    }
+    float4 sv[8], sp[NPS];
+    auto fetch = [&](int it) { // (clamped, never branched over: positions past np are zeroed when they are parked)
+        const int p0 = it * 128, off = p0 + seg * 4 < np ? p0 : 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) sv[k] = *(const float4 *)(vg + (int64_t)(2 * k) * a.n_ctx + off);
+#pragma unroll
+        for (int k = 0; k < NPS; k++) {
+            const int sg = ((int)threadIdx.x + k * NT) & 31;
+            sp[k] = *(const float4 *)(pg[k] + (p0 + sg * 4 < np ? p0 : 0));
+        }
+    };
+    auto park = [&](int it, float *buf) {
+        const int p0 = it * 128;
+        const bool vin = p0 + seg * 4 < np;
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            *(float4 *)(buf + (size_t)(d0 + 2 * k + vrow) * PVM_RS + seg * 4) = vin ? sv[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < NPS; k++) {
+            const int sg = ((int)threadIdx.x + k * NT) & 31;
+            *(float4 *)(buf + (size_t)(NW * 16 + prow[k]) * PVM_RS + sg * 4) = p0 + sg * 4 < np ? sp[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    ps_f32x4 acc[32];
+#pragma unroll
+    for (int c = 0; c < 32; c++) acc[c] = ps_f32x4{0.f, 0.f, 0.f, 0.f};
+    float *b0p = pvs, *b1p = pvs + (size_t)ROWS * PVM_RS;
+    // step `it` computes from buffer it & 1 while the block of step it + 1 (fetched a whole step ago) is parked in the other
+    // buffer and the block of step it + 2 is on its way: a fetch has one step of matrix work to hide behind
+    if (n_it > 0) { fetch(0); park(0, b0p); fetch(min(1, n_it - 1)); }
+    __syncthreads();
+    for (int it = 0; it < n_it; it++) {
+        float *cur = (it & 1) ? b1p : b0p, *nxt = (it & 1) ? b0p : b1p;
+        park(it + 1, nxt); // (past the last step: zeros nobody reads)
+        fetch(min(it + 2, n_it - 1));
+        const float *va = cur + (size_t)(d0 + rl) * PVM_RS + m * 32, *pb = cur + (size_t)(NW * 16 + rl) * PVM_RS + m * 32;
+        float av[32], bv[32];
+#pragma unroll
+        for (int q4 = 0; q4 < 8; q4++) {
+            const float4 t = *(const float4 *)(va + 4 * q4), w = *(const float4 *)(pb + 4 * q4);
+            av[4 * q4] = t.x; av[4 * q4 + 1] = t.y; av[4 * q4 + 2] = t.z; av[4 * q4 + 3] = t.w;
+            bv[4 * q4] = w.x; bv[4 * q4 + 1] = w.y; bv[4 * q4 + 2] = w.z; bv[4 * q4 + 3] = w.w;
+        }
+#pragma unroll
+        for (int c = 0; c < 32; c++) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c], bv[c], acc[c], 0, 0, 0); // sum = x*y + sum, x = V row
+        __syncthreads();
+    }
+    ps_f32x4 t3[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) // GGML_F32x8_REDUCE
+        t3[c] = ((acc[c] + acc[c + 16]) + (acc[c + 8] + acc[c + 24])) + ((acc[c + 4] + acc[c + 20]) + (acc[c + 12] + acc[c + 28]));
+    ps_f32x4 res = (t3[0] + t3[1]) + (t3[2] + t3[3]);
+    const float *pr = a.scores + ((int64_t)i * a.n_heads + (int64_t)kvh * r2 + g) * a.n_ctx;
+    const float *vl = a.v_cache + ((int64_t)kvh * hs + d0 + 4 * m) * a.n_ctx;
+    for (int jj = np; jj < n_kv; jj++) { // leftovers: sumf += x[j] * y[j], in order
         const float pj = pr[jj];
 #pragma unroll
         for (int r = 0; r < 4; r++) res[r] = __fadd_rn(res[r], __fmul_rn(vl[(int64_t)r * a.n_ctx + jj], pj));
@@ -820,8 +1042,20 @@ void psl_attn_softmax_pv(hipStream_t st, const psl_attn_args &a, int bs) {
         if (ps_first_on_device(&attrp)) { (void)hipFuncSetAttribute((const void *)attn_softmax_probs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024); }
         const int r2p = a.n_heads / a.n_kv_heads;
         const size_t ldsp = (size_t)r2p * (((size_t)a.n_ctx + 3) & ~(size_t)3) * 4;
-        hipLaunchKernelGGL(attn_softmax_probs_kernel, dim3((unsigned)a.n_kv_heads, (unsigned)bs), dim3(PV_NT), ldsp, st, a);
-        hipLaunchKernelGGL(attn_pv_mfma_kernel, dim3((unsigned)((bs * r2p + 15) / 16), (unsigned)a.n_kv_heads), dim3((unsigned)(a.head_size / 16 * 64)), 0, st, a);
+        if (a.n_ctx <= 64 * 4 * SMW_MAXQ) hipLaunchKernelGGL(attn_softmax_probs_wave_kernel, dim3((unsigned)((bs * a.n_heads + 3) / 4)), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(attn_softmax_probs_kernel, dim3((unsigned)a.n_kv_heads, (unsigned)bs), dim3(PV_NT), ldsp, st, a);
+        const dim3 gpv((unsigned)((bs * r2p + 15) / 16), (unsigned)a.n_kv_heads);
+        if (a.head_size == 128 || a.head_size == 64) {
+            static unsigned long long attrl = 0;
+            if (ps_first_on_device(&attrl)) {
+                (void)hipFuncSetAttribute((const void *)attn_pv_mfma_lds_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+                (void)hipFuncSetAttribute((const void *)attn_pv_mfma_lds_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+            }
+            if (a.head_size == 128) hipLaunchKernelGGL(attn_pv_mfma_lds_kernel<8>, gpv, dim3(512), 2 * 9 * 16 * PVM_RS * 4, st, a);
+            else hipLaunchKernelGGL(attn_pv_mfma_lds_kernel<4>, gpv, dim3(256), 2 * 5 * 16 * PVM_RS * 4, st, a);
+            return;
+        }
+        hipLaunchKernelGGL(attn_pv_mfma_kernel, gpv, dim3((unsigned)(a.head_size / 16 * 64)), 0, st, a);
         return;
     }
     if (bs > 1) { // batches: one workgroup per (kv head, column pair)

@@ -1,0 +1,17 @@
+#!/usr/bin/env python3
+"""Per-kernel average duration by call order (rocprofv3 rocpd database): the calls of each kernel are split into `groups` equal
+runs in start order -- with tools/g4k_exp.py (2048-token prompt in 128-token chunks) group i of the last pass is chunk i.
+usage: prof_by_chunk.py results.db substring[,substring...] [calls_per_group=32] [last_n_groups=16]"""
+import sqlite3, sys
+con = sqlite3.connect(sys.argv[1])
+cur = con.cursor()
+cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
+namecol = "name" if "name" in cols else "kernel_name"
+rows = sorted(cur.execute(f"select {namecol}, start, end from kernels"), key=lambda r: r[1])
+per = int(sys.argv[3]) if len(sys.argv) > 3 else 32
+last = int(sys.argv[4]) if len(sys.argv) > 4 else 16
+for pat in sys.argv[2].split(","):
+    d = [(e - s) / 1e3 for n, s, e in rows if pat in n]
+    d = d[-per * last:]
+    g = [sum(d[i:i + per]) / per for i in range(0, len(d), per)]
+    print(f"{pat:28s} n={len(d):5d} avg us by group:", " ".join(f"{x:6.1f}" for x in g))
