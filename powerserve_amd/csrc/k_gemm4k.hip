@@ -53,6 +53,7 @@ struct G4KParams {
     const float *residual;
     const int8_t *qf;   // fragment-major quants
     const uint8_t *mf;  // tile-major column metadata (ps_act::mf)
+    unsigned long long *dbg; // timeline slots (ps_hip_debug_timeline keys 48..50, 52), or null
 };
 
 __device__ __forceinline__ long g4k_pack(uint32_t lo, uint32_t hi) { return (long)(((unsigned long)hi << 32) | lo); }
@@ -134,8 +135,10 @@ __device__ __forceinline__ void g4k_produce(const uint2 q, const uint4 h, char *
 }
 
 __device__ __forceinline__ void g4k_producer_wave(const uint8_t *qs0, const uint8_t *aux0, const uint8_t *qs1, const uint8_t *aux1, const int tile,
-                                                  const int nsb, const int n_stages, char *lds, const int hw) {
+                                                  const int nsb, const int n_stages, char *lds, const int hw, unsigned long long *dbg) {
     const int lane = threadIdx.x & 63;
+    int dbg_n = 1;
+    auto mark = [&](int g) { if (dbg && (g < 8 || (g & 7) == 7) && dbg_n < 29) dbg[dbg_n++] = __builtin_amdgcn_s_memtime(); };
     const int row = 4 * hw + (lane >> 4), u = (lane >> 1) & 7, p = lane & 1, unit = row >> 3, r8 = row & 7;
     const size_t qo = ((size_t)(2 * tile + unit) * nsb << 10) + (size_t)(r8 * 32 + u * 4 + 2 * p) * 4;
     const size_t ho = (size_t)(2 * tile + unit) * nsb * 128 + (size_t)r8 * 16;
@@ -159,8 +162,9 @@ __device__ __forceinline__ void g4k_producer_wave(const uint8_t *qs0, const uint
             const uint2 q = rq[k];
             const uint4 h = rh[k];
             rq[k] = ldq(g0 + k + G4K_RING); rh[k] = ldh(g0 + k + G4K_RING);
-            g4k_produce(q, h, lds + ((g0 + k) & 1) * G4K_STAGE, row, u, p, lane);
-            __syncthreads(); // barrier #(g0 + k): stage g0 + k is parked
+            g4k_produce(q, h, lds + ((g0 + k) & 3) * G4K_STAGE, row, u, p, lane);
+            if (k & 1) __syncthreads(); // one barrier per PAIR of stages: stages g0 + k - 1, g0 + k are parked
+            mark(g0 + k);
         }
     }
 }
@@ -216,8 +220,9 @@ __device__ __forceinline__ void g4k_superblock(G4KAcc &T, const char *st, const 
 
 // one tile of the consumers' walk: `s_first` = index of its first step in the workgroup's stage sequence (LDS stage = step % 2)
 __device__ __forceinline__ void g4k_tile(const int nsb, const int8_t *qf_ct, const uint8_t *mf_ct, const int mc, const char *lds, const char *zero,
-                                         const int s_first, float (&y)[4]) {
+                                         const int s_first, float (&y)[4], unsigned long long *dbg, int &dbg_n) {
     const int lane = threadIdx.x & 63, m = lane & 15, kb = lane >> 4;
+    auto mark = [&](int g) { if (dbg && (g < 8 || (g & 7) == 7) && dbg_n < 29) dbg[dbg_n++] = __builtin_amdgcn_s_memtime(); };
     G4KAcc T;
     T.clear();
     ps_u32x4 bn[4]; // the B fragments of the next super-block (L2: a few hundred cycles -- one step ahead is enough)
@@ -233,8 +238,9 @@ __device__ __forceinline__ void g4k_tile(const int nsb, const int8_t *qf_ct, con
 #pragma unroll
             for (int up = 0; up < 4; up++) bn[up] = *(const ps_u32x4 *)(qf_ct + ((size_t)nb << 12) + up * 1024 + lane * 16);
         }
-        __syncthreads(); // barrier #(s_first + sb): the producers have parked this step
-        g4k_superblock(T, lds + ((s_first + sb) & 1) * G4K_STAGE, zero, bq, yd, b16a, b16b, m, kb);
+        if (!(sb & 1)) __syncthreads(); // (s_first is even) the producers have parked this step and the next
+        mark(s_first + sb);
+        g4k_superblock(T, lds + ((s_first + sb) & 3) * G4K_STAGE, zero, bq, yd, b16a, b16b, m, kb);
     }
     T.reduce(y);
 }
@@ -247,16 +253,20 @@ __global__ __launch_bounds__((G4K_NC + G4K_NP) * 64) void gemm4k_kernel(const G4
     // wave -> (row task, column tile)
     const int ct = (int)blockIdx.y * 8 + (wave & 7);
     const int task = (int)blockIdx.x; // (grid.x = tasks exactly; every wave stays for the barriers)
-    __shared__ __attribute__((aligned(16))) char lds[2 * G4K_STAGE + 32];
-    if (threadIdx.x < 8) ((uint32_t *)(lds + 2 * G4K_STAGE))[threadIdx.x] = 0u; // the zero operands (visible after barrier #0)
+    __shared__ __attribute__((aligned(16))) char lds[4 * G4K_STAGE + 32];
+    if (threadIdx.x < 8) ((uint32_t *)(lds + 4 * G4K_STAGE))[threadIdx.x] = 0u; // the zero operands (visible after barrier #0)
     int wi = 0, tile = task;
     if (EPI != 1) {
         if (p.n_w > 1 && tile >= p.w[0].n_tiles) { tile -= p.w[0].n_tiles; wi = 1; }
         if (p.n_w > 2 && wi == 1 && tile >= p.w[1].n_tiles) { tile -= p.w[1].n_tiles; wi = 2; }
     }
     const G4KMat &W = wi == 0 ? p.w[0] : (wi == 1 ? p.w[1] : p.w[2]);
+    // timeline: consumer wave 0 -> words 0..31, producer wave 8 -> 32..63 of the workgroup's slot ([0]/[31] entry / exit clock, [29]/[30] 100 MHz)
+    unsigned long long *const dbg = (p.dbg && blockIdx.y == 0 && blockIdx.x < 1024 && lane == 0 && (wave == 0 || wave == G4K_NC)) ? p.dbg + ((size_t)blockIdx.x * 2 + (wave == G4K_NC)) * 32 : nullptr;
+    if (dbg) { dbg[0] = __builtin_amdgcn_s_memtime(); dbg[29] = __builtin_amdgcn_s_memrealtime(); }
     if (wave >= G4K_NC) {
-        g4k_producer_wave(W.qs, W.aux, EPI == 1 ? p.w[1].qs : W.qs, EPI == 1 ? p.w[1].aux : W.aux, tile, p.nsb, EPI == 1 ? 2 * p.nsb : p.nsb, lds, wave - G4K_NC);
+        g4k_producer_wave(W.qs, W.aux, EPI == 1 ? p.w[1].qs : W.qs, EPI == 1 ? p.w[1].aux : W.aux, tile, p.nsb, EPI == 1 ? 2 * p.nsb : p.nsb, lds, wave - G4K_NC, dbg);
+        if (dbg) { dbg[31] = __builtin_amdgcn_s_memtime(); dbg[30] = __builtin_amdgcn_s_memrealtime(); }
         return;
     }
     const int col = ct * 16 + m, colc = col < p.bs ? col : p.bs - 1; // (the last tile may be ragged: clamp the column metadata)
@@ -264,12 +274,13 @@ __global__ __launch_bounds__((G4K_NC + G4K_NP) * 64) void gemm4k_kernel(const G4
     const int8_t *qf_ct = p.qf + ((size_t)ctc * p.nsb << 12);
     const uint8_t *mf_ct = p.mf + (size_t)ctc * p.nsb * 576;
     const int mc = colc & 15;
-    const char *zero = lds + 2 * G4K_STAGE;
+    const char *zero = lds + 4 * G4K_STAGE;
     float y[4];
-    g4k_tile(p.nsb, qf_ct, mf_ct, mc, lds, zero, 0, y);
+    int dbg_n = 1;
+    g4k_tile(p.nsb, qf_ct, mf_ct, mc, lds, zero, 0, y, dbg, dbg_n);
     if (EPI == 1) {
         float yu[4];
-        g4k_tile(p.nsb, qf_ct, mf_ct, mc, lds, zero, p.nsb, yu);
+        g4k_tile(p.nsb, qf_ct, mf_ct, mc, lds, zero, p.nsb, yu, dbg, dbg_n);
 #pragma unroll
         for (int r = 0; r < 4; r++) y[r] = ps_silu_mul(y[r], yu[r]);
     }
@@ -287,6 +298,7 @@ __global__ __launch_bounds__((G4K_NC + G4K_NP) * 64) void gemm4k_kernel(const G4
         }
         *(float4 *)o = make_float4(v[0], v[1], v[2], v[3]);
     }
+    if (dbg) { dbg[31] = __builtin_amdgcn_s_memtime(); dbg[30] = __builtin_amdgcn_s_memrealtime(); }
 }
 
 } // namespace
@@ -307,6 +319,7 @@ int psk_gemm4k(hipStream_t st, int n_cu, const psk_gemv_args &a, ps_act act, int
     p.n_w = a.n_w; p.nsb = (int)(K / 256); p.bs = (int)bs;
     p.n_tasks = epi == 1 ? p.w[0].n_tiles : tiles_total;
     p.residual = a.residual; p.qf = act.qf; p.mf = act.mf;
+    p.dbg = psk_gemv_dbg_buf(12 + epi, epi ? 0 : (a.n_w == 3 ? 0 : (K <= 8192 ? 1 : 2))); // keys 48 QKV, 49 O, 50 down, 52 gate/up
     const int n_ct = (int)((bs + 15) / 16);
     // Below eight column tiles a workgroup's waves would not share their weight rows any more, and the kernels that spread
     // a row group's integer work over producer waves (gemm8) are ahead there: tree forward of the 8B shape, ms by width,
