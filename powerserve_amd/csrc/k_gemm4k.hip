@@ -1,41 +1,47 @@
-// Q4_K batched mat-mul (prefill chunks, tree verify) on v_mfma_i32_16x16x32_i8 -- bit-exact with ggml_vec_dot_q4_K_q8_K.
+// Q4_K batched mat-mul (prefill chunks, tree verify) on v_mfma_f32_16x16x32_f16 -- bit-exact with ggml_vec_dot_q4_K_q8_K.
 //
 // The AVX2 kernel (libs/ggml/src/ggml-quants.c:7809-7873) keeps, per super-block of 256 weights, ONE int32 per accumulator
 // lane u:  sumi[u] = sum over the 8 sub-blocks g of  scale[g] * dot4(q[g][4u..4u+3], y[g][4u..4u+3]),  accumulated in
 // int32 before the single  acc[u] = fma(d * y.d, (float)sumi[u], acc[u]).  Integers associate, and the 32 elements lane u
 // owns in a super-block are exactly one K = 32 contraction: for a tile of 16 weight rows x 16 activation columns and one u,
-//     D[row][col] = sum_k A[row][k] * B[k][col],   k = (g, e),  A = q4 * factor,  B = y
-// is one v_mfma_i32_16x16x32_i8.  The 6-bit scale cannot ride in an int8 operand whole (15 * 63 > 127), so it is split,
-// scale = 8 * hi + lo with 3-bit halves (q * 7 <= 105):  sumi = 8 * (A_hi . B) + (A_lo . B)  -- two MFMAs, the first result
-// shifted into the C input of the second.  The mins term (ggml-quants.c:7831-7834) per accumulator lane v is
-//     prod[v] = mins[2v] * q8sum[2v] + mins[2v+1] * q8sum[2v+1]
-// -- a K = 4 contraction over the four 16-sums of the two sub-blocks, every factor an integer fp16 holds exactly (mins <= 63,
-// |16-sum| <= 2032), every partial sum below 2^24: v_mfma_f32_16x16x16_f16 returns (float)prod itself.  Everything after
-// sumi / prod is the reference's fp32 arithmetic per (row, column, lane): the eight acc chains, the four acc_m chains,
-// hsum_float_8.
+//     D[row][col] = sum_k A[row][k] * B[k][col],   k = (g, e),  A = q4 * scale[g],  B = y.
+// Every factor is an integer fp16 holds exactly (q4 * scale <= 15 * 63 = 945 < 2048, |y| <= 127), every product is exact in
+// fp32 and every partial sum stays below 2^24 (32 * 945 * 127 < 3.9 M): v_mfma_f32_16x16x32_f16 returns (float)sumi[u]
+// ITSELF, whatever order it adds in -- no scale split, no shift, no int-to-float conversion.  The mins term
+// (ggml-quants.c:7831-7834) per accumulator lane v,  prod[v] = mins[2v] * q8sum[2v] + mins[2v+1] * q8sum[2v+1],  is a K = 4
+// contraction over the four 16-sums of the two sub-blocks (mins <= 63, |16-sum| <= 2032) on v_mfma_f32_16x16x16_f16 the same
+// way.  Everything after sumi / prod is the reference's fp32 arithmetic per (row, column, lane): the eight acc chains, the
+// four acc_m chains, hsum_float_8.
 //
-// Operand layout (tools/micro/mfma32probe.hip): lane l supplies A[i = l % 16][k = 8 * (l / 16) ..+7] and
-// B[k = 8 * (l / 16) ..+7][j = l % 16]; result register r of lane l is D[i = 4 * (l / 16) + r][j = l % 16].  With
-// k = 8 * kb + 4 * half + e  <->  sub-block g = 2 * kb + half, element 4u + e:
-//   * A: the lane's 8 bytes come from ONE dword of the lane-major weight layout (ps_internal.h): byte 32 kb + 4u + e of
+// Operand layout: lane l supplies A[i = l % 16][k = 8 * (l / 16) ..+7] and B[k = 8 * (l / 16) ..+7][j = l % 16] (8 fp16 =
+// 16 B each); result register r of lane l is D[i = 4 * (l / 16) + r][j = l % 16].  With kb = l / 16 the lane's eight k are
+// the elements 4u + (0, 2, 1, 3) of sub-block 2 kb, then of sub-block 2 kb + 1 (the order the nibbles fall out in):
+//   * A: the lane's 8 weights come from ONE dword of the lane-major weight layout (ps_internal.h): byte 32 kb + 4u + e of
 //     the super-block holds element e of sub-block 2 kb in its low nibble and of sub-block 2 kb + 1 in its high nibble;
-//   * B: the quantizer writes a second, fragment-major copy of the Q8_K quants (ps_act::qf): per (16 columns,
-//     super-block) 4 KiB laid out [u / 2][lane][u % 2][half][4 B], so that a wave's B operands for two values of u are
-//     one fully coalesced 1 KiB load; the column metadata rides tile-major next to it (ps_act::mf).
+//   * B: the quantizer writes a second, fragment-major fp16 copy of the Q8_K quants (ps_act::qf): per (16 columns,
+//     super-block) 8 KiB laid out [u][lane][16 B], so that a wave's B operands for one u are one fully coalesced 1 KiB
+//     load; the column metadata rides tile-major next to it (ps_act::mf).
 //
-// A workgroup is twelve waves on 16 weight rows x 128 columns.  Waves 0-7 COMPUTE: one 16 x 16 tile each (48 fp32 chains
-// per lane), walking K.  Waves 8-11 PRODUCE: everything the eight computing waves would otherwise each derive from the
-// same 16 rows -- the nibbles times the split scales as ready MFMA A operands, the mins as fp16 A operands, d and dmin as
-// fp32 -- is made ONCE per super-block by the producers (four rows each) and parked in LDS, one step ahead of the
-// consumers, one barrier per step.  The producers own their memory pipeline: a register ring of G4K_RING super-blocks of
-// their rows is in flight from HBM, so nobody waits on a weight load (what-if, round 2: the per-wave version spent a
-// third of its vector instructions on these shared derivations, tools/g4k_exp.py).
-// EPI 1 (SiLU(gate) * up) runs the gate tile's K loop, keeps its four results, then the up tile's.
+// A workgroup is twelve waves on TWO 16-row tiles x 64 columns (an EPI 1 pair: the gate tile and the up tile of the same
+// rows; else 32 consecutive rows of one matrix).  Waves 0-7 COMPUTE: wave = (column tile ct = w % 4, accumulator half
+// uh = w / 4) owns, for BOTH row tiles, the accumulator lanes u = 4 uh .. 4 uh + 3 and the mins lanes v = 2 uh, 2 uh + 1 of
+// one 16 x 16 tile (48 fp32 chains per lane): a B operand fetched from L2 meets two row tiles, which halves the L2 traffic
+// per MFMA -- what bounded the one-row-tile form (17 TB/s of fragment reads, tools/gpu_g4k_timeline.py) -- without the 96
+// chain registers of two whole tiles.  The two halves of a tile meet once, at the end, through LDS (hsum_float_8's first
+// level adds lane u to lane u + 4: exactly the two halves).  Waves 8-11 PRODUCE: everything the computing waves would
+// otherwise each derive from the same 32 rows -- the nibbles times their scales as ready fp16 A operands, the mins as
+// fp16 A operands, d and dmin as fp32 -- is made ONCE per super-block (producer h: accumulator lanes 2h, 2h + 1 of all 32
+// rows; lane = (row, k-group pair)) and parked in LDS ahead of the consumers, one barrier per pair of steps.  The producers
+// own their memory pipeline: a register ring of G4K_RING super-blocks is in flight from HBM, nobody waits on a weight load.
+// (Round-2 history, tools/g4k_exp.py and tools/gpu_g4k_timeline.py: a per-wave int8 version -- scale split 8 hi + lo, two
+// v_mfma_i32_16x16x32_i8 with a shift between -- spent a third of its vector instructions on the shared derivations and,
+// once those had moved to producers, 64 of its remaining 176 instructions per step on the shifts and conversions the fp16
+// form does not have.)
 #include "ps_gemv_dev.h"
 
 namespace {
 
-typedef int g4k_i32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 g4k_h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 g4k_h2 __attribute__((ext_vector_type(2)));
 typedef _Float16 g4k_h4 __attribute__((ext_vector_type(4)));
 typedef float g4k_f4 __attribute__((ext_vector_type(4)));
@@ -51,67 +57,62 @@ struct G4KParams {
     G4KMat w[3];
     int n_w, nsb, bs, n_tasks;
     const float *residual;
-    const int8_t *qf;   // fragment-major quants
+    const _Float16 *qf; // fragment-major fp16 quants
     const uint8_t *mf;  // tile-major column metadata (ps_act::mf)
     unsigned long long *dbg; // timeline slots (ps_hip_debug_timeline keys 48..50, 52), or null
 };
 
-__device__ __forceinline__ long g4k_pack(uint32_t lo, uint32_t hi) { return (long)(((unsigned long)hi << 32) | lo); }
-
-// the fp32 chains of one 16 x 16 tile: rows 4 kb + r of the tile, this lane's column
-struct G4KAcc {
-    float acc[4][8], accm[4][4];
-    __device__ __forceinline__ void clear() {
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-#pragma unroll
-            for (int u = 0; u < 8; u++) acc[r][u] = 0.f;
-#pragma unroll
-            for (int v = 0; v < 4; v++) accm[r][v] = 0.f;
-        }
-    }
-    // hsum_float_8 (ggml-quants.c:62-68) and the acc_m reduction, as row_reduce<PS_Q4_K> does with lane shifts
-    __device__ __forceinline__ void reduce(float (&y)[4]) const {
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            float s[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) s[k] = __fadd_rn(acc[r][k], acc[r][k + 4]);
-            const float res = __fadd_rn(__fadd_rn(s[0], s[2]), __fadd_rn(s[1], s[3]));
-            const float mm  = __fadd_rn(__fadd_rn(accm[r][0], accm[r][2]), __fadd_rn(accm[r][1], accm[r][3]));
-            y[r] = __fadd_rn(res, mm);
-        }
-    }
-};
-
-// One LDS stage = one super-block of the workgroup's 16 rows, as the consumers want it:
-//   [row][u][kb] 16 B = (A_hi, A_lo) of lane (row, kb) for accumulator lane u; rows padded to 528 B (b128 reads of 16 rows
-//                       at one kb hit 16 distinct 16-B bank groups)
+// One LDS stage = one super-block of the workgroup's 32 rows (row tile t = row / 16), as the consumers want it:
+//   [row][u][kb] 16 B = the fp16 A operand of lane (row % 16, kb) for accumulator lane u; rows padded to 528 B (b128 reads of
+//                       16 rows at one kb hit 16 distinct 16-B bank groups)
 //   [row] 32 B   = the mins as the four fp16 A operands (m[2v], m[2v], m[2v+1], m[2v+1]), v = 0..3
 //   [row] 8 B    = (d, dmin) as fp32
-constexpr int G4K_RS = 528, G4K_MINS = 16 * G4K_RS, G4K_DD = G4K_MINS + 16 * 32, G4K_STAGE = G4K_DD + 16 * 8;
+constexpr int G4K_RS = 528, G4K_MINS = 32 * G4K_RS, G4K_DD = G4K_MINS + 32 * 32, G4K_STAGE = G4K_DD + 32 * 8;
 constexpr int G4K_NC = 8, G4K_NP = 4, G4K_RING = 4; // computing waves, producing waves, super-blocks in flight per producer
+constexpr int G4K_NST = 4;                          // LDS stages
+constexpr int G4K_XCH = G4K_NST * G4K_STAGE + 32;   // after the stages and the 32 zero bytes: the end-of-tile exchange, [ct][lane][48 floats]
+constexpr int G4K_LDS = G4K_XCH + 4 * 64 * 48 * 4;
 
-// ---- producers.  Wave h (0..3) owns rows 4h .. 4h+3 of the tile; lane = (row 4h + l / 16, u = (l / 2) % 8, kb pair l % 2):
-// its two weight dwords [row][u][kb = 2p, 2p + 1] are one 8-B load (128 lanes-worth: the 512 contiguous bytes of 4 rows).
-// stages 0 .. nsb-1: tile of (qs0, aux0); stages nsb .. n_stages-1 (EPI 1): the same tile of (qs1, aux1)
-__device__ __forceinline__ void g4k_produce(const uint2 q, const uint4 h, char *st, const int row, const int u, const int p, const int lane) {
+// the two row tiles of a task
+struct G4KRows { const uint8_t *qs[2], *aux[2]; int tile[2]; };
+
+// ---- producers.  Wave h (0..3) makes the accumulator lanes u = 2h, 2h + 1 of all 32 rows; lane = (row l / 2, kb pair p = l % 2):
+// its weight dwords [row][u][kb = 2p, 2p + 1] are one 8-B load per u.
+__device__ __forceinline__ void g4k_produce(const uint2 q0, const uint2 q1, const uint4 h, char *st, const int row, const int hw, const int p) {
     // the four sub-block scales 4p .. 4p+3 (get_scale_min_k4: 0..3 sit in the low 6 bits of scale bytes 0..3, 4..7 are
-    // spread over bytes 8..11 and the top bits of bytes 0..3), split into 3-bit halves, each replicated to a 16-bit pair
+    // spread over bytes 8..11 and the top bits of bytes 0..3) as fp16 pairs (s, s) and (-1024 s, -1024 s)
     const uint32_t scb = p ? ((h.w & 0x0f0f0f0fu) | (((h.y >> 6) & 0x03030303u) << 4)) : (h.y & 0x3f3f3f3fu);
-    const uint32_t hi4 = (scb >> 3) & 0x07070707u, lo4 = scb & 0x07070707u;
-    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-    auto pkmul = [](uint32_t a, uint32_t f) { u16x2 va, vf; __builtin_memcpy(&va, &a, 4); __builtin_memcpy(&vf, &f, 4); va = va * vf; uint32_t o; __builtin_memcpy(&o, &va, 4); return o; };
+    const g4k_h2 k1024 = {(_Float16)1024.f, (_Float16)1024.f}, km1024 = {(_Float16)-1024.f, (_Float16)-1024.f};
+    g4k_h2 sc[4], nc[4];
 #pragma unroll
-    for (int e = 0; e < 2; e++) { // kb = 2p + e: sub-blocks 2 kb (low nibbles), 2 kb + 1 (high nibbles) = bytes 2e, 2e + 1 of scb
-        const uint32_t w = e ? q.y : q.x;
-        const uint32_t lo = w & 0x0F0F0F0Fu, hi = (w >> 4) & 0x0F0F0F0Fu;
-        const uint32_t s0 = 0x0c000c00u | (uint32_t)(2 * e) * 0x00010001u, s1 = 0x0c000c00u | (uint32_t)(2 * e + 1) * 0x00010001u;
-        const uint32_t f0h = __builtin_amdgcn_perm(0u, hi4, s0), f1h = __builtin_amdgcn_perm(0u, hi4, s1);
-        const uint32_t f0l = __builtin_amdgcn_perm(0u, lo4, s0), f1l = __builtin_amdgcn_perm(0u, lo4, s1);
-        *(uint4 *)(st + row * G4K_RS + u * 64 + (2 * p + e) * 16) = make_uint4(pkmul(lo, f0h), pkmul(hi, f1h), pkmul(lo, f0l), pkmul(hi, f1l));
+    for (int i = 0; i < 4; i++) { // bytes (s, 0x64, s, 0x64) = the fp16 pair (1024 + s, 1024 + s); minus 1024 is exact
+        const uint32_t t = __builtin_amdgcn_perm(0x64646464u, scb, 0x04000400u | (uint32_t)(i * 0x00010001u));
+        g4k_h2 v;
+        __builtin_memcpy(&v, &t, 4);
+        sc[i] = v - k1024;
+        nc[i] = sc[i] * km1024; // (<= 64512: exact)
     }
-    if ((lane & 15) == 0) { // once per row: mins and (d, dmin)
+#pragma unroll
+    for (int j = 0; j < 2; j++) { // u = 2 hw + j
+        const uint2 q = j ? q1 : q0;
+#pragma unroll
+        for (int e = 0; e < 2; e++) { // kb = 2p + e: sub-blocks 2 kb (low nibbles), 2 kb + 1 (high nibbles) = scales 2e, 2e + 1 of the four
+            const uint32_t w = e ? q.y : q.x;
+            // nibble pairs as fp16 (1024 + n): (e0, e2), (e1, e3) of sub-block 2 kb, then of 2 kb + 1;  fma(1024 + n, s, -1024 s) = n s, exact
+            const uint32_t t[4] = {(w & 0x000F000Fu) | 0x64006400u, ((w >> 8) & 0x000F000Fu) | 0x64006400u,
+                                   ((w >> 4) & 0x000F000Fu) | 0x64006400u, ((w >> 12) & 0x000F000Fu) | 0x64006400u};
+            uint32_t o[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                g4k_h2 v;
+                __builtin_memcpy(&v, &t[k], 4);
+                v = __builtin_elementwise_fma(v, sc[2 * e + (k >> 1)], nc[2 * e + (k >> 1)]);
+                __builtin_memcpy(&o[k], &v, 4);
+            }
+            *(uint4 *)(st + row * G4K_RS + (2 * hw + j) * 64 + (2 * p + e) * 16) = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+    }
+    if (hw == 0 && p == 0) { // once per row: the mins operands
         const uint32_t mn03 = h.z & 0x3f3f3f3fu;
         const uint32_t mn47 = ((h.w >> 4) & 0x0f0f0f0fu) | (((h.z >> 6) & 0x03030303u) << 4);
         uint32_t o[8];
@@ -124,179 +125,211 @@ __device__ __forceinline__ void g4k_produce(const uint2 q, const uint4 h, char *
             const uint32_t p1 = __builtin_amdgcn_perm(0x64646464u, mp, 0x04000400u | (uint32_t)((e + 1) * 0x00010001u));
             g4k_h2 h0, h1;
             __builtin_memcpy(&h0, &p0, 4); __builtin_memcpy(&h1, &p1, 4);
-            const g4k_h2 k1024 = {(_Float16)1024.f, (_Float16)1024.f};
             h0 = h0 - k1024; h1 = h1 - k1024;
             __builtin_memcpy(&o[2 * v], &h0, 4); __builtin_memcpy(&o[2 * v + 1], &h1, 4);
         }
         *(uint4 *)(st + G4K_MINS + row * 32) = make_uint4(o[0], o[1], o[2], o[3]);
         *(uint4 *)(st + G4K_MINS + row * 32 + 16) = make_uint4(o[4], o[5], o[6], o[7]);
-        *(float2 *)(st + G4K_DD + row * 8) = make_float2(ps_h2f((uint16_t)(h.x & 0xffff)), ps_h2f((uint16_t)(h.x >> 16)));
     }
+    if (hw == 1 && p == 0) *(float2 *)(st + G4K_DD + row * 8) = make_float2(ps_h2f((uint16_t)(h.x & 0xffff)), ps_h2f((uint16_t)(h.x >> 16))); // (d, dmin)
 }
 
-__device__ __forceinline__ void g4k_producer_wave(const uint8_t *qs0, const uint8_t *aux0, const uint8_t *qs1, const uint8_t *aux1, const int tile,
-                                                  const int nsb, const int n_stages, char *lds, const int hw, unsigned long long *dbg) {
+__device__ __forceinline__ void g4k_producer_wave(const G4KRows R, const int nsb, char *lds, const int hw, unsigned long long *dbg) {
     const int lane = threadIdx.x & 63;
     int dbg_n = 1;
     auto mark = [&](int g) { if (dbg && (g < 8 || (g & 7) == 7) && dbg_n < 29) dbg[dbg_n++] = __builtin_amdgcn_s_memtime(); };
-    const int row = 4 * hw + (lane >> 4), u = (lane >> 1) & 7, p = lane & 1, unit = row >> 3, r8 = row & 7;
-    const size_t qo = ((size_t)(2 * tile + unit) * nsb << 10) + (size_t)(r8 * 32 + u * 4 + 2 * p) * 4;
-    const size_t ho = (size_t)(2 * tile + unit) * nsb * 128 + (size_t)r8 * 16;
-    auto ldq = [&](int g) -> uint2 { // (stages past the end are clamped, never branched over)
-        g = g < n_stages ? g : n_stages - 1;
-        const uint8_t *b = g < nsb ? qs0 : qs1;
-        return *(const uint2 *)(b + qo + ((size_t)(g < nsb ? g : g - nsb) << 10));
-    };
-    auto ldh = [&](int g) -> uint4 {
-        g = g < n_stages ? g : n_stages - 1;
-        const uint8_t *b = g < nsb ? aux0 : aux1;
-        return *(const uint4 *)(b + ho + (size_t)(g < nsb ? g : g - nsb) * 128);
-    };
-    uint2 rq[G4K_RING];
+    const int row = lane >> 1, p = lane & 1, rt = row >> 4, unit = (row >> 3) & 1, r8 = row & 7;
+    const uint8_t *qb = (rt ? R.qs[1] : R.qs[0]) + ((size_t)(2 * (rt ? R.tile[1] : R.tile[0]) + unit) * nsb << 10) + (size_t)(r8 * 32 + 2 * hw * 4 + 2 * p) * 4;
+    const uint8_t *hb = (rt ? R.aux[1] : R.aux[0]) + (size_t)(2 * (rt ? R.tile[1] : R.tile[0]) + unit) * nsb * 128 + (size_t)r8 * 16;
+    uint2 rq0[G4K_RING], rq1[G4K_RING];
     uint4 rh[G4K_RING];
+    auto load = [&](int g, uint2 &a, uint2 &b, uint4 &h) { // (stages past the end are clamped, never branched over)
+        g = g < nsb ? g : nsb - 1;
+        a = *(const uint2 *)(qb + ((size_t)g << 10));
+        b = *(const uint2 *)(qb + ((size_t)g << 10) + 16);
+        h = *(const uint4 *)(hb + (size_t)g * 128);
+    };
 #pragma unroll
-    for (int k = 0; k < G4K_RING; k++) { rq[k] = ldq(k); rh[k] = ldh(k); }
-    for (int g0 = 0; g0 < n_stages; g0 += G4K_RING) { // (n_stages % G4K_RING == 0: psk_gemm4k checks)
+    for (int k = 0; k < G4K_RING; k++) load(k, rq0[k], rq1[k], rh[k]);
+    for (int g0 = 0; g0 < nsb; g0 += G4K_RING) { // (nsb % G4K_RING == 0: psk_gemm4k checks)
 #pragma unroll
         for (int k = 0; k < G4K_RING; k++) {
-            const uint2 q = rq[k];
+            const uint2 a = rq0[k], b = rq1[k];
             const uint4 h = rh[k];
-            rq[k] = ldq(g0 + k + G4K_RING); rh[k] = ldh(g0 + k + G4K_RING);
-            g4k_produce(q, h, lds + ((g0 + k) & 3) * G4K_STAGE, row, u, p, lane);
+            load(g0 + k + G4K_RING, rq0[k], rq1[k], rh[k]);
+            g4k_produce(a, b, h, lds + ((g0 + k) & (G4K_NST - 1)) * G4K_STAGE, row, hw, p);
             if (k & 1) __syncthreads(); // one barrier per PAIR of stages: stages g0 + k - 1, g0 + k are parked
             mark(g0 + k);
         }
     }
 }
 
-// ---- consumers: one super-block of one tile from the parked operands
-__device__ __forceinline__ void g4k_superblock(G4KAcc &T, const char *st, const char *zero, const ps_u32x4 (&bq)[4], const float yd,
-                                               const ps_u32x4 b16a, const ps_u32x4 b16b, const int m, const int kb) {
-    const g4k_f4 dda = *(const g4k_f4 *)(st + G4K_DD + kb * 32), ddb = *(const g4k_f4 *)(st + G4K_DD + kb * 32 + 16); // (d, dmin) of rows 4 kb + r
-    const float dr[4] = {__fmul_rn(yd, dda[0]), __fmul_rn(yd, dda[2]), __fmul_rn(yd, ddb[0]), __fmul_rn(yd, ddb[2])};
-    const float dmin[4] = {__fmul_rn(-yd, dda[1]), __fmul_rn(-yd, dda[3]), __fmul_rn(-yd, ddb[1]), __fmul_rn(-yd, ddb[3])};
-    const char *ap = st + m * G4K_RS + kb * 16;
-    // the MFMAs in rounds of four independent ones (the second round of a group takes the first round's results, shifted,
-    // as its C input): the matrix core's latency is covered by the other three, not by wait states
+// ---- consumers
+struct G4KMeta { float yd; ps_u32x4 b16; }; // the column's scale and the fp16 16-sums of sub-blocks 4 uh .. 4 uh + 3 of one super-block
+__device__ __forceinline__ G4KMeta g4k_meta(const uint8_t *mf_ct, const int sb, const int mc, const int uh) {
+    const uint8_t *mfs = mf_ct + (size_t)sb * 576; // the (column tile, super-block) block: d[16], then the fp16 16-sums [16][16]
+    G4KMeta M;
+    M.yd = *(const float *)(mfs + mc * 4);
+    M.b16 = *(const ps_u32x4 *)(mfs + 64 + mc * 32 + uh * 16);
+    return M;
+}
+
+// the fp32 chains this wave keeps: for both row tiles, rows 4 kb + r, accumulator lanes 4 uh + k and mins lanes 2 uh + vv
+struct G4KAcc {
+    float acc[2][4][4], accm[2][4][2];
+    __device__ __forceinline__ void clear() {
 #pragma unroll
-    for (int uh = 0; uh < 8; uh += 4) {
-        g4k_i32x4 cc[4];
-        long al[4], bb[4];
+        for (int t = 0; t < 2; t++)
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int u = uh + k;
-            const uint4 ao = *(const uint4 *)(ap + u * 64);
-            al[k] = g4k_pack(ao.z, ao.w);
-            const uint32_t b0 = (u & 1) ? bq[u >> 1].z : bq[u >> 1].x, b1 = (u & 1) ? bq[u >> 1].w : bq[u >> 1].y;
-            bb[k] = g4k_pack(b0, b1);
-            const g4k_i32x4 z = {0, 0, 0, 0};
-            cc[k] = __builtin_amdgcn_mfma_i32_16x16x32_i8(g4k_pack(ao.x, ao.y), bb[k], z, 0, 0, 0);
-        }
+            for (int r = 0; r < 4; r++) {
 #pragma unroll
-        for (int k = 0; k < 4; k++) cc[k] = __builtin_amdgcn_mfma_i32_16x16x32_i8(al[k], bb[k], cc[k] << 3, 0, 0, 0); // sumi[u] of rows 4 kb + r, this lane's column
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-#pragma unroll
-            for (int r = 0; r < 4; r++) T.acc[r][uh + k] = __fmaf_rn(dr[r], (float)cc[k][r], T.acc[r][uh + k]);
-        }
+                for (int k = 0; k < 4; k++) acc[t][r][k] = 0.f;
+                accm[t][r][0] = accm[t][r][1] = 0.f;
+            }
     }
-    // acc_m: the lanes of k-group 0 supply the row's mins operands, the others zeros; B = the column's fp16 16-sums
-    const char *mp = kb == 0 ? st + G4K_MINS + m * 32 : zero;
-    const uint4 ma = *(const uint4 *)mp, mb = *(const uint4 *)(mp + 16);
+};
+
+// one super-block.  B[k] = this lane's B operand for accumulator lane 4 uh + k (loaded a step ago); as soon as both row
+// tiles have met it its registers take the load for the NEXT super-block (nq)
+__device__ __forceinline__ void g4k_superblock(G4KAcc &T, const char *st, const char *zero, ps_u32x4 (&B)[4], const char *nq, const G4KMeta M,
+                                               const int m, const int kb, const int uh) {
+    const g4k_f4 zf = {0.f, 0.f, 0.f, 0.f};
+    float dr[2][4], dmin[2][4];
 #pragma unroll
-    for (int v = 0; v < 4; v++) {
-        const uint32_t ax = v == 0 ? ma.x : v == 1 ? ma.z : v == 2 ? mb.x : mb.z, ay = v == 0 ? ma.y : v == 1 ? ma.w : v == 2 ? mb.y : mb.w;
-        const uint32_t bx = v == 0 ? b16a.x : v == 1 ? b16a.z : v == 2 ? b16b.x : b16b.z;
-        const uint32_t by = v == 0 ? b16a.y : v == 1 ? b16a.w : v == 2 ? b16b.y : b16b.w;
-        g4k_h2 a0, a1, g0, g1;
-        __builtin_memcpy(&a0, &ax, 4); __builtin_memcpy(&a1, &ay, 4); __builtin_memcpy(&g0, &bx, 4); __builtin_memcpy(&g1, &by, 4);
-        const g4k_h4 am = {a0[0], a0[1], a1[0], a1[1]}, bm = {g0[0], g0[1], g1[0], g1[1]};
-        const g4k_f4 zf = {0.f, 0.f, 0.f, 0.f};
-        const g4k_f4 pr = __builtin_amdgcn_mfma_f32_16x16x16f16(am, bm, zf, 0, 0, 0);
+    for (int t = 0; t < 2; t++) {
+        const g4k_f4 dda = *(const g4k_f4 *)(st + G4K_DD + (16 * t + 4 * kb) * 8), ddb = *(const g4k_f4 *)(st + G4K_DD + (16 * t + 4 * kb) * 8 + 16); // (d, dmin) of rows 4 kb + r
+        dr[t][0] = __fmul_rn(M.yd, dda[0]); dr[t][1] = __fmul_rn(M.yd, dda[2]); dr[t][2] = __fmul_rn(M.yd, ddb[0]); dr[t][3] = __fmul_rn(M.yd, ddb[2]);
+        dmin[t][0] = __fmul_rn(-M.yd, dda[1]); dmin[t][1] = __fmul_rn(-M.yd, dda[3]); dmin[t][2] = __fmul_rn(-M.yd, ddb[1]); dmin[t][3] = __fmul_rn(-M.yd, ddb[3]);
+    }
+    const char *ap = st + m * G4K_RS + (4 * uh) * 64 + kb * 16;
 #pragma unroll
-        for (int r = 0; r < 4; r++) T.accm[r][v] = __fmaf_rn(dmin[r], pr[r], T.accm[r][v]);
+    for (int k = 0; k < 4; k++) {
+        g4k_h8 bv;
+        __builtin_memcpy(&bv, &B[k], 16);
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            const ps_u32x4 ao = *(const ps_u32x4 *)(ap + t * 16 * G4K_RS + k * 64);
+            g4k_h8 av;
+            __builtin_memcpy(&av, &ao, 16);
+            const g4k_f4 si = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bv, zf, 0, 0, 0); // (float)sumi[4 uh + k] of rows 4 kb + r, this lane's column
+#pragma unroll
+            for (int r = 0; r < 4; r++) T.acc[t][r][k] = __fmaf_rn(dr[t][r], si[r], T.acc[t][r][k]);
+        }
+        B[k] = *(const ps_u32x4 *)(nq + k * 1024);
+    }
+    // acc_m lanes 2 uh, 2 uh + 1: the lanes of k-group 0 supply the row's mins operands, the others zeros; B = the column's fp16 16-sums
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        const char *mp = kb == 0 ? st + G4K_MINS + (16 * t + m) * 32 + uh * 16 : zero;
+        const uint4 ma = *(const uint4 *)mp;
+#pragma unroll
+        for (int vv = 0; vv < 2; vv++) {
+            const uint32_t ax = vv ? ma.z : ma.x, ay = vv ? ma.w : ma.y, bx = vv ? M.b16.z : M.b16.x, by = vv ? M.b16.w : M.b16.y;
+            g4k_h2 a0, a1, g0, g1;
+            __builtin_memcpy(&a0, &ax, 4); __builtin_memcpy(&a1, &ay, 4); __builtin_memcpy(&g0, &bx, 4); __builtin_memcpy(&g1, &by, 4);
+            const g4k_h4 am = {a0[0], a0[1], a1[0], a1[1]}, bm = {g0[0], g0[1], g1[0], g1[1]};
+            const g4k_f4 pr = __builtin_amdgcn_mfma_f32_16x16x16f16(am, bm, zf, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; r++) T.accm[t][r][vv] = __fmaf_rn(dmin[t][r], pr[r], T.accm[t][r][vv]);
+        }
     }
 }
 
-// one tile of the consumers' walk: `s_first` = index of its first step in the workgroup's stage sequence (LDS stage = step % 2)
-__device__ __forceinline__ void g4k_tile(const int nsb, const int8_t *qf_ct, const uint8_t *mf_ct, const int mc, const char *lds, const char *zero,
-                                         const int s_first, float (&y)[4], unsigned long long *dbg, int &dbg_n) {
-    const int lane = threadIdx.x & 63, m = lane & 15, kb = lane >> 4;
-    auto mark = [&](int g) { if (dbg && (g < 8 || (g & 7) == 7) && dbg_n < 29) dbg[dbg_n++] = __builtin_amdgcn_s_memtime(); };
-    G4KAcc T;
-    T.clear();
-    ps_u32x4 bn[4]; // the B fragments of the next super-block (L2: a few hundred cycles -- one step ahead is enough)
-#pragma unroll
-    for (int up = 0; up < 4; up++) bn[up] = *(const ps_u32x4 *)(qf_ct + up * 1024 + lane * 16);
-    for (int sb = 0; sb < nsb; sb++) {
-        const ps_u32x4 bq[4] = {bn[0], bn[1], bn[2], bn[3]};
-        const uint8_t *mfs = mf_ct + (size_t)sb * 576; // the (column tile, super-block) block: d[16], then the fp16 16-sums [16][16]
-        const float yd = *(const float *)(mfs + mc * 4);
-        const ps_u32x4 b16a = *(const ps_u32x4 *)(mfs + 64 + mc * 32), b16b = *(const ps_u32x4 *)(mfs + 64 + mc * 32 + 16);
-        {
-            const int nb = sb + 1 == nsb ? 0 : sb + 1; // (the following tile of an EPI 1 pair meets the same columns from super-block 0)
-#pragma unroll
-            for (int up = 0; up < 4; up++) bn[up] = *(const ps_u32x4 *)(qf_ct + ((size_t)nb << 12) + up * 1024 + lane * 16);
-        }
-        if (!(sb & 1)) __syncthreads(); // (s_first is even) the producers have parked this step and the next
-        mark(s_first + sb);
-        g4k_superblock(T, lds + ((s_first + sb) & 3) * G4K_STAGE, zero, bq, yd, b16a, b16b, m, kb);
-    }
-    T.reduce(y);
-}
-
-// twelve waves: the eight column tiles of ONE row task (128 columns per workgroup) + the four producers
+// twelve waves: (4 column tiles x 2 accumulator halves) on two row tiles + the four producers
 template <int EPI>
 __global__ __launch_bounds__((G4K_NC + G4K_NP) * 64) void gemm4k_kernel(const G4KParams p) {
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int m = lane & 15, kb = lane >> 4;
-    // wave -> (row task, column tile)
-    const int ct = (int)blockIdx.y * 8 + (wave & 7);
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    if (threadIdx.x < 8) ((uint32_t *)(lds + G4K_NST * G4K_STAGE))[threadIdx.x] = 0u; // the zero operands (visible after the first barrier)
+    // task -> the two row tiles
     const int task = (int)blockIdx.x; // (grid.x = tasks exactly; every wave stays for the barriers)
-    __shared__ __attribute__((aligned(16))) char lds[4 * G4K_STAGE + 32];
-    if (threadIdx.x < 8) ((uint32_t *)(lds + 4 * G4K_STAGE))[threadIdx.x] = 0u; // the zero operands (visible after barrier #0)
-    int wi = 0, tile = task;
+    int wi = 0, pair = task;
     if (EPI != 1) {
-        if (p.n_w > 1 && tile >= p.w[0].n_tiles) { tile -= p.w[0].n_tiles; wi = 1; }
-        if (p.n_w > 2 && wi == 1 && tile >= p.w[1].n_tiles) { tile -= p.w[1].n_tiles; wi = 2; }
+        if (p.n_w > 1 && pair >= p.w[0].n_tiles / 2) { pair -= p.w[0].n_tiles / 2; wi = 1; }
+        if (p.n_w > 2 && wi == 1 && pair >= p.w[1].n_tiles / 2) { pair -= p.w[1].n_tiles / 2; wi = 2; }
     }
     const G4KMat &W = wi == 0 ? p.w[0] : (wi == 1 ? p.w[1] : p.w[2]);
+    G4KRows R;
+    if (EPI == 1) { R.qs[0] = p.w[0].qs; R.aux[0] = p.w[0].aux; R.qs[1] = p.w[1].qs; R.aux[1] = p.w[1].aux; R.tile[0] = R.tile[1] = task; }
+    else { R.qs[0] = R.qs[1] = W.qs; R.aux[0] = R.aux[1] = W.aux; R.tile[0] = 2 * pair; R.tile[1] = 2 * pair + 1; }
     // timeline: consumer wave 0 -> words 0..31, producer wave 8 -> 32..63 of the workgroup's slot ([0]/[31] entry / exit clock, [29]/[30] 100 MHz)
     unsigned long long *const dbg = (p.dbg && blockIdx.y == 0 && blockIdx.x < 1024 && lane == 0 && (wave == 0 || wave == G4K_NC)) ? p.dbg + ((size_t)blockIdx.x * 2 + (wave == G4K_NC)) * 32 : nullptr;
     if (dbg) { dbg[0] = __builtin_amdgcn_s_memtime(); dbg[29] = __builtin_amdgcn_s_memrealtime(); }
     if (wave >= G4K_NC) {
-        g4k_producer_wave(W.qs, W.aux, EPI == 1 ? p.w[1].qs : W.qs, EPI == 1 ? p.w[1].aux : W.aux, tile, p.nsb, EPI == 1 ? 2 * p.nsb : p.nsb, lds, wave - G4K_NC, dbg);
+        g4k_producer_wave(R, p.nsb, lds, wave - G4K_NC, dbg);
         if (dbg) { dbg[31] = __builtin_amdgcn_s_memtime(); dbg[30] = __builtin_amdgcn_s_memrealtime(); }
         return;
     }
+    const int ctl = wave & 3, uh = wave >> 2;
+    const int ct = (int)blockIdx.y * 4 + ctl;
     const int col = ct * 16 + m, colc = col < p.bs ? col : p.bs - 1; // (the last tile may be ragged: clamp the column metadata)
     const int ctc = ct * 16 < p.bs ? ct : (p.bs - 1) / 16; // (a wave past the batch walks the last tile's columns and stores nothing)
-    const int8_t *qf_ct = p.qf + ((size_t)ctc * p.nsb << 12);
+    const char *qf_ct = (const char *)p.qf + ((size_t)ctc * p.nsb << 13) + (size_t)(4 * uh) * 1024 + lane * 16;
     const uint8_t *mf_ct = p.mf + (size_t)ctc * p.nsb * 576;
     const int mc = colc & 15;
-    const char *zero = lds + 4 * G4K_STAGE;
-    float y[4];
+    const char *zero = lds + G4K_NST * G4K_STAGE;
     int dbg_n = 1;
-    g4k_tile(p.nsb, qf_ct, mf_ct, mc, lds, zero, 0, y, dbg, dbg_n);
-    if (EPI == 1) {
-        float yu[4];
-        g4k_tile(p.nsb, qf_ct, mf_ct, mc, lds, zero, p.nsb, yu, dbg, dbg_n);
+    auto mark = [&](int g) { if (dbg && (g < 8 || (g & 7) == 7) && dbg_n < 29) dbg[dbg_n++] = __builtin_amdgcn_s_memtime(); };
+    ps_u32x4 B[4];
 #pragma unroll
-        for (int r = 0; r < 4; r++) y[r] = ps_silu_mul(y[r], yu[r]);
+    for (int k = 0; k < 4; k++) B[k] = *(const ps_u32x4 *)(qf_ct + k * 1024);
+    G4KMeta M = g4k_meta(mf_ct, 0, mc, uh);
+    G4KAcc T;
+    T.clear();
+    for (int sb = 0; sb < p.nsb; sb++) {
+        const int nb = sb + 1 == p.nsb ? sb : sb + 1;
+        const G4KMeta Mn = g4k_meta(mf_ct, nb, mc, uh); // a step ahead, like B
+        if (!(sb & 1)) __syncthreads(); // the producers have parked this step and the next
+        mark(sb);
+        g4k_superblock(T, lds + (sb & (G4K_NST - 1)) * G4K_STAGE, zero, B, qf_ct + ((size_t)nb << 13), M, m, kb, uh);
+        M = Mn;
     }
-    if (col < p.bs) {
-        const int64_t row0 = (int64_t)tile * 16 + kb * 4;
-        float *o = W.out + (int64_t)col * W.ldo + row0;
-        float v[4];
+    // ---- the two accumulator halves of a tile meet: uh = 1 hands its chains over, uh = 0 finishes hsum_float_8
+    // (ggml-quants.c:62-68: lane u + lane u + 4 first) and the acc_m reduction as row_reduce<PS_Q4_K> does
+    float *xch = (float *)(lds + G4K_XCH) + ((size_t)ctl * 64 + lane) * 48;
+    if (uh == 1) {
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                *(float4 *)(xch + (t * 4 + r) * 4) = make_float4(T.acc[t][r][0], T.acc[t][r][1], T.acc[t][r][2], T.acc[t][r][3]);
+                *(float2 *)(xch + 32 + (t * 4 + r) * 2) = make_float2(T.accm[t][r][0], T.accm[t][r][1]);
+            }
+    }
+    __syncthreads(); // (the producers are gone: a finished wave is not waited for)
+    if (uh == 1) return;
+    float y[2][4];
+#pragma unroll
+    for (int t = 0; t < 2; t++)
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-            v[r] = y[r];
-            if (EPI != 1) {
-                if (W.bias) v[r] = __fadd_rn(v[r], W.bias[row0 + r]);
-                if (p.residual && wi == 0) v[r] = __fadd_rn(p.residual[(int64_t)col * W.ldo + row0 + r], v[r]);
+            const float4 hi = *(const float4 *)(xch + (t * 4 + r) * 4);
+            const float2 mh = *(const float2 *)(xch + 32 + (t * 4 + r) * 2);
+            const float s0 = __fadd_rn(T.acc[t][r][0], hi.x), s1 = __fadd_rn(T.acc[t][r][1], hi.y), s2 = __fadd_rn(T.acc[t][r][2], hi.z), s3 = __fadd_rn(T.acc[t][r][3], hi.w);
+            const float res = __fadd_rn(__fadd_rn(s0, s2), __fadd_rn(s1, s3));
+            const float mm  = __fadd_rn(__fadd_rn(T.accm[t][r][0], mh.x), __fadd_rn(T.accm[t][r][1], mh.y));
+            y[t][r] = __fadd_rn(res, mm);
+        }
+    if (col < p.bs) {
+        if (EPI == 1) {
+            const int64_t row0 = (int64_t)task * 16 + kb * 4;
+            *(float4 *)(W.out + (int64_t)col * W.ldo + row0) =
+                make_float4(ps_silu_mul(y[0][0], y[1][0]), ps_silu_mul(y[0][1], y[1][1]), ps_silu_mul(y[0][2], y[1][2]), ps_silu_mul(y[0][3], y[1][3]));
+        } else {
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                const int64_t row0 = (int64_t)(2 * pair + t) * 16 + kb * 4;
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    v[r] = y[t][r];
+                    if (W.bias) v[r] = __fadd_rn(v[r], W.bias[row0 + r]);
+                    if (p.residual && wi == 0) v[r] = __fadd_rn(p.residual[(int64_t)col * W.ldo + row0 + r], v[r]);
+                }
+                *(float4 *)(W.out + (int64_t)col * W.ldo + row0) = make_float4(v[0], v[1], v[2], v[3]);
             }
         }
-        *(float4 *)o = make_float4(v[0], v[1], v[2], v[3]);
     }
     if (dbg) { dbg[31] = __builtin_amdgcn_s_memtime(); dbg[30] = __builtin_amdgcn_s_memrealtime(); }
 }
@@ -308,28 +341,31 @@ int psk_gemm4k(hipStream_t st, int n_cu, const psk_gemv_args &a, ps_act act, int
     static const bool off = getenv("PS_NO_GEMM4K") != nullptr; // (A/B switch for measurements)
     if (off || a.pro != 0 || a.rope || a.n_w < 1 || !act.qf || K % 256) return -1;
     G4KParams p{};
-    int tiles_total = 0;
+    int pairs_total = 0;
     for (int i = 0; i < a.n_w; i++) {
-        if (a.w[i]->dtype != PS_Q4_K || a.w[i]->K != K || a.w[i]->N % 16 || a.ldo[i] % 4) return -1;
+        if (a.w[i]->dtype != PS_Q4_K || a.w[i]->K != K || a.w[i]->N % 32 || a.ldo[i] % 4) return -1;
         p.w[i] = G4KMat{a.w[i]->qs, a.w[i]->aux, a.out[i], a.bias[i], a.w[i]->N, a.ldo[i], (int)(a.w[i]->N / 16)};
-        tiles_total += p.w[i].n_tiles;
+        pairs_total += p.w[i].n_tiles / 2;
     }
     const int epi = a.silu_pair ? 1 : 0;
     if (epi == 1 && (a.n_w != 2 || a.w[0]->N != a.w[1]->N || a.ldo[0] != a.ldo[1])) return -1;
     p.n_w = a.n_w; p.nsb = (int)(K / 256); p.bs = (int)bs;
-    p.n_tasks = epi == 1 ? p.w[0].n_tiles : tiles_total;
+    p.n_tasks = epi == 1 ? p.w[0].n_tiles : pairs_total;
     p.residual = a.residual; p.qf = act.qf; p.mf = act.mf;
     p.dbg = psk_gemv_dbg_buf(12 + epi, epi ? 0 : (a.n_w == 3 ? 0 : (K <= 8192 ? 1 : 2))); // keys 48 QKV, 49 O, 50 down, 52 gate/up
     const int n_ct = (int)((bs + 15) / 16);
-    // Below eight column tiles a workgroup's waves would not share their weight rows any more, and the kernels that spread
-    // a row group's integer work over producer waves (gemm8) are ahead there: tree forward of the 8B shape, ms by width,
-    // this kernel / gemm8: 2: 12.5 / 4.9, 12: 13.7 / 6.4, 32: 14.4 / 9.2, 64: 18.3 / 13.3, 128: 17.0 / 22.9
-    // (profiles/r02_tree_forward_latency_8b.json).
+    // Below eight column tiles the kernels that spread a row group's integer work over producer waves (gemm8) are ahead:
+    // tree forward of the 8B shape, profiles/r02_tree_forward_latency_8b.json.
     if (n_ct < 8 || p.nsb % 4) return -1;
     (void)n_cu;
-    const dim3 grid((unsigned)p.n_tasks, (unsigned)((n_ct + 7) / 8));
+    const dim3 grid((unsigned)p.n_tasks, (unsigned)((n_ct + 3) / 4));
     static_assert(G4K_RING == 4, "nsb % 4 == 0 is what the producers' ring is unrolled for");
-    if (epi == 1) hipLaunchKernelGGL((gemm4k_kernel<1>), grid, dim3((G4K_NC + G4K_NP) * 64), 0, st, p);
-    else hipLaunchKernelGGL((gemm4k_kernel<0>), grid, dim3((G4K_NC + G4K_NP) * 64), 0, st, p);
+    static unsigned long long attr = 0; // devices that have the attribute
+    if (ps_first_on_device(&attr)) {
+        (void)hipFuncSetAttribute((const void *)gemm4k_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, G4K_LDS);
+        (void)hipFuncSetAttribute((const void *)gemm4k_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, G4K_LDS);
+    }
+    if (epi == 1) hipLaunchKernelGGL((gemm4k_kernel<1>), grid, dim3((G4K_NC + G4K_NP) * 64), G4K_LDS, st, p);
+    else hipLaunchKernelGGL((gemm4k_kernel<0>), grid, dim3((G4K_NC + G4K_NP) * 64), G4K_LDS, st, p);
     return 0;
 }

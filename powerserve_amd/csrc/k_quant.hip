@@ -25,7 +25,7 @@ struct QuantArgs {
     int8_t *qs;
     float *d;
     int16_t *bs16;
-    int8_t *qf; // Q8_K batches: fragment-major copy for k_gemm4k.hip, or null
+    _Float16 *qf; // Q8_K batches: fragment-major fp16 copy for k_gemm4k.hip, or null
     uint8_t *mf; // ... and the tile-major copy of the column metadata (ps_act::mf), with qf
 };
 

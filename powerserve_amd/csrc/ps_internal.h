@@ -56,14 +56,14 @@ struct ps_weight {
 //   qs   [rows][K] int8
 //   d    [rows][K/blk] float   (Q8_0: the fp16-rounded scale widened back to fp32; Q8_K: fp32 scale)
 //   bs16 [rows][K/16] int16    sums of 16 consecutive quants (== block_q8_K.bsums; also kept for Q8_0)
-//   qf   Q8_K only, optional: a second copy of the quants in the fragment-major order of the Q4_K batched mat-mul
-//        (k_gemm4k.hip): per (16 columns, super-block) 4 KiB  [u / 2][lane = kb * 16 + column % 16][u % 2][half][4 B]
-//        = quants 4u..4u+3 of sub-block 2 kb + half
+//   qf   Q8_K only, optional: a second copy of the quants AS FP16 (exact: |q| <= 127) in the fragment-major order of the
+//        Q4_K batched mat-mul (k_gemm4k.hip): per (16 columns, super-block) 8 KiB  [u][lane = kb * 16 + column % 16][half][4]
+//        = quants 4u + (0, 2, 1, 3) of sub-block 2 kb + half -- one 16-B B operand of v_mfma_f32_16x16x32_f16 per lane and u
 struct ps_act {
     int8_t *qs;
     float *d;
     int16_t *bs16;
-    int8_t *qf;
+    _Float16 *qf;
     uint8_t *mf; // with qf: the column metadata tile-major, per (16 columns, super-block) 576 B = d[16] (fp32) then bsums[16][16]
                  // (int16): a wave of the Q4_K batched mat-mul reads its 16 columns' scale and sums from 5 cache lines, not 48
 };
@@ -96,7 +96,7 @@ static inline bool ps_first_on_device(unsigned long long *mask) {
 static inline size_t ps_act_bytes(int64_t K, int64_t rows) {
     // qs + d (worst case blk 32) + bs16, each 256-B aligned
     auto al = [](size_t x) { return (x + 255) / 256 * 256; };
-    return al((size_t)K * rows) + al((size_t)(K / 32) * rows * 4) + al((size_t)(K / 16) * rows * 2) + al((size_t)K * ((rows + 15) / 16 * 16)) + al((size_t)((rows + 15) / 16) * (K / 256 + 1) * 576);
+    return al((size_t)K * rows) + al((size_t)(K / 32) * rows * 4) + al((size_t)(K / 16) * rows * 2) + al((size_t)K * ((rows + 15) / 16 * 16) * 2) + al((size_t)((rows + 15) / 16) * (K / 256 + 1) * 576);
 }
 static inline ps_act ps_act_carve(void *base, int64_t K, int64_t rows) {
     auto al = [](size_t x) { return (x + 255) / 256 * 256; };
@@ -108,8 +108,8 @@ static inline ps_act ps_act_carve(void *base, int64_t K, int64_t rows) {
     p += al((size_t)(K / 32) * rows * 4);
     a.bs16 = (int16_t *)p;
     p += al((size_t)(K / 16) * rows * 2);
-    a.qf = (int8_t *)p;
-    p += al((size_t)K * ((rows + 15) / 16 * 16));
+    a.qf = (_Float16 *)p;
+    p += al((size_t)K * ((rows + 15) / 16 * 16) * 2);
     a.mf = (uint8_t *)p;
     return a;
 }

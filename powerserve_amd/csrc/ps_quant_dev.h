@@ -20,7 +20,7 @@ __device__ __forceinline__ float ps_silu_mul(float g, float u) {
 template <int VDT>
 __device__ __forceinline__ void ps_quantize_tile(const float v[4], bool live, int64_t e, int64_t t, int8_t *qs, float *d,
                                                  int16_t *bs16, int *bs32 = nullptr, // bs32: optional int sums of 32 (two bs16)
-                                                 int8_t *qf = nullptr, int64_t col = 0, int64_t nsb = 0, // qf: fragment-major copy (ps_act::qf)
+                                                 _Float16 *qf = nullptr, int64_t col = 0, int64_t nsb = 0, // qf: fragment-major fp16 copy (ps_act::qf)
                                                  uint8_t *mf = nullptr) { // mf: tile-major copy of the column metadata (ps_act::mf)
     const int lane = threadIdx.x & 63;
     int q[4];
@@ -59,9 +59,11 @@ __device__ __forceinline__ void ps_quantize_tile(const float v[4], bool live, in
         const uint32_t packed = (uint32_t)(q[0] & 0xff) | ((uint32_t)(q[1] & 0xff) << 8) |
                                 ((uint32_t)(q[2] & 0xff) << 16) | ((uint32_t)(q[3] & 0xff) << 24);
         *(uint32_t *)(qs + e) = packed;
-        if (qf) { // lane = (sub-block g, quad u) of super-block t: [16-column tile][t][u / 2][kb * 16 + col % 16][u % 2][half]
+        if (qf) { // lane = (sub-block g, quad u) of super-block t: [16-column tile][t][u][kb * 16 + col % 16][half][e0, e2, e1, e3]
             const int g = lane >> 3, u = lane & 7;
-            *(uint32_t *)(qf + ((((col >> 4) * nsb + t) << 12) + ((u >> 1) << 10) + ((((g >> 1) << 4) + (col & 15)) << 4) + ((u & 1) << 3) + ((g & 1) << 2))) = packed;
+            typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+            const h4 hv = {(_Float16)(float)q[0], (_Float16)(float)q[2], (_Float16)(float)q[1], (_Float16)(float)q[3]};
+            *(h4 *)((char *)qf + ((((col >> 4) * nsb + t) << 13) + (u << 10) + ((((g >> 1) << 4) + (col & 15)) << 4) + ((g & 1) << 3))) = hv;
         }
         if ((lane & 3) == 0) {
             bs16[e / 16] = (int16_t)s16;
@@ -168,7 +170,7 @@ __device__ __forceinline__ void ps_qrow_compute(const float4 (&xv)[TPW], const f
 // Ends with __syncthreads().
 template <int VDT, int MODE, int TPW>
 __device__ __forceinline__ void ps_quantize_row_wg(const float *x, const float *w, float eps, int64_t K, int8_t *qs, float *d,
-                                                   int16_t *bs16, double *red, int8_t *qf = nullptr, int64_t col = 0, uint8_t *mf = nullptr) {
+                                                   int16_t *bs16, double *red, _Float16 *qf = nullptr, int64_t col = 0, uint8_t *mf = nullptr) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int64_t n_tiles = (K + 255) / 256;
     for (int64_t t0 = 0; t0 < n_tiles; t0 += (int64_t)nw * TPW) { // one trip when K <= nw*TPW*256 (always, for MODE 1)
