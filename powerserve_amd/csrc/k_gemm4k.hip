@@ -55,7 +55,7 @@ struct G4KMat {
 };
 struct G4KParams {
     G4KMat w[3];
-    int n_w, nsb, bs, n_tasks;
+    int n_w, nsb, bs, n_tasks, n_cb, n_items; // n_cb: 64-column blocks; items = (task, column block), tasks padded to a multiple of 8
     const float *residual;
     const _Float16 *qf; // fragment-major fp16 quants
     const uint8_t *mf;  // tile-major column metadata (ps_act::mf)
@@ -71,7 +71,8 @@ constexpr int G4K_RS = 528, G4K_MINS = 32 * G4K_RS, G4K_DD = G4K_MINS + 32 * 32,
 constexpr int G4K_NC = 8, G4K_NP = 4, G4K_RING = 4; // computing waves, producing waves, super-blocks in flight per producer
 constexpr int G4K_NST = 4;                          // LDS stages
 constexpr int G4K_XCH = G4K_NST * G4K_STAGE + 32;   // after the stages and the 32 zero bytes: the end-of-tile exchange, [ct][lane][48 floats]
-constexpr int G4K_LDS = G4K_XCH + 4 * 64 * 48 * 4;
+constexpr int G4K_TAB = G4K_XCH + 4 * 64 * 48 * 4;   // glibc expf's exp2 table (ps_expf.h), for the SiLU epilogue: an LDS look-up, not a global one
+constexpr int G4K_LDS = G4K_TAB + PS_EXP2F_N * 8;
 
 // the two row tiles of a task
 struct G4KRows { const uint8_t *qs[2], *aux[2]; int tile[2]; };
@@ -134,34 +135,87 @@ __device__ __forceinline__ void g4k_produce(const uint2 q0, const uint2 q1, cons
     if (hw == 1 && p == 0) *(float2 *)(st + G4K_DD + row * 8) = make_float2(ps_h2f((uint16_t)(h.x & 0xffff)), ps_h2f((uint16_t)(h.x >> 16))); // (d, dmin)
 }
 
-__device__ __forceinline__ void g4k_producer_wave(const G4KRows R, const int nsb, char *lds, const int hw, unsigned long long *dbg) {
-    const int lane = threadIdx.x & 63;
+// item i -> (task, column block): 16 consecutive items are 8 tasks x 2 column blocks (for n_cb = 2), the two blocks of a task
+// 8 apart -- the same XCD at the same time, so the second one finds the weights in that L2
+__device__ __forceinline__ void g4k_item(const G4KParams &p, const int i, int &task, int &cb) {
+    cb = (i >> 3) % p.n_cb;
+    task = (i / (8 * p.n_cb)) * 8 + (i & 7);
+}
+template <int EPI>
+__device__ __forceinline__ G4KRows g4k_rows(const G4KParams &p, const int task, int &wi, int &pair) {
+    wi = 0; pair = task;
+    if (EPI != 1) {
+        if (p.n_w > 1 && pair >= p.w[0].n_tiles / 2) { pair -= p.w[0].n_tiles / 2; wi = 1; }
+        if (p.n_w > 2 && wi == 1 && pair >= p.w[1].n_tiles / 2) { pair -= p.w[1].n_tiles / 2; wi = 2; }
+    }
+    const G4KMat &W = wi == 0 ? p.w[0] : (wi == 1 ? p.w[1] : p.w[2]);
+    G4KRows R;
+    if (EPI == 1) { R.qs[0] = p.w[0].qs; R.aux[0] = p.w[0].aux; R.qs[1] = p.w[1].qs; R.aux[1] = p.w[1].aux; R.tile[0] = R.tile[1] = task; }
+    else { R.qs[0] = R.qs[1] = W.qs; R.aux[0] = R.aux[1] = W.aux; R.tile[0] = 2 * pair; R.tile[1] = 2 * pair + 1; }
+    return R;
+}
+__device__ __forceinline__ int g4k_next_item(const G4KParams &p, int i) { // the next item of this workgroup with a real task, or n_items
+    for (i += (int)gridDim.x; i < p.n_items; i += (int)gridDim.x) {
+        int t, c;
+        g4k_item(p, i, t, c);
+        if (t < p.n_tasks) break;
+    }
+    return i < p.n_items ? i : p.n_items;
+}
+
+// The producers of a PERSISTENT workgroup: the stage stream runs on across the workgroup's items -- the ring is already
+// loading the next item's first super-blocks while the consumers finish this one, and its first two stages are parked
+// before the consumers' end-of-item exchange barrier (X), so a new item starts at full speed.
+template <int EPI>
+__device__ __forceinline__ void g4k_producer_wave(const G4KParams &p, int item, char *lds, const int hw, unsigned long long *dbg) {
+    const int lane = threadIdx.x & 63, nsb = p.nsb;
     int dbg_n = 1;
     auto mark = [&](int g) { if (dbg && (g < 8 || (g & 7) == 7) && dbg_n < 29) dbg[dbg_n++] = __builtin_amdgcn_s_memtime(); };
-    const int row = lane >> 1, p = lane & 1, rt = row >> 4, unit = (row >> 3) & 1, r8 = row & 7;
-    const uint8_t *qb = (rt ? R.qs[1] : R.qs[0]) + ((size_t)(2 * (rt ? R.tile[1] : R.tile[0]) + unit) * nsb << 10) + (size_t)(r8 * 32 + 2 * hw * 4 + 2 * p) * 4;
-    const uint8_t *hb = (rt ? R.aux[1] : R.aux[0]) + (size_t)(2 * (rt ? R.tile[1] : R.tile[0]) + unit) * nsb * 128 + (size_t)r8 * 16;
+    const int row = lane >> 1, pp = lane & 1, rt = row >> 4, unit = (row >> 3) & 1, r8 = row & 7;
+    const uint8_t *qb, *hb; // the load cursor's item
+    auto point = [&](int it) {
+        int task, cb, wi, pair;
+        g4k_item(p, it, task, cb);
+        const G4KRows R = g4k_rows<EPI>(p, task, wi, pair);
+        qb = (rt ? R.qs[1] : R.qs[0]) + ((size_t)(2 * (rt ? R.tile[1] : R.tile[0]) + unit) * nsb << 10) + (size_t)(r8 * 32 + 2 * hw * 4 + 2 * pp) * 4;
+        hb = (rt ? R.aux[1] : R.aux[0]) + (size_t)(2 * (rt ? R.tile[1] : R.tile[0]) + unit) * nsb * 128 + (size_t)r8 * 16;
+    };
     uint2 rq0[G4K_RING], rq1[G4K_RING];
     uint4 rh[G4K_RING];
-    auto load = [&](int g, uint2 &a, uint2 &b, uint4 &h) { // (stages past the end are clamped, never branched over)
-        g = g < nsb ? g : nsb - 1;
+    auto load = [&](int g, uint2 &a, uint2 &b, uint4 &h) {
         a = *(const uint2 *)(qb + ((size_t)g << 10));
         b = *(const uint2 *)(qb + ((size_t)g << 10) + 16);
         h = *(const uint4 *)(hb + (size_t)g * 128);
     };
+    point(item);
 #pragma unroll
     for (int k = 0; k < G4K_RING; k++) load(k, rq0[k], rq1[k], rh[k]);
-    for (int g0 = 0; g0 < nsb; g0 += G4K_RING) { // (nsb % G4K_RING == 0: psk_gemm4k checks)
+    int c_item = item, c_g = G4K_RING; // the cursor: the ring's next loads
+    bool first = true;
+    while (item < p.n_items) {
+        for (int g0 = 0; g0 < nsb; g0 += G4K_RING) { // (nsb % G4K_RING == 0: psk_gemm4k checks)
+            if (c_g == nsb) { // the ring moves on to the workgroup's next item (past the last one: reloads that one's tail, unused)
+                const int nx = g4k_next_item(p, c_item);
+                if (nx < p.n_items) { c_item = nx; c_g = 0; point(nx); } else c_g = nsb - G4K_RING;
+            }
 #pragma unroll
-        for (int k = 0; k < G4K_RING; k++) {
-            const uint2 a = rq0[k], b = rq1[k];
-            const uint4 h = rh[k];
-            load(g0 + k + G4K_RING, rq0[k], rq1[k], rh[k]);
-            g4k_produce(a, b, h, lds + ((g0 + k) & (G4K_NST - 1)) * G4K_STAGE, row, hw, p);
-            if (k & 1) __syncthreads(); // one barrier per PAIR of stages: stages g0 + k - 1, g0 + k are parked
-            mark(g0 + k);
+            for (int k = 0; k < G4K_RING; k++) {
+                const uint2 a = rq0[k], b = rq1[k];
+                const uint4 h = rh[k];
+                load(c_g + k, rq0[k], rq1[k], rh[k]);
+                g4k_produce(a, b, h, lds + ((g0 + k) & (G4K_NST - 1)) * G4K_STAGE, row, hw, pp);
+                if (k & 1) {
+                    if (g0 == 0 && k == 1 && !first) __syncthreads(); // X of the previous item: its consumers have exchanged
+                    __syncthreads(); // one barrier per PAIR of stages: stages g0 + k - 1, g0 + k are parked
+                }
+                mark(g0 + k);
+            }
+            c_g += G4K_RING;
         }
+        first = false;
+        item = g4k_next_item(p, item);
     }
+    __syncthreads(); // X of the last item
 }
 
 // ---- consumers
@@ -235,101 +289,142 @@ __device__ __forceinline__ void g4k_superblock(G4KAcc &T, const char *st, const 
     }
 }
 
-// twelve waves: (4 column tiles x 2 accumulator halves) on two row tiles + the four producers
+// twelve waves: (4 column tiles x 2 accumulator halves) on two row tiles + the four producers; persistent over the items
+// blockIdx.x, blockIdx.x + gridDim.x, ... (the launcher keeps the column block of a workgroup fixed across its items)
 template <int EPI>
 __global__ __launch_bounds__((G4K_NC + G4K_NP) * 64) void gemm4k_kernel(const G4KParams p) {
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int m = lane & 15, kb = lane >> 4;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     if (threadIdx.x < 8) ((uint32_t *)(lds + G4K_NST * G4K_STAGE))[threadIdx.x] = 0u; // the zero operands (visible after the first barrier)
-    // task -> the two row tiles
-    const int task = (int)blockIdx.x; // (grid.x = tasks exactly; every wave stays for the barriers)
-    int wi = 0, pair = task;
-    if (EPI != 1) {
-        if (p.n_w > 1 && pair >= p.w[0].n_tiles / 2) { pair -= p.w[0].n_tiles / 2; wi = 1; }
-        if (p.n_w > 2 && wi == 1 && pair >= p.w[1].n_tiles / 2) { pair -= p.w[1].n_tiles / 2; wi = 2; }
+    if (EPI == 1 && threadIdx.x >= 64 && threadIdx.x < 64 + PS_EXP2F_N) ((uint64_t *)(lds + G4K_TAB))[threadIdx.x - 64] = ps_exp2f_tab[threadIdx.x - 64];
+    int item = (int)blockIdx.x;
+    {
+        int t, c;
+        g4k_item(p, item, t, c);
+        if (t >= p.n_tasks) item = g4k_next_item(p, item);
     }
-    const G4KMat &W = wi == 0 ? p.w[0] : (wi == 1 ? p.w[1] : p.w[2]);
-    G4KRows R;
-    if (EPI == 1) { R.qs[0] = p.w[0].qs; R.aux[0] = p.w[0].aux; R.qs[1] = p.w[1].qs; R.aux[1] = p.w[1].aux; R.tile[0] = R.tile[1] = task; }
-    else { R.qs[0] = R.qs[1] = W.qs; R.aux[0] = R.aux[1] = W.aux; R.tile[0] = 2 * pair; R.tile[1] = 2 * pair + 1; }
+    if (item >= p.n_items) return; // (the whole workgroup)
     // timeline: consumer wave 0 -> words 0..31, producer wave 8 -> 32..63 of the workgroup's slot ([0]/[31] entry / exit clock, [29]/[30] 100 MHz)
-    unsigned long long *const dbg = (p.dbg && blockIdx.y == 0 && blockIdx.x < 1024 && lane == 0 && (wave == 0 || wave == G4K_NC)) ? p.dbg + ((size_t)blockIdx.x * 2 + (wave == G4K_NC)) * 32 : nullptr;
+    unsigned long long *const dbg = (p.dbg && blockIdx.x < 1024 && lane == 0 && (wave == 0 || wave == G4K_NC)) ? p.dbg + ((size_t)blockIdx.x * 2 + (wave == G4K_NC)) * 32 : nullptr;
     if (dbg) { dbg[0] = __builtin_amdgcn_s_memtime(); dbg[29] = __builtin_amdgcn_s_memrealtime(); }
     if (wave >= G4K_NC) {
-        g4k_producer_wave(R, p.nsb, lds, wave - G4K_NC, dbg);
+        g4k_producer_wave<EPI>(p, item, lds, wave - G4K_NC, dbg);
         if (dbg) { dbg[31] = __builtin_amdgcn_s_memtime(); dbg[30] = __builtin_amdgcn_s_memrealtime(); }
         return;
     }
     const int ctl = wave & 3, uh = wave >> 2;
-    const int ct = (int)blockIdx.y * 4 + ctl;
+    int task, cb;
+    g4k_item(p, item, task, cb);
+    const int ct = cb * 4 + ctl;
     const int col = ct * 16 + m, colc = col < p.bs ? col : p.bs - 1; // (the last tile may be ragged: clamp the column metadata)
     const int ctc = ct * 16 < p.bs ? ct : (p.bs - 1) / 16; // (a wave past the batch walks the last tile's columns and stores nothing)
     const char *qf_ct = (const char *)p.qf + ((size_t)ctc * p.nsb << 13) + (size_t)(4 * uh) * 1024 + lane * 16;
     const uint8_t *mf_ct = p.mf + (size_t)ctc * p.nsb * 576;
     const int mc = colc & 15;
     const char *zero = lds + G4K_NST * G4K_STAGE;
+    float *xch = (float *)(lds + G4K_XCH) + ((size_t)ctl * 64 + lane) * 48;
     int dbg_n = 1;
     auto mark = [&](int g) { if (dbg && (g < 8 || (g & 7) == 7) && dbg_n < 29) dbg[dbg_n++] = __builtin_amdgcn_s_memtime(); };
     ps_u32x4 B[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) B[k] = *(const ps_u32x4 *)(qf_ct + k * 1024);
     G4KMeta M = g4k_meta(mf_ct, 0, mc, uh);
-    G4KAcc T;
-    T.clear();
-    for (int sb = 0; sb < p.nsb; sb++) {
-        const int nb = sb + 1 == p.nsb ? sb : sb + 1;
-        const G4KMeta Mn = g4k_meta(mf_ct, nb, mc, uh); // a step ahead, like B
-        if (!(sb & 1)) __syncthreads(); // the producers have parked this step and the next
-        mark(sb);
-        g4k_superblock(T, lds + (sb & (G4K_NST - 1)) * G4K_STAGE, zero, B, qf_ct + ((size_t)nb << 13), M, m, kb, uh);
-        M = Mn;
-    }
-    // ---- the two accumulator halves of a tile meet: uh = 1 hands its chains over, uh = 0 finishes hsum_float_8
-    // (ggml-quants.c:62-68: lane u + lane u + 4 first) and the acc_m reduction as row_reduce<PS_Q4_K> does
-    float *xch = (float *)(lds + G4K_XCH) + ((size_t)ctl * 64 + lane) * 48;
-    if (uh == 1) {
-#pragma unroll
-        for (int t = 0; t < 2; t++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                *(float4 *)(xch + (t * 4 + r) * 4) = make_float4(T.acc[t][r][0], T.acc[t][r][1], T.acc[t][r][2], T.acc[t][r][3]);
-                *(float2 *)(xch + 32 + (t * 4 + r) * 2) = make_float2(T.accm[t][r][0], T.accm[t][r][1]);
-            }
-    }
-    __syncthreads(); // (the producers are gone: a finished wave is not waited for)
-    if (uh == 1) return;
-    float y[2][4];
-#pragma unroll
-    for (int t = 0; t < 2; t++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const float4 hi = *(const float4 *)(xch + (t * 4 + r) * 4);
-            const float2 mh = *(const float2 *)(xch + 32 + (t * 4 + r) * 2);
-            const float s0 = __fadd_rn(T.acc[t][r][0], hi.x), s1 = __fadd_rn(T.acc[t][r][1], hi.y), s2 = __fadd_rn(T.acc[t][r][2], hi.z), s3 = __fadd_rn(T.acc[t][r][3], hi.w);
-            const float res = __fadd_rn(__fadd_rn(s0, s2), __fadd_rn(s1, s3));
-            const float mm  = __fadd_rn(__fadd_rn(T.accm[t][r][0], mh.x), __fadd_rn(T.accm[t][r][1], mh.y));
-            y[t][r] = __fadd_rn(res, mm);
-        }
-    if (col < p.bs) {
-        if (EPI == 1) {
-            const int64_t row0 = (int64_t)task * 16 + kb * 4;
-            *(float4 *)(W.out + (int64_t)col * W.ldo + row0) =
-                make_float4(ps_silu_mul(y[0][0], y[1][0]), ps_silu_mul(y[0][1], y[1][1]), ps_silu_mul(y[0][2], y[1][2]), ps_silu_mul(y[0][3], y[1][3]));
-        } else {
+    while (item < p.n_items) {
+        g4k_item(p, item, task, cb);
+        int wi, pair;
+        (void)g4k_rows<EPI>(p, task, wi, pair);
+        const G4KMat &W = wi == 0 ? p.w[0] : (wi == 1 ? p.w[1] : p.w[2]);
+        G4KAcc T;
+        T.clear();
+        auto step = [&](const int sb) {
+            const int nb = sb + 1 == p.nsb ? 0 : sb + 1; // (the next item meets the same columns from super-block 0)
+            const G4KMeta Mn = g4k_meta(mf_ct, nb, mc, uh); // a step ahead, like B
+            if (!(sb & 1)) __syncthreads(); // the producers have parked this step and the next
+            mark(sb);
+            g4k_superblock(T, lds + (sb & (G4K_NST - 1)) * G4K_STAGE, zero, B, qf_ct + ((size_t)nb << 13), M, m, kb, uh);
+            M = Mn;
+        };
+        for (int sb = 0; sb < p.nsb - 1; sb++) step(sb);
+        // what the epilogue adds is fetched a step early (clamped addresses, never a branch around a load).  The epilogue is
+        // shared: accumulator half uh finishes rows 4 kb + 2 uh, + 1 of both tiles.
+        float2 rsd[2], bia[2];
+        if (EPI != 1) {
+            const int cole = col < p.bs ? col : 0;
 #pragma unroll
             for (int t = 0; t < 2; t++) {
-                const int64_t row0 = (int64_t)(2 * pair + t) * 16 + kb * 4;
-                float v[4];
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    v[r] = y[t][r];
-                    if (W.bias) v[r] = __fadd_rn(v[r], W.bias[row0 + r]);
-                    if (p.residual && wi == 0) v[r] = __fadd_rn(p.residual[(int64_t)col * W.ldo + row0 + r], v[r]);
-                }
-                *(float4 *)(W.out + (int64_t)col * W.ldo + row0) = make_float4(v[0], v[1], v[2], v[3]);
+                const int64_t row0 = (int64_t)(2 * pair + t) * 16 + kb * 4 + 2 * uh;
+                rsd[t] = *(const float2 *)((p.residual && wi == 0 ? p.residual : W.out) + (int64_t)cole * W.ldo + row0);
+                bia[t] = *(const float2 *)((W.bias ? W.bias : W.out) + row0);
             }
         }
+        step(p.nsb - 1);
+        // ---- the two accumulator halves of a tile meet (hsum_float_8, ggml-quants.c:62-68, adds lane u to lane u + 4 first:
+        // exactly the two halves; the acc_m reduction as row_reduce<PS_Q4_K> does): each hands the other the chains of the
+        // rows the other finishes
+        {
+            float *mine = xch + uh * 24;
+#pragma unroll
+            for (int t = 0; t < 2; t++)
+#pragma unroll
+                for (int rr = 0; rr < 2; rr++) {
+                    // the other half's rows: 2 (1 - uh) + rr (selects, not a runtime index: the chains stay in registers)
+#define G4K_SEL(arr, k) (uh ? arr[t][rr][k] : arr[t][2 + rr][k])
+                    *(float4 *)(mine + (t * 2 + rr) * 4) = make_float4(G4K_SEL(T.acc, 0), G4K_SEL(T.acc, 1), G4K_SEL(T.acc, 2), G4K_SEL(T.acc, 3));
+                    *(float2 *)(mine + 16 + (t * 2 + rr) * 2) = make_float2(G4K_SEL(T.accm, 0), G4K_SEL(T.accm, 1));
+#undef G4K_SEL
+                }
+        }
+        __syncthreads(); // X: (a whole item of barriers lies between this exchange and the next one's stores)
+        mark(0);
+        {
+            const float *theirs = xch + (1 - uh) * 24;
+            float y[2][2];
+#pragma unroll
+            for (int t = 0; t < 2; t++)
+#pragma unroll
+                for (int rr = 0; rr < 2; rr++) {
+#define G4K_OWN(arr, k) (uh ? arr[t][2 + rr][k] : arr[t][rr][k])
+                    const float4 o4 = *(const float4 *)(theirs + (t * 2 + rr) * 4);
+                    const float2 o2 = *(const float2 *)(theirs + 16 + (t * 2 + rr) * 2);
+                    // lanes u < 4 (and mins lanes 0, 1) are half 0's, lanes u + 4 (mins 2, 3) half 1's
+                    const float s0 = __fadd_rn(G4K_OWN(T.acc, 0), o4.x), s1 = __fadd_rn(G4K_OWN(T.acc, 1), o4.y), s2 = __fadd_rn(G4K_OWN(T.acc, 2), o4.z), s3 = __fadd_rn(G4K_OWN(T.acc, 3), o4.w);
+                    const float res = __fadd_rn(__fadd_rn(s0, s2), __fadd_rn(s1, s3));
+                    const float w0 = G4K_OWN(T.accm, 0), w1 = G4K_OWN(T.accm, 1);
+                    const float ma = uh ? o2.x : w0, mb = uh ? o2.y : w1;   // acc_m lanes 0, 1
+                    const float mc2 = uh ? w0 : o2.x, md = uh ? w1 : o2.y;  // acc_m lanes 2, 3
+#undef G4K_OWN
+                    const float mm = __fadd_rn(__fadd_rn(ma, mc2), __fadd_rn(mb, md));
+                    y[t][rr] = __fadd_rn(res, mm);
+                }
+            if (col < p.bs) {
+                if (EPI == 1) {
+                    const int64_t row0 = (int64_t)task * 16 + kb * 4 + 2 * uh;
+                    const uint64_t *tab = (const uint64_t *)(lds + G4K_TAB);
+                    float o[2];
+#pragma unroll
+                    for (int rr = 0; rr < 2; rr++) // ps_silu_mul with the table in LDS
+                        o[rr] = __fmul_rn(__fmul_rn(y[0][rr], __fdiv_rn(1.0f, __fadd_rn(1.0f, ps_expf_glibc(-y[0][rr], tab)))), y[1][rr]);
+                    *(float2 *)(W.out + (int64_t)col * W.ldo + row0) = make_float2(o[0], o[1]);
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 2; t++) {
+                        const int64_t row0 = (int64_t)(2 * pair + t) * 16 + kb * 4 + 2 * uh;
+                        float v[2];
+                        const float bv[2] = {bia[t].x, bia[t].y}, rv[2] = {rsd[t].x, rsd[t].y};
+#pragma unroll
+                        for (int rr = 0; rr < 2; rr++) {
+                            v[rr] = y[t][rr];
+                            if (W.bias) v[rr] = __fadd_rn(v[rr], bv[rr]);
+                            if (p.residual && wi == 0) v[rr] = __fadd_rn(rv[rr], v[rr]);
+                        }
+                        *(float2 *)(W.out + (int64_t)col * W.ldo + row0) = make_float2(v[0], v[1]);
+                    }
+                }
+            }
+        }
+        mark(0);
+        item = g4k_next_item(p, item);
     }
     if (dbg) { dbg[31] = __builtin_amdgcn_s_memtime(); dbg[30] = __builtin_amdgcn_s_memrealtime(); }
 }
@@ -357,8 +452,13 @@ int psk_gemm4k(hipStream_t st, int n_cu, const psk_gemv_args &a, ps_act act, int
     // Below eight column tiles the kernels that spread a row group's integer work over producer waves (gemm8) are ahead:
     // tree forward of the 8B shape, profiles/r02_tree_forward_latency_8b.json.
     if (n_ct < 8 || p.nsb % 4) return -1;
-    (void)n_cu;
-    const dim3 grid((unsigned)p.n_tasks, (unsigned)((n_ct + 3) / 4));
+    p.n_cb = (n_ct + 3) / 4;
+    p.n_items = (p.n_tasks + 7) / 8 * 8 * p.n_cb;
+    // persistent: one workgroup per CU walks the items w, w + n_wg, ... -- as long as that keeps its column block fixed
+    // (the consumers prefetch the next item's first fragments with this item's column pointers)
+    int n_wg = p.n_items;
+    if (n_cu > 0 && n_wg > n_cu && n_cu % (8 * p.n_cb) == 0) n_wg = n_cu;
+    const dim3 grid((unsigned)n_wg);
     static_assert(G4K_RING == 4, "nsb % 4 == 0 is what the producers' ring is unrolled for");
     static unsigned long long attr = 0; // devices that have the attribute
     if (ps_first_on_device(&attr)) {
