@@ -63,11 +63,12 @@ struct G4KParams {
 };
 
 // One LDS stage = one super-block of the workgroup's 32 rows (row tile t = row / 16), as the consumers want it:
-//   [row][u][kb] 16 B = the fp16 A operand of lane (row % 16, kb) for accumulator lane u; rows padded to 528 B (b128 reads of
-//                       16 rows at one kb hit 16 distinct 16-B bank groups)
+//   [kb][row][u] 16 B = the fp16 A operand of lane (row % 16, kb) for accumulator lane u; rows of 8 operands padded to 144 B
+//                       (9 bank quads: the 16 rows of a tile land on 16 distinct quads) and the kb planes a multiple of 16
+//                       quads apart, so each 16-lane group of a ds_read_b128 (which mixes lanes of two kb) is conflict-free
 //   [row] 32 B   = the mins as the four fp16 A operands (m[2v], m[2v], m[2v+1], m[2v+1]), v = 0..3
 //   [row] 8 B    = (d, dmin) as fp32
-constexpr int G4K_RS = 528, G4K_MINS = 32 * G4K_RS, G4K_DD = G4K_MINS + 32 * 32, G4K_STAGE = G4K_DD + 32 * 8;
+constexpr int G4K_RS = 144, G4K_KB = 32 * G4K_RS, G4K_MINS = 4 * G4K_KB, G4K_DD = G4K_MINS + 32 * 32, G4K_STAGE = G4K_DD + 32 * 8;
 constexpr int G4K_NC = 8, G4K_NP = 4, G4K_RING = 4; // computing waves, producing waves, super-blocks in flight per producer
 constexpr int G4K_NST = 4;                          // LDS stages
 constexpr int G4K_XCH = G4K_NST * G4K_STAGE + 32;   // after the stages and the 32 zero bytes: the end-of-tile exchange, [ct][lane][48 floats]
@@ -110,7 +111,7 @@ __device__ __forceinline__ void g4k_produce(const uint2 q0, const uint2 q1, cons
                 v = __builtin_elementwise_fma(v, sc[2 * e + (k >> 1)], nc[2 * e + (k >> 1)]);
                 __builtin_memcpy(&o[k], &v, 4);
             }
-            *(uint4 *)(st + row * G4K_RS + (2 * hw + j) * 64 + (2 * p + e) * 16) = make_uint4(o[0], o[1], o[2], o[3]);
+            *(uint4 *)(st + (2 * p + e) * G4K_KB + row * G4K_RS + (2 * hw + j) * 16) = make_uint4(o[0], o[1], o[2], o[3]);
         }
     }
     if (hw == 0 && p == 0) { // once per row: the mins operands
@@ -255,14 +256,14 @@ __device__ __forceinline__ void g4k_superblock(G4KAcc &T, const char *st, const 
         dr[t][0] = __fmul_rn(M.yd, dda[0]); dr[t][1] = __fmul_rn(M.yd, dda[2]); dr[t][2] = __fmul_rn(M.yd, ddb[0]); dr[t][3] = __fmul_rn(M.yd, ddb[2]);
         dmin[t][0] = __fmul_rn(-M.yd, dda[1]); dmin[t][1] = __fmul_rn(-M.yd, dda[3]); dmin[t][2] = __fmul_rn(-M.yd, ddb[1]); dmin[t][3] = __fmul_rn(-M.yd, ddb[3]);
     }
-    const char *ap = st + m * G4K_RS + (4 * uh) * 64 + kb * 16;
+    const char *ap = st + kb * G4K_KB + m * G4K_RS + (4 * uh) * 16;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         g4k_h8 bv;
         __builtin_memcpy(&bv, &B[k], 16);
 #pragma unroll
         for (int t = 0; t < 2; t++) {
-            const ps_u32x4 ao = *(const ps_u32x4 *)(ap + t * 16 * G4K_RS + k * 64);
+            const ps_u32x4 ao = *(const ps_u32x4 *)(ap + t * 16 * G4K_RS + k * 16);
             g4k_h8 av;
             __builtin_memcpy(&av, &ao, 16);
             const g4k_f4 si = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bv, zf, 0, 0, 0); // (float)sumi[4 uh + k] of rows 4 kb + r, this lane's column
