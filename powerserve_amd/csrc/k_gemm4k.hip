@@ -450,9 +450,10 @@ int psk_gemm4k(hipStream_t st, int n_cu, const psk_gemv_args &a, ps_act act, int
     p.residual = a.residual; p.qf = act.qf; p.mf = act.mf;
     p.dbg = psk_gemv_dbg_buf(12 + epi, epi ? 0 : (a.n_w == 3 ? 0 : (K <= 8192 ? 1 : 2))); // keys 48 QKV, 49 O, 50 down, 52 gate/up
     const int n_ct = (int)((bs + 15) / 16);
-    // Below eight column tiles the kernels that spread a row group's integer work over producer waves (gemm8) are ahead:
-    // tree forward of the 8B shape, profiles/r02_tree_forward_latency_8b.json.
-    if (n_ct < 8 || p.nsb % 4) return -1;
+    // Narrow batches stay with the kernels that spread a row group's integer work over producer waves (gemm8): tree forward
+    // of the 8B shape, ms by width, this kernel / gemm8: 2: 5.9 / 4.8, 8: 5.8 / 5.0, 12: 5.9 / 6.1, 16: 5.9 / 6.2, 32: 5.9 / 8.8,
+    // 64: 6.3 / 12.8, 96: 8.1 / 19.9, 128: 8.4 / - (profiles/r02_tree_forward_latency_8b.json; PS_GEMM4K_MIN_COLS moves the switch).
+    if (bs < ps_gemm4k_min_cols() || p.nsb % 4) return -1;
     p.n_cb = (n_ct + 3) / 4;
     p.n_items = (p.n_tasks + 7) / 8 * 8 * p.n_cb;
     // persistent: one workgroup per CU walks the items w, w + n_wg, ... -- as long as that keeps its column block fixed

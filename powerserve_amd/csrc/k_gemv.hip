@@ -1652,7 +1652,7 @@ static int launch_gemm8(hipStream_t st, const GemvParams &p, int epi, int nwv, c
 }
 int psk_gemm8(hipStream_t st, int n_cu, const psk_gemv_args &a, ps_act act, int64_t K, int64_t bs) {
     if (a.pro != 0 || a.rope || a.n_w < 1) return -1;
-    if (a.w[0]->dtype == PS_Q4_K) { // K = 32 integer matrix cores (k_gemm4k.hip)
+    if (a.w[0]->dtype == PS_Q4_K) { // prefill chunks: fp16 matrix cores on exact integers, producer / consumer waves (k_gemm4k.hip)
         const int rc = psk_gemm4k(st, n_cu, a, act, K, bs);
         if (rc != -1) return rc;
     }

@@ -173,7 +173,7 @@ __global__ void repack_q5_K_kernel(const uint8_t *raw, int64_t nblk, uint8_t *qs
 
 void psk_quantize_act(hipStream_t st, int vdt, int mode, const float *x, const float *x2, const float *w, float eps,
                       int64_t K, int64_t rows, ps_act out) {
-    const bool frag = vdt == PS_Q8_K && rows > 112 && K % 1024 == 0; // exactly when psk_gemm4k takes the batch
+    const bool frag = vdt == PS_Q8_K && rows >= ps_gemm4k_min_cols() && K % 1024 == 0; // exactly when psk_gemm4k takes the batch
     QuantArgs a{x, x2, w, eps, K, out.qs, out.d, out.bs16, frag ? out.qf : nullptr, frag ? out.mf : nullptr};
     if (mode == 1) {
         dim3 g((unsigned)rows), b(256);

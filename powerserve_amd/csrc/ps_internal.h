@@ -93,6 +93,11 @@ static inline bool ps_first_on_device(unsigned long long *mask) {
         return 2;                                                                                    \
     } while (0)
 
+// smallest batch the Q4_K chunk mat-mul (k_gemm4k.hip) takes; the quantizer writes the fragment-major copy from here on
+static inline int64_t ps_gemm4k_min_cols() {
+    static const int64_t v = [] { const char *e = getenv("PS_GEMM4K_MIN_COLS"); return e ? (int64_t)atoll(e) : (int64_t)12; }();
+    return v;
+}
 static inline size_t ps_act_bytes(int64_t K, int64_t rows) {
     // qs + d (worst case blk 32) + bs16, each 256-B aligned
     auto al = [](size_t x) { return (x + 255) / 256 * 256; };
