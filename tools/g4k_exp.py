@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
-"""What-if sweep of the Q4_K prefill mat-mul (k_gemm4k.hip experiment switches, ps_hip_debug_set(2, flags)): prefill
-tokens/s of the bench model per switch set.  Results are WRONG for flags != 0 -- timing only.  usage: g4k_exp.py [flags ...]"""
+"""Prefill timer of the bench model: 2048 tokens in 128-token chunks, best of two passes per value of ps_hip_debug_set(2, v)
+(the what-if switch the mat-mul kernels may read while experimenting; 0 = production).  usage: g4k_exp.py [v ...]"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from powerserve_amd import gguf, hip, synth
 
-flags = [int(a) for a in sys.argv[1:]] or [0, 1, 2, 3, 4, 8, 16, 32, 11, 15, 31, 63]
+flags = [int(a) for a in sys.argv[1:]] or [0]
 d = os.path.join(os.environ.get("TMPDIR", "/tmp"), "ps_bench_llama-3.1-8b_Q4_K_1234")
 if not os.path.exists(os.path.join(d, ".done")):
     synth.write_model_dir(d, "llama-3.1-8b", gguf.NAME_TYPE["Q4_K"], n_ctx=4096, seed=1234)
