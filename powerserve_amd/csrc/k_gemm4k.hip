@@ -450,6 +450,13 @@ int psk_gemm4k(hipStream_t st, int n_cu, const psk_gemv_args &a, ps_act act, int
     p.residual = a.residual; p.qf = act.qf; p.mf = act.mf;
     p.dbg = psk_gemv_dbg_buf(12 + epi, epi ? 0 : (a.n_w == 3 ? 0 : (K <= 8192 ? 1 : 2))); // keys 48 QKV, 49 O, 50 down, 52 gate/up
     const int n_ct = (int)((bs + 15) / 16);
+    // (Measured, not kept.  (1) 64 rows x 32 columns per workgroup for batches of at most 32 columns -- every prepared weight
+    // operand meeting every live column -- is SLOWER, 12 wide 6.3 vs 5.9 ms: with N = 4096 rows there are only 64 such
+    // workgroups for 256 CUs, and a K walk is sequential by the reference's accumulation order; narrow batches are bound by
+    // steps x step time.  (2) Letting the consumer waves past the batch skip their step does not shorten it: a consumer's
+    // step is its own chain of LDS round trips (operands, d / dmin, mins), 0.83 us whether two or eight waves walk it.
+    // (3) Unrolling the steps in pairs behind one barrier, so that the second step's LDS reads issue under the first one's
+    // arithmetic, needs more than the 168 registers of a twelve-wave workgroup: 30 spills, 12.2 k tok/s.)
     // Narrow batches stay with the kernels that spread a row group's integer work over producer waves (gemm8): tree forward
     // of the 8B shape, ms by width, this kernel / gemm8: 2: 5.9 / 4.8, 8: 5.8 / 5.0, 12: 5.9 / 6.1, 16: 5.9 / 6.2, 32: 5.9 / 8.8,
     // 64: 6.3 / 12.8, 96: 8.1 / 19.9, 128: 8.4 / - (profiles/r02_tree_forward_latency_8b.json; PS_GEMM4K_MIN_COLS moves the switch).

@@ -20,7 +20,8 @@ for c in range(2):
 NW = 1024
 for key in keys:
     ctx.check(ctx.L.ps_hip_debug_timeline(ctx.h, key, None, 0))
-    m.forward(prompt[256:384], np.arange(256, 384), lm_head=False)
+    bs = int(os.environ.get('TL_BS', '128'))  # width of the recorded forward
+    m.forward(prompt[256:256 + bs], np.arange(256, 256 + bs), lm_head=False)
     buf = np.zeros(NW * 64, dtype=np.uint64)
     ctx.check(ctx.L.ps_hip_debug_timeline(ctx.h, key, buf.ctypes.data_as(C.c_void_p), buf.size))
     ctx.check(ctx.L.ps_hip_debug_timeline(ctx.h, -1, None, 0))
