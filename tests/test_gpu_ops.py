@@ -103,9 +103,9 @@ def test_mul_mat_batched(ctx, oracle, hip, wt, K, N, bs):
     W.free()
 
 
-@pytest.mark.parametrize("K,N,bs", [(4096, 512, 128), (1024, 96, 120), (14336, 64, 113), (2048, 288, 128)])
+@pytest.mark.parametrize("K,N,bs", [(4096, 512, 128), (1024, 96, 120), (14336, 64, 113), (2048, 288, 128), (1024, 64, 160), (2048, 96, 200), (1024, 8224, 70), (1024, 32, 12)])
 def test_mul_mat_q4k_chunk_on_matrix_cores(ctx, oracle, hip, K, N, bs):
-    """Prefill chunks of a Q4_K weight (>= 113 columns, N % 32 == 0, K % 1024 == 0) take k_gemm4k.hip: fp16 MFMA contractions of
+    """Batches of a Q4_K weight from 12 columns (N % 32 == 0, K % 1024 == 0) take k_gemm4k.hip: fp16 MFMA contractions of
     exact integers, producer / consumer waves, two accumulator halves per tile -- still bit-for-bit ggml_vec_dot_q4_K_q8_K
     per column, including a ragged last column tile and an item count that is not a multiple of the padding."""
     from powerserve_amd import synth
