@@ -430,6 +430,193 @@ __global__ __launch_bounds__((G4K_NC + G4K_NP) * 64) void gemm4k_kernel(const G4
     if (dbg) { dbg[31] = __builtin_amdgcn_s_memtime(); dbg[30] = __builtin_amdgcn_s_memrealtime(); }
 }
 
+// ---- narrow batches (at most 32 columns: tree verify, prompt tails).  With one or two live column tiles the wide mapping
+// leaves most consumers walking dead columns, and a consumer's step is a chain of LDS and L2 round trips (0.83 us) that does
+// not get shorter when others idle.  Here the eight consumers split ONE tile's work eight ways (CT = 1: wave = accumulator
+// lane u, waves 0..3 also mins lane v = u) or two tiles' four ways (CT = 2: two lanes u per wave, mins lane v = group): two
+// or four matrix instructions and a handful of chains per wave and step, and the B / column-metadata ring runs FOUR steps
+// ahead (a short step would otherwise wait for L2), so the workgroup runs at the producers' pace.  Same producers, same LDS
+// stages, same persistent items; every wave parks its chains at the end of an item and the waves of groups 0 and 1 finish
+// rows 4 kb + 0, 1 and 4 kb + 2, 3 (hsum_float_8's order) from LDS.
+template <int EPI, int CT>
+__global__ __launch_bounds__((G4K_NC + G4K_NP) * 64) void gemm4k_narrow_kernel(const G4KParams p) {
+    constexpr int NU = CT, XW = CT == 1 ? 2 : 4; // accumulator lanes per wave; floats per (tile, row) in the exchange (NU chains + 1 mins chain, padded)
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int m = lane & 15, kb = lane >> 4;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    if (threadIdx.x < 8) ((uint32_t *)(lds + G4K_NST * G4K_STAGE))[threadIdx.x] = 0u; // the zero operands (visible after the first barrier)
+    constexpr int TAB = G4K_XCH + 8 * 64 * 8 * XW * 4;
+    if (EPI == 1 && threadIdx.x >= 64 && threadIdx.x < 64 + PS_EXP2F_N) ((uint64_t *)(lds + TAB))[threadIdx.x - 64] = ps_exp2f_tab[threadIdx.x - 64];
+    int item = (int)blockIdx.x;
+    {
+        int t, c;
+        g4k_item(p, item, t, c);
+        if (t >= p.n_tasks) item = g4k_next_item(p, item);
+    }
+    if (item >= p.n_items) return; // (the whole workgroup)
+    unsigned long long *const dbg = (p.dbg && blockIdx.x < 1024 && lane == 0 && (wave == 0 || wave == G4K_NC)) ? p.dbg + ((size_t)blockIdx.x * 2 + (wave == G4K_NC)) * 32 : nullptr;
+    if (dbg) { dbg[0] = __builtin_amdgcn_s_memtime(); dbg[29] = __builtin_amdgcn_s_memrealtime(); }
+    if (wave >= G4K_NC) {
+        g4k_producer_wave<EPI>(p, item, lds, wave - G4K_NC, dbg);
+        if (dbg) { dbg[31] = __builtin_amdgcn_s_memtime(); dbg[30] = __builtin_amdgcn_s_memrealtime(); }
+        return;
+    }
+    const int ctl = wave % CT, ug = wave / CT; // (column tile, accumulator-lane group: lanes u = NU ug .. NU ug + NU - 1)
+    const bool has_v = ug < 4;                  // mins lane v = ug
+    int task, cb;
+    g4k_item(p, item, task, cb);
+    const int ct = cb * CT + ctl;
+    const int col = ct * 16 + m, colc = col < p.bs ? col : p.bs - 1;
+    const int ctc = ct * 16 < p.bs ? ct : (p.bs - 1) / 16;
+    const char *qf_ct = (const char *)p.qf + ((size_t)ctc * p.nsb << 13) + (size_t)(NU * ug) * 1024 + lane * 16;
+    const uint8_t *mf_ct = p.mf + (size_t)ctc * p.nsb * 576 + (colc & 15) * 4;                          // the column's scale
+    const uint8_t *ms_ct = p.mf + (size_t)ctc * p.nsb * 576 + 64 + (colc & 15) * 32 + (has_v ? ug : 0) * 8; // the four 16-sums of mins lane v
+    const char *zero = lds + G4K_NST * G4K_STAGE;
+    float *xall = (float *)(lds + G4K_XCH);
+    int dbg_n = 1;
+    auto mark = [&](int g) { if (dbg && (g < 8 || (g & 7) == 7) && dbg_n < 29) dbg[dbg_n++] = __builtin_amdgcn_s_memtime(); };
+    const g4k_f4 zf = {0.f, 0.f, 0.f, 0.f};
+    // the ring: operands of the next four super-blocks
+    ps_u32x4 B[4][NU];
+    float yd[4];
+    uint2 b16[4];
+    auto ring_load = [&](const int j, const int sb) {
+#pragma unroll
+        for (int k = 0; k < NU; k++) B[j][k] = *(const ps_u32x4 *)(qf_ct + ((size_t)sb << 13) + k * 1024);
+        yd[j] = *(const float *)(mf_ct + (size_t)sb * 576);
+        b16[j] = *(const uint2 *)(ms_ct + (size_t)sb * 576);
+    };
+#pragma unroll
+    for (int j = 0; j < 4; j++) ring_load(j, j); // (nsb >= 4)
+    int nx = 4 == p.nsb ? 0 : 4; // the super-block the ring fetches next (wraps: the next item meets the same columns from super-block 0)
+    while (item < p.n_items) {
+        g4k_item(p, item, task, cb);
+        int wi, pair;
+        (void)g4k_rows<EPI>(p, task, wi, pair);
+        const G4KMat &W = wi == 0 ? p.w[0] : (wi == 1 ? p.w[1] : p.w[2]);
+        float acc[2][4][NU], accm[2][4];
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+#pragma unroll
+                for (int k = 0; k < NU; k++) acc[t][r][k] = 0.f;
+                accm[t][r] = 0.f;
+            }
+#pragma clang loop unroll(disable)
+        for (int sb0 = 0; sb0 < p.nsb; sb0 += 4) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int sb = sb0 + j;
+                if (!(j & 1)) __syncthreads(); // the producers have parked this step and the next
+                mark(sb);
+                int so = j * G4K_STAGE; // (sb0 % 4 == 0: stage sb % 4 = j)
+                asm volatile("" : "+s"(so)); // (opaque: or the addresses of all four stages are hoisted out of the loop and spilled)
+                const char *st = lds + so;
+                float dr[2][4], dmin[2][4];
+#pragma unroll
+                for (int t = 0; t < 2; t++) {
+                    const g4k_f4 dda = *(const g4k_f4 *)(st + G4K_DD + (16 * t + 4 * kb) * 8), ddb = *(const g4k_f4 *)(st + G4K_DD + (16 * t + 4 * kb) * 8 + 16);
+                    dr[t][0] = __fmul_rn(yd[j], dda[0]); dr[t][1] = __fmul_rn(yd[j], dda[2]); dr[t][2] = __fmul_rn(yd[j], ddb[0]); dr[t][3] = __fmul_rn(yd[j], ddb[2]);
+                    dmin[t][0] = __fmul_rn(-yd[j], dda[1]); dmin[t][1] = __fmul_rn(-yd[j], dda[3]); dmin[t][2] = __fmul_rn(-yd[j], ddb[1]); dmin[t][3] = __fmul_rn(-yd[j], ddb[3]);
+                }
+                const char *ap = st + kb * G4K_KB + m * G4K_RS + (NU * ug) * 16;
+#pragma unroll
+                for (int k = 0; k < NU; k++) {
+                    g4k_h8 bv;
+                    __builtin_memcpy(&bv, &B[j][k], 16);
+#pragma unroll
+                    for (int t = 0; t < 2; t++) {
+                        const ps_u32x4 ao = *(const ps_u32x4 *)(ap + t * 16 * G4K_RS + k * 16);
+                        g4k_h8 av;
+                        __builtin_memcpy(&av, &ao, 16);
+                        const g4k_f4 si = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bv, zf, 0, 0, 0);
+#pragma unroll
+                        for (int r = 0; r < 4; r++) acc[t][r][k] = __fmaf_rn(dr[t][r], si[r], acc[t][r][k]);
+                    }
+                }
+                if (has_v) { // (wave-uniform)
+                    g4k_h2 g0, g1;
+                    __builtin_memcpy(&g0, &b16[j].x, 4); __builtin_memcpy(&g1, &b16[j].y, 4);
+                    const g4k_h4 bm = {g0[0], g0[1], g1[0], g1[1]};
+#pragma unroll
+                    for (int t = 0; t < 2; t++) {
+                        const uint2 ma = *(const uint2 *)(kb == 0 ? st + G4K_MINS + (16 * t + m) * 32 + ug * 8 : zero);
+                        g4k_h2 a0, a1;
+                        __builtin_memcpy(&a0, &ma.x, 4); __builtin_memcpy(&a1, &ma.y, 4);
+                        const g4k_h4 am = {a0[0], a0[1], a1[0], a1[1]};
+                        const g4k_f4 pr = __builtin_amdgcn_mfma_f32_16x16x16f16(am, bm, zf, 0, 0, 0);
+#pragma unroll
+                        for (int r = 0; r < 4; r++) accm[t][r] = __fmaf_rn(dmin[t][r], pr[r], accm[t][r]);
+                    }
+                }
+                ring_load(j, nx);
+                nx = nx + 1 == p.nsb ? 0 : nx + 1;
+            }
+        }
+        // ---- every wave parks its chains; groups 0 and 1 finish rows 4 kb + 2 ug, + 1 of both tiles
+        {
+            float *mine = xall + ((size_t)wave * 64 + lane) * (8 * XW);
+#pragma unroll
+            for (int t = 0; t < 2; t++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    if (NU == 1) *(float2 *)(mine + (t * 4 + r) * XW) = make_float2(acc[t][r][0], accm[t][r]);
+                    else *(float4 *)(mine + (t * 4 + r) * XW) = make_float4(acc[t][r][0], acc[t][r][NU - 1], accm[t][r], 0.f);
+                }
+        }
+        __syncthreads(); // X
+        mark(0);
+        if (ug < 2) {
+            float y[2][2];
+#pragma unroll
+            for (int t = 0; t < 2; t++)
+#pragma unroll
+                for (int rr = 0; rr < 2; rr++) {
+                    const int r = 2 * ug + rr;
+                    float au[8], mv[4];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) // lane u lives in wave (ctl, group u / NU), slot u % NU
+                        au[u] = xall[((size_t)(ctl + CT * (u / NU)) * 64 + lane) * (8 * XW) + (t * 4 + r) * XW + (u % NU)];
+#pragma unroll
+                    for (int v = 0; v < 4; v++) // mins lane v lives in group v, after the NU chains
+                        mv[v] = xall[((size_t)(ctl + CT * v) * 64 + lane) * (8 * XW) + (t * 4 + r) * XW + NU];
+                    const float s0 = __fadd_rn(au[0], au[4]), s1 = __fadd_rn(au[1], au[5]), s2 = __fadd_rn(au[2], au[6]), s3 = __fadd_rn(au[3], au[7]);
+                    const float res = __fadd_rn(__fadd_rn(s0, s2), __fadd_rn(s1, s3));
+                    const float mm = __fadd_rn(__fadd_rn(mv[0], mv[2]), __fadd_rn(mv[1], mv[3]));
+                    y[t][rr] = __fadd_rn(res, mm);
+                }
+            if (col < p.bs) {
+                if (EPI == 1) {
+                    const int64_t row0 = (int64_t)task * 16 + kb * 4 + 2 * ug;
+                    const uint64_t *tab = (const uint64_t *)(lds + TAB);
+                    float o[2];
+#pragma unroll
+                    for (int rr = 0; rr < 2; rr++) // ps_silu_mul with the table in LDS
+                        o[rr] = __fmul_rn(__fmul_rn(y[0][rr], __fdiv_rn(1.0f, __fadd_rn(1.0f, ps_expf_glibc(-y[0][rr], tab)))), y[1][rr]);
+                    *(float2 *)(W.out + (int64_t)col * W.ldo + row0) = make_float2(o[0], o[1]);
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 2; t++) {
+                        const int64_t row0 = (int64_t)(2 * pair + t) * 16 + kb * 4 + 2 * ug;
+                        float v[2];
+#pragma unroll
+                        for (int rr = 0; rr < 2; rr++) {
+                            v[rr] = y[t][rr];
+                            if (W.bias) v[rr] = __fadd_rn(v[rr], W.bias[row0 + rr]);
+                            if (p.residual && wi == 0) v[rr] = __fadd_rn(p.residual[(int64_t)col * W.ldo + row0 + rr], v[rr]);
+                        }
+                        *(float2 *)(W.out + (int64_t)col * W.ldo + row0) = make_float2(v[0], v[1]);
+                    }
+                }
+            }
+        }
+        mark(0);
+        item = g4k_next_item(p, item);
+    }
+    if (dbg) { dbg[31] = __builtin_amdgcn_s_memtime(); dbg[30] = __builtin_amdgcn_s_memrealtime(); }
+}
+
 } // namespace
 
 // Q4_K batched mat-mul from fragment-major Q8_K activations (act.qf).  -1: not covered (the caller takes gemm8m).
@@ -461,20 +648,32 @@ int psk_gemm4k(hipStream_t st, int n_cu, const psk_gemv_args &a, ps_act act, int
     // of the 8B shape, ms by width, this kernel / gemm8: 2: 5.9 / 4.8, 8: 5.8 / 5.0, 12: 5.9 / 6.1, 16: 5.9 / 6.2, 32: 5.9 / 8.8,
     // 64: 6.3 / 12.8, 96: 8.1 / 19.9, 128: 8.4 / - (profiles/r02_tree_forward_latency_8b.json; PS_GEMM4K_MIN_COLS moves the switch).
     if (bs < ps_gemm4k_min_cols() || p.nsb % 4) return -1;
-    p.n_cb = (n_ct + 3) / 4;
+    const int ctw = n_ct <= 1 ? 1 : 4; // column tiles per workgroup: the narrow kernel for at most 16 columns (its two-tile form spills at the 168-register cap: 13.7 ms per 8B forward against 5.9 ms, not dispatched)
+    p.n_cb = (n_ct + ctw - 1) / ctw;
     p.n_items = (p.n_tasks + 7) / 8 * 8 * p.n_cb;
     // persistent: one workgroup per CU walks the items w, w + n_wg, ... -- as long as that keeps its column block fixed
     // (the consumers prefetch the next item's first fragments with this item's column pointers)
     int n_wg = p.n_items;
     if (n_cu > 0 && n_wg > n_cu && n_cu % (8 * p.n_cb) == 0) n_wg = n_cu;
-    const dim3 grid((unsigned)n_wg);
+    const dim3 grid((unsigned)n_wg), blk((G4K_NC + G4K_NP) * 64);
     static_assert(G4K_RING == 4, "nsb % 4 == 0 is what the producers' ring is unrolled for");
+    constexpr int LDS1 = G4K_XCH + 8 * 64 * 8 * 2 * 4 + PS_EXP2F_N * 8, LDS2 = G4K_XCH + 8 * 64 * 8 * 4 * 4 + PS_EXP2F_N * 8;
     static unsigned long long attr = 0; // devices that have the attribute
     if (ps_first_on_device(&attr)) {
         (void)hipFuncSetAttribute((const void *)gemm4k_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, G4K_LDS);
         (void)hipFuncSetAttribute((const void *)gemm4k_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, G4K_LDS);
+        (void)hipFuncSetAttribute((const void *)gemm4k_narrow_kernel<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS1);
+        (void)hipFuncSetAttribute((const void *)gemm4k_narrow_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS1);
+        (void)hipFuncSetAttribute((const void *)gemm4k_narrow_kernel<0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2);
+        (void)hipFuncSetAttribute((const void *)gemm4k_narrow_kernel<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2);
     }
-    if (epi == 1) hipLaunchKernelGGL((gemm4k_kernel<1>), grid, dim3((G4K_NC + G4K_NP) * 64), G4K_LDS, st, p);
-    else hipLaunchKernelGGL((gemm4k_kernel<0>), grid, dim3((G4K_NC + G4K_NP) * 64), G4K_LDS, st, p);
+    if (ctw == 1) {
+        if (epi == 1) hipLaunchKernelGGL((gemm4k_narrow_kernel<1, 1>), grid, blk, LDS1, st, p);
+        else hipLaunchKernelGGL((gemm4k_narrow_kernel<0, 1>), grid, blk, LDS1, st, p);
+    } else if (ctw == 2) {
+        if (epi == 1) hipLaunchKernelGGL((gemm4k_narrow_kernel<1, 2>), grid, blk, LDS2, st, p);
+        else hipLaunchKernelGGL((gemm4k_narrow_kernel<0, 2>), grid, blk, LDS2, st, p);
+    } else if (epi == 1) hipLaunchKernelGGL((gemm4k_kernel<1>), grid, blk, G4K_LDS, st, p);
+    else hipLaunchKernelGGL((gemm4k_kernel<0>), grid, blk, G4K_LDS, st, p);
     return 0;
 }
