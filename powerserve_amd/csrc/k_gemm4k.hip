@@ -80,7 +80,8 @@ struct G4KRows { const uint8_t *qs[2], *aux[2]; int tile[2]; };
 
 // ---- producers.  Wave h (0..3) makes the accumulator lanes u = 2h, 2h + 1 of all 32 rows; lane = (row l / 2, kb pair p = l % 2):
 // its weight dwords [row][u][kb = 2p, 2p + 1] are one 8-B load per u.
-__device__ __forceinline__ void g4k_produce(const uint2 q0, const uint2 q1, const uint4 h, char *st, const int row, const int hw, const int p) {
+template <int UPP> // accumulator lanes per producer wave: u = UPP hw .. UPP hw + UPP - 1
+__device__ __forceinline__ void g4k_produce(const uint2 (&qq)[UPP], const uint4 h, char *st, const int row, const int hw, const int p) {
     // the four sub-block scales 4p .. 4p+3 (get_scale_min_k4: 0..3 sit in the low 6 bits of scale bytes 0..3, 4..7 are
     // spread over bytes 8..11 and the top bits of bytes 0..3) as fp16 pairs (s, s) and (-1024 s, -1024 s)
     const uint32_t scb = p ? ((h.w & 0x0f0f0f0fu) | (((h.y >> 6) & 0x03030303u) << 4)) : (h.y & 0x3f3f3f3fu);
@@ -95,8 +96,8 @@ __device__ __forceinline__ void g4k_produce(const uint2 q0, const uint2 q1, cons
         nc[i] = sc[i] * km1024; // (<= 64512: exact)
     }
 #pragma unroll
-    for (int j = 0; j < 2; j++) { // u = 2 hw + j
-        const uint2 q = j ? q1 : q0;
+    for (int j = 0; j < UPP; j++) { // u = UPP hw + j
+        const uint2 q = qq[j];
 #pragma unroll
         for (int e = 0; e < 2; e++) { // kb = 2p + e: sub-blocks 2 kb (low nibbles), 2 kb + 1 (high nibbles) = scales 2e, 2e + 1 of the four
             const uint32_t w = e ? q.y : q.x;
@@ -111,7 +112,7 @@ __device__ __forceinline__ void g4k_produce(const uint2 q0, const uint2 q1, cons
                 v = __builtin_elementwise_fma(v, sc[2 * e + (k >> 1)], nc[2 * e + (k >> 1)]);
                 __builtin_memcpy(&o[k], &v, 4);
             }
-            *(uint4 *)(st + (2 * p + e) * G4K_KB + row * G4K_RS + (2 * hw + j) * 16) = make_uint4(o[0], o[1], o[2], o[3]);
+            *(uint4 *)(st + (2 * p + e) * G4K_KB + row * G4K_RS + (UPP * hw + j) * 16) = make_uint4(o[0], o[1], o[2], o[3]);
         }
     }
     if (hw == 0 && p == 0) { // once per row: the mins operands
@@ -167,8 +168,9 @@ __device__ __forceinline__ int g4k_next_item(const G4KParams &p, int i) { // the
 // The producers of a PERSISTENT workgroup: the stage stream runs on across the workgroup's items -- the ring is already
 // loading the next item's first super-blocks while the consumers finish this one, and its first two stages are parked
 // before the consumers' end-of-item exchange barrier (X), so a new item starts at full speed.
-template <int EPI>
+template <int EPI, int NPW, int RING> // NPW producer waves: wave hw makes the accumulator lanes 8 / NPW * hw ..; RING super-blocks in flight (nsb % RING == 0)
 __device__ __forceinline__ void g4k_producer_wave(const G4KParams &p, int item, char *lds, const int hw, unsigned long long *dbg) {
+    constexpr int UPP = 8 / NPW;
     const int lane = threadIdx.x & 63, nsb = p.nsb;
     int dbg_n = 1;
     auto mark = [&](int g) { if (dbg && (g < 8 || (g & 7) == 7) && dbg_n < 29) dbg[dbg_n++] = __builtin_amdgcn_s_memtime(); };
@@ -178,40 +180,42 @@ __device__ __forceinline__ void g4k_producer_wave(const G4KParams &p, int item, 
         int task, cb, wi, pair;
         g4k_item(p, it, task, cb);
         const G4KRows R = g4k_rows<EPI>(p, task, wi, pair);
-        qb = (rt ? R.qs[1] : R.qs[0]) + ((size_t)(2 * (rt ? R.tile[1] : R.tile[0]) + unit) * nsb << 10) + (size_t)(r8 * 32 + 2 * hw * 4 + 2 * pp) * 4;
+        qb = (rt ? R.qs[1] : R.qs[0]) + ((size_t)(2 * (rt ? R.tile[1] : R.tile[0]) + unit) * nsb << 10) + (size_t)(r8 * 32 + UPP * hw * 4 + 2 * pp) * 4;
         hb = (rt ? R.aux[1] : R.aux[0]) + (size_t)(2 * (rt ? R.tile[1] : R.tile[0]) + unit) * nsb * 128 + (size_t)r8 * 16;
     };
-    uint2 rq0[G4K_RING], rq1[G4K_RING];
-    uint4 rh[G4K_RING];
-    auto load = [&](int g, uint2 &a, uint2 &b, uint4 &h) {
-        a = *(const uint2 *)(qb + ((size_t)g << 10));
-        b = *(const uint2 *)(qb + ((size_t)g << 10) + 16);
+    uint2 rq[RING][UPP];
+    uint4 rh[RING];
+    auto load = [&](int g, uint2 (&a)[UPP], uint4 &h) {
+#pragma unroll
+        for (int j = 0; j < UPP; j++) a[j] = *(const uint2 *)(qb + ((size_t)g << 10) + j * 16);
         h = *(const uint4 *)(hb + (size_t)g * 128);
     };
     point(item);
 #pragma unroll
-    for (int k = 0; k < G4K_RING; k++) load(k, rq0[k], rq1[k], rh[k]);
-    int c_item = item, c_g = G4K_RING; // the cursor: the ring's next loads
+    for (int k = 0; k < RING; k++) load(k, rq[k], rh[k]);
+    int c_item = item, c_g = RING; // the cursor: the ring's next loads
     bool first = true;
     while (item < p.n_items) {
-        for (int g0 = 0; g0 < nsb; g0 += G4K_RING) { // (nsb % G4K_RING == 0: psk_gemm4k checks)
+        for (int g0 = 0; g0 < nsb; g0 += RING) { // (nsb % RING == 0: psk_gemm4k checks)
             if (c_g == nsb) { // the ring moves on to the workgroup's next item (past the last one: reloads that one's tail, unused)
                 const int nx = g4k_next_item(p, c_item);
-                if (nx < p.n_items) { c_item = nx; c_g = 0; point(nx); } else c_g = nsb - G4K_RING;
+                if (nx < p.n_items) { c_item = nx; c_g = 0; point(nx); } else c_g = nsb - RING;
             }
 #pragma unroll
-            for (int k = 0; k < G4K_RING; k++) {
-                const uint2 a = rq0[k], b = rq1[k];
+            for (int k = 0; k < RING; k++) {
+                uint2 a[UPP];
+#pragma unroll
+                for (int j = 0; j < UPP; j++) a[j] = rq[k][j];
                 const uint4 h = rh[k];
-                load(c_g + k, rq0[k], rq1[k], rh[k]);
-                g4k_produce(a, b, h, lds + ((g0 + k) & (G4K_NST - 1)) * G4K_STAGE, row, hw, pp);
+                load(c_g + k, rq[k], rh[k]);
+                g4k_produce<UPP>(a, h, lds + ((g0 + k) & (G4K_NST - 1)) * G4K_STAGE, row, hw, pp);
                 if (k & 1) {
                     if (g0 == 0 && k == 1 && !first) __syncthreads(); // X of the previous item: its consumers have exchanged
                     __syncthreads(); // one barrier per PAIR of stages: stages g0 + k - 1, g0 + k are parked
                 }
                 mark(g0 + k);
             }
-            c_g += G4K_RING;
+            c_g += RING;
         }
         first = false;
         item = g4k_next_item(p, item);
@@ -310,7 +314,7 @@ __global__ __launch_bounds__((G4K_NC + G4K_NP) * 64) void gemm4k_kernel(const G4
     unsigned long long *const dbg = (p.dbg && blockIdx.x < 1024 && lane == 0 && (wave == 0 || wave == G4K_NC)) ? p.dbg + ((size_t)blockIdx.x * 2 + (wave == G4K_NC)) * 32 : nullptr;
     if (dbg) { dbg[0] = __builtin_amdgcn_s_memtime(); dbg[29] = __builtin_amdgcn_s_memrealtime(); }
     if (wave >= G4K_NC) {
-        g4k_producer_wave<EPI>(p, item, lds, wave - G4K_NC, dbg);
+        g4k_producer_wave<EPI, G4K_NP, G4K_RING>(p, item, lds, wave - G4K_NC, dbg);
         if (dbg) { dbg[31] = __builtin_amdgcn_s_memtime(); dbg[30] = __builtin_amdgcn_s_memrealtime(); }
         return;
     }
@@ -438,8 +442,10 @@ __global__ __launch_bounds__((G4K_NC + G4K_NP) * 64) void gemm4k_kernel(const G4
 // ahead (a short step would otherwise wait for L2), so the workgroup runs at the producers' pace.  Same producers, same LDS
 // stages, same persistent items; every wave parks its chains at the end of an item and the waves of groups 0 and 1 finish
 // rows 4 kb + 0, 1 and 4 kb + 2, 3 (hsum_float_8's order) from LDS.
+constexpr int G4K_RINGN = 4; // (a ring of eight super-blocks measured slower: 12 wide 5.09 vs 4.78 ms)
+constexpr int G4K_NPN = 8; // producing waves of the narrow kernel: one accumulator lane each (the consumers are light there, the producers set the pace)
 template <int EPI, int CT>
-__global__ __launch_bounds__((G4K_NC + G4K_NP) * 64) void gemm4k_narrow_kernel(const G4KParams p) {
+__global__ __launch_bounds__((G4K_NC + G4K_NPN) * 64) void gemm4k_narrow_kernel(const G4KParams p) {
     constexpr int NU = CT, XW = CT == 1 ? 2 : 4; // accumulator lanes per wave; floats per (tile, row) in the exchange (NU chains + 1 mins chain, padded)
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int m = lane & 15, kb = lane >> 4;
@@ -457,7 +463,7 @@ __global__ __launch_bounds__((G4K_NC + G4K_NP) * 64) void gemm4k_narrow_kernel(c
     unsigned long long *const dbg = (p.dbg && blockIdx.x < 1024 && lane == 0 && (wave == 0 || wave == G4K_NC)) ? p.dbg + ((size_t)blockIdx.x * 2 + (wave == G4K_NC)) * 32 : nullptr;
     if (dbg) { dbg[0] = __builtin_amdgcn_s_memtime(); dbg[29] = __builtin_amdgcn_s_memrealtime(); }
     if (wave >= G4K_NC) {
-        g4k_producer_wave<EPI>(p, item, lds, wave - G4K_NC, dbg);
+        g4k_producer_wave<EPI, G4K_NPN, G4K_RINGN>(p, item, lds, wave - G4K_NC, dbg);
         if (dbg) { dbg[31] = __builtin_amdgcn_s_memtime(); dbg[30] = __builtin_amdgcn_s_memrealtime(); }
         return;
     }
@@ -473,8 +479,6 @@ __global__ __launch_bounds__((G4K_NC + G4K_NP) * 64) void gemm4k_narrow_kernel(c
     const uint8_t *ms_ct = p.mf + (size_t)ctc * p.nsb * 576 + 64 + (colc & 15) * 32 + (has_v ? ug : 0) * 8; // the four 16-sums of mins lane v
     const char *zero = lds + G4K_NST * G4K_STAGE;
     float *xall = (float *)(lds + G4K_XCH);
-    int dbg_n = 1;
-    auto mark = [&](int g) { if (dbg && (g < 8 || (g & 7) == 7) && dbg_n < 29) dbg[dbg_n++] = __builtin_amdgcn_s_memtime(); };
     const g4k_f4 zf = {0.f, 0.f, 0.f, 0.f};
     // the ring: operands of the next four super-blocks
     ps_u32x4 B[4][NU];
@@ -507,9 +511,7 @@ __global__ __launch_bounds__((G4K_NC + G4K_NP) * 64) void gemm4k_narrow_kernel(c
         for (int sb0 = 0; sb0 < p.nsb; sb0 += 4) {
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                const int sb = sb0 + j;
                 if (!(j & 1)) __syncthreads(); // the producers have parked this step and the next
-                mark(sb);
                 int so = j * G4K_STAGE; // (sb0 % 4 == 0: stage sb % 4 = j)
                 asm volatile("" : "+s"(so)); // (opaque: or the addresses of all four stages are hoisted out of the loop and spilled)
                 const char *st = lds + so;
@@ -535,13 +537,13 @@ __global__ __launch_bounds__((G4K_NC + G4K_NP) * 64) void gemm4k_narrow_kernel(c
                         for (int r = 0; r < 4; r++) acc[t][r][k] = __fmaf_rn(dr[t][r], si[r], acc[t][r][k]);
                     }
                 }
-                if (has_v) { // (wave-uniform)
+                { // (waves without a mins lane read the zero operands: their chains stay 0 and nobody reads them)
                     g4k_h2 g0, g1;
                     __builtin_memcpy(&g0, &b16[j].x, 4); __builtin_memcpy(&g1, &b16[j].y, 4);
                     const g4k_h4 bm = {g0[0], g0[1], g1[0], g1[1]};
 #pragma unroll
                     for (int t = 0; t < 2; t++) {
-                        const uint2 ma = *(const uint2 *)(kb == 0 ? st + G4K_MINS + (16 * t + m) * 32 + ug * 8 : zero);
+                        const uint2 ma = *(const uint2 *)(kb == 0 && has_v ? st + G4K_MINS + (16 * t + m) * 32 + ug * 8 : zero);
                         g4k_h2 a0, a1;
                         __builtin_memcpy(&a0, &ma.x, 4); __builtin_memcpy(&a1, &ma.y, 4);
                         const g4k_h4 am = {a0[0], a0[1], a1[0], a1[1]};
@@ -566,7 +568,6 @@ __global__ __launch_bounds__((G4K_NC + G4K_NP) * 64) void gemm4k_narrow_kernel(c
                 }
         }
         __syncthreads(); // X
-        mark(0);
         if (ug < 2) {
             float y[2][2];
 #pragma unroll
@@ -611,7 +612,6 @@ __global__ __launch_bounds__((G4K_NC + G4K_NP) * 64) void gemm4k_narrow_kernel(c
                 }
             }
         }
-        mark(0);
         item = g4k_next_item(p, item);
     }
     if (dbg) { dbg[31] = __builtin_amdgcn_s_memtime(); dbg[30] = __builtin_amdgcn_s_memrealtime(); }
@@ -644,18 +644,18 @@ int psk_gemm4k(hipStream_t st, int n_cu, const psk_gemv_args &a, ps_act act, int
     // step is its own chain of LDS round trips (operands, d / dmin, mins), 0.83 us whether two or eight waves walk it.
     // (3) Unrolling the steps in pairs behind one barrier, so that the second step's LDS reads issue under the first one's
     // arithmetic, needs more than the 168 registers of a twelve-wave workgroup: 30 spills, 12.2 k tok/s.)
-    // Narrow batches stay with the kernels that spread a row group's integer work over producer waves (gemm8): tree forward
-    // of the 8B shape, ms by width, this kernel / gemm8: 2: 5.9 / 4.8, 8: 5.8 / 5.0, 12: 5.9 / 6.1, 16: 5.9 / 6.2, 32: 5.9 / 8.8,
-    // 64: 6.3 / 12.8, 96: 8.1 / 19.9, 128: 8.4 / - (profiles/r02_tree_forward_latency_8b.json; PS_GEMM4K_MIN_COLS moves the switch).
+    // 8B tree forward, ms by width (profiles/r02_tree_forward_latency_8b.json): 2: 4.7, 8: 4.7, 12: 4.8, 16: 4.8 (narrow kernel),
+    // 32: 5.9, 64: 6.3, 128: 8.4 (wide); the round-1 kernels that spread a row group's integer work over producer waves
+    // (gemm8): 2: 4.9, 8: 5.0, 12: 6.1, 16: 6.2, 32: 8.8, 64: 12.8, 96: 19.9.  PS_GEMM4K_MIN_COLS moves the switch (default 2).
     if (bs < ps_gemm4k_min_cols() || p.nsb % 4) return -1;
-    const int ctw = n_ct <= 1 ? 1 : 4; // column tiles per workgroup: the narrow kernel for at most 16 columns (its two-tile form spills at the 168-register cap: 13.7 ms per 8B forward against 5.9 ms, not dispatched)
+    const int ctw = n_ct <= 1 && p.nsb % G4K_RINGN == 0 ? 1 : 4; // column tiles per workgroup: the narrow kernel for at most 16 columns (its two-tile form spills at the 168-register cap: 13.7 ms per 8B forward against 5.9 ms, not dispatched)
     p.n_cb = (n_ct + ctw - 1) / ctw;
     p.n_items = (p.n_tasks + 7) / 8 * 8 * p.n_cb;
     // persistent: one workgroup per CU walks the items w, w + n_wg, ... -- as long as that keeps its column block fixed
     // (the consumers prefetch the next item's first fragments with this item's column pointers)
     int n_wg = p.n_items;
     if (n_cu > 0 && n_wg > n_cu && n_cu % (8 * p.n_cb) == 0) n_wg = n_cu;
-    const dim3 grid((unsigned)n_wg), blk((G4K_NC + G4K_NP) * 64);
+    const dim3 grid((unsigned)n_wg), blk((G4K_NC + G4K_NP) * 64), blkn((G4K_NC + G4K_NPN) * 64);
     static_assert(G4K_RING == 4, "nsb % 4 == 0 is what the producers' ring is unrolled for");
     constexpr int LDS1 = G4K_XCH + 8 * 64 * 8 * 2 * 4 + PS_EXP2F_N * 8, LDS2 = G4K_XCH + 8 * 64 * 8 * 4 * 4 + PS_EXP2F_N * 8;
     static unsigned long long attr = 0; // devices that have the attribute
@@ -668,11 +668,11 @@ int psk_gemm4k(hipStream_t st, int n_cu, const psk_gemv_args &a, ps_act act, int
         (void)hipFuncSetAttribute((const void *)gemm4k_narrow_kernel<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2);
     }
     if (ctw == 1) {
-        if (epi == 1) hipLaunchKernelGGL((gemm4k_narrow_kernel<1, 1>), grid, blk, LDS1, st, p);
-        else hipLaunchKernelGGL((gemm4k_narrow_kernel<0, 1>), grid, blk, LDS1, st, p);
+        if (epi == 1) hipLaunchKernelGGL((gemm4k_narrow_kernel<1, 1>), grid, blkn, LDS1, st, p);
+        else hipLaunchKernelGGL((gemm4k_narrow_kernel<0, 1>), grid, blkn, LDS1, st, p);
     } else if (ctw == 2) {
-        if (epi == 1) hipLaunchKernelGGL((gemm4k_narrow_kernel<1, 2>), grid, blk, LDS2, st, p);
-        else hipLaunchKernelGGL((gemm4k_narrow_kernel<0, 2>), grid, blk, LDS2, st, p);
+        if (epi == 1) hipLaunchKernelGGL((gemm4k_narrow_kernel<1, 2>), grid, blkn, LDS2, st, p);
+        else hipLaunchKernelGGL((gemm4k_narrow_kernel<0, 2>), grid, blkn, LDS2, st, p);
     } else if (epi == 1) hipLaunchKernelGGL((gemm4k_kernel<1>), grid, blk, G4K_LDS, st, p);
     else hipLaunchKernelGGL((gemm4k_kernel<0>), grid, blk, G4K_LDS, st, p);
     return 0;

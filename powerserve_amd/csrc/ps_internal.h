@@ -95,7 +95,7 @@ static inline bool ps_first_on_device(unsigned long long *mask) {
 
 // smallest batch the Q4_K chunk mat-mul (k_gemm4k.hip) takes; the quantizer writes the fragment-major copy from here on
 static inline int64_t ps_gemm4k_min_cols() {
-    static const int64_t v = [] { const char *e = getenv("PS_GEMM4K_MIN_COLS"); return e ? (int64_t)atoll(e) : (int64_t)12; }();
+    static const int64_t v = [] { const char *e = getenv("PS_GEMM4K_MIN_COLS"); return e ? (int64_t)atoll(e) : (int64_t)2; }();
     return v;
 }
 static inline size_t ps_act_bytes(int64_t K, int64_t rows) {
