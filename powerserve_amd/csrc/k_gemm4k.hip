@@ -648,7 +648,7 @@ int psk_gemm4k(hipStream_t st, int n_cu, const psk_gemv_args &a, ps_act act, int
     // 32: 5.9, 64: 6.3, 128: 8.4 (wide); the round-1 kernels that spread a row group's integer work over producer waves
     // (gemm8): 2: 4.9, 8: 5.0, 12: 6.1, 16: 6.2, 32: 8.8, 64: 12.8, 96: 19.9.  PS_GEMM4K_MIN_COLS moves the switch (default 2).
     if (bs < ps_gemm4k_min_cols() || p.nsb % 4) return -1;
-    const int ctw = n_ct <= 1 && p.nsb % G4K_RINGN == 0 ? 1 : 4; // column tiles per workgroup: the narrow kernel for at most 16 columns (its two-tile form spills at the 168-register cap: 13.7 ms per 8B forward against 5.9 ms, not dispatched)
+    const int ctw = n_ct <= 1 ? 1 : 4; // column tiles per workgroup: the narrow kernel for at most 16 columns (its two-tile form, CT = 2, spills: 13.7 ms per 8B forward against 5.9 ms, not instantiated)
     p.n_cb = (n_ct + ctw - 1) / ctw;
     p.n_items = (p.n_tasks + 7) / 8 * 8 * p.n_cb;
     // persistent: one workgroup per CU walks the items w, w + n_wg, ... -- as long as that keeps its column block fixed
@@ -657,22 +657,17 @@ int psk_gemm4k(hipStream_t st, int n_cu, const psk_gemv_args &a, ps_act act, int
     if (n_cu > 0 && n_wg > n_cu && n_cu % (8 * p.n_cb) == 0) n_wg = n_cu;
     const dim3 grid((unsigned)n_wg), blk((G4K_NC + G4K_NP) * 64), blkn((G4K_NC + G4K_NPN) * 64);
     static_assert(G4K_RING == 4, "nsb % 4 == 0 is what the producers' ring is unrolled for");
-    constexpr int LDS1 = G4K_XCH + 8 * 64 * 8 * 2 * 4 + PS_EXP2F_N * 8, LDS2 = G4K_XCH + 8 * 64 * 8 * 4 * 4 + PS_EXP2F_N * 8;
+    constexpr int LDS1 = G4K_XCH + 8 * 64 * 8 * 2 * 4 + PS_EXP2F_N * 8;
     static unsigned long long attr = 0; // devices that have the attribute
     if (ps_first_on_device(&attr)) {
         (void)hipFuncSetAttribute((const void *)gemm4k_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, G4K_LDS);
         (void)hipFuncSetAttribute((const void *)gemm4k_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, G4K_LDS);
         (void)hipFuncSetAttribute((const void *)gemm4k_narrow_kernel<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS1);
         (void)hipFuncSetAttribute((const void *)gemm4k_narrow_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS1);
-        (void)hipFuncSetAttribute((const void *)gemm4k_narrow_kernel<0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2);
-        (void)hipFuncSetAttribute((const void *)gemm4k_narrow_kernel<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2);
     }
     if (ctw == 1) {
         if (epi == 1) hipLaunchKernelGGL((gemm4k_narrow_kernel<1, 1>), grid, blkn, LDS1, st, p);
         else hipLaunchKernelGGL((gemm4k_narrow_kernel<0, 1>), grid, blkn, LDS1, st, p);
-    } else if (ctw == 2) {
-        if (epi == 1) hipLaunchKernelGGL((gemm4k_narrow_kernel<1, 2>), grid, blkn, LDS2, st, p);
-        else hipLaunchKernelGGL((gemm4k_narrow_kernel<0, 2>), grid, blkn, LDS2, st, p);
     } else if (epi == 1) hipLaunchKernelGGL((gemm4k_kernel<1>), grid, blk, G4K_LDS, st, p);
     else hipLaunchKernelGGL((gemm4k_kernel<0>), grid, blk, G4K_LDS, st, p);
     return 0;

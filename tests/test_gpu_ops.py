@@ -103,16 +103,16 @@ def test_mul_mat_batched(ctx, oracle, hip, wt, K, N, bs):
     W.free()
 
 
-@pytest.mark.parametrize("K,N,bs", [(4096, 512, 128), (1024, 96, 120), (14336, 64, 113), (2048, 288, 128), (1024, 64, 160), (2048, 96, 200), (1024, 8224, 70), (1024, 32, 12)])
+@pytest.mark.parametrize("K,N,bs", [(4096, 512, 128), (1024, 96, 120), (14336, 64, 113), (2048, 288, 128), (1024, 64, 160), (2048, 96, 200), (1024, 8224, 70), (1024, 32, 12), (4096, 160, 2), (2048, 8224, 16), (1024, 64, 5)])
 def test_mul_mat_q4k_chunk_on_matrix_cores(ctx, oracle, hip, K, N, bs):
-    """Batches of a Q4_K weight from 12 columns (N % 32 == 0, K % 1024 == 0) take k_gemm4k.hip: fp16 MFMA contractions of
+    """Batches of a Q4_K weight from 2 columns (N % 32 == 0, K % 1024 == 0) take k_gemm4k.hip (17 and more: the wide kernel, fewer: the narrow one): fp16 MFMA contractions of
     exact integers, producer / consumer waves, two accumulator halves per tile -- still bit-for-bit ggml_vec_dot_q4_K_q8_K
     per column, including a ragged last column tile and an item count that is not a multiple of the padding."""
     from powerserve_amd import synth
     rng = np.random.default_rng(K + N + bs)
     w = synth.random_blocks(rng, 12, N, K)
     x = (rng.standard_normal((bs, K)) * rng.uniform(0.1, 30.0, (bs, 1))).astype(np.float32)
-    x[3, 256:512] = 0.0  # an all-zero super-block (d = 0)
+    x[min(3, bs - 1), 256:512] = 0.0  # an all-zero super-block (d = 0)
     want = oracle.mul_mat(12, w, K, N, x)
     W = ctx.upload_weight(12, w, K, N)
     dx, dy = ctx.to_device(x), ctx.empty((bs, N))
