@@ -617,6 +617,242 @@ __global__ __launch_bounds__((G4K_NC + G4K_NPN) * 64) void gemm4k_narrow_kernel(
     if (dbg) { dbg[31] = __builtin_amdgcn_s_memtime(); dbg[30] = __builtin_amdgcn_s_memrealtime(); }
 }
 
+// ================================================================ Q6_K (the Q4_K_M / Q5_K_M mixes: attn_v, half of the ffn_down, output)
+// ggml_vec_dot_q6_K_q8_K (AVX2, libs/ggml/src/ggml-quants.c:8713-8790) has the same shape: per super-block one int32 per
+// accumulator lane u,  sumi[u] = sum over the eight 32-element vectors g of  scale[g][u / 4] * dot4((q6 - 32)[g][4u..], y[g][4u..])
+// (the -32 is applied through the q8 sums there: the same integer), then  acc[u] = fma(d * y.d, (float)sumi[u], acc[u])  and
+// hsum_float_8 -- no mins term.  The B operand is the SAME fragment-major fp16 copy of the Q8_K quants.  |(q6 - 32) * scale|
+// reaches 32 * 128 = 4096, past the 2048 up to which fp16 holds every integer, so the int8 scale is split  scale = even + odd
+// (even = scale & ~1, odd = scale & 1):  A_hi = (q6 - 32) * even  is an EVEN integer <= 4096 (exact in fp16),  A_lo = (q6 - 32) or 0;
+// two MFMAs on the same B, the second accumulating onto the first (every partial sum < 32 * 4096 * 127 < 2^24: exact).
+// Workgroup = the wide Q4_K form (two row tiles x 64 columns, 4 column tiles x 2 accumulator halves, four producers,
+// persistent items); two LDS stages of (A_hi, A_lo planes, d), one barrier per step.
+struct G6KParams {
+    const uint8_t *ql, *qh;   // [N][nsb][u][16 B], [N][nsb][u][8 B]   (ps_internal.h)
+    const int8_t *sc;         // [N][nsb][16]
+    const uint16_t *d;        // [N][nsb] fp16
+    float *out;
+    const float *bias, *residual;
+    int64_t N, ldo;
+    int nsb, bs, n_tasks, n_cb, n_items;
+    const _Float16 *qf;
+    const uint8_t *mf;
+};
+constexpr int G6K_PLANE = 4 * G4K_KB, G6K_DD = 2 * G6K_PLANE, G6K_STAGE = G6K_DD + 32 * 4, G6K_NST = 2;
+constexpr int G6K_XCH = G6K_NST * G6K_STAGE, G6K_LDS = G6K_XCH + 2 * 4 * 64 * 16 * 4; // exchange: [half][column tile][lane][16 floats]
+
+__device__ __forceinline__ void g6k_item(const G6KParams &p, const int i, int &task, int &cb) {
+    cb = (i >> 3) % p.n_cb;
+    task = (i / (8 * p.n_cb)) * 8 + (i & 7);
+}
+__device__ __forceinline__ int g6k_next_item(const G6KParams &p, int i) {
+    for (i += (int)gridDim.x; i < p.n_items; i += (int)gridDim.x) {
+        int t, c;
+        g6k_item(p, i, t, c);
+        if (t < p.n_tasks) break;
+    }
+    return i < p.n_items ? i : p.n_items;
+}
+
+// producer wave hw: accumulator lanes u = 2 hw, 2 hw + 1 of the 32 rows; lane = (row l / 2, half p = l % 2 of the super-block:
+// k-groups kb = 2p, 2p + 1 = vectors 4p .. 4p + 3)
+__device__ __forceinline__ void g6k_produce(const uint2 (&q)[2], const uint32_t (&hq)[2], const uint2 scl, const uint32_t dh, char *st, const int row,
+                                            const int hw, const int p) {
+    const g4k_h2 k1056 = {(_Float16)1056.f, (_Float16)1056.f};
+    const int ush = 8 * (hw >> 1); // the 16-block of u within a vector: u / 4 = hw / 2
+#pragma unroll
+    for (int e = 0; e < 2; e++) { // kb = 2p + e: vectors g0 = 2 kb (scale bytes 0 / 1 of the pair), g1 = 2 kb + 1 (bytes 2 / 3)
+        const uint32_t sw = e ? scl.y : scl.x;
+        const int s0i = (int)(int8_t)(sw >> ush), s1i = (int)(int8_t)(sw >> (16 + ush));
+        const _Float16 e0 = (_Float16)(float)(s0i & ~1), e1 = (_Float16)(float)(s1i & ~1);
+        const g4k_h2 ev0 = {e0, e0}, ev1 = {e1, e1};
+        const uint32_t om0 = (s0i & 1) ? 0xffffffffu : 0u, om1 = (s1i & 1) ? 0xffffffffu : 0u;
+#pragma unroll
+        for (int j = 0; j < 2; j++) { // u = 2 hw + j
+            const uint32_t w0 = q[j].x, w1 = q[j].y, h = hq[j];
+            // 6-bit values as fp16 (1024 + v): (e0, e2), (e1, e3) of vector g0, then of g1; minus 1056 = v - 32, exact
+            const uint32_t t[4] = {((w0 >> (4 * e)) & 0x000F000Fu) | (((h >> (4 * e)) & 0x00030003u) << 4) | 0x64006400u,
+                                   ((w0 >> (4 * e + 8)) & 0x000F000Fu) | (((h >> (4 * e + 8)) & 0x00030003u) << 4) | 0x64006400u,
+                                   ((w1 >> (4 * e)) & 0x000F000Fu) | (((h >> (4 * e + 2)) & 0x00030003u) << 4) | 0x64006400u,
+                                   ((w1 >> (4 * e + 8)) & 0x000F000Fu) | (((h >> (4 * e + 10)) & 0x00030003u) << 4) | 0x64006400u};
+            uint32_t hi[4], lo[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                g4k_h2 v;
+                __builtin_memcpy(&v, &t[k], 4);
+                v = v - k1056;
+                uint32_t vb;
+                __builtin_memcpy(&vb, &v, 4);
+                lo[k] = vb & (k < 2 ? om0 : om1);
+                v = v * (k < 2 ? ev0 : ev1); // (even, |.| <= 4096: exact)
+                __builtin_memcpy(&hi[k], &v, 4);
+            }
+            char *dst = st + (2 * p + e) * G4K_KB + row * G4K_RS + (2 * hw + j) * 16;
+            *(uint4 *)dst = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+            *(uint4 *)(dst + G6K_PLANE) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+        }
+    }
+    if (hw == 1 && p == 0) *(float *)(st + G6K_DD + row * 4) = ps_h2f((uint16_t)dh);
+}
+
+__device__ __forceinline__ void g6k_producer_wave(const G6KParams &p, int item, char *lds, const int hw) {
+    const int lane = threadIdx.x & 63, nsb = p.nsb;
+    const int row = lane >> 1, pp = lane & 1;
+    const uint8_t *qb, *hb, *sb_, *db;
+    auto point = [&](int it) {
+        int task, cb;
+        g6k_item(p, it, task, cb);
+        const int64_t gr = (int64_t)task * 32 + row; // (two consecutive row tiles)
+        qb = p.ql + (gr * nsb * 8 + 2 * hw) * 16 + pp * 8;
+        hb = p.qh + (gr * nsb * 8 + 2 * hw) * 8 + pp * 4;
+        sb_ = (const uint8_t *)p.sc + gr * nsb * 16 + pp * 8;
+        db = (const uint8_t *)p.d + gr * nsb * 2;
+    };
+    uint2 rq[G4K_RING][2], rs[G4K_RING];
+    uint32_t rh[G4K_RING][2], rd[G4K_RING];
+    auto load = [&](int g, uint2 (&a)[2], uint32_t (&h)[2], uint2 &sc, uint32_t &dh) {
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            a[j] = *(const uint2 *)(qb + (size_t)g * 128 + j * 16);
+            h[j] = *(const uint32_t *)(hb + (size_t)g * 64 + j * 8);
+        }
+        sc = *(const uint2 *)(sb_ + (size_t)g * 16);
+        dh = *(const uint16_t *)(db + (size_t)g * 2);
+    };
+    point(item);
+#pragma unroll
+    for (int k = 0; k < G4K_RING; k++) load(k, rq[k], rh[k], rs[k], rd[k]);
+    int c_item = item, c_g = G4K_RING;
+    bool first = true;
+    while (item < p.n_items) {
+        for (int g0 = 0; g0 < nsb; g0 += G4K_RING) {
+            if (c_g == nsb) {
+                const int nx = g6k_next_item(p, c_item);
+                if (nx < p.n_items) { c_item = nx; c_g = 0; point(nx); } else c_g = nsb - G4K_RING;
+            }
+#pragma unroll
+            for (int k = 0; k < G4K_RING; k++) {
+                uint2 a[2] = {rq[k][0], rq[k][1]};
+                uint32_t h[2] = {rh[k][0], rh[k][1]};
+                const uint2 sc = rs[k];
+                const uint32_t dh = rd[k];
+                load(c_g + k, rq[k], rh[k], rs[k], rd[k]);
+                g6k_produce(a, h, sc, dh, lds + ((g0 + k) & 1) * G6K_STAGE, row, hw, pp);
+                if (g0 == 0 && k == 0 && !first) __syncthreads(); // X of the previous item
+                __syncthreads(); // stage g0 + k is parked
+            }
+            c_g += G4K_RING;
+        }
+        first = false;
+        item = g6k_next_item(p, item);
+    }
+    __syncthreads(); // X of the last item
+}
+
+__global__ __launch_bounds__((G4K_NC + G4K_NP) * 64) void gemm6k_kernel(const G6KParams p) {
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int m = lane & 15, kb = lane >> 4;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    int item = (int)blockIdx.x;
+    {
+        int t, c;
+        g6k_item(p, item, t, c);
+        if (t >= p.n_tasks) item = g6k_next_item(p, item);
+    }
+    if (item >= p.n_items) return;
+    if (wave >= G4K_NC) { g6k_producer_wave(p, item, lds, wave - G4K_NC); return; }
+    const int ctl = wave & 3, uh = wave >> 2;
+    int task, cb;
+    g6k_item(p, item, task, cb);
+    const int ct = cb * 4 + ctl;
+    const int col = ct * 16 + m, colc = col < p.bs ? col : p.bs - 1;
+    const int ctc = ct * 16 < p.bs ? ct : (p.bs - 1) / 16;
+    const char *qf_ct = (const char *)p.qf + ((size_t)ctc * p.nsb << 13) + (size_t)(4 * uh) * 1024 + lane * 16;
+    const uint8_t *mf_ct = p.mf + (size_t)ctc * p.nsb * 576 + (colc & 15) * 4;
+    float *xch = (float *)(lds + G6K_XCH) + ((size_t)ctl * 64 + lane) * 16;
+    const g4k_f4 zf = {0.f, 0.f, 0.f, 0.f};
+    ps_u32x4 B[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) B[k] = *(const ps_u32x4 *)(qf_ct + k * 1024);
+    float yd = *(const float *)mf_ct;
+    while (item < p.n_items) {
+        g6k_item(p, item, task, cb);
+        float acc[2][4][4];
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+#pragma unroll
+                for (int k = 0; k < 4; k++) acc[t][r][k] = 0.f;
+        for (int sb = 0; sb < p.nsb; sb++) {
+            const int nb = sb + 1 == p.nsb ? 0 : sb + 1;
+            const float ydn = *(const float *)(mf_ct + (size_t)nb * 576);
+            __syncthreads(); // the producers have parked this step
+            const char *st = lds + (sb & 1) * G6K_STAGE;
+            float dr[2][4];
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                const g4k_f4 dd = *(const g4k_f4 *)(st + G6K_DD + (16 * t + 4 * kb) * 4); // d of rows 4 kb + r
+#pragma unroll
+                for (int r = 0; r < 4; r++) dr[t][r] = __fmul_rn(yd, dd[r]);
+            }
+            const char *ap = st + kb * G4K_KB + m * G4K_RS + (4 * uh) * 16;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                g4k_h8 bv;
+                __builtin_memcpy(&bv, &B[k], 16);
+#pragma unroll
+                for (int t = 0; t < 2; t++) {
+                    const ps_u32x4 ah = *(const ps_u32x4 *)(ap + t * 16 * G4K_RS + k * 16), al = *(const ps_u32x4 *)(ap + G6K_PLANE + t * 16 * G4K_RS + k * 16);
+                    g4k_h8 avh, avl;
+                    __builtin_memcpy(&avh, &ah, 16); __builtin_memcpy(&avl, &al, 16);
+                    g4k_f4 si = __builtin_amdgcn_mfma_f32_16x16x32_f16(avh, bv, zf, 0, 0, 0);
+                    si = __builtin_amdgcn_mfma_f32_16x16x32_f16(avl, bv, si, 0, 0, 0); // (float)sumi[4 uh + k] of rows 4 kb + r, this lane's column
+#pragma unroll
+                    for (int r = 0; r < 4; r++) acc[t][r][k] = __fmaf_rn(dr[t][r], si[r], acc[t][r][k]);
+                }
+                B[k] = *(const ps_u32x4 *)(qf_ct + ((size_t)nb << 13) + k * 1024);
+            }
+            yd = ydn;
+        }
+        // ---- the halves meet (hsum_float_8: lane u + lane u + 4 first); half uh finishes rows 4 kb + 2 uh, + 1 of both tiles
+        {
+            float *mine = xch + uh * 16 * 64 * 4; // (second half of the exchange area)
+#pragma unroll
+            for (int t = 0; t < 2; t++)
+#pragma unroll
+                for (int rr = 0; rr < 2; rr++) {
+#define G6K_SEL(k) (uh ? acc[t][rr][k] : acc[t][2 + rr][k])
+                    *(float4 *)(mine + (t * 2 + rr) * 4) = make_float4(G6K_SEL(0), G6K_SEL(1), G6K_SEL(2), G6K_SEL(3));
+#undef G6K_SEL
+                }
+        }
+        __syncthreads(); // X
+        {
+            const float *theirs = xch + (1 - uh) * 16 * 64 * 4;
+            if (col < p.bs) {
+#pragma unroll
+                for (int t = 0; t < 2; t++) {
+                    const int64_t row0 = (int64_t)task * 32 + t * 16 + kb * 4 + 2 * uh;
+                    float v[2];
+#pragma unroll
+                    for (int rr = 0; rr < 2; rr++) {
+                        const float4 o4 = *(const float4 *)(theirs + (t * 2 + rr) * 4);
+#define G6K_OWN(k) (uh ? acc[t][2 + rr][k] : acc[t][rr][k])
+                        const float s0 = __fadd_rn(G6K_OWN(0), o4.x), s1 = __fadd_rn(G6K_OWN(1), o4.y), s2 = __fadd_rn(G6K_OWN(2), o4.z), s3 = __fadd_rn(G6K_OWN(3), o4.w);
+#undef G6K_OWN
+                        v[rr] = __fadd_rn(__fadd_rn(s0, s2), __fadd_rn(s1, s3));
+                        if (p.bias) v[rr] = __fadd_rn(v[rr], p.bias[row0 + rr]);
+                        if (p.residual) v[rr] = __fadd_rn(p.residual[(int64_t)col * p.ldo + row0 + rr], v[rr]);
+                    }
+                    *(float2 *)(p.out + (int64_t)col * p.ldo + row0) = make_float2(v[0], v[1]);
+                }
+            }
+        }
+        item = g6k_next_item(p, item);
+    }
+}
+
 } // namespace
 
 // Q4_K batched mat-mul from fragment-major Q8_K activations (act.qf).  -1: not covered (the caller takes gemm8m).
@@ -670,5 +906,26 @@ int psk_gemm4k(hipStream_t st, int n_cu, const psk_gemv_args &a, ps_act act, int
         else hipLaunchKernelGGL((gemm4k_narrow_kernel<0, 1>), grid, blkn, LDS1, st, p);
     } else if (epi == 1) hipLaunchKernelGGL((gemm4k_kernel<1>), grid, blk, G4K_LDS, st, p);
     else hipLaunchKernelGGL((gemm4k_kernel<0>), grid, blk, G4K_LDS, st, p);
+    return 0;
+}
+
+// Q6_K batched mat-mul from the same fragment-major activations.  -1: not covered (the caller keeps the 8-column mat-vec launches).
+int psk_gemm6k(hipStream_t st, int n_cu, const psk_gemv6_args &a, ps_act act, int64_t K, int64_t bs) {
+    static const bool off = getenv("PS_NO_GEMM6K") != nullptr; // (A/B switch for measurements)
+    const ps_weight *w = a.w;
+    if (off || !w || w->dtype != PS_Q6_K || w->K != K || K % 1024 || w->N % 32 || a.ldo % 2 || !act.qf || bs < 17 || bs < ps_gemm4k_min_cols()) return -1;
+    G6KParams p{};
+    p.ql = w->qs; p.qh = w->qh; p.sc = (const int8_t *)w->sc; p.d = (const uint16_t *)w->aux;
+    p.out = a.out; p.bias = a.bias; p.residual = a.residual; p.N = w->N; p.ldo = a.ldo;
+    p.nsb = (int)(K / 256); p.bs = (int)bs; p.n_tasks = (int)(w->N / 32);
+    p.qf = act.qf; p.mf = act.mf;
+    const int n_ct = (int)((bs + 15) / 16);
+    p.n_cb = (n_ct + 3) / 4;
+    p.n_items = (p.n_tasks + 7) / 8 * 8 * p.n_cb;
+    int n_wg = p.n_items;
+    if (n_cu > 0 && n_wg > n_cu && n_cu % (8 * p.n_cb) == 0) n_wg = n_cu;
+    static unsigned long long attr = 0;
+    if (ps_first_on_device(&attr)) (void)hipFuncSetAttribute((const void *)gemm6k_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, G6K_LDS);
+    hipLaunchKernelGGL(gemm6k_kernel, dim3((unsigned)n_wg), dim3((G4K_NC + G4K_NP) * 64), G6K_LDS, st, p);
     return 0;
 }

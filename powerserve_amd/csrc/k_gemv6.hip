@@ -237,6 +237,10 @@ int psk_gemv6(hipStream_t st, int n_cu, const psk_gemv6_args &a, ps_act act, int
     const ps_weight *w = a.w;
     if (w->dtype == PS_Q5_K && w->K == K && K % 256 == 0) return launch_gemv5(st, n_cu, a, act, K, bs);
     if (w->dtype != PS_Q6_K || w->K != K || K % 256) return 4;
+    { // chunks and wide trees: the matrix-core mat-mul (k_gemm4k.hip)
+        const int rc = psk_gemm6k(st, n_cu, a, act, K, bs);
+        if (rc != -1) return rc;
+    }
     Gemv6Params p{};
     p.ql = w->qs; p.qh = w->qh; p.sc = w->sc; p.d = (const uint16_t *)w->aux;
     p.K = K; p.N = w->N; p.nsb = (int)(K / 256);

@@ -122,6 +122,32 @@ def test_mul_mat_q4k_chunk_on_matrix_cores(ctx, oracle, hip, K, N, bs):
     W.free()
 
 
+@pytest.mark.parametrize("K,N,bs", [(4096, 512, 128), (1024, 96, 120), (14336, 64, 113), (2048, 8224, 40), (1024, 64, 160), (1024, 32, 17)])
+def test_mul_mat_q6k_chunk_on_matrix_cores(ctx, oracle, hip, K, N, bs):
+    """Q6_K weights (attn_v, ffn_down, output of the Q4_K_M / Q5_K_M mixes), batches from 17 columns: gemm6k_kernel in
+    k_gemm4k.hip -- (q6 - 32) x the even / odd parts of the int8 scale as two fp16 MFMA contractions of exact integers --
+    bit-for-bit ggml_vec_dot_q6_K_q8_K per column; scales are drawn over the whole int8 range, +-128 x +-32 included."""
+    from powerserve_amd import synth
+    rng = np.random.default_rng(K + N + bs + 6)
+    w = synth.random_blocks(rng, 14, N, K)
+    blocks = w.reshape(-1, 210)  # block_q6_K: ql[128], qh[64], scales[16] (int8), d
+    blocks[:, 192:208] = rng.integers(-128, 128, (blocks.shape[0], 16), dtype=np.int8).view(np.uint8)
+    blocks[0, 192:208] = np.array([-128, 127] * 8, dtype=np.int8).view(np.uint8)  # the extremes against q6 = 0 and 63 everywhere
+    blocks[0, 0:128] = 0; blocks[0, 128:192] = 0
+    blocks[1, 192:208] = np.array([127, -128] * 8, dtype=np.int8).view(np.uint8)
+    blocks[1, 0:192] = 0xff
+    x = (rng.standard_normal((bs, K)) * rng.uniform(0.1, 30.0, (bs, 1))).astype(np.float32)
+    x[min(3, bs - 1), 256:512] = 0.0
+    x[0, 0:512] = np.where(rng.random(512) < 0.5, 1.0, -1.0) * 7.0  # every quant of these super-blocks at +-127
+    want = oracle.mul_mat(14, w, K, N, x)
+    W = ctx.upload_weight(14, w, K, N)
+    dx, dy = ctx.to_device(x), ctx.empty((bs, N))
+    ctx.check(ctx.L.ps_hip_mul_mat(ctx.h, C.byref(dy.tensor()), C.byref(W.tensor()), C.byref(dx.tensor())))
+    got = dy.numpy()
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (rel_err(got, want), np.argwhere(got != want)[:8])
+    W.free()
+
+
 def test_mul_mat_f32_gqa_views(ctx, oracle, hip):
     """K-cache view x permuted q (norm_attention.cpp:115-129) and V-cache view x kq (:138-147)."""
     rng = np.random.default_rng(7)
