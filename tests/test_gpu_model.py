@@ -163,14 +163,15 @@ def test_tree_mask_plumbing(ctx, tmp_path):
     gm.close()
 
 
-def test_long_context_batches_match_oracle(ctx, oracle, tmp_path):
+@pytest.mark.parametrize("wt", [12, 1015])  # pure Q4_K; the Q4_K_M mix (Q6_K attn_v / ffn_down / output: the prefill chunks take gemm6k)
+def test_long_context_batches_match_oracle(ctx, oracle, tmp_path, wt):
     """Batches appended behind a long KV prefix (n_kv > 256: several 32-column chain rounds, leftovers, softmax tails):
     bit-exact against the oracle for decode steps and for batches of 3 and 12, and a tree whose root only sees itself
     gives the root the logits of the causal batch (the children are masked exactly like future tokens)."""
     from oracle import binding as B
     from powerserve_amd import hip, synth
     d = str(tmp_path / "m")
-    mj = synth.write_model_dir(d, "small-llama-hs128", 12, n_ctx=512, seed=5)
+    mj = synth.write_model_dir(d, "small-llama-hs128", wt, n_ctx=512, seed=5)
     cfg = B.make_config(mj["llm_config"])
     om = oracle.model(cfg, mj["model_arch"], load_tensors(os.path.join(d, "ggml/weights.gguf")), n_threads=16)
     gm = hip.Model(ctx, d, max_batch=128, n_ctx=512)
