@@ -47,7 +47,8 @@ typedef _Float16 g4k_h4 __attribute__((ext_vector_type(4)));
 typedef float g4k_f4 __attribute__((ext_vector_type(4)));
 
 struct G4KMat {
-    const uint8_t *qs, *aux;
+    const uint8_t *qs, *aux; // Q4_K: row-group units + headers;  Q5_K: per-row planes qs [N][nsb][u][16 B], aux = headers [N][nsb] 16 B
+    const uint8_t *qh;       // Q5_K: the fifth bits, [N][nsb][u][4 B]
     float *out;
     const float *bias;
     int64_t N, ldo;
@@ -55,6 +56,7 @@ struct G4KMat {
 };
 struct G4KParams {
     G4KMat w[3];
+    int wt;                  // PS_Q4_K or PS_Q5_K (one producer each; the consumers are the same)
     int n_w, nsb, bs, n_tasks, n_cb, n_items; // n_cb: 64-column blocks; items = (task, column block), tasks padded to a multiple of 8
     const float *residual;
     const _Float16 *qf; // fragment-major fp16 quants
@@ -76,12 +78,15 @@ constexpr int G4K_TAB = G4K_XCH + 4 * 64 * 48 * 4;   // glibc expf's exp2 table 
 constexpr int G4K_LDS = G4K_TAB + PS_EXP2F_N * 8;
 
 // the two row tiles of a task
-struct G4KRows { const uint8_t *qs[2], *aux[2]; int tile[2]; };
+struct G4KRows { const uint8_t *qs[2], *aux[2], *qh[2]; int tile[2]; };
 
 // ---- producers.  Wave h (0..3) makes the accumulator lanes u = 2h, 2h + 1 of all 32 rows; lane = (row l / 2, kb pair p = l % 2):
 // its weight dwords [row][u][kb = 2p, 2p + 1] are one 8-B load per u.
-template <int UPP> // accumulator lanes per producer wave: u = UPP hw .. UPP hw + UPP - 1
-__device__ __forceinline__ void g4k_produce(const uint2 (&qq)[UPP], const uint4 h, char *st, const int row, const int hw, const int p) {
+// Q5_K (ggml_vec_dot_q5_K_q8_K, ggml-quants.c:8237-8320: the Q4_K kernel with a fifth bit per weight, value <= 31, x scale
+// <= 1953 < 2048: still one exact fp16 operand): hq = the lane's four qh bytes (bit g of byte i = fifth bit of element 4u + i of
+// sub-block g); zero for Q4_K.
+template <int UPP, int WT> // accumulator lanes per producer wave: u = UPP hw .. UPP hw + UPP - 1
+__device__ __forceinline__ void g4k_produce(const uint2 (&qq)[UPP], const uint32_t (&hq)[UPP], const uint4 h, char *st, const int row, const int hw, const int p) {
     // the four sub-block scales 4p .. 4p+3 (get_scale_min_k4: 0..3 sit in the low 6 bits of scale bytes 0..3, 4..7 are
     // spread over bytes 8..11 and the top bits of bytes 0..3) as fp16 pairs (s, s) and (-1024 s, -1024 s)
     const uint32_t scb = p ? ((h.w & 0x0f0f0f0fu) | (((h.y >> 6) & 0x03030303u) << 4)) : (h.y & 0x3f3f3f3fu);
@@ -102,8 +107,13 @@ __device__ __forceinline__ void g4k_produce(const uint2 (&qq)[UPP], const uint4 
         for (int e = 0; e < 2; e++) { // kb = 2p + e: sub-blocks 2 kb (low nibbles), 2 kb + 1 (high nibbles) = scales 2e, 2e + 1 of the four
             const uint32_t w = e ? q.y : q.x;
             // nibble pairs as fp16 (1024 + n): (e0, e2), (e1, e3) of sub-block 2 kb, then of 2 kb + 1;  fma(1024 + n, s, -1024 s) = n s, exact
-            const uint32_t t[4] = {(w & 0x000F000Fu) | 0x64006400u, ((w >> 8) & 0x000F000Fu) | 0x64006400u,
-                                   ((w >> 4) & 0x000F000Fu) | 0x64006400u, ((w >> 12) & 0x000F000Fu) | 0x64006400u};
+            uint32_t t[4] = {(w & 0x000F000Fu) | 0x64006400u, ((w >> 8) & 0x000F000Fu) | 0x64006400u,
+                             ((w >> 4) & 0x000F000Fu) | 0x64006400u, ((w >> 12) & 0x000F000Fu) | 0x64006400u};
+            if (WT == PS_Q5_K) { // the fifth bits of sub-blocks g0 = 4p + 2e (t[0], t[1]) and g0 + 1 (t[2], t[3])
+                const uint32_t hg = hq[j] >> (4 * p + 2 * e);
+                t[0] |= (hg & 0x00010001u) << 4; t[1] |= ((hg >> 8) & 0x00010001u) << 4;
+                t[2] |= ((hg >> 1) & 0x00010001u) << 4; t[3] |= ((hg >> 9) & 0x00010001u) << 4;
+            }
             uint32_t o[4];
 #pragma unroll
             for (int k = 0; k < 4; k++) {
@@ -152,8 +162,8 @@ __device__ __forceinline__ G4KRows g4k_rows(const G4KParams &p, const int task, 
     }
     const G4KMat &W = wi == 0 ? p.w[0] : (wi == 1 ? p.w[1] : p.w[2]);
     G4KRows R;
-    if (EPI == 1) { R.qs[0] = p.w[0].qs; R.aux[0] = p.w[0].aux; R.qs[1] = p.w[1].qs; R.aux[1] = p.w[1].aux; R.tile[0] = R.tile[1] = task; }
-    else { R.qs[0] = R.qs[1] = W.qs; R.aux[0] = R.aux[1] = W.aux; R.tile[0] = 2 * pair; R.tile[1] = 2 * pair + 1; }
+    if (EPI == 1) { R.qs[0] = p.w[0].qs; R.aux[0] = p.w[0].aux; R.qh[0] = p.w[0].qh; R.qs[1] = p.w[1].qs; R.aux[1] = p.w[1].aux; R.qh[1] = p.w[1].qh; R.tile[0] = R.tile[1] = task; }
+    else { R.qs[0] = R.qs[1] = W.qs; R.aux[0] = R.aux[1] = W.aux; R.qh[0] = R.qh[1] = W.qh; R.tile[0] = 2 * pair; R.tile[1] = 2 * pair + 1; }
     return R;
 }
 __device__ __forceinline__ int g4k_next_item(const G4KParams &p, int i) { // the next item of this workgroup with a real task, or n_items
@@ -168,31 +178,42 @@ __device__ __forceinline__ int g4k_next_item(const G4KParams &p, int i) { // the
 // The producers of a PERSISTENT workgroup: the stage stream runs on across the workgroup's items -- the ring is already
 // loading the next item's first super-blocks while the consumers finish this one, and its first two stages are parked
 // before the consumers' end-of-item exchange barrier (X), so a new item starts at full speed.
-template <int EPI, int NPW, int RING> // NPW producer waves: wave hw makes the accumulator lanes 8 / NPW * hw ..; RING super-blocks in flight (nsb % RING == 0)
+template <int EPI, int NPW, int RING, int WT> // NPW producer waves: wave hw makes the accumulator lanes 8 / NPW * hw ..; RING super-blocks in flight (nsb % RING == 0)
 __device__ __forceinline__ void g4k_producer_wave(const G4KParams &p, int item, char *lds, const int hw, unsigned long long *dbg) {
     constexpr int UPP = 8 / NPW;
     const int lane = threadIdx.x & 63, nsb = p.nsb;
     int dbg_n = 1;
     auto mark = [&](int g) { if (dbg && (g < 8 || (g & 7) == 7) && dbg_n < 29) dbg[dbg_n++] = __builtin_amdgcn_s_memtime(); };
     const int row = lane >> 1, pp = lane & 1, rt = row >> 4, unit = (row >> 3) & 1, r8 = row & 7;
-    const uint8_t *qb, *hb; // the load cursor's item
+    const uint8_t *qb, *hb, *fb = nullptr; // the load cursor's item (fb: Q5_K's fifth bits)
     auto point = [&](int it) {
         int task, cb, wi, pair;
         g4k_item(p, it, task, cb);
         const G4KRows R = g4k_rows<EPI>(p, task, wi, pair);
-        qb = (rt ? R.qs[1] : R.qs[0]) + ((size_t)(2 * (rt ? R.tile[1] : R.tile[0]) + unit) * nsb << 10) + (size_t)(r8 * 32 + UPP * hw * 4 + 2 * pp) * 4;
-        hb = (rt ? R.aux[1] : R.aux[0]) + (size_t)(2 * (rt ? R.tile[1] : R.tile[0]) + unit) * nsb * 128 + (size_t)r8 * 16;
+        if (WT == PS_Q5_K) { // per-row planes
+            const size_t gr = (size_t)(rt ? R.tile[1] : R.tile[0]) * 16 + (row & 15);
+            qb = (rt ? R.qs[1] : R.qs[0]) + (gr * nsb * 8 + UPP * hw) * 16 + pp * 8;
+            fb = (rt ? R.qh[1] : R.qh[0]) + (gr * nsb * 8 + UPP * hw) * 4;
+            hb = (rt ? R.aux[1] : R.aux[0]) + gr * nsb * 16;
+        } else {
+            qb = (rt ? R.qs[1] : R.qs[0]) + ((size_t)(2 * (rt ? R.tile[1] : R.tile[0]) + unit) * nsb << 10) + (size_t)(r8 * 32 + UPP * hw * 4 + 2 * pp) * 4;
+            hb = (rt ? R.aux[1] : R.aux[0]) + (size_t)(2 * (rt ? R.tile[1] : R.tile[0]) + unit) * nsb * 128 + (size_t)r8 * 16;
+        }
     };
     uint2 rq[RING][UPP];
+    uint32_t rf[RING][UPP];
     uint4 rh[RING];
-    auto load = [&](int g, uint2 (&a)[UPP], uint4 &h) {
+    auto load = [&](int g, uint2 (&a)[UPP], uint32_t (&f)[UPP], uint4 &h) {
 #pragma unroll
-        for (int j = 0; j < UPP; j++) a[j] = *(const uint2 *)(qb + ((size_t)g << 10) + j * 16);
-        h = *(const uint4 *)(hb + (size_t)g * 128);
+        for (int j = 0; j < UPP; j++) {
+            if (WT == PS_Q5_K) { a[j] = *(const uint2 *)(qb + (size_t)g * 128 + j * 16); f[j] = *(const uint32_t *)(fb + (size_t)g * 32 + j * 4); }
+            else { a[j] = *(const uint2 *)(qb + ((size_t)g << 10) + j * 16); f[j] = 0u; }
+        }
+        h = *(const uint4 *)(hb + (size_t)g * (WT == PS_Q5_K ? 16 : 128));
     };
     point(item);
 #pragma unroll
-    for (int k = 0; k < RING; k++) load(k, rq[k], rh[k]);
+    for (int k = 0; k < RING; k++) load(k, rq[k], rf[k], rh[k]);
     int c_item = item, c_g = RING; // the cursor: the ring's next loads
     bool first = true;
     while (item < p.n_items) {
@@ -204,11 +225,12 @@ __device__ __forceinline__ void g4k_producer_wave(const G4KParams &p, int item, 
 #pragma unroll
             for (int k = 0; k < RING; k++) {
                 uint2 a[UPP];
+                uint32_t f[UPP];
 #pragma unroll
-                for (int j = 0; j < UPP; j++) a[j] = rq[k][j];
+                for (int j = 0; j < UPP; j++) { a[j] = rq[k][j]; f[j] = rf[k][j]; }
                 const uint4 h = rh[k];
-                load(c_g + k, rq[k], rh[k]);
-                g4k_produce<UPP>(a, h, lds + ((g0 + k) & (G4K_NST - 1)) * G4K_STAGE, row, hw, pp);
+                load(c_g + k, rq[k], rf[k], rh[k]);
+                g4k_produce<UPP, WT>(a, f, h, lds + ((g0 + k) & (G4K_NST - 1)) * G4K_STAGE, row, hw, pp);
                 if (k & 1) {
                     if (g0 == 0 && k == 1 && !first) __syncthreads(); // X of the previous item: its consumers have exchanged
                     __syncthreads(); // one barrier per PAIR of stages: stages g0 + k - 1, g0 + k are parked
@@ -225,11 +247,11 @@ __device__ __forceinline__ void g4k_producer_wave(const G4KParams &p, int item, 
 
 // ---- consumers
 struct G4KMeta { float yd; ps_u32x4 b16; }; // the column's scale and the fp16 16-sums of sub-blocks 4 uh .. 4 uh + 3 of one super-block
-__device__ __forceinline__ G4KMeta g4k_meta(const uint8_t *mf_ct, const int sb, const int mc, const int uh) {
+__device__ __forceinline__ G4KMeta g4k_meta(const uint8_t *mf_ct, const int sb, const int mc, const int boff) { // boff: which 16 B of the column's 16-sums
     const uint8_t *mfs = mf_ct + (size_t)sb * 576; // the (column tile, super-block) block: d[16], then the fp16 16-sums [16][16]
     G4KMeta M;
     M.yd = *(const float *)(mfs + mc * 4);
-    M.b16 = *(const ps_u32x4 *)(mfs + 64 + mc * 32 + uh * 16);
+    M.b16 = *(const ps_u32x4 *)(mfs + 64 + mc * 32 + boff);
     return M;
 }
 
@@ -250,6 +272,7 @@ struct G4KAcc {
 
 // one super-block.  B[k] = this lane's B operand for accumulator lane 4 uh + k (loaded a step ago); as soon as both row
 // tiles have met it its registers take the load for the NEXT super-block (nq)
+template <int WT>
 __device__ __forceinline__ void g4k_superblock(G4KAcc &T, const char *st, const char *zero, ps_u32x4 (&B)[4], const char *nq, const G4KMeta M,
                                                const int m, const int kb, const int uh) {
     const g4k_f4 zf = {0.f, 0.f, 0.f, 0.f};
@@ -276,6 +299,28 @@ __device__ __forceinline__ void g4k_superblock(G4KAcc &T, const char *st, const 
         }
         B[k] = *(const ps_u32x4 *)(nq + k * 1024);
     }
+    if (WT == PS_Q5_K) {
+        // Q5_K keeps the mins in ONE scalar chain per (row, column), multiply then add (ggml-quants.c:8411, two roundings):
+        // summs += dmin * (float)(sum over all eight sub-blocks of mins * q8sum) -- a K = 16 contraction: k-group kb supplies
+        // mins lane v = kb's operand and the column's 16-sums 4 kb .. 4 kb + 3.  Half 0 keeps the chain (accm[.][.][0]).
+        if (uh == 0) {
+            const uint32_t bx = (kb & 1) ? M.b16.z : M.b16.x, by = (kb & 1) ? M.b16.w : M.b16.y; // (b16 = the 16 B holding lane kb's sums)
+            g4k_h2 g0, g1;
+            __builtin_memcpy(&g0, &bx, 4); __builtin_memcpy(&g1, &by, 4);
+            const g4k_h4 bm = {g0[0], g0[1], g1[0], g1[1]};
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                const uint2 ma = *(const uint2 *)(st + G4K_MINS + (16 * t + m) * 32 + kb * 8);
+                g4k_h2 a0, a1;
+                __builtin_memcpy(&a0, &ma.x, 4); __builtin_memcpy(&a1, &ma.y, 4);
+                const g4k_h4 am = {a0[0], a0[1], a1[0], a1[1]};
+                const g4k_f4 pr = __builtin_amdgcn_mfma_f32_16x16x16f16(am, bm, zf, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; r++) T.accm[t][r][0] = __fadd_rn(T.accm[t][r][0], __fmul_rn(dmin[t][r], pr[r]));
+            }
+        }
+        return;
+    }
     // acc_m lanes 2 uh, 2 uh + 1: the lanes of k-group 0 supply the row's mins operands, the others zeros; B = the column's fp16 16-sums
 #pragma unroll
     for (int t = 0; t < 2; t++) {
@@ -296,7 +341,7 @@ __device__ __forceinline__ void g4k_superblock(G4KAcc &T, const char *st, const 
 
 // twelve waves: (4 column tiles x 2 accumulator halves) on two row tiles + the four producers; persistent over the items
 // blockIdx.x, blockIdx.x + gridDim.x, ... (the launcher keeps the column block of a workgroup fixed across its items)
-template <int EPI>
+template <int EPI, int WT>
 __global__ __launch_bounds__((G4K_NC + G4K_NP) * 64) void gemm4k_kernel(const G4KParams p) {
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int m = lane & 15, kb = lane >> 4;
@@ -314,7 +359,7 @@ __global__ __launch_bounds__((G4K_NC + G4K_NP) * 64) void gemm4k_kernel(const G4
     unsigned long long *const dbg = (p.dbg && blockIdx.x < 1024 && lane == 0 && (wave == 0 || wave == G4K_NC)) ? p.dbg + ((size_t)blockIdx.x * 2 + (wave == G4K_NC)) * 32 : nullptr;
     if (dbg) { dbg[0] = __builtin_amdgcn_s_memtime(); dbg[29] = __builtin_amdgcn_s_memrealtime(); }
     if (wave >= G4K_NC) {
-        g4k_producer_wave<EPI, G4K_NP, G4K_RING>(p, item, lds, wave - G4K_NC, dbg);
+        g4k_producer_wave<EPI, G4K_NP, G4K_RING, WT>(p, item, lds, wave - G4K_NC, dbg);
         if (dbg) { dbg[31] = __builtin_amdgcn_s_memtime(); dbg[30] = __builtin_amdgcn_s_memrealtime(); }
         return;
     }
@@ -334,7 +379,8 @@ __global__ __launch_bounds__((G4K_NC + G4K_NP) * 64) void gemm4k_kernel(const G4
     ps_u32x4 B[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) B[k] = *(const ps_u32x4 *)(qf_ct + k * 1024);
-    G4KMeta M = g4k_meta(mf_ct, 0, mc, uh);
+    const int boff = WT == PS_Q5_K ? (kb >> 1) * 16 : uh * 16;
+    G4KMeta M = g4k_meta(mf_ct, 0, mc, boff);
     while (item < p.n_items) {
         g4k_item(p, item, task, cb);
         int wi, pair;
@@ -344,10 +390,10 @@ __global__ __launch_bounds__((G4K_NC + G4K_NP) * 64) void gemm4k_kernel(const G4
         T.clear();
         auto step = [&](const int sb) {
             const int nb = sb + 1 == p.nsb ? 0 : sb + 1; // (the next item meets the same columns from super-block 0)
-            const G4KMeta Mn = g4k_meta(mf_ct, nb, mc, uh); // a step ahead, like B
+            const G4KMeta Mn = g4k_meta(mf_ct, nb, mc, boff); // a step ahead, like B
             if (!(sb & 1)) __syncthreads(); // the producers have parked this step and the next
             mark(sb);
-            g4k_superblock(T, lds + (sb & (G4K_NST - 1)) * G4K_STAGE, zero, B, qf_ct + ((size_t)nb << 13), M, m, kb, uh);
+            g4k_superblock<WT>(T, lds + (sb & (G4K_NST - 1)) * G4K_STAGE, zero, B, qf_ct + ((size_t)nb << 13), M, m, kb, uh);
             M = Mn;
         };
         for (int sb = 0; sb < p.nsb - 1; sb++) step(sb);
@@ -399,7 +445,7 @@ __global__ __launch_bounds__((G4K_NC + G4K_NP) * 64) void gemm4k_kernel(const G4
                     const float ma = uh ? o2.x : w0, mb = uh ? o2.y : w1;   // acc_m lanes 0, 1
                     const float mc2 = uh ? w0 : o2.x, md = uh ? w1 : o2.y;  // acc_m lanes 2, 3
 #undef G4K_OWN
-                    const float mm = __fadd_rn(__fadd_rn(ma, mc2), __fadd_rn(mb, md));
+                    const float mm = WT == PS_Q5_K ? ma : __fadd_rn(__fadd_rn(ma, mc2), __fadd_rn(mb, md)); // (Q5_K: hsum_float_8(acc) + summs)
                     y[t][rr] = __fadd_rn(res, mm);
                 }
             if (col < p.bs) {
@@ -444,7 +490,7 @@ __global__ __launch_bounds__((G4K_NC + G4K_NP) * 64) void gemm4k_kernel(const G4
 // rows 4 kb + 0, 1 and 4 kb + 2, 3 (hsum_float_8's order) from LDS.
 constexpr int G4K_RINGN = 4; // (a ring of eight super-blocks measured slower: 12 wide 5.09 vs 4.78 ms)
 constexpr int G4K_NPN = 8; // producing waves of the narrow kernel: one accumulator lane each (the consumers are light there, the producers set the pace)
-template <int EPI, int CT>
+template <int EPI, int CT, int WT>
 __global__ __launch_bounds__((G4K_NC + G4K_NPN) * 64) void gemm4k_narrow_kernel(const G4KParams p) {
     constexpr int NU = CT, XW = CT == 1 ? 2 : 4; // accumulator lanes per wave; floats per (tile, row) in the exchange (NU chains + 1 mins chain, padded)
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
@@ -463,12 +509,12 @@ __global__ __launch_bounds__((G4K_NC + G4K_NPN) * 64) void gemm4k_narrow_kernel(
     unsigned long long *const dbg = (p.dbg && blockIdx.x < 1024 && lane == 0 && (wave == 0 || wave == G4K_NC)) ? p.dbg + ((size_t)blockIdx.x * 2 + (wave == G4K_NC)) * 32 : nullptr;
     if (dbg) { dbg[0] = __builtin_amdgcn_s_memtime(); dbg[29] = __builtin_amdgcn_s_memrealtime(); }
     if (wave >= G4K_NC) {
-        g4k_producer_wave<EPI, G4K_NPN, G4K_RINGN>(p, item, lds, wave - G4K_NC, dbg);
+        g4k_producer_wave<EPI, G4K_NPN, G4K_RINGN, WT>(p, item, lds, wave - G4K_NC, dbg);
         if (dbg) { dbg[31] = __builtin_amdgcn_s_memtime(); dbg[30] = __builtin_amdgcn_s_memrealtime(); }
         return;
     }
     const int ctl = wave % CT, ug = wave / CT; // (column tile, accumulator-lane group: lanes u = NU ug .. NU ug + NU - 1)
-    const bool has_v = ug < 4;                  // mins lane v = ug
+    const bool has_v = WT == PS_Q5_K ? ug == 0 : ug < 4; // mins lane v = ug (Q5_K: group 0 keeps the one scalar chain, k-group kb supplying lane v = kb)
     int task, cb;
     g4k_item(p, item, task, cb);
     const int ct = cb * CT + ctl;
@@ -476,7 +522,7 @@ __global__ __launch_bounds__((G4K_NC + G4K_NPN) * 64) void gemm4k_narrow_kernel(
     const int ctc = ct * 16 < p.bs ? ct : (p.bs - 1) / 16;
     const char *qf_ct = (const char *)p.qf + ((size_t)ctc * p.nsb << 13) + (size_t)(NU * ug) * 1024 + lane * 16;
     const uint8_t *mf_ct = p.mf + (size_t)ctc * p.nsb * 576 + (colc & 15) * 4;                          // the column's scale
-    const uint8_t *ms_ct = p.mf + (size_t)ctc * p.nsb * 576 + 64 + (colc & 15) * 32 + (has_v ? ug : 0) * 8; // the four 16-sums of mins lane v
+    const uint8_t *ms_ct = p.mf + (size_t)ctc * p.nsb * 576 + 64 + (colc & 15) * 32 + (WT == PS_Q5_K ? kb : (has_v ? ug : 0)) * 8; // the four 16-sums of mins lane v
     const char *zero = lds + G4K_NST * G4K_STAGE;
     float *xall = (float *)(lds + G4K_XCH);
     const g4k_f4 zf = {0.f, 0.f, 0.f, 0.f};
@@ -543,13 +589,14 @@ __global__ __launch_bounds__((G4K_NC + G4K_NPN) * 64) void gemm4k_narrow_kernel(
                     const g4k_h4 bm = {g0[0], g0[1], g1[0], g1[1]};
 #pragma unroll
                     for (int t = 0; t < 2; t++) {
-                        const uint2 ma = *(const uint2 *)(kb == 0 && has_v ? st + G4K_MINS + (16 * t + m) * 32 + ug * 8 : zero);
+                        const uint2 ma = *(const uint2 *)(WT == PS_Q5_K ? (has_v ? st + G4K_MINS + (16 * t + m) * 32 + kb * 8 : zero)
+                                                                          : (kb == 0 && has_v ? st + G4K_MINS + (16 * t + m) * 32 + ug * 8 : zero));
                         g4k_h2 a0, a1;
                         __builtin_memcpy(&a0, &ma.x, 4); __builtin_memcpy(&a1, &ma.y, 4);
                         const g4k_h4 am = {a0[0], a0[1], a1[0], a1[1]};
                         const g4k_f4 pr = __builtin_amdgcn_mfma_f32_16x16x16f16(am, bm, zf, 0, 0, 0);
 #pragma unroll
-                        for (int r = 0; r < 4; r++) accm[t][r] = __fmaf_rn(dmin[t][r], pr[r], accm[t][r]);
+                        for (int r = 0; r < 4; r++) accm[t][r] = WT == PS_Q5_K ? __fadd_rn(accm[t][r], __fmul_rn(dmin[t][r], pr[r])) : __fmaf_rn(dmin[t][r], pr[r], accm[t][r]);
                     }
                 }
                 ring_load(j, nx);
@@ -584,7 +631,7 @@ __global__ __launch_bounds__((G4K_NC + G4K_NPN) * 64) void gemm4k_narrow_kernel(
                         mv[v] = xall[((size_t)(ctl + CT * v) * 64 + lane) * (8 * XW) + (t * 4 + r) * XW + NU];
                     const float s0 = __fadd_rn(au[0], au[4]), s1 = __fadd_rn(au[1], au[5]), s2 = __fadd_rn(au[2], au[6]), s3 = __fadd_rn(au[3], au[7]);
                     const float res = __fadd_rn(__fadd_rn(s0, s2), __fadd_rn(s1, s3));
-                    const float mm = __fadd_rn(__fadd_rn(mv[0], mv[2]), __fadd_rn(mv[1], mv[3]));
+                    const float mm = WT == PS_Q5_K ? mv[0] : __fadd_rn(__fadd_rn(mv[0], mv[2]), __fadd_rn(mv[1], mv[3]));
                     y[t][rr] = __fadd_rn(res, mm);
                 }
             if (col < p.bs) {
@@ -855,23 +902,8 @@ __global__ __launch_bounds__((G4K_NC + G4K_NP) * 64) void gemm6k_kernel(const G6
 
 } // namespace
 
-// Q4_K batched mat-mul from fragment-major Q8_K activations (act.qf).  -1: not covered (the caller takes gemm8m).
-int psk_gemm4k(hipStream_t st, int n_cu, const psk_gemv_args &a, ps_act act, int64_t K, int64_t bs) {
-    static const bool off = getenv("PS_NO_GEMM4K") != nullptr; // (A/B switch for measurements)
-    if (off || a.pro != 0 || a.rope || a.n_w < 1 || !act.qf || K % 256) return -1;
-    G4KParams p{};
-    int pairs_total = 0;
-    for (int i = 0; i < a.n_w; i++) {
-        if (a.w[i]->dtype != PS_Q4_K || a.w[i]->K != K || a.w[i]->N % 32 || a.ldo[i] % 4) return -1;
-        p.w[i] = G4KMat{a.w[i]->qs, a.w[i]->aux, a.out[i], a.bias[i], a.w[i]->N, a.ldo[i], (int)(a.w[i]->N / 16)};
-        pairs_total += p.w[i].n_tiles / 2;
-    }
-    const int epi = a.silu_pair ? 1 : 0;
-    if (epi == 1 && (a.n_w != 2 || a.w[0]->N != a.w[1]->N || a.ldo[0] != a.ldo[1])) return -1;
-    p.n_w = a.n_w; p.nsb = (int)(K / 256); p.bs = (int)bs;
-    p.n_tasks = epi == 1 ? p.w[0].n_tiles : pairs_total;
-    p.residual = a.residual; p.qf = act.qf; p.mf = act.mf;
-    p.dbg = psk_gemv_dbg_buf(12 + epi, epi ? 0 : (a.n_w == 3 ? 0 : (K <= 8192 ? 1 : 2))); // keys 48 QKV, 49 O, 50 down, 52 gate/up
+// grid, persistence and the wide / narrow choice for a filled-in G4KParams (tasks, pointers, wt)
+static int g4k_launch(hipStream_t st, int n_cu, G4KParams &p, const int epi, const int64_t bs) {
     const int n_ct = (int)((bs + 15) / 16);
     // (Measured, not kept.  (1) 64 rows x 32 columns per workgroup for batches of at most 32 columns -- every prepared weight
     // operand meeting every live column -- is SLOWER, 12 wide 6.3 vs 5.9 ms: with N = 4096 rows there are only 64 such
@@ -896,17 +928,56 @@ int psk_gemm4k(hipStream_t st, int n_cu, const psk_gemv_args &a, ps_act act, int
     constexpr int LDS1 = G4K_XCH + 8 * 64 * 8 * 2 * 4 + PS_EXP2F_N * 8;
     static unsigned long long attr = 0; // devices that have the attribute
     if (ps_first_on_device(&attr)) {
-        (void)hipFuncSetAttribute((const void *)gemm4k_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, G4K_LDS);
-        (void)hipFuncSetAttribute((const void *)gemm4k_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, G4K_LDS);
-        (void)hipFuncSetAttribute((const void *)gemm4k_narrow_kernel<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS1);
-        (void)hipFuncSetAttribute((const void *)gemm4k_narrow_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS1);
+        (void)hipFuncSetAttribute((const void *)gemm4k_kernel<0, PS_Q4_K>, hipFuncAttributeMaxDynamicSharedMemorySize, G4K_LDS);
+        (void)hipFuncSetAttribute((const void *)gemm4k_kernel<1, PS_Q4_K>, hipFuncAttributeMaxDynamicSharedMemorySize, G4K_LDS);
+        (void)hipFuncSetAttribute((const void *)gemm4k_kernel<0, PS_Q5_K>, hipFuncAttributeMaxDynamicSharedMemorySize, G4K_LDS);
+        (void)hipFuncSetAttribute((const void *)gemm4k_narrow_kernel<0, 1, PS_Q4_K>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS1);
+        (void)hipFuncSetAttribute((const void *)gemm4k_narrow_kernel<1, 1, PS_Q4_K>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS1);
+        (void)hipFuncSetAttribute((const void *)gemm4k_narrow_kernel<0, 1, PS_Q5_K>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS1);
     }
-    if (ctw == 1) {
-        if (epi == 1) hipLaunchKernelGGL((gemm4k_narrow_kernel<1, 1>), grid, blkn, LDS1, st, p);
-        else hipLaunchKernelGGL((gemm4k_narrow_kernel<0, 1>), grid, blkn, LDS1, st, p);
-    } else if (epi == 1) hipLaunchKernelGGL((gemm4k_kernel<1>), grid, blk, G4K_LDS, st, p);
-    else hipLaunchKernelGGL((gemm4k_kernel<0>), grid, blk, G4K_LDS, st, p);
+    if (p.wt == PS_Q5_K) { // (single matrix, EPI 0)
+        if (epi != 0) return -1;
+        if (ctw == 1) hipLaunchKernelGGL((gemm4k_narrow_kernel<0, 1, PS_Q5_K>), grid, blkn, LDS1, st, p);
+        else hipLaunchKernelGGL((gemm4k_kernel<0, PS_Q5_K>), grid, blk, G4K_LDS, st, p);
+    } else if (ctw == 1) {
+        if (epi == 1) hipLaunchKernelGGL((gemm4k_narrow_kernel<1, 1, PS_Q4_K>), grid, blkn, LDS1, st, p);
+        else hipLaunchKernelGGL((gemm4k_narrow_kernel<0, 1, PS_Q4_K>), grid, blkn, LDS1, st, p);
+    } else if (epi == 1) hipLaunchKernelGGL((gemm4k_kernel<1, PS_Q4_K>), grid, blk, G4K_LDS, st, p);
+    else hipLaunchKernelGGL((gemm4k_kernel<0, PS_Q4_K>), grid, blk, G4K_LDS, st, p);
     return 0;
+}
+
+// Q4_K batched mat-mul from fragment-major Q8_K activations (act.qf).  -1: not covered (the caller takes gemm8m).
+int psk_gemm4k(hipStream_t st, int n_cu, const psk_gemv_args &a, ps_act act, int64_t K, int64_t bs) {
+    static const bool off = getenv("PS_NO_GEMM4K") != nullptr; // (A/B switch for measurements)
+    if (off || a.pro != 0 || a.rope || a.n_w < 1 || !act.qf || K % 256) return -1;
+    G4KParams p{};
+    int pairs_total = 0;
+    for (int i = 0; i < a.n_w; i++) {
+        if (a.w[i]->dtype != PS_Q4_K || a.w[i]->K != K || a.w[i]->N % 32 || a.ldo[i] % 4) return -1;
+        p.w[i] = G4KMat{a.w[i]->qs, a.w[i]->aux, nullptr, a.out[i], a.bias[i], a.w[i]->N, a.ldo[i], (int)(a.w[i]->N / 16)};
+        pairs_total += p.w[i].n_tiles / 2;
+    }
+    const int epi = a.silu_pair ? 1 : 0;
+    if (epi == 1 && (a.n_w != 2 || a.w[0]->N != a.w[1]->N || a.ldo[0] != a.ldo[1])) return -1;
+    p.n_w = a.n_w; p.nsb = (int)(K / 256); p.bs = (int)bs;
+    p.n_tasks = epi == 1 ? p.w[0].n_tiles : pairs_total;
+    p.residual = a.residual; p.qf = act.qf; p.mf = act.mf;
+    p.dbg = psk_gemv_dbg_buf(12 + epi, epi ? 0 : (a.n_w == 3 ? 0 : (K <= 8192 ? 1 : 2))); // keys 48 QKV, 49 O, 50 down, 52 gate/up
+    p.wt = PS_Q4_K;
+    return g4k_launch(st, n_cu, p, epi, bs);
+}
+
+// Q5_K (single matrix, the Q5_K_M mix): the same kernels with the Q5_K producer.  -1: not covered.
+int psk_gemm5k(hipStream_t st, int n_cu, const psk_gemv6_args &a, ps_act act, int64_t K, int64_t bs) {
+    static const bool off = getenv("PS_NO_GEMM5K") != nullptr; // (A/B switch for measurements)
+    const ps_weight *w = a.w;
+    if (off || !w || w->dtype != PS_Q5_K || w->K != K || K % 1024 || w->N % 32 || a.ldo % 4 || !act.qf) return -1;
+    G4KParams p{};
+    p.w[0] = G4KMat{w->qs, w->sc, w->qh, a.out, a.bias, w->N, a.ldo, (int)(w->N / 16)};
+    p.n_w = 1; p.nsb = (int)(K / 256); p.bs = (int)bs; p.n_tasks = p.w[0].n_tiles / 2;
+    p.residual = a.residual; p.qf = act.qf; p.mf = act.mf; p.dbg = nullptr; p.wt = PS_Q5_K;
+    return g4k_launch(st, n_cu, p, 0, bs);
 }
 
 // Q6_K batched mat-mul from the same fragment-major activations.  -1: not covered (the caller keeps the 8-column mat-vec launches).

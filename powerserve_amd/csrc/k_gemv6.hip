@@ -235,7 +235,13 @@ int launch_gemv5(hipStream_t st, int n_cu, const psk_gemv6_args &a, ps_act act, 
 
 int psk_gemv6(hipStream_t st, int n_cu, const psk_gemv6_args &a, ps_act act, int64_t K, int64_t bs) {
     const ps_weight *w = a.w;
-    if (w->dtype == PS_Q5_K && w->K == K && K % 256 == 0) return launch_gemv5(st, n_cu, a, act, K, bs);
+    if (w->dtype == PS_Q5_K && w->K == K && K % 256 == 0) {
+        if (bs >= ps_gemm4k_min_cols()) { // batches: the matrix-core mat-mul with the Q5_K producer (k_gemm4k.hip)
+            const int rc = psk_gemm5k(st, n_cu, a, act, K, bs);
+            if (rc != -1) return rc;
+        }
+        return launch_gemv5(st, n_cu, a, act, K, bs);
+    }
     if (w->dtype != PS_Q6_K || w->K != K || K % 256) return 4;
     { // chunks and wide trees: the matrix-core mat-mul (k_gemm4k.hip)
         const int rc = psk_gemm6k(st, n_cu, a, act, K, bs);

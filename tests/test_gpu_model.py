@@ -163,7 +163,7 @@ def test_tree_mask_plumbing(ctx, tmp_path):
     gm.close()
 
 
-@pytest.mark.parametrize("wt", [12, 1015])  # pure Q4_K; the Q4_K_M mix (Q6_K attn_v / ffn_down / output: the prefill chunks take gemm6k)
+@pytest.mark.parametrize("wt", [12, 1015, 1017])  # pure Q4_K; the Q4_K_M mix (Q6_K attn_v / ffn_down / output: the prefill chunks take gemm6k); Q5_K_M (Q5_K producer + gemm6k)
 def test_long_context_batches_match_oracle(ctx, oracle, tmp_path, wt):
     """Batches appended behind a long KV prefix (n_kv > 256: several 32-column chain rounds, leftovers, softmax tails):
     bit-exact against the oracle for decode steps and for batches of 3 and 12, and a tree whose root only sees itself

@@ -148,6 +148,27 @@ def test_mul_mat_q6k_chunk_on_matrix_cores(ctx, oracle, hip, K, N, bs):
     W.free()
 
 
+@pytest.mark.parametrize("K,N,bs", [(4096, 512, 128), (1024, 96, 120), (14336, 64, 113), (2048, 8224, 40), (1024, 64, 160), (1024, 32, 12), (2048, 160, 3)])
+def test_mul_mat_q5k_batch_on_matrix_cores(ctx, oracle, hip, K, N, bs):
+    """Q5_K weights (the Q5_K_M mix), batches from 2 columns: the Q4_K chunk kernels with the Q5_K producer (fifth bit from
+    the qh plane; value x scale <= 31 * 63 stays an exact fp16 integer) -- bit-for-bit ggml_vec_dot_q5_K_q8_K per column."""
+    from powerserve_amd import synth
+    rng = np.random.default_rng(K + N + bs + 5)
+    w = synth.random_blocks(rng, 13, N, K)
+    blocks = w.reshape(-1, 176)  # block_q5_K: d, dmin, scales[12], qh[32], qs[128]
+    blocks[0, 4:16] = 0xff; blocks[0, 16:] = 0xff  # every scale and min 63, every weight 31
+    x = (rng.standard_normal((bs, K)) * rng.uniform(0.1, 30.0, (bs, 1))).astype(np.float32)
+    x[min(3, bs - 1), 256:512] = 0.0
+    x[0, 0:256] = np.where(rng.random(256) < 0.5, 1.0, -1.0) * 7.0  # every quant of this super-block at +-127
+    want = oracle.mul_mat(13, w, K, N, x)
+    W = ctx.upload_weight(13, w, K, N)
+    dx, dy = ctx.to_device(x), ctx.empty((bs, N))
+    ctx.check(ctx.L.ps_hip_mul_mat(ctx.h, C.byref(dy.tensor()), C.byref(W.tensor()), C.byref(dx.tensor())))
+    got = dy.numpy()
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (rel_err(got, want), np.argwhere(got != want)[:8])
+    W.free()
+
+
 def test_mul_mat_f32_gqa_views(ctx, oracle, hip):
     """K-cache view x permuted q (norm_attention.cpp:115-129) and V-cache view x kq (:138-147)."""
     rng = np.random.default_rng(7)
