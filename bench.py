@@ -54,7 +54,7 @@ def parse():
 
 def ensure_model(args, rank, barrier):
     from powerserve_amd import gguf, synth
-    wt = synth.Q4_K_M if args.wtype == "Q4_K_M" else gguf.NAME_TYPE[args.wtype]  # Q4_K_M: llama.cpp's Q4_K + Q6_K per-tensor mix
+    wt = {"Q4_K_M": synth.Q4_K_M, "Q5_K_M": synth.Q5_K_M}.get(args.wtype) or gguf.NAME_TYPE[args.wtype]  # Q4_K_M / Q5_K_M: llama.cpp's per-tensor mixes with Q6_K
     d = args.model_dir or os.path.join(os.environ.get("TMPDIR", "/tmp"), f"ps_bench_{args.preset}_{args.wtype}_{args.seed}")
     marker = os.path.join(d, ".done")
     if rank == 0 and not os.path.exists(marker):
@@ -328,7 +328,7 @@ def main():
         kv_bytes = cfg.n_layers * 2 * n_kv_mid * cfg.kv_dim * 4
         # ---- roofline of the dominant kernel (gate/up mat-vec), event-bracketed replay
         from powerserve_amd import gguf as _gguf
-        gate_up_bytes = 2 * cfg.hidden_dim * _gguf.row_size(_gguf.NAME_TYPE["Q4_K" if args.wtype == "Q4_K_M" else args.wtype], cfg.dim)
+        gate_up_bytes = 2 * cfg.hidden_dim * _gguf.row_size(_gguf.NAME_TYPE[{"Q4_K_M": "Q4_K", "Q5_K_M": "Q5_K"}.get(args.wtype, args.wtype)], cfg.dim)
         rf = gemv_roofline(ctx, model, wbytes, gate_up_bytes, args.preset == "llama-3.1-8b" and args.wtype == "Q4_K")
         out = {
             "metric": "decode tokens/s (greedy, Llama-3.1-8B Q4_K, 1 GPU per replica)" if args.preset == "llama-3.1-8b" and args.wtype == "Q4_K"
@@ -337,7 +337,7 @@ def main():
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int8 x int4 block dot, fp32 accumulate (ggml Q4_K x Q8_K semantics)" if args.wtype == "Q4_K" else "int8 block dot, fp32 accumulate",
             "data": "synthetic (random-init weights generated in the quantized domain; random prompt ids, seed 42)",
-            "config": {"workload": f"{args.preset} {'mixed' if args.wtype == 'Q4_K_M' else 'pure'} {args.wtype}, prefill {args.prompt_len} + decode {args.steps}, n_ctx {args.n_ctx}, FP32 KV",
+            "config": {"workload": f"{args.preset} {'mixed' if args.wtype in ('Q4_K_M', 'Q5_K_M') else 'pure'} {args.wtype}, prefill {args.prompt_len} + decode {args.steps}, n_ctx {args.n_ctx}, FP32 KV",
                        "prefill_chunk": args.batch, "replicas": world, "collectives": "RCCL broadcast(prompt) + all_gather(ids)" if world > 1 else "none"},
             "prefill_tokens_per_s": world * (args.prompt_len - 1) / prefill_s, "prefill_s": prefill_s,
             "decode_device_ms_per_step": dev_ms / args.steps, "model_load_s": load_s,
