@@ -984,7 +984,8 @@ int psk_gemm5k(hipStream_t st, int n_cu, const psk_gemv6_args &a, ps_act act, in
 int psk_gemm6k(hipStream_t st, int n_cu, const psk_gemv6_args &a, ps_act act, int64_t K, int64_t bs) {
     static const bool off = getenv("PS_NO_GEMM6K") != nullptr; // (A/B switch for measurements)
     const ps_weight *w = a.w;
-    if (off || !w || w->dtype != PS_Q6_K || w->K != K || K % 1024 || w->N % 32 || a.ldo % 2 || !act.qf || bs < 17 || bs < ps_gemm4k_min_cols()) return -1;
+    static const int64_t min_cols = [] { const char *e = getenv("PS_GEMM6K_MIN_COLS"); return e ? (int64_t)atoll(e) : (int64_t)9; }(); // (8B Q4_K_M tree forward, ms, threshold 17 / 9 / 2: 8 wide 5.9 / 6.0 / 6.2, 12: 6.9 / 6.3 / 6.3, 16: 7.6 / 6.4 / 6.3)
+    if (off || !w || w->dtype != PS_Q6_K || w->K != K || K % 1024 || w->N % 32 || a.ldo % 2 || !act.qf || bs < min_cols || bs < ps_gemm4k_min_cols()) return -1;
     G6KParams p{};
     p.ql = w->qs; p.qh = w->qh; p.sc = (const int8_t *)w->sc; p.d = (const uint16_t *)w->aux;
     p.out = a.out; p.bias = a.bias; p.residual = a.residual; p.N = w->N; p.ldo = a.ldo;

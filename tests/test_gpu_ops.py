@@ -122,9 +122,9 @@ def test_mul_mat_q4k_chunk_on_matrix_cores(ctx, oracle, hip, K, N, bs):
     W.free()
 
 
-@pytest.mark.parametrize("K,N,bs", [(4096, 512, 128), (1024, 96, 120), (14336, 64, 113), (2048, 8224, 40), (1024, 64, 160), (1024, 32, 17)])
+@pytest.mark.parametrize("K,N,bs", [(4096, 512, 128), (1024, 96, 120), (14336, 64, 113), (2048, 8224, 40), (1024, 64, 160), (1024, 32, 17), (2048, 160, 9)])
 def test_mul_mat_q6k_chunk_on_matrix_cores(ctx, oracle, hip, K, N, bs):
-    """Q6_K weights (attn_v, ffn_down, output of the Q4_K_M / Q5_K_M mixes), batches from 17 columns: gemm6k_kernel in
+    """Q6_K weights (attn_v, ffn_down, output of the Q4_K_M / Q5_K_M mixes), batches from 9 columns: gemm6k_kernel in
     k_gemm4k.hip -- (q6 - 32) x the even / odd parts of the int8 scale as two fp16 MFMA contractions of exact integers --
     bit-for-bit ggml_vec_dot_q6_K_q8_K per column; scales are drawn over the whole int8 range, +-128 x +-32 included."""
     from powerserve_amd import synth

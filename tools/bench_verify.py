@@ -9,7 +9,8 @@ wt = sys.argv[1] if len(sys.argv) > 1 else "Q4_K"
 tmp = os.environ.get("TMPDIR", "/tmp")
 d = os.path.join(tmp, f"ps_spec_llama-3.1-8b_{wt}_1234_1024")
 if not os.path.exists(d + "/.done"):
-    synth.write_model_dir(d, "llama-3.1-8b", gguf.NAME_TYPE[wt], n_ctx=1024, seed=1234); open(d + "/.done", "w").write("ok")
+    wtid = {"Q4_K_M": synth.Q4_K_M, "Q5_K_M": synth.Q5_K_M}.get(wt) or gguf.NAME_TYPE[wt]
+    synth.write_model_dir(d, "llama-3.1-8b", wtid, n_ctx=1024, seed=1234); open(d + "/.done", "w").write("ok")
 ctx = hip.Ctx(0)
 t = hip.Model(ctx, d, max_batch=128, n_ctx=1024)
 P = 256
