@@ -125,18 +125,21 @@ __global__ __launch_bounds__(256) void gemv6_kernel(Gemv6Params p) {
 // lanes in this kernel of the reference but in ONE scalar,  summs += dmin * (float)hsum(mins . bsums)  — a multiply and an
 // add (two roundings: the reference build this backend is pinned to has fp-contraction off) — so a
 // third value per super-block joins the two that are broadcast for the chain.  Result: hsum_float_8(acc) + summs.
-struct Gemv5Params {
+struct Gemv5Mat { // one weight matrix of a launch (up to three share the activation: Q / K / V, gate / up)
     const uint8_t *qs, *qh;
     const uint4 *hdr;     // [N][K/256] {d | dmin << 16, scales[12]}
-    int64_t K, N;
+    int64_t N, ldo;
+    float *out;
+    const float *bias, *residual;
+};
+struct Gemv5Params {
+    Gemv5Mat w[3];
+    int n_w;
+    int64_t K, N;         // N: rows of all matrices together
     int nsb;
     const int8_t *aq;     // [bs][K]
     const float *ad;      // [bs][K/256]
     const int16_t *abs16; // [bs][K/16]
-    float *out;
-    int64_t ldo;
-    const float *bias;
-    const float *residual;
     int nc;
 };
 
@@ -145,7 +148,12 @@ __global__ __launch_bounds__(256) void gemv5_kernel(Gemv5Params p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sbl = lane >> 3, u = lane & 7;
     const int nsb = p.nsb, nit = (nsb + 7) >> 3;
-    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < p.N; row += (int64_t)gridDim.x * 4) {
+    for (int64_t grow = (int64_t)blockIdx.x * 4 + wave; grow < p.N; grow += (int64_t)gridDim.x * 4) {
+        int64_t row = grow; // the wave's matrix and its row in it
+        int wi = 0;
+        if (p.n_w > 1 && row >= p.w[0].N) { row -= p.w[0].N; wi = 1; }
+        if (p.n_w > 2 && wi == 1 && row >= p.w[1].N) { row -= p.w[1].N; wi = 2; }
+        const Gemv5Mat &W = wi == 0 ? p.w[0] : (wi == 1 ? p.w[1] : p.w[2]);
         float acc[BS], summs[BS];
 #pragma unroll
         for (int c = 0; c < BS; c++) { acc[c] = 0.f; summs[c] = 0.f; }
@@ -153,9 +161,9 @@ __global__ __launch_bounds__(256) void gemv5_kernel(Gemv5Params p) {
         for (int it = 0; it < nit; it++) {
             const int sb0 = it * 8, sbr = sb0 + sbl;
             const int sb = sbr < nsb ? sbr : nsb - 1; // lanes past the row end re-read the last block; never chained
-            const uint4 Q = ld_stream16(p.qs + (rb + sb) * 128 + u * 16);
-            const uint32_t H = *(const uint32_t *)(p.qh + (rb + sb) * 32 + u * 4);
-            const uint4 hd = p.hdr[rb + sb];
+            const uint4 Q = ld_stream16(W.qs + (rb + sb) * 128 + u * 16);
+            const uint32_t H = *(const uint32_t *)(W.qh + (rb + sb) * 32 + u * 4);
+            const uint4 hd = W.hdr[rb + sb];
             const float dw = ps_h2f((uint16_t)(hd.x & 0xffff)), dmw = ps_h2f((uint16_t)(hd.x >> 16));
             // 5-bit weights of this lane: q[j] = elements 4u..4u+3 of sub-vector j, one per byte
             const uint32_t Qw[4] = {Q.x, Q.y, Q.z, Q.w};
@@ -203,26 +211,29 @@ __global__ __launch_bounds__(256) void gemv5_kernel(Gemv5Params p) {
             v = __fadd_rn(v, dpp_f<0x101>(v));
             v = __fadd_rn(v, summs[c]);
             if (lane == 0 && c < p.nc) {
-                if (p.bias) v = __fadd_rn(v, p.bias[row]);
-                if (p.residual) v = __fadd_rn(p.residual[(int64_t)c * p.ldo + row], v);
-                p.out[(int64_t)c * p.ldo + row] = v;
+                if (W.bias) v = __fadd_rn(v, W.bias[row]);
+                if (W.residual) v = __fadd_rn(W.residual[(int64_t)c * W.ldo + row], v);
+                W.out[(int64_t)c * W.ldo + row] = v;
             }
         }
     }
 }
 
-int launch_gemv5(hipStream_t st, int n_cu, const psk_gemv6_args &a, ps_act act, int64_t K, int64_t bs) {
-    const ps_weight *w = a.w;
+int launch_gemv5(hipStream_t st, int n_cu, const psk_gemv6_args *a, int n_w, ps_act act, int64_t K, int64_t bs) {
     Gemv5Params p{};
-    p.qs = w->qs; p.qh = w->qh; p.hdr = (const uint4 *)w->sc;
-    p.K = K; p.N = w->N; p.nsb = (int)(K / 256);
-    p.ldo = a.ldo; p.bias = a.bias;
-    const int64_t nwg = (w->N + 3) / 4;
+    p.n_w = n_w; p.K = K; p.nsb = (int)(K / 256);
+    for (int i = 0; i < n_w; i++) p.N += a[i].w->N;
+    const int64_t nwg = (p.N + 3) / 4;
     const unsigned grid = (unsigned)(nwg < (int64_t)n_cu * 16 ? nwg : (int64_t)n_cu * 16);
     for (int64_t c0 = 0; c0 < bs; c0 += 8) {
         const int nc = (int)(bs - c0 < 8 ? bs - c0 : 8);
         p.aq = act.qs + c0 * K; p.ad = act.d + c0 * (K / 256); p.abs16 = act.bs16 + c0 * (K / 16);
-        p.out = a.out + c0 * a.ldo; p.residual = a.residual ? a.residual + c0 * a.ldo : nullptr; p.nc = nc;
+        for (int i = 0; i < n_w; i++) {
+            const ps_weight *w = a[i].w;
+            p.w[i] = Gemv5Mat{w->qs, w->qh, (const uint4 *)w->sc, w->N, a[i].ldo, a[i].out + c0 * a[i].ldo, a[i].bias,
+                              a[i].residual ? a[i].residual + c0 * a[i].ldo : nullptr};
+        }
+        p.nc = nc;
         if (nc == 1) hipLaunchKernelGGL(gemv5_kernel<1>, dim3(grid), dim3(256), 0, st, p);
         else if (nc == 2) hipLaunchKernelGGL(gemv5_kernel<2>, dim3(grid), dim3(256), 0, st, p);
         else if (nc <= 4) hipLaunchKernelGGL(gemv5_kernel<4>, dim3(grid), dim3(256), 0, st, p);
@@ -240,7 +251,7 @@ int psk_gemv6(hipStream_t st, int n_cu, const psk_gemv6_args &a, ps_act act, int
             const int rc = psk_gemm5k(st, n_cu, a, act, K, bs);
             if (rc != -1) return rc;
         }
-        return launch_gemv5(st, n_cu, a, act, K, bs);
+        return launch_gemv5(st, n_cu, &a, 1, act, K, bs);
     }
     if (w->dtype != PS_Q6_K || w->K != K || K % 256) return 4;
     { // chunks and wide trees: the matrix-core mat-mul (k_gemm4k.hip)
@@ -263,4 +274,13 @@ int psk_gemv6(hipStream_t st, int n_cu, const psk_gemv6_args &a, ps_act act, int
         else hipLaunchKernelGGL(gemv6_kernel<8>, dim3(grid), dim3(256), 0, st, p);
     }
     return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
+// Q5_K matrices that share one activation (Q / K / V, gate / up) in ONE launch: single tokens and batches the chunk kernels do
+// not take.  4: not all Q5_K of this K.
+int psk_gemv5_multi(hipStream_t st, int n_cu, const psk_gemv6_args *a, int n_w, ps_act act, int64_t K, int64_t bs) {
+    if (n_w < 1 || n_w > 3 || K % 256) return 4;
+    for (int i = 0; i < n_w; i++)
+        if (!a[i].w || a[i].w->dtype != PS_Q5_K || a[i].w->K != K) return 4;
+    return launch_gemv5(st, n_cu, a, n_w, act, K, bs);
 }

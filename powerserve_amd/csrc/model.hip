@@ -78,17 +78,33 @@ static int mm(ps_hip_model *m, psk_gemv_args &g, ps_act act, int64_t K, int64_t 
 static int mm_each(ps_hip_model *m, psk_gemv_args &g, ps_act act, int64_t K, int64_t bs) {
     ps_hip_ctx *c = m->ctx;
     float *tmp[2] = {m->g1, m->u1};
+    bool quantized = false; // the K-quants of a group share ONE Q8_K quantization of the activation
+    auto quantize_once = [&]() {
+        if (g.pro && !quantized) psk_quantize_act(c->stream, PS_Q8_K, g.pro == 1 ? 1 : 0, g.pro_x, nullptr, g.pro_norm_w, g.pro_eps, K, bs, act);
+        quantized = true;
+    };
+    bool all5 = g.n_w > 1;
+    for (int i = 0; i < g.n_w; i++) all5 = all5 && g.w[i]->dtype == PS_Q5_K;
+    if (all5 && bs == 1) { // Q5_K_M: Q / K / V and gate / up as one launch each
+        quantize_once();
+        psk_gemv6_args a5[3];
+        for (int i = 0; i < g.n_w; i++) a5[i] = psk_gemv6_args{g.w[i], g.silu_pair ? tmp[i] : g.out[i], g.ldo[i], g.bias[i], (i == 0 && !g.silu_pair) ? g.residual : nullptr};
+        if (int rc = psk_gemv5_multi(c->stream, c->n_cu, a5, g.n_w, act, K, bs)) { c->err = "Q5_K mat-vec launch rc=" + std::to_string(rc); return 2; }
+        if (g.silu_pair) psl_silu_hadamard(c->stream, g.out[0], tmp[0], tmp[1], (int64_t)g.ldo[0] * bs);
+        return 0;
+    }
     for (int i = 0; i < g.n_w; i++) {
         psk_gemv_args s{};
         s.n_w = 1; s.w[0] = g.w[i]; s.out[0] = g.silu_pair ? tmp[i] : g.out[i]; s.bias[0] = g.bias[i];
         s.ldo[0] = g.ldo[i]; s.residual = (i == 0 && !g.silu_pair) ? g.residual : nullptr;
         s.pro = g.pro; s.pro_x = g.pro_x; s.pro_norm_w = g.pro_norm_w; s.pro_eps = g.pro_eps;
         if (g.w[i]->dtype == PS_Q6_K || g.w[i]->dtype == PS_Q5_K) {
-            if (g.pro) psk_quantize_act(c->stream, PS_Q8_K, g.pro == 1 ? 1 : 0, g.pro_x, nullptr, g.pro_norm_w, g.pro_eps, K, bs, act);
+            quantize_once();
             psk_gemv6_args a6{g.w[i], s.out[0], s.ldo[0], s.bias[0], s.residual};
             if (int rc = psk_gemv6(c->stream, c->n_cu, a6, act, K, bs)) { c->err = "Q5_K / Q6_K mat-vec launch rc=" + std::to_string(rc); return 2; }
-        } else if (mm(m, s, act, K, bs)) {
-            return 2;
+        } else {
+            if (mm(m, s, act, K, bs)) return 2;
+            quantized = bs >= 2 && g.pro != 0 && ps_hip_vec_dot_type(g.w[i]->dtype) == PS_Q8_K; // (a batch leaves the same Q8_K image in `act`; a single-token launch quantizes in its own prologue, into LDS)
         }
     }
     if (g.silu_pair) psl_silu_hadamard(c->stream, g.out[0], tmp[0], tmp[1], (int64_t)g.ldo[0] * bs);

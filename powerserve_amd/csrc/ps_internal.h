@@ -169,6 +169,7 @@ struct psk_gemv6_args {
     const float *residual; // optional, same layout as out (may alias out)
 };
 int psk_gemv6(hipStream_t st, int n_cu, const psk_gemv6_args &a, ps_act act, int64_t K, int64_t bs);
+int psk_gemv5_multi(hipStream_t st, int n_cu, const psk_gemv6_args *a, int n_w, ps_act act, int64_t K, int64_t bs); // up to 3 Q5_K matrices, one launch
 int psk_gemm5k(hipStream_t st, int n_cu, const psk_gemv6_args &a, ps_act act, int64_t K, int64_t bs); // Q5_K batches (k_gemm4k.hip); -1: not covered
 int psk_gemm6k(hipStream_t st, int n_cu, const psk_gemv6_args &a, ps_act act, int64_t K, int64_t bs); // Q6_K, >= 17 columns (k_gemm4k.hip); -1: not covered
 int psk_gemv_debug(int key, uint64_t *host_out, int n_words); // timeline buffer: arm / read back
