@@ -103,7 +103,13 @@ static int mm_each(ps_hip_model *m, psk_gemv_args &g, ps_act act, int64_t K, int
             psk_gemv6_args a6{g.w[i], s.out[0], s.ldo[0], s.bias[0], s.residual};
             if (int rc = psk_gemv6(c->stream, c->n_cu, a6, act, K, bs)) { c->err = "Q5_K / Q6_K mat-vec launch rc=" + std::to_string(rc); return 2; }
         } else {
+            // a run of matrices of one lane-major type goes out as ONE launch (Q4_K_M: Q and K next to a Q6_K V)
+            int run = 1;
+            while (!g.silu_pair && i + run < g.n_w && g.w[i + run]->dtype == g.w[i]->dtype) run++;
+            for (int j = 1; j < run; j++) { s.w[j] = g.w[i + j]; s.out[j] = g.out[i + j]; s.bias[j] = g.bias[i + j]; s.ldo[j] = g.ldo[i + j]; }
+            s.n_w = run;
             if (mm(m, s, act, K, bs)) return 2;
+            i += run - 1;
             quantized = bs >= 2 && g.pro != 0 && ps_hip_vec_dot_type(g.w[i]->dtype) == PS_Q8_K; // (a batch leaves the same Q8_K image in `act`; a single-token launch quantizes in its own prologue, into LDS)
         }
     }
