@@ -228,6 +228,30 @@ def test_batched_forward_logits(ctx, oracle, tmp_path):
     om.close()
 
 
+@pytest.mark.parametrize("preset,n_ctx", [("small-llama-hs128", 6144), ("tiny-llama", 8192), ("small-llama", 4096)])
+def test_batches_with_a_large_context_window(ctx, oracle, tmp_path, preset, n_ctx):
+    """n_ctx beyond 4096 takes the workgroup-per-(kv head, column) soft-max (score rows in LDS) instead of the wave-per-row one,
+    and head sizes other than 64 / 128 the direct-fetch V.p kernel: chunks of 40 and 9 tokens, then single tokens, bit-exact."""
+    from oracle import binding as B
+    from powerserve_amd import hip, synth
+    d = str(tmp_path / "m")
+    mj = synth.write_model_dir(d, preset, 12, n_ctx=n_ctx, seed=11)
+    cfg = B.make_config(mj["llm_config"])
+    om = oracle.model(cfg, mj["model_arch"], load_tensors(os.path.join(d, "ggml/weights.gguf")), n_threads=8)
+    gm = hip.Model(ctx, d, max_batch=64, n_ctx=n_ctx)
+    toks = np.random.default_rng(3).integers(0, cfg.vocab_size, 52)
+    for lo, hi in ((0, 40), (40, 49)):
+        want = om.forward(toks[lo:hi], np.arange(lo, hi), True)
+        got, _ = gm.forward(toks[lo:hi], np.arange(lo, hi), True)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (lo, rel_err(got, want))
+    for i in range(49, 52):
+        want = om.forward(toks[i:i + 1], [i], True)
+        got, _ = gm.forward(toks[i:i + 1], [i], True)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (i, rel_err(got, want))
+    gm.close()
+    om.close()
+
+
 def test_kv_full_and_bad_tokens_fail_loudly(ctx, tmp_path):
     from powerserve_amd import hip, synth
     d = str(tmp_path / "m")
