@@ -18,6 +18,7 @@
 #include "ps_dev.h"
 #include "ps_expf.h"
 #include "ps_ops.h"
+#include "ps_quant_dev.h"
 
 namespace {
 
@@ -848,6 +849,27 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_pv_mfma_lds_kernel(psl_attn_a
     }
     if ((int)blockIdx.x * 16 + rl < N)
         *(float4 *)(a.att + (int64_t)i * dim + ((int64_t)kvh * r2 + g) * hs + d0 + 4 * m) = make_float4(res[0], res[1], res[2], res[3]);
+    // ---- optional: leave the rows quantized for the O projection (saves the quantizer launch between the two).  The workgroup
+    // holds 16 (column, head) pairs x hs channels = whole Q8_K tiles of 256 consecutive `att` elements (two heads of one column
+    // when hs = 128; psl_attn_pv_quantizes checks the shape): staged through LDS, one wave per tile, ps_quantize_tile as the
+    // quantizer kernels run it.
+    if (a.qact.qs) {
+        float *tl = pvs; // (the last step's barrier is behind every wave)
+        *(float4 *)(tl + rl * hs + d0 + 4 * m) = make_float4(res[0], res[1], res[2], res[3]);
+        __syncthreads();
+        constexpr int TPW = hs * 16 / 256 / NW; // tiles per wave (1 for hs = 128)
+#pragma unroll
+        for (int tt = 0; tt < TPW; tt++) {
+            const int tile = wave * TPW + tt, p0 = tile * (256 / hs); // first pair of the tile
+            const int n0 = (int)blockIdx.x * 16 + p0;
+            const int nn = min(n0, N - 1), ci = nn / r2, g0 = nn - ci * r2;
+            const float4 xv = *(const float4 *)(tl + tile * 256 + lane * 4);
+            const float v4[4] = {xv.x, xv.y, xv.z, xv.w};
+            const int64_t K = a.qact_K, e = ((int64_t)kvh * r2 + g0) * hs + lane * 4;
+            ps_quantize_tile<PS_Q8_K>(v4, n0 < N, e, e / 256, a.qact.qs + (int64_t)ci * K, a.qact.d + (int64_t)ci * (K / 256), a.qact.bs16 + (int64_t)ci * (K / 16),
+                                      nullptr, a.qact.qf, ci, K / 256, a.qact.mf);
+        }
+    }
 }
 
 // ---------------------------------------------------------------- fp16-KV decode mode: NOT bit-exact
@@ -1035,6 +1057,10 @@ void psl_attn_scores(hipStream_t st, const psl_attn_args &a, int bs) {
 size_t psl_attn_softmax_pv_lds(const psl_attn_args &a) {
     const int r2 = a.n_heads / a.n_kv_heads;
     return ((size_t)r2 * (((size_t)a.n_ctx + 3) & ~(size_t)3) + 4 * PV_VSTR) * 4;
+}
+bool psl_attn_pv_quantizes(const psl_attn_args &a, int bs) {
+    const int r2 = a.n_heads / a.n_kv_heads;
+    return bs >= 8 && a.head_size == 128 && (r2 == 2 || r2 == 4 || r2 == 8) && a.qact.qs != nullptr;
 }
 void psl_attn_softmax_pv(hipStream_t st, const psl_attn_args &a, int bs) {
     if (bs >= 8 && a.head_size % 16 == 0) { // prefill chunks / wide trees: soft-max in place, then V·p on the matrix cores

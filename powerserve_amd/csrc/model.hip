@@ -197,19 +197,31 @@ static int enqueue_forward(ps_hip_model *m, int bs, bool lm_head, bool use_tree,
         if (mm(m, g, a1, dim, bs)) return 2;
 
         if (!fuse_rope) psl_rope_append(st, aa, bs);
+        bool att_quantized = false;
         if (bs == 1 && !use_tree && kv16 && psl_attn_decode_f16(st, aa)) {
             // fp16-KV decode mode (not bit-exact): split-KV online soft-max over the fp16 mirrors
         } else if (!(bs == 1 && !use_tree && psl_attn_decode(st, c->n_cu, aa))) {
             aa.dbg = bs == 1 ? psk_gemv_dbg_buf(10, 0) : nullptr; // timeline key 40
             psl_attn_scores(st, aa, bs);
             aa.dbg = bs == 1 ? psk_gemv_dbg_buf(10, 1) : nullptr; // timeline key 41
+            // batches: the V.p kernel can leave `att` quantized for the O projection (one launch less per layer) when the O weight
+            // takes Q8_K activations through the batched path
+            aa.qact = ps_act{}; aa.qact_K = dim;
+            if (bs >= 2 && ps_hip_vec_dot_type(m->wo[L]->dtype) == PS_Q8_K && dim % 256 == 0) {
+                aa.qact = a1;
+                if (!(bs >= ps_gemm4k_min_cols() && dim % 1024 == 0)) { aa.qact.qf = nullptr; aa.qact.mf = nullptr; } // (as psk_quantize_act decides)
+                if (!psl_attn_pv_quantizes(aa, bs)) aa.qact = ps_act{};
+            }
+            att_quantized = aa.qact.qs != nullptr;
             psl_attn_softmax_pv(st, aa, bs);
+            aa.qact = ps_act{};
             aa.dbg = nullptr;
         }
 
         psk_gemv_args go{};
         go.n_w = 1; go.w[0] = m->wo[L]; go.out[0] = m->x; go.ldo[0] = dim; go.residual = m->x;
         go.pro = 2; go.pro_x = m->att;
+        if (att_quantized) { go.pro = 0; go.pro_x = nullptr; } // (the V.p kernel left `att` quantized in a1)
         ps_act a2 = act_for(hid);
         const int vdt_d = ps_hip_vec_dot_type(m->wd[L]->dtype);
         psk_gemv_args gf{};

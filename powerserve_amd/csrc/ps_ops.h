@@ -36,6 +36,8 @@ struct psl_attn_args {
     const int32_t *rope_pos; // optional [bs]: RoPE position of each batch column (default: its cache slot pos0 + i)
     const uint8_t *kv_vis;   // optional [n_ctx]: 0 hides a cached slot (KVCacheInterface::mask / unmask)
     float scale;
+    ps_act qact;             // optional (qs != null): the V.p kernel of a batch also leaves `att` quantized (Q8_K, + the fragment copies when qf is set) for the O projection
+    int64_t qact_K;          // = n_heads * head_size
     int n_kv_host;           // pos0 + bs when the host knows it at enqueue time (eager forwards), 0 inside a captured graph: sizes the score grids
     _Float16 *k16, *v16;     // optional fp16 mirrors of the caches, both [n_ctx][kv_dim] (fp16-KV decode mode: ps_hip_model_set_mode bit 3)
     float *part;             // [n_heads][FL_SPLITS][head_size + 2] partial (o, m, l) of the split-KV decode attention
@@ -45,6 +47,7 @@ struct psl_attn_args {
 void psl_rope_append(hipStream_t st, const psl_attn_args &a, int bs);
 void psl_attn_scores(hipStream_t st, const psl_attn_args &a, int bs);
 void psl_attn_softmax_pv(hipStream_t st, const psl_attn_args &a, int bs);
+bool psl_attn_pv_quantizes(const psl_attn_args &a, int bs); // whether psl_attn_softmax_pv(a, bs) would fill a.qact (shape conditions of the fused epilogue)
 bool psl_attn_decode_f16(hipStream_t st, const psl_attn_args &a); // single token over the fp16 mirrors: split-KV online soft-max + combine (NOT bit-exact); false: not covered
 bool psl_attn_decode(hipStream_t st, int n_cu, const psl_attn_args &a); // single token, scores + softmax + V.p in one launch; false: not covered
 size_t psl_attn_softmax_pv_lds(const psl_attn_args &a); // dynamic LDS bytes (grows with n_ctx)
