@@ -62,6 +62,8 @@ struct G4KParams {
     const _Float16 *qf; // fragment-major fp16 quants
     const uint8_t *mf;  // tile-major column metadata (ps_act::mf)
     unsigned long long *dbg; // timeline slots (ps_hip_debug_timeline keys 48..50, 52), or null
+    psk_rope_kv rope;        // rope_on (Q / K / V launches, adjacent-pair RoPE): the epilogue rotates Q and K and appends K, V to the caches
+    int rope_on;
 };
 
 // One LDS stage = one super-block of the workgroup's 32 rows (row tile t = row / 16), as the consumers want it:
@@ -145,6 +147,34 @@ __device__ __forceinline__ void g4k_produce(const uint2 (&qq)[UPP], const uint32
         *(uint4 *)(st + G4K_MINS + row * 32 + 16) = make_uint4(o[4], o[5], o[6], o[7]);
     }
     if (hw == 1 && p == 0) *(float2 *)(st + G4K_DD + row * 8) = make_float2(ps_h2f((uint16_t)(h.x & 0xffff)), ps_h2f((uint16_t)(h.x >> 16))); // (d, dmin)
+}
+
+// Two adjacent result rows (row0 even) of column `col` of matrix wi.  Plain: out[col][row0 .. row0 + 1].  With rope_on the
+// launch is Q / K / V and the pair is exactly one RoPE pair (rope_append_kernel's arithmetic, k_attn.hip; ggml.c:15344-15358):
+// Q is rotated into out, K rotated into its cache row (slot pos0 + col), V appended transposed -- the separate launch between the
+// mat-mul and the attention disappears.
+template <int ROPE> // 0: never, 1: always, 2: by p.rope_on
+__device__ __forceinline__ void g4k_store_pair(const G4KParams &p, const int wi, const G4KMat &W, const int col, const int64_t row0, const float x0, const float x1) {
+    if (ROPE == 0 || (ROPE == 2 && !p.rope_on)) { *(float2 *)(W.out + (int64_t)col * W.ldo + row0) = make_float2(x0, x1); return; }
+    const psk_rope_kv &R = p.rope;
+    const int pos = R.state->pos0 + col; // cache slot
+    if (wi == 2) {
+        R.v_cache[row0 * R.n_ctx + pos] = x0; R.v_cache[(row0 + 1) * R.n_ctx + pos] = x1;
+        if (R.v16) { R.v16[(int64_t)pos * R.kv_dim + row0] = (_Float16)x0; R.v16[(int64_t)pos * R.kv_dim + row0 + 1] = (_Float16)x1; }
+        return;
+    }
+    const int rp = R.rope_pos ? R.rope_pos[col] : pos, i0 = (int)(row0 % R.head_size);
+    float ra = x0, rb = x1;
+    if (i0 < R.n_dims) {
+        const float2 cs = *(const float2 *)(R.rope_table + (int64_t)rp * R.head_size + i0);
+        ra = __fsub_rn(__fmul_rn(x0, cs.x), __fmul_rn(x1, cs.y));
+        rb = __fadd_rn(__fmul_rn(x0, cs.y), __fmul_rn(x1, cs.x));
+    }
+    if (wi == 0) *(float2 *)(W.out + (int64_t)col * W.ldo + row0) = make_float2(ra, rb);
+    else {
+        *(float2 *)(R.k_cache + (int64_t)pos * R.kv_dim + row0) = make_float2(ra, rb);
+        if (R.k16) { R.k16[(int64_t)pos * R.kv_dim + row0] = (_Float16)ra; R.k16[(int64_t)pos * R.kv_dim + row0 + 1] = (_Float16)rb; }
+    }
 }
 
 // item i -> (task, column block): 16 consecutive items are 8 tasks x 2 column blocks (for n_cb = 2), the two blocks of a task
@@ -469,7 +499,7 @@ __global__ __launch_bounds__((G4K_NC + G4K_NP) * 64) void gemm4k_kernel(const G4
                             if (W.bias) v[rr] = __fadd_rn(v[rr], bv[rr]);
                             if (p.residual && wi == 0) v[rr] = __fadd_rn(rv[rr], v[rr]);
                         }
-                        *(float2 *)(W.out + (int64_t)col * W.ldo + row0) = make_float2(v[0], v[1]);
+                        g4k_store_pair<0>(p, wi, W, col, row0, v[0], v[1]); // (the RoPE epilogue lives in the narrow kernel only: here it costs 9 spills at the 168-register cap and gives the saved launch back, 14.74 vs 14.81 k tok/s)
                     }
                 }
             }
@@ -654,7 +684,7 @@ __global__ __launch_bounds__((G4K_NC + G4K_NPN) * 64) void gemm4k_narrow_kernel(
                             if (W.bias) v[rr] = __fadd_rn(v[rr], W.bias[row0 + rr]);
                             if (p.residual && wi == 0) v[rr] = __fadd_rn(p.residual[(int64_t)col * W.ldo + row0 + rr], v[rr]);
                         }
-                        *(float2 *)(W.out + (int64_t)col * W.ldo + row0) = make_float2(v[0], v[1]);
+                        g4k_store_pair<2>(p, wi, W, col, row0, v[0], v[1]);
                     }
                 }
             }
@@ -950,7 +980,8 @@ static int g4k_launch(hipStream_t st, int n_cu, G4KParams &p, const int epi, con
 // Q4_K batched mat-mul from fragment-major Q8_K activations (act.qf).  -1: not covered (the caller takes gemm8m).
 int psk_gemm4k(hipStream_t st, int n_cu, const psk_gemv_args &a, ps_act act, int64_t K, int64_t bs) {
     static const bool off = getenv("PS_NO_GEMM4K") != nullptr; // (A/B switch for measurements)
-    if (off || a.pro != 0 || a.rope || a.n_w < 1 || !act.qf || K % 256) return -1;
+    if (off || a.pro != 0 || a.n_w < 1 || !act.qf || K % 256) return -1;
+    if (a.rope && (a.n_w != 3 || a.silu_pair || a.residual || bs > 16)) return -1;
     G4KParams p{};
     int pairs_total = 0;
     for (int i = 0; i < a.n_w; i++) {
@@ -965,6 +996,7 @@ int psk_gemm4k(hipStream_t st, int n_cu, const psk_gemv_args &a, ps_act act, int
     p.residual = a.residual; p.qf = act.qf; p.mf = act.mf;
     p.dbg = psk_gemv_dbg_buf(12 + epi, epi ? 0 : (a.n_w == 3 ? 0 : (K <= 8192 ? 1 : 2))); // keys 48 QKV, 49 O, 50 down, 52 gate/up
     p.wt = PS_Q4_K;
+    if (a.rope) { p.rope = *a.rope; p.rope_on = 1; }
     return g4k_launch(st, n_cu, p, epi, bs);
 }
 
@@ -1000,4 +1032,14 @@ int psk_gemm6k(hipStream_t st, int n_cu, const psk_gemv6_args &a, ps_act act, in
     if (ps_first_on_device(&attr)) (void)hipFuncSetAttribute((const void *)gemm6k_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, G6K_LDS);
     hipLaunchKernelGGL(gemm6k_kernel, dim3((unsigned)n_wg), dim3((G4K_NC + G4K_NP) * 64), G6K_LDS, st, p);
     return 0;
+}
+
+// Whether psk_gemm4k(a with a.rope set) will take a Q / K / V launch of `bs` columns AND do RoPE + the KV append in its epilogue
+// (tree verify, prompt tails; mirrors the checks of psk_gemm4k and g4k_launch): 8B tree forward 12 wide 4.72 -> 4.62 ms.
+bool psk_gemm4k_rope_ok(const psk_gemv_args &a, int64_t K, int64_t bs) {
+    static const bool off = getenv("PS_NO_GEMM4K") != nullptr || getenv("PS_NO_ROPE_FUSION") != nullptr;
+    if (off || a.n_w != 3 || a.silu_pair || a.residual || K % 1024 || bs < 2 || bs < ps_gemm4k_min_cols() || bs > 16) return false; // (at most 16 columns: the narrow kernel)
+    for (int i = 0; i < 3; i++)
+        if (!a.w[i] || a.w[i]->dtype != PS_Q4_K || a.w[i]->K != K || a.w[i]->N % 32 || a.ldo[i] % 4) return false;
+    return true;
 }

@@ -1651,11 +1651,13 @@ static int launch_gemm8(hipStream_t st, const GemvParams &p, int epi, int nwv, c
     return 0;
 }
 int psk_gemm8(hipStream_t st, int n_cu, const psk_gemv_args &a, ps_act act, int64_t K, int64_t bs) {
-    if (a.pro != 0 || a.rope || a.n_w < 1) return -1;
+    if (a.pro != 0 || a.n_w < 1) return -1;
+    if (a.rope && !(a.w[0]->dtype == PS_Q4_K && bs >= 2)) return -1;
     if (a.w[0]->dtype == PS_Q4_K) { // prefill chunks: fp16 matrix cores on exact integers, producer / consumer waves (k_gemm4k.hip)
         const int rc = psk_gemm4k(st, n_cu, a, act, K, bs);
         if (rc != -1) return rc;
     }
+    if (a.rope) return 3; // (a batch with the RoPE epilogue requested that the chunk mat-mul did not take: psk_gemm4k_rope_ok and psk_gemm4k disagree)
     const int wt = a.w[0]->dtype;
     if (wt != PS_Q4_K && wt != PS_Q8_0 && wt != PS_Q4_0) return -1;
     const int64_t unit = wt == PS_Q4_K ? 256 : 128, blk = wt == PS_Q4_K ? 256 : 32, rg = wt == PS_Q4_0 ? 16 : 8;

@@ -193,10 +193,12 @@ static int enqueue_forward(ps_hip_model *m, int bs, bool lm_head, bool use_tree,
         // single token, adjacent-pair RoPE: rotation and the KV append ride in the mat-vec epilogue
         const bool fuse_rope = bs == 1 && !aa.neox && psk_gemv_rope_ok(m->wq[L]->dtype, dim) && m->wk[L]->dtype == m->wq[L]->dtype && m->wv[L]->dtype == m->wq[L]->dtype;
         psk_rope_kv rk{m->state, m->rope_table, aa.k_cache, aa.v_cache, (int)f.head_size, (int)f.rope.n_dims, (int)f.seq_len, (int)kvd, aa.rope_pos, aa.k16, aa.v16};
-        if (fuse_rope) g.rope = &rk;
+        // batches of Q4_K weights: the same, in the chunk mat-mul's epilogue (k_gemm4k.hip)
+        const bool fuse_rope_b = bs > 1 && !aa.neox && psk_gemm4k_rope_ok(g, dim, bs);
+        if (fuse_rope || fuse_rope_b) g.rope = &rk;
         if (mm(m, g, a1, dim, bs)) return 2;
 
-        if (!fuse_rope) psl_rope_append(st, aa, bs);
+        if (!fuse_rope && !fuse_rope_b) psl_rope_append(st, aa, bs);
         bool att_quantized = false;
         if (bs == 1 && !use_tree && kv16 && psl_attn_decode_f16(st, aa)) {
             // fp16-KV decode mode (not bit-exact): split-KV online soft-max over the fp16 mirrors
