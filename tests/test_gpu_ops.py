@@ -169,6 +169,27 @@ def test_mul_mat_q5k_batch_on_matrix_cores(ctx, oracle, hip, K, N, bs):
     W.free()
 
 
+@pytest.mark.parametrize("wt", [12, 13, 14])
+def test_mul_mat_kquant_random_shapes(ctx, oracle, hip, wt):
+    """Seeded sweep over shapes the parametrized cases do not name: column counts 2 .. 200 (narrow kernel, wide kernel with 1 .. 4
+    column blocks, ragged last tiles), row counts that leave padded items, K = 1024 .. 4096 in steps of 1024; Q4_K, Q5_K, Q6_K."""
+    from powerserve_amd import synth
+    rng = np.random.default_rng(1000 + wt)
+    for case in range(14):
+        K = int(rng.integers(1, 5)) * 1024
+        N = int(rng.integers(1, 19)) * 32
+        bs = int(rng.choice([2, 3, 7, 9, 15, 16, 17, 31, 33, 48, 63, 64, 65, 100, 127, 129, 161, 200]))
+        w = synth.random_blocks(rng, wt, N, K)
+        x = (rng.standard_normal((bs, K)) * rng.uniform(0.05, 20.0, (bs, 1))).astype(np.float32)
+        want = oracle.mul_mat(wt, w, K, N, x)
+        W = ctx.upload_weight(wt, w, K, N)
+        dx, dy = ctx.to_device(x), ctx.empty((bs, N))
+        ctx.check(ctx.L.ps_hip_mul_mat(ctx.h, C.byref(dy.tensor()), C.byref(W.tensor()), C.byref(dx.tensor())))
+        got = dy.numpy()
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (case, K, N, bs, rel_err(got, want), np.argwhere(got != want)[:4])
+        W.free()
+
+
 def test_mul_mat_f32_gqa_views(ctx, oracle, hip):
     """K-cache view x permuted q (norm_attention.cpp:115-129) and V-cache view x kq (:138-147)."""
     rng = np.random.default_rng(7)
