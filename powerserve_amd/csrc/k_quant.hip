@@ -38,6 +38,16 @@ __global__ __launch_bounds__(256) void quantize_norm_kernel(QuantArgs a) {
     ps_quantize_row_wg<VDT, 1, TPW>(a.x + row * K, a.w, a.eps, K, a.qs + row * K, a.d + row * nblk, a.bs16 + row * (K / 16), red,
                                     VDT == PS_Q8_K ? a.qf : nullptr, row, VDT == PS_Q8_K ? a.mf : nullptr);
 }
+// the same with one wave per tile (K <= 4096: up to 16 waves): the row's tiles are quantized side by side instead of four per wave
+// in turn -- a batch row is a latency chain (load, sum of squares, barrier, quantize), not a bandwidth problem
+template <int VDT>
+__global__ __launch_bounds__(1024) void quantize_norm_wide_kernel(QuantArgs a) {
+    __shared__ double red[16];
+    const int64_t row = blockIdx.x, K = a.K;
+    const int64_t nblk = K / (VDT == PS_Q8_0 ? 32 : 256);
+    ps_quantize_row_wg<VDT, 1, 1>(a.x + row * K, a.w, a.eps, K, a.qs + row * K, a.d + row * nblk, a.bs16 + row * (K / 16), red,
+                                  VDT == PS_Q8_K ? a.qf : nullptr, row, VDT == PS_Q8_K ? a.mf : nullptr);
+}
 // MODE 0 / 2: blocks are independent -> one wave per 256-element tile, grid (tiles/4, rows)
 template <int VDT, int MODE>
 __global__ __launch_bounds__(256) void quantize_tiles_kernel(QuantArgs a) {
@@ -178,6 +188,13 @@ void psk_quantize_act(hipStream_t st, int vdt, int mode, const float *x, const f
     if (mode == 1) {
         dim3 g((unsigned)rows), b(256);
         const int64_t tpw = ((K + 255) / 256 + 3) / 4;
+        static const bool wide_off = getenv("PS_NO_QNORM_WIDE") != nullptr;
+        if (!wide_off && rows >= 2 && K % 256 == 0 && K / 256 >= 8 && K / 256 <= 16) { // batches: one wave per tile
+            dim3 bw((unsigned)(K / 256 * 64));
+            if (vdt == PS_Q8_0) hipLaunchKernelGGL((quantize_norm_wide_kernel<PS_Q8_0>), g, bw, 0, st, a);
+            else hipLaunchKernelGGL((quantize_norm_wide_kernel<PS_Q8_K>), g, bw, 0, st, a);
+            return;
+        }
 #define LN(V) do { if (tpw <= 4) hipLaunchKernelGGL((quantize_norm_kernel<V, 4>), g, b, 0, st, a); \
                    else if (tpw <= 8) hipLaunchKernelGGL((quantize_norm_kernel<V, 8>), g, b, 0, st, a); \
                    else hipLaunchKernelGGL((quantize_norm_kernel<V, 16>), g, b, 0, st, a); } while (0)
