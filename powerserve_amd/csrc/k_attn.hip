@@ -545,6 +545,307 @@ __global__ __launch_bounds__(PV_NT) void attn_decode_kernel(psl_attn_args a) {
     if (live && c == 0) a.att[((int64_t)kvh * r2 + g) * hs + blockIdx.x * 4 + dl] = out;
 }
 
+// ---------------------------------------------------------------- single token, ONE launch, second generation
+// attn_decode2_kernel: K·q, soft-max and V·p of one cached token in one launch whose critical path is
+//   q / K landed -> scores -> ONE exchange -> max -> exp -> sum -> p -> 17 dependent matrix instructions -> reduce.
+// What the round-2 timeline of the two launches showed to be waste is gone (profiles/r02_attention_timeline.txt):
+//   * scores are not parked in memory behind a flag: every score travels as an 8-byte {epoch tag, value} granule written
+//     by ONE write-through store (relaxed agent-scope atomic: global_store_dwordx2 sc1) and the readers poll the data
+//     itself with sc1 loads — no drain, no ticket round trip between "stored" and "may be read".  The tag is (forward
+//     generation, position, layer): the generation is bumped by the host for every forward / decode call and travels in the
+//     device-resident step state next to the position, a decode call's steps differ in the position, so a tag never
+//     repeats between two clears of the buffer (the host clears it when the 13-bit generation wraps) and eager
+//     launches, graph replays, rollbacks and layers share one buffer;
+//   * the K rows below the host's lower bound of the cache length (n_kv_lo: a HINT, results never depend on it) are
+//     requested before the device-resident position has arrived (that load is an L2 miss on every launch);
+//   * the scores arrive straight in the soft-max's register layout (lane = head, group of 8 positions — the reference's
+//     vector loop, ggml.c:2831-2866), the n_kv % 8 leftovers take libm's expf on lanes of their own, in parallel;
+//   * V·p runs on the matrix cores: v_mfma_f32_16x16x4_f32 is a k-ordered fma chain with one rounding per product
+//     (attn_pv_mfma_kernel above).  A workgroup owns 4 channels x r2 <= 4 heads, so one instruction carries FOUR of
+//     ggml_vec_dot_f32's 32 chains: A row = (chain ci, channel), B column = (chain cj, head), k = four successive
+//     32-position blocks, and the 4 x 4 blocks with ci == cj of the 16 x 16 result are the chains' partial sums (the
+//     others are discarded).  Eight waves, one per group of four chains, 17 dependent instructions at n_kv = 2100
+//     instead of 66 LDS round trips per lane.
+// grid: (head_size / 4) x n_kv_heads workgroups of 1024 threads, linear id = x * n_kv_heads + kv head; every workgroup
+// must be resident (the host checks the grid against the CU count; the poll is bounded and raises sync[31]).
+// LDS: p [4][RS] and V [4][RS] (RS = n_ctx rounded up to 128, + 36: rows 4 banks apart), n_ctx <= 4096.
+constexpr int D2_NT = 1024, D2_TRIPS = 2; // 256 lanes per head x 8 positions x D2_TRIPS >= n_ctx
+__device__ __forceinline__ unsigned long long coh_load_u64(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void coh_store_u64(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <int NV>
+__global__ __launch_bounds__(D2_NT) void attn_decode2_kernel(psl_attn_args a) {
+    extern __shared__ __attribute__((aligned(16))) float d2s[];
+    constexpr int hs = NV * 32, RMAX = 16 / NV, G = hs / 4; // G workgroups per kv head; slice (32 positions) s belongs to workgroup s % G
+    const int kvd = a.n_kv_heads * hs, r2 = a.n_heads / a.n_kv_heads;
+    const int kvh = (int)blockIdx.x % a.n_kv_heads, bx = (int)blockIdx.x / a.n_kv_heads;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int RS = ((a.n_ctx + 127) & ~127) + 36, XS = (a.n_ctx + 7) & ~7;
+    float *const pl = d2s, *const vt = pl + 4 * RS, *const red = vt + 4 * RS, *const pleft = red + 512, *const redf = pleft + 128;
+    float *const tails = redf + 16;
+    unsigned *const epw = (unsigned *)(tails + 32);
+    double *const redd = (double *)(epw + 4);
+    unsigned long long *const dbg = (a.dbg && blockIdx.x < 1024 && tid == 0) ? a.dbg + (size_t)blockIdx.x * 64 : nullptr; // timeline key 42
+    auto mark = [&](int k) { if (dbg) dbg[k] = __builtin_amdgcn_s_memtime(); };
+    if (dbg) { dbg[0] = __builtin_amdgcn_s_memtime(); dbg[29] = __builtin_amdgcn_s_memrealtime(); }
+
+    // ---- t = 0.  Every vector-memory instruction up to the first wait is UNCONDITIONAL (clamped addresses, selects behind
+    //      the loads), so the compiler's s_waitcnt counts stay exact: the position (first, a vector load on purpose: the scalar
+    //      counter is shared with the kernel arguments and LDS), q, then the K rows the host knows to exist
+    const ps_step_state *sp = a.state;
+    asm volatile("" : "+v"(sp)); // (opaque: keeps it a vector load, issued here; global address space: a flat load would tie up both counters)
+    const __attribute__((address_space(1))) int *spg = (const __attribute__((address_space(1))) int *)(uintptr_t)sp;
+    const int st_pos0 = spg[0], st_gen = spg[3]; // (two dword loads: unused lanes of a wider load get reused as temporaries, which waits for the load)
+    const int c = tid & 31, hw = tid >> 5;
+    const float *qb = a.q + (int64_t)kvh * r2 * hs + c;
+    float qf[4][NV];
+#pragma unroll
+    for (int g = 0; g < 4; g++)
+#pragma unroll
+        for (int m = 0; m < NV; m++) qf[g][m] = qb[(g < r2 ? g : 0) * hs + m * 32];
+    const float *kb = a.k_cache + kvh * hs + c;
+    float kf[RMAX][NV], kl[RMAX][NV];
+    const int nlo = a.n_kv_lo;
+#pragma unroll
+    for (int rd = 0; rd < RMAX; rd++) {
+        const int sl = bx + rd * G;
+        const bool early = sl * 32 + 32 <= nlo && sl * 32 + 32 <= a.n_ctx; // (uniform)
+        const float *kr = kb + (int64_t)(early ? sl * 32 + hw : 0) * kvd;
+#pragma unroll
+        for (int m = 0; m < NV; m++) kf[rd][m] = kr[m * 32];
+    }
+    mark(1);
+    const int pos0 = __builtin_amdgcn_readfirstlane(st_pos0); // (uniform: everything derived from it is scalar control flow)
+    const int n_kv = pos0 + 1, n8 = n_kv & ~7, np = n_kv & ~31, nblk = np >> 5, n_it = (nblk + 3) >> 2, np_pad = n_it * 128;
+    const int n_kv4 = (n_kv + 3) & ~3;
+    // a tag never repeats while it could be mistaken: (forward generation, position, layer); the host clears the buffer
+    // when the generation wraps (model.hip)
+    const unsigned gen = (unsigned)__builtin_amdgcn_readfirstlane(st_gen);
+    const unsigned epoch = (gen << 19) | ((unsigned)pos0 << 7) | (unsigned)a.layer;
+    // ---- the rest of this workgroup's K rows, then its four V rows (registers; parked in LDS while the scores travel)
+#pragma unroll
+    for (int rd = 0; rd < RMAX; rd++) {
+        const int sl = bx + rd * G, j = sl * 32 + hw;
+        const bool early = sl * 32 + 32 <= nlo && sl * 32 + 32 <= a.n_ctx;
+        const float *kr = kb + (int64_t)((!early && j < n_kv) ? j : 0) * kvd;
+#pragma unroll
+        for (int m = 0; m < NV; m++) kl[rd][m] = kr[m * 32];
+    }
+    const float *vbase = a.v_cache + ((int64_t)kvh * hs + bx * 4) * a.n_ctx;
+    const int RSd4 = (RS - 36) >> 2; // float4 units per padded V row
+    float4 vld[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int f = tid + D2_NT * k, row = f / RSd4, col = (f - row * RSd4) * 4;
+        const bool in = row < 4 && col < n_kv4; // n_kv4 <= n_ctx: in bounds
+        vld[k] = *(const float4 *)(vbase + (in ? (int64_t)row * a.n_ctx + col : 0));
+    }
+    mark(2);
+
+    // ---- scores of this workgroup's positions: a half-wave per position, ggml_vec_dot_f32's 32 chains + GGML_F32x8_REDUCE;
+    //      published as granules by the half-wave's first lane
+    unsigned long long *const xb = a.xchg + (size_t)kvh * 4 * XS;
+#pragma unroll
+    for (int rd = 0; rd < RMAX; rd++) {
+        const int sl = bx + rd * G, j = sl * 32 + hw;
+        const bool early = sl * 32 + 32 <= nlo && sl * 32 + 32 <= a.n_ctx;
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            float s = 0.f;
+#pragma unroll
+            for (int m = 0; m < NV; m++) s = __fmaf_rn(early ? kf[rd][m] : kl[rd][m], qf[g][m], s); // sum = x*y + sum, x = K row (src0)
+            s = reduce_f32x8x4(s);
+            if (c == 0 && j < n_kv && g < r2) coh_store_u64(xb + (size_t)g * XS + j, ((unsigned long long)epoch << 32) | __float_as_uint(s));
+        }
+    }
+    mark(3);
+    mark(4);
+
+    // ---- gather: lane (head g, t) takes the groups of 8 positions t and t + 256; polls until every tag is this launch's
+    const int g = tid >> 8, t = tid & 255;
+    const bool hl = g < r2;
+    const unsigned long long *xg = xb + (size_t)(hl ? g : 0) * XS;
+    float sv[D2_TRIPS][8];
+    bool pend[D2_TRIPS];
+#pragma unroll
+    for (int k = 0; k < D2_TRIPS; k++) {
+        pend[k] = hl && (t + 256 * k) * 8 < n_kv;
+#pragma unroll
+        for (int i = 0; i < 8; i++) sv[k][i] = 0.f;
+    }
+    for (int spins = 0;; spins++) {
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < D2_TRIPS; k++) {
+            if (pend[k]) {
+                const int j0 = (t + 256 * k) * 8;
+                unsigned long long gr[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) gr[i] = coh_load_u64(xg + j0 + i);
+                bool all = true;
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    all = all && (j0 + i >= n_kv || (unsigned)(gr[i] >> 32) == epoch);
+                    sv[k][i] = __uint_as_float((unsigned)gr[i]);
+                }
+                if (all) pend[k] = false; else ok = false;
+            }
+        }
+        if (!__any(!ok)) break;
+        __builtin_amdgcn_s_sleep(2);
+        if (spins > (1 << 15)) { // never hang the GPU: the host turns the flag into an error
+            if (lane == 0) __hip_atomic_store(a.sync + 31, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+        }
+    }
+    mark(5);
+    // ---- scale + mask (softmax_ext, ggml.c:14889-14914), row maxima
+    float lmax = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < D2_TRIPS; k++)
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int j = (t + 256 * k) * 8 + i;
+            if (hl && j < n_kv) {
+                const bool vis = (j < pos0 && a.kv_vis) ? a.kv_vis[j] != 0 : true;
+                float v = __fmul_rn(sv[k][i], a.scale);
+                v = __fadd_rn(v, vis ? 0.f : -INFINITY);
+                sv[k][i] = v;
+                lmax = fmaxf(lmax, v);
+            }
+        }
+    {
+        const float wm = wave_max_dpp(lmax);
+        if (lane == 0) redf[wave] = wm; // waves 4g .. 4g+3 belong to head g
+    }
+    // ---- V rows into LDS (zeros past the cache length: the matrix instructions run over whole groups of 4 blocks).  Here, not
+    //      right behind the loads: the granule stores above are conditional, the compiler cannot count them, and a wait for
+    //      the V registers placed before the gather would also wait for every store's write-through acknowledgement
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int f = tid + D2_NT * k, row = f / RSd4, col = (f - row * RSd4) * 4;
+        if (row < 4) *(float4 *)(vt + row * RS + col) = col < n_kv4 ? vld[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const int ntail = n_kv - n8;
+#pragma unroll
+    for (int k = 0; k < D2_TRIPS; k++)
+        if (hl && (t + 256 * k) * 8 == n8) {
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+                if (i < ntail) tails[g * 8 + i] = sv[k][i];
+        }
+    __syncthreads();
+    mark(6);
+    const float mx = fmaxf(fmaxf(redf[(wave & ~3)], redf[(wave & ~3) + 1]), fmaxf(redf[(wave & ~3) + 2], redf[(wave & ~3) + 3]));
+    // ---- e_j = exp(x_j - max): ggml_v_expf on whole groups of 8 with the reference's in-group sum tree, libm's expf on the
+    //      n_kv % 8 leftovers (one lane each), row sums in double (ggml.c:2831-2866)
+    double rs = 0.0;
+#pragma unroll
+    for (int k = 0; k < D2_TRIPS; k++) {
+        const int j0 = (t + 256 * k) * 8;
+        if (hl && j0 + 8 <= n8) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) sv[k][i] = ps_v_expf(__fsub_rn(sv[k][i], mx));
+            const float a0 = __fadd_rn(sv[k][4], sv[k][0]), a1 = __fadd_rn(sv[k][5], sv[k][1]), a2 = __fadd_rn(sv[k][6], sv[k][2]), a3 = __fadd_rn(sv[k][7], sv[k][3]);
+            rs += (double)__fadd_rn(__fadd_rn(a0, a2), __fadd_rn(a1, a3));
+        }
+    }
+    float et = 0.f;
+    if (hl && t < ntail) { et = ps_expf_glibc(__fsub_rn(tails[g * 8 + t], mx)); rs += (double)et; }
+    {
+        const double sw = wave_sum_d_dpp(rs);
+        if (lane == 0) redd[wave] = sw;
+    }
+    mark(7);
+    __syncthreads();
+    mark(8);
+    const float inv = (float)(1.0 / (((redd[(wave & ~3)] + redd[(wave & ~3) + 1]) + redd[(wave & ~3) + 2]) + redd[(wave & ~3) + 3]));
+    // ---- p_j = e_j * (float)(1/sum) (ggml_vec_scale_f32): whole blocks of 32 feed the chains (pl), positions past the last
+    //      whole block are the dot product's leftovers (pleft), and the padding of the last group of 4 blocks is zero
+#pragma unroll
+    for (int k = 0; k < D2_TRIPS; k++) {
+        const int j0 = (t + 256 * k) * 8;
+        if (!hl) continue;
+        if (j0 + 8 <= np) {
+            *(float4 *)(pl + g * RS + j0)     = make_float4(__fmul_rn(sv[k][0], inv), __fmul_rn(sv[k][1], inv), __fmul_rn(sv[k][2], inv), __fmul_rn(sv[k][3], inv));
+            *(float4 *)(pl + g * RS + j0 + 4) = make_float4(__fmul_rn(sv[k][4], inv), __fmul_rn(sv[k][5], inv), __fmul_rn(sv[k][6], inv), __fmul_rn(sv[k][7], inv));
+        } else {
+            if (j0 < np_pad) {
+                *(float4 *)(pl + g * RS + j0)     = make_float4(0.f, 0.f, 0.f, 0.f);
+                *(float4 *)(pl + g * RS + j0 + 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            if (j0 + 8 <= n8) {
+#pragma unroll
+                for (int i = 0; i < 8; i++) pleft[g * 32 + (j0 - np) + i] = __fmul_rn(sv[k][i], inv);
+            }
+        }
+    }
+    if (hl && t < ntail) pleft[g * 32 + (n8 - np) + t] = __fmul_rn(et, inv);
+    __syncthreads();
+    mark(9);
+
+    // ---- V·p: wave w < 8 owns chains 4w .. 4w+3.  A: row rl = 4 ci + channel, k = block; B: k = block, column 4 cj + head
+    if (wave < 8) {
+        const int rl = lane & 15, kk = lane >> 4, ci = rl >> 2, rh = rl & 3;
+        const float *va = vt + rh * RS + 4 * wave + ci + 32 * kk;
+        const float *pb = pl + (rh < r2 ? rh : 0) * RS + 4 * wave + ci + 32 * kk; // (heads past r2: any row, masked below)
+        const bool bl = rh < r2;
+        ps_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        // operands of four steps at a time, one group ahead of the matrix instructions (a dependent chain: 40 cycles each).
+        // Steps past the last one (the group is rounded up) read the last step's V again against p = 0: fma(v, 0, acc) = acc
+        float a0[4], b0[4], a1[4], b1[4];
+        auto fetch = [&](float (&av)[4], float (&bv)[4], int s0) { // (reads only: the mask is applied where the operand is used)
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int sc = s0 + i < n_it ? s0 + i : n_it - 1;
+                av[i] = va[128 * sc];
+                bv[i] = pb[128 * sc];
+            }
+        };
+        auto chain = [&](const float (&av)[4], const float (&bv)[4], int s0) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const float b = __uint_as_float(__float_as_uint(bv[i]) & ((bl && s0 + i < n_it) ? 0xffffffffu : 0u)); // (a mask, not a branch)
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], b, acc, 0, 0, 0); // sum = x*y + sum, x = V row (src0)
+            }
+        };
+        if (n_it > 0) {
+            fetch(a0, b0, 0);
+            for (int s0 = 0; s0 < n_it; s0 += 8) {
+                fetch(a1, b1, s0 + 4);
+                __builtin_amdgcn_sched_barrier(0); // (the reads go out BEFORE the dependent matrix instructions stall the issue)
+                chain(a0, b0, s0);
+                if (s0 + 4 < n_it) { // (uniform)
+                    fetch(a0, b0, s0 + 8);
+                    __builtin_amdgcn_sched_barrier(0);
+                    chain(a1, b1, s0 + 4);
+                }
+            }
+        }
+        // D: column = lane & 15 = 4 cj + head, rows 4 (lane >> 4) + r = 4 ci + channel r: the ci == cj blocks are the chains
+        if ((lane >> 4) == ((lane & 15) >> 2)) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) red[((4 * wave + (lane >> 4)) * 4 + r) * 4 + (lane & 3)] = acc[r];
+        }
+    }
+    __syncthreads();
+    mark(10);
+    if (tid < 16) {
+        const int ch = tid >> 2, h = tid & 3;
+        float xc[32];
+#pragma unroll
+        for (int cc = 0; cc < 32; cc++) xc[cc] = red[(cc * 4 + ch) * 4 + h];
+        float t3[4];
+#pragma unroll
+        for (int cc = 0; cc < 4; cc++) // GGML_F32x8_REDUCE (ggml.c:1354-1371)
+            t3[cc] = __fadd_rn(__fadd_rn(__fadd_rn(xc[cc], xc[cc + 16]), __fadd_rn(xc[cc + 8], xc[cc + 24])),
+                               __fadd_rn(__fadd_rn(xc[cc + 4], xc[cc + 20]), __fadd_rn(xc[cc + 12], xc[cc + 28])));
+        float res = __fadd_rn(__fadd_rn(t3[0], t3[1]), __fadd_rn(t3[2], t3[3]));
+        for (int jj = np; jj < n_kv; jj++) res = __fadd_rn(res, __fmul_rn(vt[ch * RS + jj], pleft[h * 32 + (jj - np)])); // leftovers, in order
+        if (h < r2) a.att[((int64_t)kvh * r2 + h) * hs + bx * 4 + ch] = res;
+    }
+    if (dbg) { dbg[11] = __builtin_amdgcn_s_memtime(); dbg[30] = __builtin_amdgcn_s_memrealtime(); }
+}
+
 // Batches (prefill chunks, tree verify): one workgroup per (kv head, CI batch columns).  The softmax of a row is computed
 // once (not once per channel tile as in the single-token kernel, whose grid has to fill the chip from one column), and a
 // V element fetched from L2 serves r2 heads x CI columns.  thread: chain c = tid & 31, channels (tid >> 5) + 32k.
@@ -1138,6 +1439,25 @@ bool psl_attn_decode(hipStream_t st, int n_cu, const psl_attn_args &a) {
     if (a.head_size == 128) hipLaunchKernelGGL(attn_decode_kernel<4>, g, dim3(PV_NT), lds, st, a);
     else if (a.head_size == 64) hipLaunchKernelGGL(attn_decode_kernel<2>, g, dim3(PV_NT), lds, st, a);
     else return false;
+    return true;
+}
+
+// single token, one launch, second generation (attn_decode2_kernel); false: not covered
+size_t psl_attn_decode2_xchg_bytes(int n_kv_heads, int n_ctx) { return (size_t)n_kv_heads * 4 * (((size_t)n_ctx + 7) & ~(size_t)7) * 8; }
+bool psl_attn_decode2(hipStream_t st, int n_cu, const psl_attn_args &a) {
+    const int r2 = a.n_heads / a.n_kv_heads, gx = a.head_size / 4;
+    if (!a.xchg || !a.sync || a.tree || a.layer < 0 || a.layer > 127 || r2 > 4 || a.n_ctx > 256 * 8 * D2_TRIPS || (a.head_size != 128 && a.head_size != 64)) return false;
+    if (gx * a.n_kv_heads > n_cu) return false; // every workgroup resident (one per CU at n_ctx = 4096)
+    const int RS = ((a.n_ctx + 127) & ~127) + 36;
+    const size_t lds = ((size_t)8 * RS + 512 + 128 + 16 + 32 + 4 + 32) * 4;
+    static unsigned long long attr = 0; // devices that have the attribute
+    if (ps_first_on_device(&attr)) {
+        (void)hipFuncSetAttribute((const void *)attn_decode2_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+        (void)hipFuncSetAttribute((const void *)attn_decode2_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+    }
+    const dim3 g((unsigned)(gx * a.n_kv_heads));
+    if (a.head_size == 128) hipLaunchKernelGGL(attn_decode2_kernel<4>, g, dim3(D2_NT), lds, st, a);
+    else hipLaunchKernelGGL(attn_decode2_kernel<2>, g, dim3(D2_NT), lds, st, a);
     return true;
 }
 

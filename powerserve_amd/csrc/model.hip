@@ -17,8 +17,8 @@
 
 
 namespace {
-__global__ void set_state_kernel(ps_step_state *s, int pos0, int bs, int n_out) {
-    s->pos0 = pos0; s->bs = bs; s->n_out = n_out;
+__global__ void set_state_kernel(ps_step_state *s, int pos0, int bs, int n_out, int gen) {
+    s->pos0 = pos0; s->bs = bs; s->n_out = n_out; s->gen = gen;
 }
 __global__ void null_kernel(int *p) { if (p && threadIdx.x == 12345) *p = 0; }
 __global__ void kv_move_kernel(float *k, float *v, _Float16 *k16, _Float16 *v16, int kvd, int n_ctx, int dst, int src) {
@@ -42,7 +42,10 @@ struct ps_hip_model {
     // arena
     float *x = nullptr, *q = nullptr, *k = nullptr, *v = nullptr, *att = nullptr, *hb = nullptr, *g1 = nullptr, *u1 = nullptr;
     unsigned *bars = nullptr; // device-wide barrier words of the chained launches, [n_layers][12*32]
-    unsigned *attn_sync = nullptr; // [32] ticket counters of the one-launch decode attention
+    unsigned *attn_sync = nullptr; // [2048] words: [31] rendezvous-timeout flag of the one-launch attentions, [64 + 64 * kv head] tickets of the first one
+    unsigned long long *attn_xchg = nullptr; // attn_decode2: score granules (k_attn.hip)
+    int gen = 0;                             // forward generation (ps_step_state::gen): 1 .. 8191, the granule buffer is cleared when it wraps
+    size_t graph_hint = 0;                   // KV position the captured step was given as its prefetch hint (n_kv_lo)
     int n_kv_host = 0;             // pos0 + bs of the forward being enqueued eagerly (0 while a graph is captured / replayed)
     float *scores = nullptr, *logits = nullptr, *rope_table = nullptr;
     void *act_mem = nullptr;
@@ -65,11 +68,23 @@ struct ps_hip_model {
     std::vector<void *> owned;
 };
 
+static int mode_env_or();
 static int dmalloc(ps_hip_model *m, void **p, size_t bytes) {
     ps_hip_ctx *c = m->ctx;
     PS_CHECK(c, hipMalloc(p, bytes ? bytes : 16));
     m->owned.push_back(*p);
     return 0;
+}
+
+// Every forward / decode call gets a generation of its own (ps_step_state::gen): with the position and the layer it tags the
+// score granules of attn_decode2 (k_attn.hip).  13 bits; when it wraps the granule buffer is cleared (stream-ordered), so a
+// tag of an earlier period can never be mistaken for a fresh one.
+static int next_gen(ps_hip_model *m) {
+    if (++m->gen > 8191) {
+        m->gen = 1;
+        (void)hipMemsetAsync(m->attn_xchg, 0, psl_attn_decode2_xchg_bytes((int)m->cfg.n_kv_heads, (int)m->cfg.seq_len), m->ctx->stream);
+    }
+    return m->gen;
 }
 
 static int mm(ps_hip_model *m, psk_gemv_args &g, ps_act act, int64_t K, int64_t bs);
@@ -176,7 +191,11 @@ static int enqueue_forward(ps_hip_model *m, int bs, bool lm_head, bool use_tree,
     aa.kv_vis = m->n_hidden ? m->kv_vis_dev : nullptr;
     aa.scale = 1.0f / sqrtf((float)f.head_size);
     aa.n_kv_host = m->n_kv_host;
-    aa.sync = (m->mode & 4) ? m->attn_sync : nullptr; // mode bit 2: one-launch decode attention (measured equal to the two launches, 16.2 us; needs the GPU to itself)
+    aa.sync = m->attn_sync;
+    const bool one_launch_v1 = (m->mode & 4) != 0;  // mode bit 2: the first one-launch decode attention (round 2; measured equal to the two launches)
+    const bool one_launch_v2 = (m->mode & 16) == 0; // default; mode bit 4 switches attn_decode2 off (two launches)
+    aa.xchg = m->attn_xchg;
+    aa.n_kv_lo = m->n_kv_host > 0 ? m->n_kv_host : (int)m->position; // (a hint: rows below it are requested before the device-side position has arrived)
 
     for (uint32_t L = 0; L < f.n_layers; L++) {
         ps_act a1 = act_for(dim);
@@ -187,7 +206,7 @@ static int enqueue_forward(ps_hip_model *m, int bs, bool lm_head, bool use_tree,
         g.ldo[0] = dim; g.ldo[1] = kvd; g.ldo[2] = kvd;
         if (m->qwen2) { g.bias[0] = m->bq[L]; g.bias[1] = m->bk[L]; g.bias[2] = m->bv[L]; }
         g.pro = 1; g.pro_x = m->x; g.pro_norm_w = m->attn_norm[L]; g.pro_eps = f.norm_eps; // RMSNorm + quantize in the prologue
-        aa.k_cache = m->k_cache[L]; aa.v_cache = m->v_cache[L];
+        aa.k_cache = m->k_cache[L]; aa.v_cache = m->v_cache[L]; aa.layer = (int)L;
         const bool kv16 = (m->mode & 8) && !m->k16.empty();
         aa.k16 = kv16 ? m->k16[L] : nullptr; aa.v16 = kv16 ? m->v16[L] : nullptr; aa.part = m->attn_part;
         // single token, adjacent-pair RoPE: rotation and the KV append ride in the mat-vec epilogue
@@ -202,7 +221,9 @@ static int enqueue_forward(ps_hip_model *m, int bs, bool lm_head, bool use_tree,
         bool att_quantized = false;
         if (bs == 1 && !use_tree && kv16 && psl_attn_decode_f16(st, aa)) {
             // fp16-KV decode mode (not bit-exact): split-KV online soft-max over the fp16 mirrors
-        } else if (!(bs == 1 && !use_tree && psl_attn_decode(st, c->n_cu, aa))) {
+        } else if (bs == 1 && !use_tree && one_launch_v2 && (aa.dbg = psk_gemv_dbg_buf(10, 2), psl_attn_decode2(st, c->n_cu, aa))) { // timeline key 42
+            aa.dbg = nullptr;
+        } else if (!(bs == 1 && !use_tree && one_launch_v1 && psl_attn_decode(st, c->n_cu, aa))) {
             aa.dbg = bs == 1 ? psk_gemv_dbg_buf(10, 0) : nullptr; // timeline key 40
             psl_attn_scores(st, aa, bs);
             aa.dbg = bs == 1 ? psk_gemv_dbg_buf(10, 1) : nullptr; // timeline key 41
@@ -299,6 +320,7 @@ int ps_hip_model_create(ps_hip_ctx *c, const ps_model_desc *d, ps_hip_model **ou
     PS_CHECK(c, hipSetDevice(c->device));
     auto m = new ps_hip_model();
     m->ctx = c; m->cfg = f; m->qwen2 = d->is_qwen2 != 0; m->max_batch = d->max_batch > 0 ? d->max_batch : 1;
+    m->mode = mode_env_or() & ~8; // (the fp16-KV mode allocates: only through set_mode)
     m->token_embd = d->token_embd; m->output = d->output; m->output_norm = d->output_norm;
     const uint32_t L = f.n_layers;
     auto cpf = [&](std::vector<const float *> &v, const float *const *src) { v.assign(L, nullptr); if (src) for (uint32_t i = 0; i < L; i++) v[i] = src[i]; };
@@ -319,6 +341,7 @@ int ps_hip_model_create(ps_hip_ctx *c, const ps_model_desc *d, ps_hip_model **ou
         dmalloc(m, (void **)&m->att, mb * dim * 4) || dmalloc(m, (void **)&m->hb, mb * hid * 4) ||
         dmalloc(m, (void **)&m->g1, mb * hid * 4) || dmalloc(m, (void **)&m->u1, mb * hid * 4) ||
         dmalloc(m, (void **)&m->bars, (size_t)f.n_layers * 12 * 32 * 4) || dmalloc(m, (void **)&m->attn_sync, 2048 * 4) ||
+        dmalloc(m, (void **)&m->attn_xchg, psl_attn_decode2_xchg_bytes((int)f.n_kv_heads, (int)nctx)) ||
         dmalloc(m, (void **)&m->scores, mb * f.n_heads * nctx * 4) || dmalloc(m, (void **)&m->logits, mb * f.vocab_size * 4) ||
         dmalloc(m, (void **)&m->rope_table, nctx * f.head_size * 4) ||
         dmalloc(m, &m->act_mem, ps_act_bytes(dim > hid ? dim : hid, mb)) ||
@@ -328,6 +351,7 @@ int ps_hip_model_create(ps_hip_ctx *c, const ps_model_desc *d, ps_hip_model **ou
         return fail();
     (void)hipMemsetAsync(m->bars, 0, (size_t)f.n_layers * 12 * 32 * 4, c->stream);
     (void)hipMemsetAsync(m->attn_sync, 0, 2048 * 4, c->stream);
+    (void)hipMemsetAsync(m->attn_xchg, 0, psl_attn_decode2_xchg_bytes((int)f.n_kv_heads, (int)nctx), c->stream); // tag 0 is never an epoch
     (void)hipMemsetAsync(m->kv_vis_dev, 1, nctx, c->stream);
     m->kv_vis_host.assign(nctx, 1);
     m->k_cache.assign(L, nullptr); m->v_cache.assign(L, nullptr);
@@ -397,6 +421,22 @@ int ps_hip_model_kv_move(ps_hip_model *m, size_t dst, size_t src) {
 
 static int model_forward_impl(ps_hip_model *m, const int32_t *tokens, int n, const int32_t *pos, const uint8_t *tree, int lm_head,
                               int32_t *argmax_host, bool advance);
+// The one-launch attentions wait for each other's workgroups inside the launch (bounded); a wait that gave up raises
+// attn_sync[31].  Read it behind every synchronised single-token forward, clear it, and fall back to the two launches
+// from here on (mode bit 4): the forward that timed out has no valid result.  Expects the stream to be idle.
+static int check_attn_timeout(ps_hip_model *m, const char *who) {
+    ps_hip_ctx *c = m->ctx;
+    if ((m->mode & 16) && !(m->mode & 4)) return 0; // neither one-launch form is in use
+    unsigned stuck = 0;
+    PS_CHECK(c, hipMemcpy(&stuck, m->attn_sync + 31, 4, hipMemcpyDeviceToHost));
+    if (!stuck) return 0;
+    PS_CHECK(c, hipMemset(m->attn_sync + 31, 0, 4));
+    if (m->step_graph) { (void)hipGraphExecDestroy(m->step_graph); m->step_graph = nullptr; }
+    m->mode = (m->mode | 16) & ~4;
+    c->err = std::string(who) + ": the one-launch attention timed out at its score exchange (GPU shared or partitioned?); this forward has no valid "
+             "result, the cache position is unchanged, and the model now uses the two-launch attention (mode bit 4)";
+    return 2;
+}
 int ps_hip_model_forward(ps_hip_model *m, const int32_t *tokens, int n, const int32_t *pos, const uint8_t *tree, int lm_head,
                          int32_t *argmax_host) {
     return model_forward_impl(m, tokens, n, pos, tree, lm_head, argmax_host, true);
@@ -416,7 +456,7 @@ static int model_forward_impl(ps_hip_model *m, const int32_t *tokens, int n, con
     PS_CHECK(c, hipSetDevice(c->device));
     PS_CHECK(c, hipMemcpyAsync(m->tokens_dev, tokens, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
     if (tree) PS_CHECK(c, hipMemcpyAsync(m->tree_dev, tree, (size_t)n * n, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(1), 0, c->stream, m->state, pos[0], n, 0);
+    hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(1), 0, c->stream, m->state, pos[0], n, 0, next_gen(m));
     PS_CHECK(c, hipStreamSynchronize(c->stream)); // tokens/tree may be host temporaries
     m->n_kv_host = pos[0] + n;
     const int rc_fw = enqueue_forward(m, n, lm_head != 0, tree != nullptr);
@@ -425,6 +465,7 @@ static int model_forward_impl(ps_hip_model *m, const int32_t *tokens, int n, con
     if (lm_head && argmax_host) PS_CHECK(c, hipMemcpyAsync(argmax_host, m->argmax_dev, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
     if (!advance) return 0; // lowered graph: the executor's caller syncs when it reads the logits and advances the cache itself
     PS_CHECK(c, hipStreamSynchronize(c->stream));
+    if (n == 1 && !tree) if (int rc = check_attn_timeout(m, "model_forward")) return rc;
     unmask_range(m, (size_t)pos[0], (size_t)n);
     m->position = (size_t)pos[0] + (size_t)n; // m_kv->advance (llama_model.cpp:109)
     return 0;
@@ -443,7 +484,7 @@ int ps_hip_model_forward_tree(ps_hip_model *m, const int32_t *tokens, int n, con
     PS_CHECK(c, hipMemcpyAsync(m->tokens_dev, tokens, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
     PS_CHECK(c, hipMemcpyAsync(m->rope_pos_dev, rope_pos, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
     if (tree) PS_CHECK(c, hipMemcpyAsync(m->tree_dev, tree, (size_t)n * n, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(1), 0, c->stream, m->state, (int)m->position, n, 0);
+    hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(1), 0, c->stream, m->state, (int)m->position, n, 0, next_gen(m));
     PS_CHECK(c, hipStreamSynchronize(c->stream));
     m->n_kv_host = (int)m->position + n;
     const int rc_fw = enqueue_forward(m, n, lm_head != 0, tree != nullptr, false, true);
@@ -451,6 +492,7 @@ int ps_hip_model_forward_tree(ps_hip_model *m, const int32_t *tokens, int n, con
     if (rc_fw) return rc_fw;
     if (lm_head && argmax_host) PS_CHECK(c, hipMemcpyAsync(argmax_host, m->argmax_dev, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
     PS_CHECK(c, hipStreamSynchronize(c->stream));
+    if (n == 1 && !tree) if (int rc = check_attn_timeout(m, "model_forward_tree")) return rc;
     if (advance) { unmask_range(m, m->position, (size_t)n); m->position += (size_t)n; }
     return 0;
 }
@@ -474,9 +516,12 @@ int ps_hip_model_decode_greedy(ps_hip_model *m, int32_t token, int steps, int32_
     if (token < 0 || (uint32_t)token >= m->cfg.vocab_size) PS_FAIL(c, "decode_greedy: token id out of range");
     PS_CHECK(c, hipSetDevice(c->device));
     PS_CHECK(c, hipMemcpyAsync(m->tokens_dev, &token, 4, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(1), 0, c->stream, m->state, (int)m->position, 1, 0);
+    hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(1), 0, c->stream, m->state, (int)m->position, 1, 0, next_gen(m));
     PS_CHECK(c, hipStreamSynchronize(c->stream));
     int s = 0;
+    // the captured step carries the position it was captured at as a prefetch hint (n_kv_lo): keep it a LOWER bound that
+    // is not far behind (a stale hint costs time, never results)
+    if (m->step_graph && (m->position < m->graph_hint || m->position >= m->graph_hint + 1024)) { (void)hipGraphExecDestroy(m->step_graph); m->step_graph = nullptr; }
     if ((m->mode & 1) == 0 && !m->step_graph) {
         // first step runs eagerly (also performs every one-time hipFuncSetAttribute), then the identical
         // launch sequence is captured; capture itself executes nothing
@@ -484,6 +529,7 @@ int ps_hip_model_decode_greedy(ps_hip_model *m, int32_t token, int steps, int32_
         PS_CHECK(c, hipStreamSynchronize(c->stream));
         s = 1;
         hipGraph_t g = nullptr;
+        m->graph_hint = m->position;
         PS_CHECK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
         int rc = enqueue_forward(m, 1, true, false, true);
         hipError_t e = hipStreamEndCapture(c->stream, &g);
@@ -499,8 +545,7 @@ int ps_hip_model_decode_greedy(ps_hip_model *m, int32_t token, int steps, int32_
         }
     }
     PS_CHECK(c, hipMemcpyAsync(out_ids, m->ids_dev, (size_t)steps * 4, hipMemcpyDeviceToHost, c->stream));
-    unsigned stuck = 0, bar_err = 0;
-    PS_CHECK(c, hipMemcpyAsync(&stuck, m->attn_sync + 31, 4, hipMemcpyDeviceToHost, c->stream));
+    unsigned bar_err = 0;
     if (m->mode & 2) // chained launches: a device-wide barrier that gave up raises word 32 * 11 of its launch site
         for (uint32_t L = 0; L < m->cfg.n_layers && !bar_err; L++) {
             unsigned e = 0;
@@ -510,7 +555,7 @@ int ps_hip_model_decode_greedy(ps_hip_model *m, int32_t token, int steps, int32_
         }
     PS_CHECK(c, hipStreamSynchronize(c->stream));
     if (bar_err) PS_FAIL(c, "decode_greedy: a device-wide barrier of the chained launch timed out (mode bit 1 needs every CU for this process); results are not valid");
-    if (stuck) PS_FAIL(c, "decode_greedy: the one-launch attention timed out at its rendezvous (GPU shared or partitioned?); clear mode bit 2 for the two-launch path");
+    if (int rc = check_attn_timeout(m, "decode_greedy")) return rc;
     m->position += (size_t)steps;
     return 0;
 }
@@ -606,7 +651,13 @@ int ps_hip_model_bench_gemv(ps_hip_model *m, int reps, int which, double *seq_ms
     return 0;
 }
 
+// PS_HIP_MODE_OR: mode bits OR-ed into every model's mode (A/B runs of unmodified drivers, e.g. bench.py with 16 = two-launch attention)
+static int mode_env_or() {
+    static const int v = [] { const char *e = getenv("PS_HIP_MODE_OR"); return e ? atoi(e) : 0; }();
+    return v;
+}
 int ps_hip_model_set_mode(ps_hip_model *m, int mode) {
+    mode |= mode_env_or();
     if ((mode & 8) && m->k16.empty()) { // fp16 mirrors of the caches: filled from now on, so the cache must be empty
         if (m->position != 0) { m->ctx->err = "set_mode: the fp16-KV decode mode must be switched on while the cache is empty"; return 2; }
         const size_t n = (size_t)m->cfg.seq_len * m->cfg.kv_dim * 2;
@@ -619,7 +670,7 @@ int ps_hip_model_set_mode(ps_hip_model *m, int mode) {
         if (dmalloc(m, (void **)&m->attn_part, (size_t)m->cfg.n_heads * 32 * (m->cfg.head_size + 2) * 4)) return 2;
     }
     if ((mode & 8) && !(m->mode & 8) && m->position != 0) { m->ctx->err = "set_mode: the fp16-KV decode mode must be switched on while the cache is empty"; return 2; }
-    if (((m->mode ^ mode) & 14) && m->step_graph) { // the captured step bakes the launch plan in
+    if (((m->mode ^ mode) & 30) && m->step_graph) { // the captured step bakes the launch plan in
         (void)hipGraphExecDestroy(m->step_graph);
         m->step_graph = nullptr;
     }

@@ -19,7 +19,7 @@ struct ps_step_state {
     int32_t pos0;    // KV position of the first token of this forward
     int32_t bs;      // tokens in this forward
     int32_t n_out;   // decode: number of ids written so far
-    int32_t _pad;
+    int32_t gen;     // forward generation: bumped by the host per forward / decode call, 1 .. 8191 (tags of attn_decode2's score granules)
 };
 
 struct psl_attn_args {
@@ -43,6 +43,9 @@ struct psl_attn_args {
     float *part;             // [n_heads][FL_SPLITS][head_size + 2] partial (o, m, l) of the split-KV decode attention
     unsigned long long *dbg; // timeline buffer of the single-token kernels (ps_hip_debug_timeline keys 40 / 41), or null
     unsigned *sync;          // [2048] words, zeroed once: [31] spin-timeout flag, [64 + 64 * kv head] ticket counter of the one-launch decode attention
+    unsigned long long *xchg; // attn_decode2: score granules {epoch tag, value}, [n_kv_heads][4][n_ctx rounded up to 8], zeroed at creation and whenever the generation wraps; null: not used
+    int layer;               // attn_decode2: layer index (part of the granule tag), 0 .. 127
+    int n_kv_lo;             // attn_decode2: a lower bound of pos0 + 1 known to the host at enqueue time (a prefetch HINT only)
 };
 void psl_rope_append(hipStream_t st, const psl_attn_args &a, int bs);
 void psl_attn_scores(hipStream_t st, const psl_attn_args &a, int bs);
@@ -50,6 +53,8 @@ void psl_attn_softmax_pv(hipStream_t st, const psl_attn_args &a, int bs);
 bool psl_attn_pv_quantizes(const psl_attn_args &a, int bs); // whether psl_attn_softmax_pv(a, bs) would fill a.qact (shape conditions of the fused epilogue)
 bool psl_attn_decode_f16(hipStream_t st, const psl_attn_args &a); // single token over the fp16 mirrors: split-KV online soft-max + combine (NOT bit-exact); false: not covered
 bool psl_attn_decode(hipStream_t st, int n_cu, const psl_attn_args &a); // single token, scores + softmax + V.p in one launch; false: not covered
+bool psl_attn_decode2(hipStream_t st, int n_cu, const psl_attn_args &a); // the same, second generation (tagged score granules, V.p on the matrix cores); false: not covered
+size_t psl_attn_decode2_xchg_bytes(int n_kv_heads, int n_ctx);
 size_t psl_attn_softmax_pv_lds(const psl_attn_args &a); // dynamic LDS bytes (grows with n_ctx)
 // two-stage arg-max (64 partials per row).  With state != NULL the final stage also does the greedy-decode
 // bookkeeping: token[0] = id, ids[state->n_out++] = id, state->pos0++.

@@ -108,7 +108,7 @@ def test_one_launch_attention_is_bit_identical(ctx, oracle, tmp_path):
     om = oracle.model(cfg, mj["model_arch"], load_tensors(os.path.join(d, "ggml/weights.gguf")), n_threads=8)
     prompt = np.random.default_rng(5).integers(0, cfg.vocab_size, 150)
     want_ids, want_logits, *_ = om.generate(prompt, 32, 10, want_logits=True)
-    for mode in (4, 5):
+    for mode in (0, 1, 16, 17, 20, 21):  # default = the second one-launch form (attn_decode2); 16: two launches; 20: the first one-launch form; +1: eager
         gm = hip.Model(ctx, d, max_batch=32)
         gm.set_mode(mode)
         assert np.array_equal(gm.generate(prompt, 32, 10), want_ids), mode
@@ -124,6 +124,55 @@ def test_one_launch_attention_is_bit_identical(ctx, oracle, tmp_path):
             assert np.array_equal(np.asarray(lg[0]).view(np.uint32), np.asarray(want_logits[s]).view(np.uint32)), (mode, s)
             cur = int(want_ids[s])
         gm.close()
+    om.close()
+
+
+@pytest.mark.parametrize("preset,n_ctx,P", [("small-llama-hs128", 4096, 2090), ("small-llama-hs128", 2048, 1031), ("small-llama", 4096, 2215),
+                                            ("small-llama-hs128", 160, 97)])
+def test_decode_attention_long_cache_matches_oracle(ctx, oracle, tmp_path, preset, n_ctx, P):
+    """The single-token attention (attn_decode2: scores exchanged as tagged granules, soft-max in registers, V.p on the
+    matrix cores) behind a LONG cache — several position rounds per workgroup, hinted and un-hinted K rows, both gather
+    trips, the n_kv % 8 / n_kv % 32 leftovers walking through all their values — bit-exact against the oracle, eager and
+    hipGraph replay, and identical to the two-launch kernels (mode bit 4) also with hidden cache slots (kv_mask), which the
+    CPU executor cannot express."""
+    from oracle import binding as B
+    from powerserve_amd import hip, synth
+    d = str(tmp_path / "m")
+    mj = synth.write_model_dir(d, preset, 12, n_ctx=n_ctx, seed=9)
+    cfg = B.make_config(mj["llm_config"])
+    om = oracle.model(cfg, mj["model_arch"], load_tensors(os.path.join(d, "ggml/weights.gguf")), n_threads=16)
+    prompt = np.random.default_rng(17).integers(0, cfg.vocab_size, P)
+    steps = 40
+    want_ids, want_logits, *_ = om.generate(prompt, 128, steps, want_logits=True)
+    gm = hip.Model(ctx, d, max_batch=128, n_ctx=n_ctx)
+    assert np.array_equal(gm.generate(prompt, 128, steps), want_ids)           # hipGraph replay
+    gm.set_mode(1)
+    assert np.array_equal(gm.generate(prompt, 128, steps), want_ids)           # eager launches
+    gm.set_mode(0)
+    gm.kv_rollback(steps)                                                      # back to the end of the prompt
+    cur = int(prompt[-1])
+    for s in range(steps):                                                     # eager single-token forwards: exact host hint
+        lg, am = gm.forward([cur], [gm.position], lm_head=True)
+        assert np.array_equal(np.asarray(lg[0]).view(np.uint32), np.asarray(want_logits[s]).view(np.uint32)), s
+        cur = int(want_ids[s])
+    # hidden slots: the two attention plans agree bit for bit (and differ from the unmasked logits)
+    hidden = [3, 40, P // 2, P - 2]
+    outs = []
+    for mode in (0, 16):
+        gm.set_mode(mode)
+        gm.kv_rollback(5)
+        for h in hidden:
+            gm.kv_mask(h, False)
+        res = []
+        for s in range(5):
+            lg, am = gm.forward([int(want_ids[steps - 6 + s])], [gm.position], lm_head=True)  # (teacher forcing: step k is fed id k - 1)
+            res.append(np.asarray(lg[0]).copy())
+        for h in hidden:
+            gm.kv_mask(h, True)
+        outs.append(np.stack(res))
+    assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32))
+    assert not np.array_equal(outs[0][0], np.asarray(want_logits[steps - 5]))                     # (unmasked, these would be step steps - 5's logits)
+    gm.close()
     om.close()
 
 

@@ -11,14 +11,17 @@ d = tempfile.mkdtemp(prefix="ps_atl_")
 synth.write_model_dir(d, "llama-8b-dims-4l", 12, n_ctx=4096, seed=1)
 ctx = hip.Ctx(0)
 m = hip.Model(ctx, d, max_batch=128, n_ctx=4096)
-m.set_mode(1)  # eager launches
 rng = np.random.default_rng(0)
 for lo in range(0, P, 128):
     m.forward(rng.integers(0, 4096, 128), np.arange(lo, lo + 128), lm_head=False)
 NW = 1024
 names = {40: ["entry", "loads issued", "q + first K round landed", "end"],
-         41: ["entry", "V + score loads issued", "scores landed, logits in LDS", "barrier", "exp + row sums", "barrier", "1/sum", "V landed, stored to LDS", "barrier", "chains + reduce done", "end"]}
-for key in (40, 41):
+         41: ["entry", "V + score loads issued", "scores landed, logits in LDS", "barrier", "exp + row sums", "barrier", "1/sum", "V landed, stored to LDS", "barrier", "chains + reduce done", "end"],
+         42: ["entry", "q + hinted K requested", "position landed; rest of K, V requested", "scores computed + published", "-", "gather done (all tags seen)",
+              "max barrier passed (V parked)", "exp + partial sums", "sum barrier passed", "p in LDS, barrier passed", "matrix chains + barrier", "end"]}
+MODES = {40: 17, 41: 17, 42: 1}  # two launches (mode bit 4) / the one-launch form; + eager
+for key in (42, 40, 41):
+    m.set_mode(MODES[key])
     ctx.check(ctx.L.ps_hip_debug_timeline(ctx.h, key, None, 0))
     for _ in range(3):
         m.decode_greedy(7, 2)
