@@ -547,210 +547,279 @@ __global__ __launch_bounds__(PV_NT) void attn_decode_kernel(psl_attn_args a) {
 
 // ---------------------------------------------------------------- single token, ONE launch, second generation
 // attn_decode2_kernel: K·q, soft-max and V·p of one cached token in one launch whose critical path is
-//   q / K landed -> scores -> ONE exchange -> max -> exp -> sum -> p -> 17 dependent matrix instructions -> reduce.
+//   q / K landed -> scores -> ONE exchange -> max -> exp -> sum -> 17 dependent matrix instructions -> reduce.
 // What the round-2 timeline of the two launches showed to be waste is gone (profiles/r02_attention_timeline.txt):
-//   * scores are not parked in memory behind a flag: every score travels as an 8-byte {epoch tag, value} granule written
-//     by ONE write-through store (relaxed agent-scope atomic: global_store_dwordx2 sc1) and the readers poll the data
-//     itself with sc1 loads — no drain, no ticket round trip between "stored" and "may be read".  The tag is (forward
-//     generation, position, layer): the generation is bumped by the host for every forward / decode call and travels in the
-//     device-resident step state next to the position, a decode call's steps differ in the position, so a tag never
-//     repeats between two clears of the buffer (the host clears it when the 13-bit generation wraps) and eager
-//     launches, graph replays, rollbacks and layers share one buffer;
 //   * the K rows below the host's lower bound of the cache length (n_kv_lo: a HINT, results never depend on it) are
-//     requested before the device-resident position has arrived (that load is an L2 miss on every launch);
-//   * the scores arrive straight in the soft-max's register layout (lane = head, group of 8 positions — the reference's
-//     vector loop, ggml.c:2831-2866), the n_kv % 8 leftovers take libm's expf on lanes of their own, in parallel;
+//     requested before the device-resident position has arrived (that load is an L2 miss on every launch); the loads in
+//     front of that wait are unconditional so that it is an exact count; q is fetched once per workgroup (through LDS), not
+//     once per half-wave: the start-up was bound by the ISSUE of 50 dword loads per lane.  With 1024 threads every
+//     instruction costs 16 wave issues per CU (the first version spent 1.2 us ISSUING the scores and 2 us on the scale /
+//     mask / address arithmetic around the gather): eight lanes per cached position hold a K row as four 16-byte loads, a
+//     lane runs four of ggml_vec_dot_f32's chains over all their steps and GGML_F32x8_REDUCE is three row shifts on four
+//     values plus three in-lane adds — 15 instead of 56 instructions per eight positions and head, and a wave whose slice
+//     lies behind the cache length does nothing at all;
+//   * the scores are exchanged once per kv head: write-through (sc1) stores, drained, one ticket per workgroup on the kv
+//     head's counter (epoch = ticket / workgroups per head: nothing is ever reset), ONE lane polls that ONE word, then every
+//     lane fetches its scores straight into the soft-max's register layout (lane = head, group of 8 positions — the
+//     reference's vector loop, ggml.c:2831-2866).  The V rows are requested BEHIND the drain (in front of it the drain
+//     would wait for them, too).  (Tried first: scores as self-describing {tag, value} granules polled by every lane —
+//     correct: profiles/r03_micro_stale.txt shows that an agent-scope load never returns a line from before another
+//     workgroup's write-through store — but 256 x 1024 polling lanes starve the very stores they wait for: 40 us per
+//     exchange, and 30 ms time-outs in one run.)
+//   * the n_kv % 8 leftovers take libm's expf on lanes of their own, in parallel; e_j goes to LDS as it is and
+//     p_j = e_j * (float)(1/sum) is formed where it is used (the same single rounding): one barrier less;
 //   * V·p runs on the matrix cores: v_mfma_f32_16x16x4_f32 is a k-ordered fma chain with one rounding per product
 //     (attn_pv_mfma_kernel above).  A workgroup owns 4 channels x r2 <= 4 heads, so one instruction carries FOUR of
 //     ggml_vec_dot_f32's 32 chains: A row = (chain ci, channel), B column = (chain cj, head), k = four successive
 //     32-position blocks, and the 4 x 4 blocks with ci == cj of the 16 x 16 result are the chains' partial sums (the
 //     others are discarded).  Eight waves, one per group of four chains, 17 dependent instructions at n_kv = 2100
 //     instead of 66 LDS round trips per lane.
-// grid: (head_size / 4) x n_kv_heads workgroups of 1024 threads, linear id = x * n_kv_heads + kv head; every workgroup
-// must be resident (the host checks the grid against the CU count; the poll is bounded and raises sync[31]).
-// LDS: p [4][RS] and V [4][RS] (RS = n_ctx rounded up to 128, + 36: rows 4 banks apart), n_ctx <= 4096.
-constexpr int D2_NT = 1024, D2_TRIPS = 2; // 256 lanes per head x 8 positions x D2_TRIPS >= n_ctx
-__device__ __forceinline__ unsigned long long coh_load_u64(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void coh_store_u64(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-template <int NV>
-__global__ __launch_bounds__(D2_NT) void attn_decode2_kernel(psl_attn_args a) {
+// grid: (head_size / 4) x n_kv_heads workgroups of 1024 threads, linear id = x * n_kv_heads + kv head (with 8 kv heads a
+// head's workgroups share an XCD, i.e. an L2); every workgroup must be resident (the host checks the grid against the CU
+// count; the poll is bounded and raises sync[31]).
+// LDS: e [4][RS] and V [4][RS] (RS = n_ctx rounded up to 128, + 36: rows 4 banks apart), n_ctx <= 4096.
+// NT threads: 1024, or 512 (tried for its shorter kernel boundary; the per-lane work doubles and the launch measured 0.4 us slower).  LPH = NT / 4 lanes per head take groups of 8 positions: LPH x 8 x TRIPS >= n_ctx
+constexpr int D2_MAXCTX = 4096;
+template <int NV, int NT>
+__global__ __launch_bounds__(NT) void attn_decode2_kernel(psl_attn_args a) {
+    constexpr int NW = NT / 64, SPP = NW / 4, LPH = NT / 4, WPH = LPH / 64, D2_TRIPS = D2_MAXCTX / (8 * LPH), VCH = D2_MAXCTX / (4 * NT); // SPP: slices per pass
     extern __shared__ __attribute__((aligned(16))) float d2s[];
     constexpr int hs = NV * 32, RMAX = 16 / NV, G = hs / 4; // G workgroups per kv head; slice (32 positions) s belongs to workgroup s % G
     const int kvd = a.n_kv_heads * hs, r2 = a.n_heads / a.n_kv_heads;
     const int kvh = (int)blockIdx.x % a.n_kv_heads, bx = (int)blockIdx.x / a.n_kv_heads;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int RS = ((a.n_ctx + 127) & ~127) + 36, XS = (a.n_ctx + 7) & ~7;
+    const int RS = ((a.n_ctx + 127) & ~127) + 36, XS = (a.n_ctx + 31) & ~31; // (XS: a 128-byte line of the exchange buffer belongs to one workgroup)
     float *const pl = d2s, *const vt = pl + 4 * RS, *const red = vt + 4 * RS, *const pleft = red + 512, *const redf = pleft + 128;
-    float *const tails = redf + 16;
-    unsigned *const epw = (unsigned *)(tails + 32);
-    double *const redd = (double *)(epw + 4);
+    float *const tails = redf + 16, *const qs = tails + 32, *const sst = qs + 4 * hs; // sst [RMAX][4][32]: scores staged for whole-row stores
+    double *const redd = (double *)(sst + RMAX * 128);
+    uint64_t *const etab = (uint64_t *)(redd + 16); // glibc's expf table (a constant-memory lookup behind the V requests costs > 1 us)
     unsigned long long *const dbg = (a.dbg && blockIdx.x < 1024 && tid == 0) ? a.dbg + (size_t)blockIdx.x * 64 : nullptr; // timeline key 42
     auto mark = [&](int k) { if (dbg) dbg[k] = __builtin_amdgcn_s_memtime(); };
     if (dbg) { dbg[0] = __builtin_amdgcn_s_memtime(); dbg[29] = __builtin_amdgcn_s_memrealtime(); }
 
-    // ---- t = 0.  Every vector-memory instruction up to the first wait is UNCONDITIONAL (clamped addresses, selects behind
-    //      the loads), so the compiler's s_waitcnt counts stay exact: the position (first, a vector load on purpose: the scalar
-    //      counter is shared with the kernel arguments and LDS), q, then the K rows the host knows to exist
+    // ---- t = 0.  The position first (a vector load on purpose: the scalar counter is shared with the kernel arguments and
+    //      LDS), then q (once per workgroup, through LDS) and the K rows the host knows to exist — all UNCONDITIONAL (clamped
+    //      addresses), so that the wait for the position is an exact count and does not wait for the K rows behind it
     const ps_step_state *sp = a.state;
     asm volatile("" : "+v"(sp)); // (opaque: keeps it a vector load, issued here; global address space: a flat load would tie up both counters)
-    const __attribute__((address_space(1))) int *spg = (const __attribute__((address_space(1))) int *)(uintptr_t)sp;
-    const int st_pos0 = spg[0], st_gen = spg[3]; // (two dword loads: unused lanes of a wider load get reused as temporaries, which waits for the load)
-    const int c = tid & 31, hw = tid >> 5;
-    const float *qb = a.q + (int64_t)kvh * r2 * hs + c;
-    float qf[4][NV];
-#pragma unroll
-    for (int g = 0; g < 4; g++)
-#pragma unroll
-        for (int m = 0; m < NV; m++) qf[g][m] = qb[(g < r2 ? g : 0) * hs + m * 32];
-    const float *kb = a.k_cache + kvh * hs + c;
-    float kf[RMAX][NV], kl[RMAX][NV];
+    const int st_pos0 = *(const __attribute__((address_space(1))) int *)(uintptr_t)sp; // (a dword: unused lanes of a wider load get reused as temporaries, which waits for the load)
+    const int uw = __builtin_amdgcn_readfirstlane(wave); // (provably uniform: scalar branches)
+    const int p8 = lane >> 3, tq = lane & 7;              // eight lanes per cached position; lane tq owns chains 4 tq .. 4 tq + 3
+    constexpr int PASSES = RMAX / SPP;                     // a pass = NW waves x 8 positions = SPP 32-position slices
+    const int nq4 = r2 * hs / 4; // float4 units of this kv head's q rows
+    const float4 q4 = *(const float4 *)(a.q + (int64_t)kvh * r2 * hs + (tid < nq4 ? tid : 0) * 4);
+    const uint64_t et_w = ps_exp2f_tab[tid & (PS_EXP2F_N - 1)];
+    const float *kb = a.k_cache + kvh * hs + 4 * tq;
+    float4 kf[PASSES][NV]; // K row of this lane's position: elements 32 i + 4 tq .. + 3 = step i of chains 4 tq .. 4 tq + 3
     const int nlo = a.n_kv_lo;
 #pragma unroll
-    for (int rd = 0; rd < RMAX; rd++) {
-        const int sl = bx + rd * G;
+    for (int ps = 0; ps < PASSES; ps++) {
+        const int sl = bx + ((uw >> 2) + SPP * ps) * G;
         const bool early = sl * 32 + 32 <= nlo && sl * 32 + 32 <= a.n_ctx; // (uniform)
-        const float *kr = kb + (int64_t)(early ? sl * 32 + hw : 0) * kvd;
+        const float *kr = kb + (int64_t)(early ? sl * 32 + (uw & 3) * 8 + p8 : 0) * kvd; // (not hinted: row 0 once more, a cache hit)
 #pragma unroll
-        for (int m = 0; m < NV; m++) kf[rd][m] = kr[m * 32];
+        for (int m = 0; m < NV; m++) kf[ps][m] = *(const float4 *)(kr + m * 32);
     }
     mark(1);
     const int pos0 = __builtin_amdgcn_readfirstlane(st_pos0); // (uniform: everything derived from it is scalar control flow)
     const int n_kv = pos0 + 1, n8 = n_kv & ~7, np = n_kv & ~31, nblk = np >> 5, n_it = (nblk + 3) >> 2, np_pad = n_it * 128;
-    const int n_kv4 = (n_kv + 3) & ~3;
-    // a tag never repeats while it could be mistaken: (forward generation, position, layer); the host clears the buffer
-    // when the generation wraps (model.hip)
-    const unsigned gen = (unsigned)__builtin_amdgcn_readfirstlane(st_gen);
-    const unsigned epoch = (gen << 19) | ((unsigned)pos0 << 7) | (unsigned)a.layer;
-    // ---- the rest of this workgroup's K rows, then its four V rows (registers; parked in LDS while the scores travel)
+    const int ntail = n_kv - n8, nleft = n_kv - np;
+    // ---- the rest of this workgroup's K rows (only the waves that have any: uniform branches)
 #pragma unroll
-    for (int rd = 0; rd < RMAX; rd++) {
-        const int sl = bx + rd * G, j = sl * 32 + hw;
+    for (int ps = 0; ps < PASSES; ps++) {
+        const int sl = bx + ((uw >> 2) + SPP * ps) * G, j = sl * 32 + (uw & 3) * 8 + p8;
         const bool early = sl * 32 + 32 <= nlo && sl * 32 + 32 <= a.n_ctx;
-        const float *kr = kb + (int64_t)((!early && j < n_kv) ? j : 0) * kvd;
+        if (!early && sl * 32 + (uw & 3) * 8 < n_kv) {
+            const float *kr = kb + (int64_t)(j < n_kv ? j : 0) * kvd;
 #pragma unroll
-        for (int m = 0; m < NV; m++) kl[rd][m] = kr[m * 32];
-    }
-    const float *vbase = a.v_cache + ((int64_t)kvh * hs + bx * 4) * a.n_ctx;
-    const int RSd4 = (RS - 36) >> 2; // float4 units per padded V row
-    float4 vld[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int f = tid + D2_NT * k, row = f / RSd4, col = (f - row * RSd4) * 4;
-        const bool in = row < 4 && col < n_kv4; // n_kv4 <= n_ctx: in bounds
-        vld[k] = *(const float4 *)(vbase + (in ? (int64_t)row * a.n_ctx + col : 0));
-    }
-    mark(2);
-
-    // ---- scores of this workgroup's positions: a half-wave per position, ggml_vec_dot_f32's 32 chains + GGML_F32x8_REDUCE;
-    //      published as granules by the half-wave's first lane
-    unsigned long long *const xb = a.xchg + (size_t)kvh * 4 * XS;
-#pragma unroll
-    for (int rd = 0; rd < RMAX; rd++) {
-        const int sl = bx + rd * G, j = sl * 32 + hw;
-        const bool early = sl * 32 + 32 <= nlo && sl * 32 + 32 <= a.n_ctx;
-#pragma unroll
-        for (int g = 0; g < 4; g++) {
-            float s = 0.f;
-#pragma unroll
-            for (int m = 0; m < NV; m++) s = __fmaf_rn(early ? kf[rd][m] : kl[rd][m], qf[g][m], s); // sum = x*y + sum, x = K row (src0)
-            s = reduce_f32x8x4(s);
-            if (c == 0 && j < n_kv && g < r2) coh_store_u64(xb + (size_t)g * XS + j, ((unsigned long long)epoch << 32) | __float_as_uint(s));
+            for (int m = 0; m < NV; m++) kf[ps][m] = *(const float4 *)(kr + m * 32);
         }
+    }
+    // ---- this workgroup's four V rows, columns below the cache length (registers; parked in LDS with the drain below).  Here,
+    //      right behind K, so that the two streams are over before the exchange: the CU's vector-memory queue is first in, first
+    //      out across its waves — requested later, the V rows sit in front of the polls, of the gathered scores or of whatever
+    //      runs next (measured: the 8.6 MB cost 1.4 us wherever they were put).  Load k = row k, columns 4 tid .. 4 tid + 3
+    const float *vbase = a.v_cache + ((int64_t)kvh * hs + bx * 4) * a.n_ctx;
+    float4 vld[VCH][4];
+#pragma unroll
+    for (int cc = 0; cc < VCH; cc++) {
+        const int col = 4 * (tid + NT * cc);
+        const bool v_in = col < ((n_kv + 3) & ~3); // (n_kv rounded up to 4 <= n_ctx: in bounds)
+#pragma unroll
+        for (int k = 0; k < 4; k++) vld[cc][k] = *(const float4 *)(vbase + (v_in ? (int64_t)k * a.n_ctx + col : 0));
+    }
+    if (tid < nq4) *(float4 *)(qs + tid * 4) = q4;
+    if (tid < PS_EXP2F_N) etab[tid] = et_w;
+    mark(2);
+    __syncthreads();
+
+    // ---- scores of this workgroup's positions, stored write-through.  ggml_vec_dot_f32 (ggml.c:2092-2133): chain c = 8 a + u runs
+    //      over the elements 32 i + c; here lane tq holds chains 4 tq + e (e = 0..3) with all their steps i.  GGML_F32x8_REDUCE
+    //      (ggml.c:1354-1371): acc0 += acc2, acc1 += acc3 = chain c + chain c + 16 = lane tq + lane tq + 4; acc0 += acc1 = lane + 2;
+    //      low + high 128 bits = lane + 1; then the two hadds inside lane 0: (x0 + x1) + (x2 + x3)
+    float *const xb = a.xchg + (size_t)kvh * 4 * XS;
+#pragma unroll
+    for (int ps = 0; ps < PASSES; ps++) {
+        const int sl = bx + ((uw >> 2) + SPP * ps) * G;
+        if (sl * 32 + (uw & 3) * 8 < n_kv) { // (uniform: a wave behind the cache length does nothing)
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                if (g < r2) { // (uniform)
+                    float x[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int m = 0; m < NV; m++) {
+                        const float4 qv = *(const float4 *)(qs + g * hs + m * 32 + 4 * tq);
+                        x[0] = __fmaf_rn(kf[ps][m].x, qv.x, x[0]); // sum = x*y + sum, x = K row (src0)
+                        x[1] = __fmaf_rn(kf[ps][m].y, qv.y, x[1]);
+                        x[2] = __fmaf_rn(kf[ps][m].z, qv.z, x[2]);
+                        x[3] = __fmaf_rn(kf[ps][m].w, qv.w, x[3]);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; e++) x[e] = __fadd_rn(x[e], dpp_f<0x104>(x[e])); // tq < 4: + lane tq + 4
+#pragma unroll
+                    for (int e = 0; e < 4; e++) x[e] = __fadd_rn(x[e], dpp_f<0x102>(x[e])); // tq < 2: + lane tq + 2
+#pragma unroll
+                    for (int e = 0; e < 4; e++) x[e] = __fadd_rn(x[e], dpp_f<0x101>(x[e])); // tq = 0: + lane 1
+                    const float s = __fadd_rn(__fadd_rn(x[0], x[1]), __fadd_rn(x[2], x[3]));
+                    if (tq == 0) sst[(((uw >> 2) + SPP * ps) * 4 + g) * 32 + (uw & 3) * 8 + p8] = s;
+                }
+            }
+        }
+    }
+    // one 128-byte row per (slice, head), a whole line per store instruction: 8 positions x 4 bytes at a time made every line a
+    // read-modify-write at the memory side (drain 0.5 -> 0.3 us, the counter complete 0.9 us earlier)
+    __syncthreads();
+#pragma unroll
+    for (int rr = 0; rr < RMAX * 4 / NW; rr++) {
+        const int row = uw + NW * rr, rd = row >> 2, gg = row & 3, sl = bx + rd * G;
+        if (sl * 32 < n_kv && gg < r2 && lane < 32) coh_store_f(xb + (size_t)gg * XS + sl * 32 + lane, sst[row * 32 + lane]);
     }
     mark(3);
+    // ---- exchange: every wave drains its stores (and its V rows), one ticket per workgroup, ONE lane polls the kv head's counter
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // V rows into LDS (they landed with the drain); zeros past the cache length: the matrix instructions run over whole groups of
+    // 4 blocks of positions
+#pragma unroll
+    for (int cc = 0; cc < VCH; cc++) {
+        const int col = 4 * (tid + NT * cc);
+        if (col < RS - 36) {
+            const bool v_in = col < ((n_kv + 3) & ~3);
+#pragma unroll
+            for (int k = 0; k < 4; k++) *(float4 *)(vt + k * RS + col) = v_in ? vld[cc][k] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    __syncthreads();
     mark(4);
+    if (wave == 0) { // (uniform) the polling wave asks for its V rows AFTER the poll: loads return in order
+        if (tid == 0) {
+            unsigned *ctr = a.tick + kvh * 64; // (a 256-byte stretch per kv head)
+            const unsigned ticket = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned target = (ticket / (unsigned)G + 1u) * (unsigned)G; // exactly G arrivals per head and launch
+            int spins = 0;
+            while ((int)(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1 << 16)) { __hip_atomic_store(a.sync + 31, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; } // never hang the GPU: the host turns the flag into an error
+            }
+        }
+        asm volatile("" ::: "memory"); // (nothing below moves above the poll)
+    }
+    __syncthreads();
+    mark(5);
 
-    // ---- gather: lane (head g, t) takes the groups of 8 positions t and t + 256; polls until every tag is this launch's
-    const int g = tid >> 8, t = tid & 255;
+    // ---- gather: lane (head g, t) takes the groups of 8 positions t, t + LPH, ...  Plain loads: this launch has not touched
+    //      these lines before the counter completed (L1 and L2 hold nothing older than the kernel boundary), every byte was
+    //      written through and acknowledged before its workgroup's ticket, and the 32 workgroups of a kv head share an L2
+    const int g = tid / LPH, t = tid % LPH;
     const bool hl = g < r2;
-    const unsigned long long *xg = xb + (size_t)(hl ? g : 0) * XS;
+    const float *xg = xb + (size_t)(hl ? g : 0) * XS;
     float sv[D2_TRIPS][8];
-    bool pend[D2_TRIPS];
 #pragma unroll
     for (int k = 0; k < D2_TRIPS; k++) {
-        pend[k] = hl && (t + 256 * k) * 8 < n_kv;
-#pragma unroll
-        for (int i = 0; i < 8; i++) sv[k][i] = 0.f;
+        const int j0 = (t + LPH * k) * 8;
+        const float *src = xg + ((hl && j0 < n_kv) ? j0 : 0); // (unconditional, clamped)
+        const float4 lo = *(const float4 *)src, hi = *(const float4 *)(src + 4);
+        sv[k][0] = lo.x; sv[k][1] = lo.y; sv[k][2] = lo.z; sv[k][3] = lo.w; sv[k][4] = hi.x; sv[k][5] = hi.y; sv[k][6] = hi.z; sv[k][7] = hi.w;
     }
-    for (int spins = 0;; spins++) {
-        bool ok = true;
+    // ---- scale + mask (softmax_ext, ggml.c:14889-14914), row maxima.  (Without hidden slots the mask term is + 0.0f, which
+    //      changes no value the soft-max can tell apart: skipped.)
+    float lmax = -INFINITY;
+    if (a.kv_vis) { // (uniform) hidden cache slots (KVCacheInterface::mask): -inf before the maximum
+#pragma unroll
+        for (int k = 0; k < D2_TRIPS; k++)
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const int j = (t + LPH * k) * 8 + i;
+                if (hl && j < n_kv) {
+                    const bool vis = j < pos0 ? a.kv_vis[j] != 0 : true;
+                    float v = __fmul_rn(sv[k][i], a.scale);
+                    v = __fadd_rn(v, vis ? 0.f : -INFINITY);
+                    sv[k][i] = v;
+                    lmax = fmaxf(lmax, v);
+                }
+            }
+    } else {
 #pragma unroll
         for (int k = 0; k < D2_TRIPS; k++) {
-            if (pend[k]) {
-                const int j0 = (t + 256 * k) * 8;
-                unsigned long long gr[8];
-#pragma unroll
-                for (int i = 0; i < 8; i++) gr[i] = coh_load_u64(xg + j0 + i);
-                bool all = true;
+            const int j0 = (t + LPH * k) * 8;
+            if (hl && j0 < n_kv) {
 #pragma unroll
                 for (int i = 0; i < 8; i++) {
-                    all = all && (j0 + i >= n_kv || (unsigned)(gr[i] >> 32) == epoch);
-                    sv[k][i] = __uint_as_float((unsigned)gr[i]);
+                    sv[k][i] = __fmul_rn(sv[k][i], a.scale);
+                    if (j0 + 8 <= n_kv || j0 + i < n_kv) lmax = fmaxf(lmax, sv[k][i]);
                 }
-                if (all) pend[k] = false; else ok = false;
             }
-        }
-        if (!__any(!ok)) break;
-        __builtin_amdgcn_s_sleep(2);
-        if (spins > (1 << 15)) { // never hang the GPU: the host turns the flag into an error
-            if (lane == 0) __hip_atomic_store(a.sync + 31, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            break;
         }
     }
-    mark(5);
-    // ---- scale + mask (softmax_ext, ggml.c:14889-14914), row maxima
-    float lmax = -INFINITY;
-#pragma unroll
-    for (int k = 0; k < D2_TRIPS; k++)
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const int j = (t + 256 * k) * 8 + i;
-            if (hl && j < n_kv) {
-                const bool vis = (j < pos0 && a.kv_vis) ? a.kv_vis[j] != 0 : true;
-                float v = __fmul_rn(sv[k][i], a.scale);
-                v = __fadd_rn(v, vis ? 0.f : -INFINITY);
-                sv[k][i] = v;
-                lmax = fmaxf(lmax, v);
-            }
-        }
     {
         const float wm = wave_max_dpp(lmax);
-        if (lane == 0) redf[wave] = wm; // waves 4g .. 4g+3 belong to head g
+        if (lane == 0) redf[wave] = wm; // waves WPH g .. WPH g + WPH - 1 belong to head g
     }
-    // ---- V rows into LDS (zeros past the cache length: the matrix instructions run over whole groups of 4 blocks).  Here, not
-    //      right behind the loads: the granule stores above are conditional, the compiler cannot count them, and a wait for
-    //      the V registers placed before the gather would also wait for every store's write-through acknowledgement
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int f = tid + D2_NT * k, row = f / RSd4, col = (f - row * RSd4) * 4;
-        if (row < 4) *(float4 *)(vt + row * RS + col) = col < n_kv4 ? vld[k] : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    const int ntail = n_kv - n8;
 #pragma unroll
     for (int k = 0; k < D2_TRIPS; k++)
-        if (hl && (t + 256 * k) * 8 == n8) {
+        if (hl && (t + LPH * k) * 8 == n8) { // the lane that holds the n_kv % 8 leftovers hands them to lanes of their own
 #pragma unroll
             for (int i = 0; i < 8; i++)
                 if (i < ntail) tails[g * 8 + i] = sv[k][i];
         }
     __syncthreads();
     mark(6);
-    const float mx = fmaxf(fmaxf(redf[(wave & ~3)], redf[(wave & ~3) + 1]), fmaxf(redf[(wave & ~3) + 2], redf[(wave & ~3) + 3]));
+    float mx = redf[g * WPH];
+#pragma unroll
+    for (int w = 1; w < WPH; w++) mx = fmaxf(mx, redf[g * WPH + w]);
     // ---- e_j = exp(x_j - max): ggml_v_expf on whole groups of 8 with the reference's in-group sum tree, libm's expf on the
-    //      n_kv % 8 leftovers (one lane each), row sums in double (ggml.c:2831-2866)
+    //      n_kv % 8 leftovers (the last lanes of the head's last wave, one each), row sums in double (ggml.c:2831-2866).
+    //      e goes to LDS as it is; p_j = e_j * (float)(1/sum) (ggml_vec_scale_f32) is formed where it is used, the same
+    //      single rounding.  Whole blocks of 32 positions feed the chains (pl), positions past the last whole block are the
+    //      dot product's leftovers (pleft), and the padding of the last group of 4 blocks is zero
     double rs = 0.0;
 #pragma unroll
     for (int k = 0; k < D2_TRIPS; k++) {
-        const int j0 = (t + 256 * k) * 8;
-        if (hl && j0 + 8 <= n8) {
+        const int j0 = (t + LPH * k) * 8;
+        if (!hl) continue;
+        if (j0 + 8 <= n8) {
 #pragma unroll
             for (int i = 0; i < 8; i++) sv[k][i] = ps_v_expf(__fsub_rn(sv[k][i], mx));
             const float a0 = __fadd_rn(sv[k][4], sv[k][0]), a1 = __fadd_rn(sv[k][5], sv[k][1]), a2 = __fadd_rn(sv[k][6], sv[k][2]), a3 = __fadd_rn(sv[k][7], sv[k][3]);
             rs += (double)__fadd_rn(__fadd_rn(a0, a2), __fadd_rn(a1, a3));
+            if (j0 + 8 <= np) {
+                *(float4 *)(pl + g * RS + j0)     = make_float4(sv[k][0], sv[k][1], sv[k][2], sv[k][3]);
+                *(float4 *)(pl + g * RS + j0 + 4) = make_float4(sv[k][4], sv[k][5], sv[k][6], sv[k][7]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; i++) pleft[g * 32 + (j0 - np) + i] = sv[k][i];
+            }
+        }
+        if (j0 >= np && j0 < np_pad) {
+            *(float4 *)(pl + g * RS + j0)     = make_float4(0.f, 0.f, 0.f, 0.f);
+            *(float4 *)(pl + g * RS + j0 + 4) = make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
-    float et = 0.f;
-    if (hl && t < ntail) { et = ps_expf_glibc(__fsub_rn(tails[g * 8 + t], mx)); rs += (double)et; }
+    if (hl && LPH - 1 - t < ntail) {
+        const int idx = LPH - 1 - t;
+        const float et = ps_expf_glibc(__fsub_rn(tails[g * 8 + idx], mx), etab);
+        rs += (double)et;
+        pleft[g * 32 + (n8 - np) + idx] = et;
+    }
     {
         const double sw = wave_sum_d_dpp(rs);
         if (lane == 0) redd[wave] = sw;
@@ -758,42 +827,23 @@ __global__ __launch_bounds__(D2_NT) void attn_decode2_kernel(psl_attn_args a) {
     mark(7);
     __syncthreads();
     mark(8);
-    const float inv = (float)(1.0 / (((redd[(wave & ~3)] + redd[(wave & ~3) + 1]) + redd[(wave & ~3) + 2]) + redd[(wave & ~3) + 3]));
-    // ---- p_j = e_j * (float)(1/sum) (ggml_vec_scale_f32): whole blocks of 32 feed the chains (pl), positions past the last
-    //      whole block are the dot product's leftovers (pleft), and the padding of the last group of 4 blocks is zero
-#pragma unroll
-    for (int k = 0; k < D2_TRIPS; k++) {
-        const int j0 = (t + 256 * k) * 8;
-        if (!hl) continue;
-        if (j0 + 8 <= np) {
-            *(float4 *)(pl + g * RS + j0)     = make_float4(__fmul_rn(sv[k][0], inv), __fmul_rn(sv[k][1], inv), __fmul_rn(sv[k][2], inv), __fmul_rn(sv[k][3], inv));
-            *(float4 *)(pl + g * RS + j0 + 4) = make_float4(__fmul_rn(sv[k][4], inv), __fmul_rn(sv[k][5], inv), __fmul_rn(sv[k][6], inv), __fmul_rn(sv[k][7], inv));
-        } else {
-            if (j0 < np_pad) {
-                *(float4 *)(pl + g * RS + j0)     = make_float4(0.f, 0.f, 0.f, 0.f);
-                *(float4 *)(pl + g * RS + j0 + 4) = make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-            if (j0 + 8 <= n8) {
-#pragma unroll
-                for (int i = 0; i < 8; i++) pleft[g * 32 + (j0 - np) + i] = __fmul_rn(sv[k][i], inv);
-            }
-        }
-    }
-    if (hl && t < ntail) pleft[g * 32 + (n8 - np) + t] = __fmul_rn(et, inv);
-    __syncthreads();
-    mark(9);
 
     // ---- V·p: wave w < 8 owns chains 4w .. 4w+3.  A: row rl = 4 ci + channel, k = block; B: k = block, column 4 cj + head
-    if (wave < 8) {
+    if (wave < 8) { // (NT = 512: every wave)
         const int rl = lane & 15, kk = lane >> 4, ci = rl >> 2, rh = rl & 3;
-        const float *va = vt + rh * RS + 4 * wave + ci + 32 * kk;
-        const float *pb = pl + (rh < r2 ? rh : 0) * RS + 4 * wave + ci + 32 * kk; // (heads past r2: any row, masked below)
         const bool bl = rh < r2;
+        const int rb = bl ? rh : 0; // (heads past r2: head 0's row, masked below)
+        double tot = redd[WPH * rb];
+#pragma unroll
+        for (int w = 1; w < WPH; w++) tot += redd[WPH * rb + w];
+        const float inv = (float)(1.0 / tot);
+        const float *va = vt + rh * RS + 4 * wave + ci + 32 * kk;
+        const float *pb = pl + rb * RS + 4 * wave + ci + 32 * kk;
         ps_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         // operands of four steps at a time, one group ahead of the matrix instructions (a dependent chain: 40 cycles each).
         // Steps past the last one (the group is rounded up) read the last step's V again against p = 0: fma(v, 0, acc) = acc
         float a0[4], b0[4], a1[4], b1[4];
-        auto fetch = [&](float (&av)[4], float (&bv)[4], int s0) { // (reads only: the mask is applied where the operand is used)
+        auto fetch = [&](float (&av)[4], float (&bv)[4], int s0) { // (reads only: scale and mask are applied where the operand is used)
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 const int sc = s0 + i < n_it ? s0 + i : n_it - 1;
@@ -804,7 +854,8 @@ __global__ __launch_bounds__(D2_NT) void attn_decode2_kernel(psl_attn_args a) {
         auto chain = [&](const float (&av)[4], const float (&bv)[4], int s0) {
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                const float b = __uint_as_float(__float_as_uint(bv[i]) & ((bl && s0 + i < n_it) ? 0xffffffffu : 0u)); // (a mask, not a branch)
+                const float p = __fmul_rn(bv[i], inv); // p_j = e_j * (float)(1/sum)
+                const float b = __uint_as_float(__float_as_uint(p) & ((bl && s0 + i < n_it) ? 0xffffffffu : 0u)); // (a mask, not a branch)
                 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], b, acc, 0, 0, 0); // sum = x*y + sum, x = V row (src0)
             }
         };
@@ -827,10 +878,24 @@ __global__ __launch_bounds__(D2_NT) void attn_decode2_kernel(psl_attn_args a) {
             for (int r = 0; r < 4; r++) red[((4 * wave + (lane >> 4)) * 4 + r) * 4 + (lane & 3)] = acc[r];
         }
     }
+    // the leftovers' operands meanwhile (the last 16 lanes of wave 15, which has no chains): v[jj], e[jj] * inv
+    float lv[32], lp[32];
+    if (tid >= NT - 16) {
+        const int ch = (tid >> 2) & 3, h = tid & 3, hb = h < r2 ? h : 0;
+        double tot = redd[WPH * hb];
+#pragma unroll
+        for (int w = 1; w < WPH; w++) tot += redd[WPH * hb + w];
+        const float inv = (float)(1.0 / tot);
+#pragma unroll
+        for (int jj = 0; jj < 32; jj++) { // (np + 31 < RS: in bounds; entries past the cache length are never added)
+            lv[jj] = vt[ch * RS + np + jj];
+            lp[jj] = __fmul_rn(pleft[hb * 32 + jj], inv);
+        }
+    }
     __syncthreads();
-    mark(10);
-    if (tid < 16) {
-        const int ch = tid >> 2, h = tid & 3;
+    mark(9);
+    if (tid >= NT - 16) {
+        const int ch = (tid >> 2) & 3, h = tid & 3;
         float xc[32];
 #pragma unroll
         for (int cc = 0; cc < 32; cc++) xc[cc] = red[(cc * 4 + ch) * 4 + h];
@@ -840,10 +905,12 @@ __global__ __launch_bounds__(D2_NT) void attn_decode2_kernel(psl_attn_args a) {
             t3[cc] = __fadd_rn(__fadd_rn(__fadd_rn(xc[cc], xc[cc + 16]), __fadd_rn(xc[cc + 8], xc[cc + 24])),
                                __fadd_rn(__fadd_rn(xc[cc + 4], xc[cc + 20]), __fadd_rn(xc[cc + 12], xc[cc + 28])));
         float res = __fadd_rn(__fadd_rn(t3[0], t3[1]), __fadd_rn(t3[2], t3[3]));
-        for (int jj = np; jj < n_kv; jj++) res = __fadd_rn(res, __fmul_rn(vt[ch * RS + jj], pleft[h * 32 + (jj - np)])); // leftovers, in order
+#pragma unroll
+        for (int jj = 0; jj < 32; jj++)
+            if (jj < nleft) res = __fadd_rn(res, __fmul_rn(lv[jj], lp[jj])); // leftovers, in order (uniform bound)
         if (h < r2) a.att[((int64_t)kvh * r2 + h) * hs + bx * 4 + ch] = res;
     }
-    if (dbg) { dbg[11] = __builtin_amdgcn_s_memtime(); dbg[30] = __builtin_amdgcn_s_memrealtime(); }
+    if (dbg) { dbg[10] = __builtin_amdgcn_s_memtime(); dbg[30] = __builtin_amdgcn_s_memrealtime(); }
 }
 
 // Batches (prefill chunks, tree verify): one workgroup per (kv head, CI batch columns).  The softmax of a row is computed
@@ -1443,21 +1510,22 @@ bool psl_attn_decode(hipStream_t st, int n_cu, const psl_attn_args &a) {
 }
 
 // single token, one launch, second generation (attn_decode2_kernel); false: not covered
-size_t psl_attn_decode2_xchg_bytes(int n_kv_heads, int n_ctx) { return (size_t)n_kv_heads * 4 * (((size_t)n_ctx + 7) & ~(size_t)7) * 8; }
+size_t psl_attn_decode2_xchg_bytes(int n_kv_heads, int n_ctx) { return (size_t)n_kv_heads * 4 * (((size_t)n_ctx + 31) & ~(size_t)31) * 4; }
 bool psl_attn_decode2(hipStream_t st, int n_cu, const psl_attn_args &a) {
     const int r2 = a.n_heads / a.n_kv_heads, gx = a.head_size / 4;
-    if (!a.xchg || !a.sync || a.tree || a.layer < 0 || a.layer > 127 || r2 > 4 || a.n_ctx > 256 * 8 * D2_TRIPS || (a.head_size != 128 && a.head_size != 64)) return false;
+    if (!a.xchg || !a.tick || !a.sync || a.tree || r2 > 4 || a.n_kv_heads > 32 || a.n_ctx > D2_MAXCTX || (a.head_size != 128 && a.head_size != 64)) return false;
     if (gx * a.n_kv_heads > n_cu) return false; // every workgroup resident (one per CU at n_ctx = 4096)
     const int RS = ((a.n_ctx + 127) & ~127) + 36;
-    const size_t lds = ((size_t)8 * RS + 512 + 128 + 16 + 32 + 4 + 32) * 4;
+    const size_t lds = ((size_t)8 * RS + 512 + 128 + 16 + 32 + 4 * a.head_size + (16 * 32 / (a.head_size / 32)) * 4 + 32 + 64) * 4;
     static unsigned long long attr = 0; // devices that have the attribute
     if (ps_first_on_device(&attr)) {
-        (void)hipFuncSetAttribute((const void *)attn_decode2_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
-        (void)hipFuncSetAttribute((const void *)attn_decode2_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+        (void)hipFuncSetAttribute((const void *)attn_decode2_kernel<4, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+        (void)hipFuncSetAttribute((const void *)attn_decode2_kernel<2, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
     }
     const dim3 g((unsigned)(gx * a.n_kv_heads));
-    if (a.head_size == 128) hipLaunchKernelGGL(attn_decode2_kernel<4>, g, dim3(D2_NT), lds, st, a);
-    else hipLaunchKernelGGL(attn_decode2_kernel<2>, g, dim3(D2_NT), lds, st, a);
+    // (512-thread workgroups — template parameter NT — measured slower: 14.05 vs 13.66 us, the soft-max numerators are issue-bound)
+    if (a.head_size == 128) hipLaunchKernelGGL((attn_decode2_kernel<4, 1024>), g, dim3(1024), lds, st, a);
+    else hipLaunchKernelGGL((attn_decode2_kernel<2, 1024>), g, dim3(1024), lds, st, a);
     return true;
 }
 

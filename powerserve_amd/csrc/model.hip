@@ -17,8 +17,8 @@
 
 
 namespace {
-__global__ void set_state_kernel(ps_step_state *s, int pos0, int bs, int n_out, int gen) {
-    s->pos0 = pos0; s->bs = bs; s->n_out = n_out; s->gen = gen;
+__global__ void set_state_kernel(ps_step_state *s, int pos0, int bs, int n_out) {
+    s->pos0 = pos0; s->bs = bs; s->n_out = n_out;
 }
 __global__ void null_kernel(int *p) { if (p && threadIdx.x == 12345) *p = 0; }
 __global__ void kv_move_kernel(float *k, float *v, _Float16 *k16, _Float16 *v16, int kvd, int n_ctx, int dst, int src) {
@@ -43,8 +43,8 @@ struct ps_hip_model {
     float *x = nullptr, *q = nullptr, *k = nullptr, *v = nullptr, *att = nullptr, *hb = nullptr, *g1 = nullptr, *u1 = nullptr;
     unsigned *bars = nullptr; // device-wide barrier words of the chained launches, [n_layers][12*32]
     unsigned *attn_sync = nullptr; // [2048] words: [31] rendezvous-timeout flag of the one-launch attentions, [64 + 64 * kv head] tickets of the first one
-    unsigned long long *attn_xchg = nullptr; // attn_decode2: score granules (k_attn.hip)
-    int gen = 0;                             // forward generation (ps_step_state::gen): 1 .. 8191, the granule buffer is cleared when it wraps
+    float *attn_xchg = nullptr;    // attn_decode2: scores in flight between workgroups (k_attn.hip)
+    unsigned *attn_tick = nullptr; // attn_decode2: [64 * kv head] arrival counters
     size_t graph_hint = 0;                   // KV position the captured step was given as its prefetch hint (n_kv_lo)
     int n_kv_host = 0;             // pos0 + bs of the forward being enqueued eagerly (0 while a graph is captured / replayed)
     float *scores = nullptr, *logits = nullptr, *rope_table = nullptr;
@@ -74,17 +74,6 @@ static int dmalloc(ps_hip_model *m, void **p, size_t bytes) {
     PS_CHECK(c, hipMalloc(p, bytes ? bytes : 16));
     m->owned.push_back(*p);
     return 0;
-}
-
-// Every forward / decode call gets a generation of its own (ps_step_state::gen): with the position and the layer it tags the
-// score granules of attn_decode2 (k_attn.hip).  13 bits; when it wraps the granule buffer is cleared (stream-ordered), so a
-// tag of an earlier period can never be mistaken for a fresh one.
-static int next_gen(ps_hip_model *m) {
-    if (++m->gen > 8191) {
-        m->gen = 1;
-        (void)hipMemsetAsync(m->attn_xchg, 0, psl_attn_decode2_xchg_bytes((int)m->cfg.n_kv_heads, (int)m->cfg.seq_len), m->ctx->stream);
-    }
-    return m->gen;
 }
 
 static int mm(ps_hip_model *m, psk_gemv_args &g, ps_act act, int64_t K, int64_t bs);
@@ -194,7 +183,7 @@ static int enqueue_forward(ps_hip_model *m, int bs, bool lm_head, bool use_tree,
     aa.sync = m->attn_sync;
     const bool one_launch_v1 = (m->mode & 4) != 0;  // mode bit 2: the first one-launch decode attention (round 2; measured equal to the two launches)
     const bool one_launch_v2 = (m->mode & 16) == 0; // default; mode bit 4 switches attn_decode2 off (two launches)
-    aa.xchg = m->attn_xchg;
+    aa.xchg = m->attn_xchg; aa.tick = m->attn_tick;
     aa.n_kv_lo = m->n_kv_host > 0 ? m->n_kv_host : (int)m->position; // (a hint: rows below it are requested before the device-side position has arrived)
 
     for (uint32_t L = 0; L < f.n_layers; L++) {
@@ -206,7 +195,7 @@ static int enqueue_forward(ps_hip_model *m, int bs, bool lm_head, bool use_tree,
         g.ldo[0] = dim; g.ldo[1] = kvd; g.ldo[2] = kvd;
         if (m->qwen2) { g.bias[0] = m->bq[L]; g.bias[1] = m->bk[L]; g.bias[2] = m->bv[L]; }
         g.pro = 1; g.pro_x = m->x; g.pro_norm_w = m->attn_norm[L]; g.pro_eps = f.norm_eps; // RMSNorm + quantize in the prologue
-        aa.k_cache = m->k_cache[L]; aa.v_cache = m->v_cache[L]; aa.layer = (int)L;
+        aa.k_cache = m->k_cache[L]; aa.v_cache = m->v_cache[L];
         const bool kv16 = (m->mode & 8) && !m->k16.empty();
         aa.k16 = kv16 ? m->k16[L] : nullptr; aa.v16 = kv16 ? m->v16[L] : nullptr; aa.part = m->attn_part;
         // single token, adjacent-pair RoPE: rotation and the KV append ride in the mat-vec epilogue
@@ -341,7 +330,7 @@ int ps_hip_model_create(ps_hip_ctx *c, const ps_model_desc *d, ps_hip_model **ou
         dmalloc(m, (void **)&m->att, mb * dim * 4) || dmalloc(m, (void **)&m->hb, mb * hid * 4) ||
         dmalloc(m, (void **)&m->g1, mb * hid * 4) || dmalloc(m, (void **)&m->u1, mb * hid * 4) ||
         dmalloc(m, (void **)&m->bars, (size_t)f.n_layers * 12 * 32 * 4) || dmalloc(m, (void **)&m->attn_sync, 2048 * 4) ||
-        dmalloc(m, (void **)&m->attn_xchg, psl_attn_decode2_xchg_bytes((int)f.n_kv_heads, (int)nctx)) ||
+        dmalloc(m, (void **)&m->attn_xchg, psl_attn_decode2_xchg_bytes((int)f.n_kv_heads, (int)nctx)) || dmalloc(m, (void **)&m->attn_tick, (size_t)f.n_kv_heads * 64 * 4) ||
         dmalloc(m, (void **)&m->scores, mb * f.n_heads * nctx * 4) || dmalloc(m, (void **)&m->logits, mb * f.vocab_size * 4) ||
         dmalloc(m, (void **)&m->rope_table, nctx * f.head_size * 4) ||
         dmalloc(m, &m->act_mem, ps_act_bytes(dim > hid ? dim : hid, mb)) ||
@@ -351,7 +340,7 @@ int ps_hip_model_create(ps_hip_ctx *c, const ps_model_desc *d, ps_hip_model **ou
         return fail();
     (void)hipMemsetAsync(m->bars, 0, (size_t)f.n_layers * 12 * 32 * 4, c->stream);
     (void)hipMemsetAsync(m->attn_sync, 0, 2048 * 4, c->stream);
-    (void)hipMemsetAsync(m->attn_xchg, 0, psl_attn_decode2_xchg_bytes((int)f.n_kv_heads, (int)nctx), c->stream); // tag 0 is never an epoch
+    (void)hipMemsetAsync(m->attn_tick, 0, (size_t)f.n_kv_heads * 64 * 4, c->stream);
     (void)hipMemsetAsync(m->kv_vis_dev, 1, nctx, c->stream);
     m->kv_vis_host.assign(nctx, 1);
     m->k_cache.assign(L, nullptr); m->v_cache.assign(L, nullptr);
@@ -456,7 +445,7 @@ static int model_forward_impl(ps_hip_model *m, const int32_t *tokens, int n, con
     PS_CHECK(c, hipSetDevice(c->device));
     PS_CHECK(c, hipMemcpyAsync(m->tokens_dev, tokens, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
     if (tree) PS_CHECK(c, hipMemcpyAsync(m->tree_dev, tree, (size_t)n * n, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(1), 0, c->stream, m->state, pos[0], n, 0, next_gen(m));
+    hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(1), 0, c->stream, m->state, pos[0], n, 0);
     PS_CHECK(c, hipStreamSynchronize(c->stream)); // tokens/tree may be host temporaries
     m->n_kv_host = pos[0] + n;
     const int rc_fw = enqueue_forward(m, n, lm_head != 0, tree != nullptr);
@@ -484,7 +473,7 @@ int ps_hip_model_forward_tree(ps_hip_model *m, const int32_t *tokens, int n, con
     PS_CHECK(c, hipMemcpyAsync(m->tokens_dev, tokens, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
     PS_CHECK(c, hipMemcpyAsync(m->rope_pos_dev, rope_pos, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
     if (tree) PS_CHECK(c, hipMemcpyAsync(m->tree_dev, tree, (size_t)n * n, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(1), 0, c->stream, m->state, (int)m->position, n, 0, next_gen(m));
+    hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(1), 0, c->stream, m->state, (int)m->position, n, 0);
     PS_CHECK(c, hipStreamSynchronize(c->stream));
     m->n_kv_host = (int)m->position + n;
     const int rc_fw = enqueue_forward(m, n, lm_head != 0, tree != nullptr, false, true);
@@ -516,7 +505,7 @@ int ps_hip_model_decode_greedy(ps_hip_model *m, int32_t token, int steps, int32_
     if (token < 0 || (uint32_t)token >= m->cfg.vocab_size) PS_FAIL(c, "decode_greedy: token id out of range");
     PS_CHECK(c, hipSetDevice(c->device));
     PS_CHECK(c, hipMemcpyAsync(m->tokens_dev, &token, 4, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(1), 0, c->stream, m->state, (int)m->position, 1, 0, next_gen(m));
+    hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(1), 0, c->stream, m->state, (int)m->position, 1, 0);
     PS_CHECK(c, hipStreamSynchronize(c->stream));
     int s = 0;
     // the captured step carries the position it was captured at as a prefetch hint (n_kv_lo): keep it a LOWER bound that

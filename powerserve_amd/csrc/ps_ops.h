@@ -19,7 +19,7 @@ struct ps_step_state {
     int32_t pos0;    // KV position of the first token of this forward
     int32_t bs;      // tokens in this forward
     int32_t n_out;   // decode: number of ids written so far
-    int32_t gen;     // forward generation: bumped by the host per forward / decode call, 1 .. 8191 (tags of attn_decode2's score granules)
+    int32_t _pad;
 };
 
 struct psl_attn_args {
@@ -43,8 +43,8 @@ struct psl_attn_args {
     float *part;             // [n_heads][FL_SPLITS][head_size + 2] partial (o, m, l) of the split-KV decode attention
     unsigned long long *dbg; // timeline buffer of the single-token kernels (ps_hip_debug_timeline keys 40 / 41), or null
     unsigned *sync;          // [2048] words, zeroed once: [31] spin-timeout flag, [64 + 64 * kv head] ticket counter of the one-launch decode attention
-    unsigned long long *xchg; // attn_decode2: score granules {epoch tag, value}, [n_kv_heads][4][n_ctx rounded up to 8], zeroed at creation and whenever the generation wraps; null: not used
-    int layer;               // attn_decode2: layer index (part of the granule tag), 0 .. 127
+    float *xchg;             // attn_decode2: raw scores in flight between the workgroups of a kv head, [n_kv_heads][4][n_ctx rounded up to 32]; null: not used
+    unsigned *tick;          // attn_decode2: [64 * kv head] arrival counters, zeroed once (epoch = ticket / workgroups per head)
     int n_kv_lo;             // attn_decode2: a lower bound of pos0 + 1 known to the host at enqueue time (a prefetch HINT only)
 };
 void psl_rope_append(hipStream_t st, const psl_attn_args &a, int bs);

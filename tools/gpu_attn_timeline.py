@@ -17,8 +17,8 @@ for lo in range(0, P, 128):
 NW = 1024
 names = {40: ["entry", "loads issued", "q + first K round landed", "end"],
          41: ["entry", "V + score loads issued", "scores landed, logits in LDS", "barrier", "exp + row sums", "barrier", "1/sum", "V landed, stored to LDS", "barrier", "chains + reduce done", "end"],
-         42: ["entry", "q + hinted K requested", "position landed; rest of K, V requested", "scores computed + published", "-", "gather done (all tags seen)",
-              "max barrier passed (V parked)", "exp + partial sums", "sum barrier passed", "p in LDS, barrier passed", "matrix chains + barrier", "end"]}
+         42: ["entry", "position, q, hinted K requested", "position landed, rest of K and V requested, q -> LDS", "scores computed + stored", "stores drained, V parked, barrier",
+              "counter complete, barrier", "scores gathered, max barrier passed", "exp + partial sums", "sum barrier passed", "matrix chains + barrier", "end"]}
 MODES = {40: 17, 41: 17, 42: 1}  # two launches (mode bit 4) / the one-launch form; + eager
 for key in (42, 40, 41):
     m.set_mode(MODES[key])
@@ -31,7 +31,7 @@ for key in (42, 40, 41):
     ev = buf.reshape(NW, 64).astype(np.int64)
     ev = ev[(ev[:, 0] > 0) & (ev[:, 30] > 0)]
     n = ev.shape[0]
-    last = len(names[key]) - 1
+    last = 10 if key == 42 else len(names[key]) - 1
     dt_ref = (ev[:, 30] - ev[:, 29]) / 100.0
     mhz = np.median((ev[:, last] - ev[:, 0]) / np.maximum(dt_ref, 1e-3))
     t0 = ev[:, 29].min()
