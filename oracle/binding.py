@@ -103,6 +103,11 @@ class Oracle:
         L.pso_model_rollback.argtypes = [C.c_void_p, C.c_size_t]
         L.pso_model_rollback.restype = None
         L.pso_model_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        L.pso_model_forward_tree.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.pso_model_kv_move.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t]
+        L.pso_model_kv_move.restype = None
+        L.pso_model_kv_advance.argtypes = [C.c_void_p, C.c_size_t]
+        L.pso_model_kv_advance.restype = None
         L.pso_model_generate.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_void_p]
         L.pso_model_k_cache.restype = C.c_void_p
@@ -225,6 +230,26 @@ class OracleModel:
         rc = self.o.L.pso_model_forward(self.h, _p(tokens), tokens.size, _p(pos), int(lm_head), _p(out))
         assert rc == 0
         return out
+
+    def forward_tree(self, tokens, rope_pos, tree=None, kv_vis=None, lm_head=True, advance=False):
+        """Token-tree forward: tokens at the slots [position, position + n), column i rotated with rope_pos[i], batch visibility
+        tree[i][j] (None: causal), cache-slot visibility kv_vis[n_ctx] (None: all).  Returns logits [n, vocab] or None."""
+        tokens, rope_pos = _i32(tokens), _i32(rope_pos)
+        n = tokens.size
+        tr = np.ascontiguousarray(tree, dtype=np.uint8) if tree is not None else None
+        kv = np.ascontiguousarray(kv_vis, dtype=np.uint8) if kv_vis is not None else None
+        assert tr is None or tr.shape == (n, n)
+        assert kv is None or kv.size == self.cfg.seq_len
+        out = np.empty((n, self.cfg.vocab_size), dtype=np.float32) if lm_head else None
+        rc = self.o.L.pso_model_forward_tree(self.h, _p(tokens), n, _p(rope_pos), _p(tr), _p(kv), int(lm_head), _p(out), int(advance))
+        assert rc == 0
+        return out
+
+    def kv_move(self, dst, src):
+        self.o.L.pso_model_kv_move(self.h, int(dst), int(src))
+
+    def kv_advance(self, n):
+        self.o.L.pso_model_kv_advance(self.h, int(n))
 
     def generate(self, prompt, batch_size, steps, want_logits=False):
         prompt = _i32(prompt)

@@ -613,19 +613,17 @@ static void mm(pso_model *m, const pso_w *w, const float *x, int64_t bs, float *
 }
 
 typedef struct {
-    pso_model *m; int L; int64_t bs, n_kv; const float *q; const int32_t *pos; float *att_out;
+    pso_model *m; int L; int64_t bs, n_kv; const float *q; const float *mask /* [bs][n_kv]: 0 or -inf */; float *att_out;
 } attn_args;
-/* per q-head: KQ (F32 mat-mul of the K-cache view, norm_attention.cpp:115-129), mask (executor.cpp:210-224),
- * softmax_ext (norm_attention.cpp:130-134), V·kq (:138-147), permute+cont (:149-151) */
+/* per q-head: KQ (F32 mat-mul of the K-cache view, norm_attention.cpp:115-129), softmax_ext with the caller's mask
+ * (norm_attention.cpp:130-134; ggml.c:14901-14914 honours any mask), V·kq (:138-147), permute+cont (:149-151) */
 static void attn_heads(void *p, int64_t lo, int64_t hi) {
     attn_args *a = p; const pso_llm_config *c = &a->m->cfg;
     const int64_t hs = c->head_size, kvd = c->kv_dim, nctx = c->seq_len, dim = (int64_t)c->n_heads * hs;
     const int64_t r2 = c->n_heads / c->n_kv_heads, bs = a->bs, n_kv = a->n_kv;
     const float scale = 1.0f / sqrtf((float)hs);
     float *kq = malloc(sizeof(float) * (size_t)(n_kv * bs)), *sm = malloc(sizeof(float) * (size_t)(n_kv * bs));
-    float *mask = malloc(sizeof(float) * (size_t)(n_kv * bs));
-    for (int64_t i = 0; i < bs; i++)
-        for (int64_t j = 0; j < n_kv; j++) mask[i * n_kv + j] = (j <= a->pos[i]) ? 0.f : -INFINITY;
+    const float *mask = a->mask;
     for (int64_t h = lo; h < hi; h++) {
         const int64_t kvh = h / r2;
         const float *K = a->m->k_cache[a->L]; const float *V = a->m->v_cache[a->L];
@@ -637,15 +635,18 @@ static void attn_heads(void *p, int64_t lo, int64_t hi) {
             for (int64_t d = 0; d < hs; d++)
                 a->att_out[i * dim + h * hs + d] = pso_vec_dot_f32(n_kv, V + (kvh * hs + d) * nctx, sm + i * n_kv);
     }
-    free(kq); free(sm); free(mask);
+    free(kq); free(sm);
 }
 
 /* LlamaModel::forward (src/model/llama/llama_model.cpp:52-117) with NormAttention::build
  * (src/model/module/norm_attention.cpp:26-160) and FFN::build (src/model/module/ffn.cpp:22-42) */
-int pso_model_forward(pso_model *m, const int32_t *tokens, int n, const int32_t *pos, int lm_head, float *logits_out) {
+/* the forward with everything the graph derives from `pos` made explicit: cache slots [slot0, slot0 + n), RoPE positions,
+ * n_kv and the additive mask [n][n_kv] */
+static int forward_impl(pso_model *m, const int32_t *tokens, int n, size_t slot0, const int32_t *pos, int64_t n_kv, const float *mask,
+                        int lm_head, float *logits_out, int advance) {
     const pso_llm_config *c = &m->cfg; const int64_t bs = n, dim = c->dim, kvd = c->kv_dim, hid = c->hidden_dim;
     const int64_t nctx = c->seq_len, hs = c->head_size;
-    if ((size_t)pos[0] + (size_t)n > (size_t)nctx) return -1;
+    if (slot0 + (size_t)n > (size_t)nctx) return -1;
     float *x = malloc(sizeof(float) * bs * dim), *nrm = malloc(sizeof(float) * bs * dim);
     float *q = malloc(sizeof(float) * bs * dim), *k = malloc(sizeof(float) * bs * kvd), *v = malloc(sizeof(float) * bs * kvd);
     float *qr = malloc(sizeof(float) * bs * dim), *kr = malloc(sizeof(float) * bs * kvd);
@@ -653,7 +654,7 @@ int pso_model_forward(pso_model *m, const int32_t *tokens, int n, const int32_t 
     float *g = malloc(sizeof(float) * bs * hid), *u = malloc(sizeof(float) * bs * hid), *hb = malloc(sizeof(float) * bs * hid);
     float *dn = malloc(sizeof(float) * bs * dim);
     pso_get_embedding(m->token_embd.type, m->token_embd.data, dim, tokens, n, x);
-    const size_t cur_pos = (size_t)pos[0]; const int64_t n_kv = pos[n - 1] + 1;
+    const size_t cur_pos = slot0;
     for (uint32_t L = 0; L < c->n_layers; L++) {
         pso_layer *l = &m->lw[L];
         pso_rms_norm(x, l->attn_norm.data, nrm, dim, bs, c->norm_eps);
@@ -668,7 +669,7 @@ int pso_model_forward(pso_model *m, const int32_t *tokens, int n, const int32_t 
         memcpy(m->k_cache[L] + cur_pos * kvd, kr, sizeof(float) * bs * kvd);
         for (int64_t i = 0; i < bs; i++)
             for (int64_t d = 0; d < kvd; d++) m->v_cache[L][d * nctx + cur_pos + i] = v[i * kvd + d];
-        attn_args a = {m, (int)L, bs, n_kv, qr, pos, att};
+        attn_args a = {m, (int)L, bs, n_kv, qr, mask, att};
         parallel_for(m->n_threads, c->n_heads, attn_heads, &a);
         mm(m, &l->attn_output, att, bs, ao);
         pso_add(x, ao, x, dim, bs, 0);
@@ -683,9 +684,49 @@ int pso_model_forward(pso_model *m, const int32_t *tokens, int n, const int32_t 
         const pso_w *ow = m->output.data ? &m->output : &m->token_embd; /* tied lm_head (weights.hpp:67-68) */
         mm(m, ow, nrm, bs, logits_out);
     }
-    m->position += (size_t)n; /* m_kv->advance(batch_size) (llama_model.cpp:109) */
+    if (advance) m->position += (size_t)n; /* m_kv->advance(batch_size) (llama_model.cpp:109) */
     free(x); free(nrm); free(q); free(k); free(v); free(qr); free(kr); free(att); free(ao); free(g); free(u); free(hb); free(dn);
     return 0;
+}
+
+/* LlamaModel::forward as the reference runs it: slots = positions, n_kv = pos.back() + 1 (norm_attention.cpp:111), mask
+ * j <= pos[i] (executor.cpp:210-224) */
+int pso_model_forward(pso_model *m, const int32_t *tokens, int n, const int32_t *pos, int lm_head, float *logits_out) {
+    const int64_t n_kv = pos[n - 1] + 1;
+    float *mask = malloc(sizeof(float) * (size_t)(n_kv * n));
+    for (int64_t i = 0; i < n; i++)
+        for (int64_t j = 0; j < n_kv; j++) mask[i * n_kv + j] = (j <= pos[i]) ? 0.f : -INFINITY;
+    const int rc = forward_impl(m, tokens, n, (size_t)pos[0], pos, n_kv, mask, lm_head, logits_out, 1);
+    free(mask);
+    return rc;
+}
+
+/* Token-tree forward (src/speculative/token_tree.cpp:181-234 verify, :297-315 the tree mask; the QNN backend's mask fill,
+ * src/backend/qnn/causal_models.hpp:117-128): the n tokens go to the cache slots [position, position + n), column i is rotated
+ * with rope_pos[i] (its depth in the tree, not its slot), sees the cached slot j < position iff kv_vis[j] (KVCacheInterface::mask;
+ * NULL: all) and the batch column j iff tree[i * n + j] (NULL: causal).  The same op sequence as pso_model_forward — softmax_ext
+ * takes any mask (ggml.c:14901-14914); only the CPU executor's GET_MASK cannot express this one. */
+int pso_model_forward_tree(pso_model *m, const int32_t *tokens, int n, const int32_t *rope_pos, const uint8_t *tree,
+                           const uint8_t *kv_vis, int lm_head, float *logits_out, int advance) {
+    const int64_t p0 = (int64_t)m->position, n_kv = p0 + n;
+    float *mask = malloc(sizeof(float) * (size_t)(n_kv * n));
+    for (int64_t i = 0; i < n; i++)
+        for (int64_t j = 0; j < n_kv; j++) {
+            const int vis = j < p0 ? (kv_vis ? kv_vis[j] != 0 : 1) : (tree ? tree[i * n + (j - p0)] != 0 : (j - p0) <= i);
+            mask[i * n_kv + j] = vis ? 0.f : -INFINITY;
+        }
+    const int rc = forward_impl(m, tokens, n, (size_t)p0, rope_pos, n_kv, mask, lm_head, logits_out, advance);
+    free(mask);
+    return rc;
+}
+void pso_model_kv_advance(pso_model *m, size_t n) { m->position += n; } /* advance_tokens (kv_cache.hpp:249-255) */
+/* KVCacheInterface::move (kv_cache.hpp): slot src -> slot dst in every layer */
+void pso_model_kv_move(pso_model *m, size_t dst, size_t src) {
+    const pso_llm_config *c = &m->cfg;
+    for (uint32_t L = 0; L < c->n_layers; L++) {
+        memcpy(m->k_cache[L] + dst * c->kv_dim, m->k_cache[L] + src * c->kv_dim, sizeof(float) * c->kv_dim);
+        for (uint32_t d = 0; d < c->kv_dim; d++) m->v_cache[L][(size_t)d * c->seq_len + dst] = m->v_cache[L][(size_t)d * c->seq_len + src];
+    }
 }
 
 static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }

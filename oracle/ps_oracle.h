@@ -86,6 +86,12 @@ size_t pso_model_kv_position(const pso_model *m);
 void pso_model_reset(pso_model *m);
 void pso_model_rollback(pso_model *m, size_t n); /* rollback_tokens: the last n slots become free again */
 int pso_model_forward(pso_model *m, const int32_t *tokens, int n, const int32_t *pos, int lm_head, float *logits_out);
+/* token-tree forward: slots [position, position + n), per-column RoPE positions, tree mask [n][n] (NULL: causal), visibility of
+ * the cached slots [n_ctx] (NULL: all); advance = 0 leaves the position where it was */
+int pso_model_forward_tree(pso_model *m, const int32_t *tokens, int n, const int32_t *rope_pos, const uint8_t *tree,
+                           const uint8_t *kv_vis, int lm_head, float *logits_out, int advance);
+void pso_model_kv_move(pso_model *m, size_t dst, size_t src);
+void pso_model_kv_advance(pso_model *m, size_t n);
 int pso_model_generate(pso_model *m, const int32_t *prompt, int n_prompt, int batch_size, int steps,
                        int32_t *out_tokens, float *logits_out, double *t_prefill_s, double *t_decode_s);
 /* read-only access to layer L's caches for tests: K [n_ctx][kv_dim], V [kv_dim][n_ctx] */

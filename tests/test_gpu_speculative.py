@@ -5,6 +5,8 @@ the domain offers a size-independent property instead: with a greedy target samp
 model's own greedy output, whatever the draft model proposes.  Checked with an unrelated draft model (nearly nothing
 accepted: exercises catch-up forwards, branch switching with hidden cache slots, KV moves) and with the target as its own
 draft (long accepted paths)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -103,3 +105,62 @@ def test_tree_forward_positions_and_masks(ctx, tmp_path):
     assert not np.array_equal(base, hid)
     assert np.array_equal(base.view(np.uint32), back.view(np.uint32))
     gm.close()
+
+
+def _sha(path):
+    import hashlib
+    return hashlib.sha256(open(path, "rb").read()).hexdigest()
+
+
+@pytest.mark.parametrize("ci", [0, 1, 2, 3])
+@pytest.mark.parametrize("mode", [0, 16])
+def test_tree_forward_all_nodes_match_reference_operators(ctx, oracle, tmp_path, ci, mode):
+    """SURVEY 8 f1 pinned: ps_hip_model_forward_tree for a BRANCHING 12-node tree behind a prefix with two hidden cache
+    slots and RoPE positions = prefix + depth gives, for EVERY node, the logits that the reference's own operators give
+    under that mask (tests/golden/tree_forward.npz = oracle/_ref via oracle/ref_ops_forward.py) and that the restatement
+    gives live — bit for bit; then the accepted path is compacted (kv_move), the cache advanced, and one token decoded
+    behind the hidden slots (the single-token attention kernels; mode 16 = the two-launch plan) — bit for bit again.
+    Cases: Llama Q8_0, Qwen2 (bias, NEOX) Q4_0, head size 128 Q4_K, the Q4_K_M mix."""
+    from oracle import binding as B
+    from powerserve_amd import gguf, hip, synth
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tree_forward.npz"))
+    k = f"c{ci}_"
+    d = str(tmp_path / "m")
+    n_ctx, prefix = int(g[k + "n_ctx"]), g[k + "prefix"]
+    P = len(prefix)
+    mj = synth.write_model_dir(d, str(g[k + "preset"]), int(g[k + "wt"]), n_ctx=n_ctx, seed=int(g[k + "seed"]))
+    path = os.path.join(d, "ggml", "weights.gguf")
+    assert _sha(path) == str(g[k + "gguf_sha256"])
+    rd = gguf.GGUFReader(path)
+    tensors = {n: (ti.type, np.array(rd.data(n)), ti.ne[0], (list(ti.ne) + [1])[1]) for n, ti in rd.tensors.items()}
+    om = oracle.model(B.make_config(mj["llm_config"]), mj["model_arch"], tensors, n_threads=8)
+    gm = hip.Model(ctx, d, max_batch=32, n_ctx=n_ctx)
+    gm.set_mode(mode)
+    done = 0
+    while done < P:
+        bs = min(32, P - done)
+        om.forward(prefix[done:done + bs], np.arange(done, done + bs), False)
+        gm.forward(prefix[done:done + bs], np.arange(done, done + bs), lm_head=False)
+        done += bs
+    kv_vis = np.ones(n_ctx, dtype=np.uint8)
+    kv_vis[g[k + "hidden"]] = 0
+    for h in g[k + "hidden"]:
+        gm.kv_mask(int(h), False)
+    toks, rope, tree = g[k + "tokens"], g[k + "rope"], g[k + "tree"]
+    want = om.forward_tree(toks, rope, tree, kv_vis, True, advance=False)
+    got, am = gm.forward_tree(toks, rope, tree, lm_head=True, want_logits=True, advance=False)
+    assert np.array_equal(want.view(np.uint32), g[k + "logits"].view(np.uint32))
+    assert np.array_equal(got.view(np.uint32), g[k + "logits"].view(np.uint32)), [i for i in range(12) if not np.array_equal(got[i], g[k + "logits"][i])]
+    assert np.array_equal(am, np.argmax(g[k + "logits"], axis=1))
+    for L in range(gm.cfg.n_layers):  # the appended K rows / V columns
+        assert np.array_equal(gm.k_cache(L)[:P + 12].view(np.uint32), om.k_cache(L)[:P + 12].view(np.uint32))
+        assert np.array_equal(gm.v_cache(L)[:, :P + 12].view(np.uint32), om.v_cache(L)[:, :P + 12].view(np.uint32))
+    acc = g[k + "accept"]
+    for u, a in enumerate(acc):
+        if a != u:
+            gm.kv_move(P + u, P + int(a))
+    gm.kv_advance(len(acc))
+    step, _ = gm.forward_tree(g[k + "next"], [P + len(acc)], None, lm_head=True, want_logits=True, advance=False)
+    assert np.array_equal(step.view(np.uint32), g[k + "step_logits"].view(np.uint32))
+    gm.close()
+    om.close()

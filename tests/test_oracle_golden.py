@@ -81,3 +81,39 @@ def test_e2e_bit_exact(oracle, tmp_path, preset, tn):
     m.reset()
     assert np.array_equal(bits(m.forward(g["prompt"][:9], np.arange(9), True)), bits(g["batch_logits"]))
     m.close()
+
+
+@pytest.mark.parametrize("ci", [0, 1, 2, 3])
+def test_tree_forward_golden(oracle, tmp_path, ci):
+    """Token-tree forward of the restatement == the reference's own operators given the tree mask
+    (tests/golden/tree_forward.npz, oracle/gen_golden_tree.py): every node's logits, then the compacted cache + one decoded
+    token behind hidden slots — bit for bit."""
+    from oracle import binding as B
+    from powerserve_amd import gguf, synth
+    g = np.load(os.path.join(GOLD, "tree_forward.npz"))
+    k = f"c{ci}_"
+    d = str(tmp_path / "m")
+    n_ctx, P = int(g[k + "n_ctx"]), len(g[k + "prefix"])
+    mj = synth.write_model_dir(d, str(g[k + "preset"]), int(g[k + "wt"]), n_ctx=n_ctx, seed=int(g[k + "seed"]))
+    path = os.path.join(d, "ggml", "weights.gguf")
+    assert _sha(path) == str(g[k + "gguf_sha256"]), "synthetic model generator drifted: regenerate (oracle/gen_golden_tree.py)"
+    rd = gguf.GGUFReader(path)
+    tensors = {n: (ti.type, np.array(rd.data(n)), ti.ne[0], (list(ti.ne) + [1])[1]) for n, ti in rd.tensors.items()}
+    m = oracle.model(B.make_config(mj["llm_config"]), mj["model_arch"], tensors, n_threads=4)
+    done = 0
+    while done < P:
+        bs = min(32, P - done)
+        m.forward(g[k + "prefix"][done:done + bs], np.arange(done, done + bs), False)
+        done += bs
+    kv_vis = np.ones(n_ctx, dtype=np.uint8)
+    kv_vis[g[k + "hidden"]] = 0
+    got = m.forward_tree(g[k + "tokens"], g[k + "rope"], g[k + "tree"], kv_vis, True, advance=False)
+    assert np.array_equal(bits(got), bits(g[k + "logits"]))
+    acc = g[k + "accept"]
+    for u, a in enumerate(acc):
+        if a != u:
+            m.kv_move(P + u, P + int(a))
+    m.kv_advance(len(acc))
+    step = m.forward_tree(g[k + "next"], [P + len(acc)], None, kv_vis, True, advance=False)
+    assert np.array_equal(bits(step), bits(g[k + "step_logits"]))
+    m.close()

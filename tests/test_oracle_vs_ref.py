@@ -1,5 +1,7 @@
 """CPU, dev container only: restatement vs the live reference library (oracle/_ref), randomized, incl. Q4_K/Q5_K/Q6_K
 which the reference can only run at op level (its loader aborts on K-quants).  Skipped where _ref is absent."""
+import os
+
 import numpy as np
 import pytest
 
@@ -44,3 +46,91 @@ def test_embedding(oracle, ref):
         tab = synth.random_blocks(rng, t, 50, 256)
         toks = [0, 49, 7]
         assert np.array_equal(ref.get_embedding(t, tab, 256, 50, toks), oracle.get_embedding(t, tab, 256, toks))
+
+
+# ---------------------------------------------------------------- token-tree forward
+def _load_tensors(path):
+    from powerserve_amd import gguf
+    rd = gguf.GGUFReader(path)
+    return {n: (ti.type, np.array(rd.data(n)), ti.ne[0], (list(ti.ne) + [1])[1]) for n, ti in rd.tensors.items()}
+
+
+TREE = np.array([[1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0],   # 0 root
+                 [1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0],   # 1 <- 0
+                 [1, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0],   # 2 <- 0
+                 [1, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0],   # 3 <- 0
+                 [1, 1, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0],   # 4 <- 1
+                 [1, 1, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0],   # 5 <- 1
+                 [1, 0, 1, 0, 0, 0, 1, 0, 0, 0, 0, 0],   # 6 <- 2
+                 [1, 1, 0, 0, 1, 0, 0, 1, 0, 0, 0, 0],   # 7 <- 4
+                 [1, 1, 0, 0, 1, 0, 0, 1, 1, 0, 0, 0],   # 8 <- 7
+                 [1, 0, 1, 0, 0, 0, 1, 0, 0, 1, 0, 0],   # 9 <- 6
+                 [1, 1, 0, 0, 1, 0, 0, 1, 1, 0, 1, 0],   # 10 <- 8
+                 [1, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 1]],  # 11 <- 3
+                dtype=np.uint8)
+TREE_DEPTH = np.array([0, 1, 1, 1, 2, 2, 2, 3, 4, 3, 5, 2])
+
+
+@pytest.mark.parametrize("preset,t", [("tiny-llama", 8), ("tiny-qwen2", 2)])
+def test_ref_ops_forward_reproduces_the_real_model_forward(ref, tmp_path, preset, t):
+    """The plumbing of oracle/ref_ops_forward.py (the reference's compiled operators sequenced by this repository) is right:
+    with the executor's own mask it gives the logits of the real LlamaModel / Qwen2Model::forward bit for bit — prefill
+    batches behind each other and single-token steps."""
+    from oracle import binding as B
+    from oracle.ref_ops_forward import RefOpsModel
+    from powerserve_amd import synth
+    d = str(tmp_path / "m")
+    mj = synth.write_model_dir(d, preset, t, n_ctx=96, seed=21)
+    cfg = B.make_config(mj["llm_config"])
+    path = os.path.join(d, "ggml", "weights.gguf")
+    real = ref.model(path, mj["model_arch"], cfg, 2)
+    mine = RefOpsModel(ref, cfg, mj["model_arch"], _load_tensors(path))
+    toks = np.random.default_rng(3).integers(0, cfg.vocab_size, 40)
+    done = 0
+    for bs in (7, 12, 1, 1, 5, 1):
+        pos = np.arange(done, done + bs)
+        want = real.forward(toks[done:done + bs], pos, True)
+        got = mine.forward_causal(toks[done:done + bs], pos, True)
+        assert np.array_equal(bits(got), bits(want)), (preset, done, bs)
+        done += bs
+    real.close()
+
+
+@pytest.mark.parametrize("preset,t", [("tiny-llama", 8), ("tiny-qwen2", 2), ("small-llama-hs128", 12), ("tiny-llama", 1015)])
+def test_tree_forward_restatement_vs_reference_operators(oracle, ref, tmp_path, preset, t):
+    """pso_model_forward_tree (oracle/ps_oracle.c) against the reference's own operators given the tree mask: a branching
+    12-node tree behind a 37-token prefix with two hidden cache slots, RoPE positions = prefix + depth (not the slots) —
+    the logits of EVERY node bit for bit, and the K / V rows that were appended."""
+    from oracle import binding as B
+    from oracle.ref_ops_forward import RefOpsModel
+    from powerserve_amd import synth
+    d = str(tmp_path / "m")
+    mj = synth.write_model_dir(d, preset, t, n_ctx=96, seed=33)
+    cfg = B.make_config(mj["llm_config"])
+    tensors = _load_tensors(os.path.join(d, "ggml", "weights.gguf"))
+    om = oracle.model(cfg, mj["model_arch"], tensors, n_threads=4)
+    rm = RefOpsModel(ref, cfg, mj["model_arch"], tensors)
+    rng = np.random.default_rng(8)
+    P = 37
+    prefix = rng.integers(0, cfg.vocab_size, P)
+    for lo in (0, 20):
+        hi = min(P, lo + 20)
+        a = om.forward(prefix[lo:hi], np.arange(lo, hi), True)
+        b = rm.forward_causal(prefix[lo:hi], np.arange(lo, hi), True)
+        assert np.array_equal(bits(a), bits(b))
+    kv_vis = np.ones(cfg.seq_len, dtype=np.uint8)
+    kv_vis[[5, 33]] = 0
+    toks = rng.integers(0, cfg.vocab_size, 12)
+    rope = P + TREE_DEPTH
+    want = rm.forward_tree(toks, rope, TREE, kv_vis, True, advance=False)
+    got = om.forward_tree(toks, rope, TREE, kv_vis, True, advance=False)
+    assert np.array_equal(bits(got), bits(want))
+    assert om.position == P == rm.position
+    for L in range(cfg.n_layers):
+        assert np.array_equal(bits(om.k_cache(L)[:P + 12]), bits(rm.k_cache[L][:P + 12]))
+        assert np.array_equal(bits(om.v_cache(L)[:, :P + 12]), bits(rm.v_cache[L][:, :P + 12]))
+    # the mask matters: the causal reading of the same batch differs for every node but the root
+    causal = om.forward_tree(toks, rope, None, None, True, advance=False)
+    assert np.array_equal(bits(causal[0]), bits(om.forward_tree(toks, rope, TREE, None, True, advance=False)[0]))
+    assert not any(np.array_equal(causal[i], got[i]) for i in range(12))
+    om.close()
