@@ -88,44 +88,74 @@ def cpu_port(model_dir, prompt, steps):
                       f"prefill {(p.size - 1) / max(tp, 1e-9):.2f} tok/s", "host_cores": cores, "ids": [int(i) for i in ids]}, p, ids, logits
 
 
-def cpu_reference(model_dir, cfg, tokens=2):
+def _one_socket_cpus():
+    """the logical CPUs of the package this process mostly runs on (sysfs topology); None where that cannot be read"""
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+        pk = {}
+        for c in allowed:
+            with open(f"/sys/devices/system/cpu/cpu{c}/topology/physical_package_id") as f:
+                pk.setdefault(int(f.read()), []).append(c)
+        return max(pk.values(), key=len) if pk else None
+    except Exception:
+        return None
+
+
+def cpu_reference(model_dir, cfg, passes=7):
     """The REAL reference on this host: powerserve_compute_forward_mul_mat of the vendored ggml (AVX2 vec_dot_q4_K_q8_K,
     quantize_row_q8_K) compiled from /root/reference into oracle/_ref/libps_ref.so, called through the reference's own
     ThreadPool over the 7 * L + 1 mat-muls of a decode token (the op that is > 90 % of the reference's decode time,
-    SURVEY.md 8a3) on the bench model's weights.  Bounded sample: `tokens` passes over all layers.  Returns None when
-    the library is not there."""
+    SURVEY.md 8a3) on the bench model's weights.  Made reproducible (round-2 review: 10 .. 38 tok/s on one host class): the
+    pool is pinned to the CPUs of ONE socket (sched_setaffinity before the pool's threads are created: they inherit it),
+    the weights are touched before anything is timed (two untimed passes), and the MEDIAN of `passes` timed passes is
+    reported with their min / max.  Returns None when the library is not there."""
     from oracle import binding as B  # baseline only
     from powerserve_amd import gguf
     if not B.have_ref():
         return None
     cores = os.cpu_count() or 1
-    nth = max(1, min(cores - 1, 48))
-    ref = B.Ref(n_threads=nth)
-    rd = gguf.GGUFReader(os.path.join(model_dir, "ggml", "weights.gguf"))
-    rng = np.random.default_rng(1)
-    xs = {k: rng.standard_normal(k).astype(np.float32) for k in (cfg.dim, cfg.hidden_dim)}
-    names = []
-    for L in range(cfg.n_layers):
-        names += [f"blk.{L}.{n}.weight" for n in ("attn_q", "attn_k", "attn_v", "attn_output", "ffn_gate", "ffn_up", "ffn_down")]
-    names.append("output.weight" if "output.weight" in rd.tensors else "token_embd.weight")
-    mats = []
-    for n in names:
-        ti = rd.tensors[n]
-        mats.append((ti.type, np.asarray(rd.data(n)), int(ti.ne[0]), int(ti.ne[1])))
-    nbytes = sum(m[1].nbytes for m in mats)
-    times = []
-    for _ in range(tokens + 1):  # the first pass pages the mmap'ed weights and the pool in and is not counted
-        t0 = time.perf_counter()
-        for t, w, K, N in mats:
-            ref.mul_mat(t, w, K, N, xs[K])
-        times.append(time.perf_counter() - t0)
-    dt = min(times[1:])  # the reference's best pass: the host is shared, a slow pass is noise in its disfavour
-    ref.close()
-    return {"value": 1.0 / dt, "unit": "tokens/s", "cores": nth, "kind": "reference",
-            "sample": f"best of {tokens} warm passes over the {len(mats)} quantized mat-muls of one decode token ({nbytes / 1e9:.2f} GB of GGUF weights) through "
-                      f"powerserve_compute_forward_mul_mat on the reference's ThreadPool ({nth} threads; attention, norms and sampling "
+    saved = None
+    cpus = _one_socket_cpus()
+    try:
+        if cpus:
+            saved = os.sched_getaffinity(0)
+            os.sched_setaffinity(0, cpus)
+        avail = len(cpus) if cpus else cores
+        nth = max(1, min(avail - 1, 48))  # never = the CPU count: the reference's spin barrier does not survive oversubscription (SURVEY 6)
+        ref = B.Ref(n_threads=nth)
+        rd = gguf.GGUFReader(os.path.join(model_dir, "ggml", "weights.gguf"))
+        rng = np.random.default_rng(1)
+        xs = {k: rng.standard_normal(k).astype(np.float32) for k in (cfg.dim, cfg.hidden_dim)}
+        names = []
+        for L in range(cfg.n_layers):
+            names += [f"blk.{L}.{n}.weight" for n in ("attn_q", "attn_k", "attn_v", "attn_output", "ffn_gate", "ffn_up", "ffn_down")]
+        names.append("output.weight" if "output.weight" in rd.tensors else "token_embd.weight")
+        mats = []
+        for n in names:
+            ti = rd.tensors[n]
+            w = np.array(rd.data(n))  # a private, resident copy: no page faults on the mmap inside the timed passes
+            mats.append((ti.type, w, int(ti.ne[0]), int(ti.ne[1])))
+        nbytes = sum(m[1].nbytes for m in mats)
+        times = []
+        for i in range(passes + 2):  # two untimed passes: pool start-up, caches, frequency
+            t0 = time.perf_counter()
+            for t, w, K, N in mats:
+                ref.mul_mat(t, w, K, N, xs[K])
+            if i >= 2:
+                times.append(time.perf_counter() - t0)
+        ref.close()
+    finally:
+        if saved is not None:
+            os.sched_setaffinity(0, saved)
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": 1.0 / med, "unit": "tokens/s", "cores": nth, "kind": "reference", "statistic": f"median of {passes} passes",
+            "min": 1.0 / times[-1], "max": 1.0 / times[0],
+            "pinned_to": f"{len(cpus)} logical CPUs of one socket" if cpus else "not pinned (topology unreadable)",
+            "sample": f"{passes} timed warm passes (after 2 untimed) over the {len(mats)} quantized mat-muls of one decode token ({nbytes / 1e9:.2f} GB of GGUF weights, resident copies) "
+                      f"through powerserve_compute_forward_mul_mat on the reference's ThreadPool ({nth} threads; attention, norms and sampling "
                       f"not included: an upper bound of the reference's decode rate)",
-            "host_cores": cores, "weight_GBps": nbytes / dt / 1e9}
+            "host_cores": cores, "weight_GBps": nbytes / med / 1e9}
 
 
 def graph_path(model_dir, device, args, prompt):
@@ -357,6 +387,8 @@ def main():
             "decode_effective_GBps": (wbytes + kv_bytes) / (dt / args.steps) / 1e9,
             "replicas_agree": replicas_agree, "first_ids": [int(i) for i in ids[:8]],
             "roofline": rf,
+            "prefill_roofline": prefill_roofline(ctx, model, cfg, args.prompt_len - 1, prefill_s, prefill_warm_s, args.batch,
+                                                 args.preset == "llama-3.1-8b" and args.wtype == "Q4_K"),
         }
         if not args.no_kv_f16 and dist is None:
             try:
@@ -393,20 +425,32 @@ def main():
         print(json.dumps(out), flush=True)
 
 
-GATE_UP_KERNEL = "gemv4_kernel<8, 2, 2, 2, 1, 1>"  # <NW 8, DC 2, TPW 2, staged, EPI 1 SiLU(gate)*up, PRO 1 RMSNorm+Q8_K>
+MFMA_F16_PEAK_TFLOPS = 2500.0  # dense fp16 matrix-core peak (MI355X_MICROARCH.md): the pipe the Q4_K chunk mat-mul runs its exact-integer contractions on
+TRAFFIC_FILE = os.path.join("profiles", "r03_pmc_traffic.json")
 
 
 def _pmc_traffic(kernel):
-    """HBM bytes per launch of the dominant kernel from the committed PMC pass (profiles/r02_pmc_traffic.json, produced by
-    tools/pmc_summary.py from a separate `rocprofv3 --pmc FETCH_SIZE` run of this same command; FETCH_SIZE doubled as
-    MI355X_MICROARCH.md prescribes for gfx950).  A live bench run cannot collect counters: the record is keyed by the
-    kernel's full template name, so a kernel that has changed since the pass reports null instead of a stale number."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_traffic.json")
+    """HBM bytes per launch of `kernel` from the committed PMC pass (tools/pmc_summary.py over a separate
+    `rocprofv3 --pmc FETCH_SIZE` run of this same command; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).
+    A live bench run cannot collect counters: the record is keyed by the kernel's full template name, so a kernel that has
+    changed since the pass reports null instead of a stale number.  Returns (bytes | None, source)."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), TRAFFIC_FILE)
     try:
         with open(path) as f:
-            return json.load(f).get(kernel, {}).get("hbm_bytes_per_launch")
+            return json.load(f).get(kernel, {}).get("hbm_bytes_per_launch"), TRAFFIC_FILE + " (rocprofv3 --pmc FETCH_SIZE x 2, separate pass of this command)"
     except Exception:
-        return None
+        return None, None
+
+
+def _bench_matmul(ctx, model, which, bs, reps=20):
+    import ctypes as C
+    L = ctx.L
+    L.ps_hip_model_bench_matmul.restype = C.c_int
+    L.ps_hip_model_bench_matmul.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]
+    L.ps_hip_last_matmul_kernel.restype = C.c_char_p
+    seq_ms, null_ms, n = C.c_double(), C.c_double(), C.c_int()
+    ctx.check(L.ps_hip_model_bench_matmul(model.h, reps, which, bs, C.byref(seq_ms), C.byref(null_ms), C.byref(n)))
+    return seq_ms.value, null_ms.value, n.value, L.ps_hip_last_matmul_kernel().decode()
 
 
 def gemv_roofline(ctx, model, wbytes, gate_up_bytes, is_headline):
@@ -414,32 +458,46 @@ def gemv_roofline(ctx, model, wbytes, gate_up_bytes, is_headline):
 
     The library replays that launch for every layer (each layer's own weights, so every launch streams HBM-cold bytes
     exactly like in the real step; same kernel and fused RMSNorm prologue as the decode step) between HIP events on the
-    backend stream: achieved = GGUF bytes of the two matrices / average launch duration.  rocprofv3's per-kernel
-    average for that kernel (profiles/r02_decode_kernel_stats_*) is the cross-check.  The same measurement over ALL mat-vec
-    launches of a token and the cost of an empty launch are reported next to it."""
-    import ctypes as C
-    L = ctx.L
-    if not hasattr(L, "ps_hip_model_bench_gemv"):
+    backend stream: achieved = GGUF bytes of the two matrices / average launch duration.  `kernel` is the template instance
+    that launch actually went to (the library records it), rocprofv3's per-kernel average for it
+    (profiles/r03_decode_kernel_stats_*) is the cross-check.  The same measurement over ALL mat-vec launches of a token and
+    the cost of an empty launch are reported next to it."""
+    if not hasattr(ctx.L, "ps_hip_model_bench_matmul"):
         return None
-    L.ps_hip_model_bench_gemv.restype = C.c_int
-    L.ps_hip_model_bench_gemv.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]
-
-    def run(which):
-        seq_ms, null_ms, n = C.c_double(), C.c_double(), C.c_int()
-        ctx.check(L.ps_hip_model_bench_gemv(model.h, 20, which, C.byref(seq_ms), C.byref(null_ms), C.byref(n)))
-        return seq_ms.value, null_ms.value, n.value
-
-    g_ms, g_null, g_n = run(1)
-    a_ms, a_null, a_n = run(0)
+    g_ms, g_null, g_n, kernel = _bench_matmul(ctx, model, 1, 1)
+    a_ms, a_null, a_n, _ = _bench_matmul(ctx, model, 0, 1)
     avg_us = 1e3 * g_ms / g_n
     achieved = gate_up_bytes / (avg_us * 1e-6) / 1e9
-    return {"bound": "hbm", "kernel": GATE_UP_KERNEL + ": gate/up mat-vec (Q4_K, RMSNorm + Q8_K prologue, SiLU(gate)*up epilogue), one launch per layer",
+    traffic, src = _pmc_traffic(kernel) if is_headline else (None, None)
+    return {"bound": "hbm", "kernel": kernel + ": gate/up mat-vec (RMSNorm + activation-quantizer prologue, SiLU(gate)*up epilogue), one launch per layer",
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": _pmc_traffic(GATE_UP_KERNEL) if is_headline else None,
+            "traffic": traffic, "traffic_source": src,
             "bytes_per_launch": gate_up_bytes, "avg_launch_us": avg_us, "launches_timed": 20 * g_n,
             "empty_launch_us": 1e3 * g_null / g_n,
             "all_matvec": {"launches_per_token": a_n, "ms_per_token": a_ms, "bytes_per_token": wbytes,
                            "achieved": wbytes / (a_ms * 1e-3) / 1e9, "frac": wbytes / (a_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}}
+
+
+def prefill_roofline(ctx, model, cfg, n_tok, prefill_s, prefill_warm_s, batch, is_headline):
+    """Prefill against the matrix-core peak (north_star: "MFMA utilisation (prefill) against gfx950 peak").  flops =
+    2 * n_tok * sum K * N over the layer mat-muls (lm_head is skipped during prefill, src/model/model.hpp:157; SURVEY 8d);
+    the whole-prefill figure divides by the measured prefill time (attention, quantizers and launches included), the
+    per-launch figure is the gate/up chunk mat-mul replayed over all layers between HIP events (its activation-quantizer
+    launch included).  peak = the dense fp16 MFMA rate: the kernel contracts exact integers on v_mfma_f32_16x16x32_f16."""
+    layer_kn = 2 * cfg.dim * cfg.dim + 2 * cfg.dim * cfg.kv_dim + 3 * cfg.dim * cfg.hidden_dim
+    flops = 2.0 * n_tok * cfg.n_layers * layer_kn
+    out = {"bound": "mfma", "flops": flops, "achieved": flops / prefill_s / 1e12, "achieved_warm": flops / prefill_warm_s / 1e12,
+           "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flops / prefill_s / 1e12 / MFMA_F16_PEAK_TFLOPS,
+           "what": "2 * n_tok * sum(K * N) of the layer mat-muls / measured prefill time (first pass of the process; attention, quantizers, launches included)"}
+    if hasattr(ctx.L, "ps_hip_model_bench_matmul") and batch <= model.max_batch:
+        g_ms, _, g_n, kernel = _bench_matmul(ctx, model, 1, batch, reps=5)
+        us = 1e3 * g_ms / g_n
+        fl = 2.0 * batch * cfg.dim * 2 * cfg.hidden_dim
+        traffic, src = _pmc_traffic(kernel) if is_headline else (None, None)
+        out["dominant_launch"] = {"kernel": kernel + f": gate/up mat-mul of a {batch}-token chunk (+ its RMSNorm / quantizer launch)", "flops_per_launch": fl,
+                                  "avg_launch_us": us, "achieved": fl / (us * 1e-6) / 1e12, "frac": fl / (us * 1e-6) / 1e12 / MFMA_F16_PEAK_TFLOPS,
+                                  "traffic": traffic, "traffic_source": src}
+    return out
 
 
 if __name__ == "__main__":

@@ -200,11 +200,15 @@ uint64_t ps_hip_model_weight_bytes_per_token(const ps_hip_model *m);
 * (which: 0 every quantized mat-vec of a token, 1 gate/up, 2 QKV, 3 O, 4 down, 5 lm_head)
  * null_ms = the same number of empty launches (launch-boundary cost); n_launches = launches per token. */
 int ps_hip_model_bench_gemv(ps_hip_model *m, int reps, int which, double *seq_ms, double *null_ms, int *n_launches);
+/* the same replay with bs activation columns (a prefill chunk's mat-muls with their quantizer launches) */
+int ps_hip_model_bench_matmul(ps_hip_model *m, int reps, int which, int bs, double *seq_ms, double *null_ms, int *n_launches);
 /* Diagnostic: in-kernel timeline of the decode mat-vec (tools/gpu_timeline.py).  With host_out == NULL, arm
  * (key >= 0: record launches with epilogue*4 + prologue == key; key < 0: disarm).  With host_out != NULL, copy
  * the last recorded launch: n_words uint64 = [workgroup][role 0 producer wave 0 / 1 chain wave][32 events],
  * shader-clock ticks (s_memtime).  key = k1 + 100 * (k2 + 1) records a second launch family into a second block of
  * the same size (kernel-boundary gaps). */
+/* diagnostics: the kernel (rocprofv3's template name) the most recent quantized mat-mul launch of this process went to */
+const char *ps_hip_last_matmul_kernel(void);
 int ps_hip_debug_timeline(ps_hip_ctx *ctx, int key, uint64_t *host_out, int n_words);
 /* Diagnostic: tunables of the library (process-wide).  key 1: wave configuration of the decode mat-vec (k_gemv4.hip,
  * tools/g4_variants.py).  Returns non-zero for an unknown key. */

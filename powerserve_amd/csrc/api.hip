@@ -1,3 +1,5 @@
+#include <cstdarg>
+#include <cstdio>
 // C-ABI (include/ps_hip.h): context, memory, weights and the reference-shaped operator entry points.
 #include "ps_internal.h"
 #include "ps_ops.h"
@@ -385,6 +387,17 @@ int ps_hip_argmax(ps_hip_ctx *c, const float *src, int64_t n, int64_t rows, int3
     return 0;
 }
 
+} // extern "C"
+static char g_last_kernel[128] = "";
+void psk_note_kernel(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_last_kernel, sizeof(g_last_kernel), fmt, ap);
+    va_end(ap);
+}
+const char *psk_last_kernel() { return g_last_kernel; }
+extern "C" {
+const char *ps_hip_last_matmul_kernel(void) { return psk_last_kernel(); }
 int ps_hip_debug_timeline(ps_hip_ctx *ctx, int key, uint64_t *host_out, int n_words) {
     if (!ctx) return 1;
     if (host_out) PS_CHECK(ctx, hipStreamSynchronize(ctx->stream));

@@ -967,13 +967,13 @@ static int g4k_launch(hipStream_t st, int n_cu, G4KParams &p, const int epi, con
     }
     if (p.wt == PS_Q5_K) { // (single matrix, EPI 0)
         if (epi != 0) return -1;
-        if (ctw == 1) hipLaunchKernelGGL((gemm4k_narrow_kernel<0, 1, PS_Q5_K>), grid, blkn, LDS1, st, p);
-        else hipLaunchKernelGGL((gemm4k_kernel<0, PS_Q5_K>), grid, blk, G4K_LDS, st, p);
+        if (ctw == 1) { psk_note_kernel("gemm4k_narrow_kernel<0, 1, 13>"); hipLaunchKernelGGL((gemm4k_narrow_kernel<0, 1, PS_Q5_K>), grid, blkn, LDS1, st, p); }
+        else { psk_note_kernel("gemm4k_kernel<0, 13>"); hipLaunchKernelGGL((gemm4k_kernel<0, PS_Q5_K>), grid, blk, G4K_LDS, st, p); }
     } else if (ctw == 1) {
-        if (epi == 1) hipLaunchKernelGGL((gemm4k_narrow_kernel<1, 1, PS_Q4_K>), grid, blkn, LDS1, st, p);
-        else hipLaunchKernelGGL((gemm4k_narrow_kernel<0, 1, PS_Q4_K>), grid, blkn, LDS1, st, p);
-    } else if (epi == 1) hipLaunchKernelGGL((gemm4k_kernel<1, PS_Q4_K>), grid, blk, G4K_LDS, st, p);
-    else hipLaunchKernelGGL((gemm4k_kernel<0, PS_Q4_K>), grid, blk, G4K_LDS, st, p);
+        if (epi == 1) { psk_note_kernel("gemm4k_narrow_kernel<1, 1, 12>"); hipLaunchKernelGGL((gemm4k_narrow_kernel<1, 1, PS_Q4_K>), grid, blkn, LDS1, st, p); }
+        else { psk_note_kernel("gemm4k_narrow_kernel<0, 1, 12>"); hipLaunchKernelGGL((gemm4k_narrow_kernel<0, 1, PS_Q4_K>), grid, blkn, LDS1, st, p); }
+    } else if (epi == 1) { psk_note_kernel("gemm4k_kernel<1, 12>"); hipLaunchKernelGGL((gemm4k_kernel<1, PS_Q4_K>), grid, blk, G4K_LDS, st, p); }
+    else { psk_note_kernel("gemm4k_kernel<0, 12>"); hipLaunchKernelGGL((gemm4k_kernel<0, PS_Q4_K>), grid, blk, G4K_LDS, st, p); }
     return 0;
 }
 
@@ -1030,6 +1030,7 @@ int psk_gemm6k(hipStream_t st, int n_cu, const psk_gemv6_args &a, ps_act act, in
     if (n_cu > 0 && n_wg > n_cu && n_cu % (8 * p.n_cb) == 0) n_wg = n_cu;
     static unsigned long long attr = 0;
     if (ps_first_on_device(&attr)) (void)hipFuncSetAttribute((const void *)gemm6k_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, G6K_LDS);
+    psk_note_kernel("gemm6k_kernel");
     hipLaunchKernelGGL(gemm6k_kernel, dim3((unsigned)n_wg), dim3((G4K_NC + G4K_NP) * 64), G6K_LDS, st, p);
     return 0;
 }

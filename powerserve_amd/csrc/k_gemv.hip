@@ -404,6 +404,7 @@ void launch_g1(hipStream_t st, int n_cu, const GemvParams &p) {
     const int64_t cap = (int64_t)n_cu * occ;
     if (grid > cap) grid = cap;
     if (grid < 1) grid = 1;
+    psk_note_kernel("gemv1_kernel<%d, %d, %d, %d, %d>", WT, UPW, NW, EPI, PRO);
     hipLaunchKernelGGL((gemv1_kernel<WT, UPW, NW, EPI, PRO>), dim3((unsigned)grid), dim3(NW * 64), smem, st, p);
 }
 
@@ -906,6 +907,7 @@ void launch_g3(hipStream_t st, int n_cu, const GemvParams &p) {
         if (k1 == EPI * 4 + PRO) pd.dbg = g_dbg_buf;
         else if (k2 == EPI * 4 + PRO) pd.dbg = g_dbg_buf + (size_t)G3_DBG_WGS * 64;
     }
+    psk_note_kernel("gemv3_kernel<%d, %d, %d, %d, %d, %d>", WT, UPW, NW, TPW, EPI, PRO);
     hipLaunchKernelGGL((gemv3_kernel<WT, UPW, NW, TPW, EPI, PRO>), dim3((unsigned)grid), dim3(g3_waves(NW) * 64), smem, st, pd);
 }
 
@@ -964,6 +966,7 @@ void launch_one(hipStream_t st, int n_cu, const GemvParams &p) {
     if (ps_first_on_device(&attr_set) && smem > 48 * 1024) {
         (void)hipFuncSetAttribute((const void *)gemv_kernel<WT, BS, EPI, PRO, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
     }
+    psk_note_kernel("gemv_kernel<%d, %d, %d, %d, %d>", WT, BS, EPI, PRO, NWV);
     hipLaunchKernelGGL((gemv_kernel<WT, BS, EPI, PRO, NWV>), dim3((unsigned)grid), dim3(NWV * 64), smem, st, p);
 }
 
@@ -1615,18 +1618,21 @@ template <int WT, int EPI, int NWV>
 static void launch_gemm8_k(hipStream_t st, const GemvParams &p, const dim3 grid, size_t smem) {
     static unsigned long long attr = 0; // devices that have the attribute
     if (ps_first_on_device(&attr)) { (void)hipFuncSetAttribute((const void *)gemm8_kernel<WT, EPI, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024); }
+    psk_note_kernel("gemm8_kernel<%d, %d, %d>", WT, EPI, NWV);
     hipLaunchKernelGGL((gemm8_kernel<WT, EPI, NWV>), grid, dim3(NWV * 64), smem, st, p);
 }
 template <int EPI, int NWV, int C>
 static void launch_gemm8m_k(hipStream_t st, const GemvParams &p, const dim3 grid, size_t smem) {
     static unsigned long long attr = 0; // devices that have the attribute
     if (ps_first_on_device(&attr)) { (void)hipFuncSetAttribute((const void *)gemm8m_kernel<EPI, NWV, C>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024); }
+    psk_note_kernel("gemm8m_kernel<%d, %d, %d>", EPI, NWV, C);
     hipLaunchKernelGGL((gemm8m_kernel<EPI, NWV, C>), grid, dim3(NWV * 64), smem, st, p);
 }
 template <int WT, int EPI, int NWV>
 static void launch_gemm8b_k(hipStream_t st, const GemvParams &p, const dim3 grid, size_t smem) {
     static unsigned long long attr = 0; // devices that have the attribute
     if (ps_first_on_device(&attr)) { (void)hipFuncSetAttribute((const void *)gemm8b_kernel<WT, EPI, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024); }
+    psk_note_kernel("gemm8b_kernel<%d, %d, %d>", WT, EPI, NWV);
     hipLaunchKernelGGL((gemm8b_kernel<WT, EPI, NWV>), grid, dim3(NWV * 64), smem, st, p);
 }
 template <int WT>

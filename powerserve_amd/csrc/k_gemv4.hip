@@ -453,6 +453,7 @@ void launch_g4(hipStream_t st, int grid, const G4Params &p) {
     if (ps_first_on_device(&attr) && smem > 48 * 1024) {
         (void)hipFuncSetAttribute((const void *)gemv4_kernel<NW, DC, TPW, XW, EPI, PRO>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     }
+    psk_note_kernel("gemv4_kernel<%d, %d, %d, %d, %d, %d>", NW, DC, TPW, XW, EPI, PRO);
     hipLaunchKernelGGL((gemv4_kernel<NW, DC, TPW, XW, EPI, PRO>), dim3((unsigned)grid), dim3((NW + 1) * 64), smem, st, p);
 }
 

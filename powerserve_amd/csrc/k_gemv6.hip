@@ -234,10 +234,10 @@ int launch_gemv5(hipStream_t st, int n_cu, const psk_gemv6_args *a, int n_w, ps_
                               a[i].residual ? a[i].residual + c0 * a[i].ldo : nullptr};
         }
         p.nc = nc;
-        if (nc == 1) hipLaunchKernelGGL(gemv5_kernel<1>, dim3(grid), dim3(256), 0, st, p);
-        else if (nc == 2) hipLaunchKernelGGL(gemv5_kernel<2>, dim3(grid), dim3(256), 0, st, p);
-        else if (nc <= 4) hipLaunchKernelGGL(gemv5_kernel<4>, dim3(grid), dim3(256), 0, st, p);
-        else hipLaunchKernelGGL(gemv5_kernel<8>, dim3(grid), dim3(256), 0, st, p);
+        if (nc == 1) { psk_note_kernel("gemv5_kernel<1>"); hipLaunchKernelGGL(gemv5_kernel<1>, dim3(grid), dim3(256), 0, st, p); }
+        else if (nc == 2) { psk_note_kernel("gemv5_kernel<2>"); hipLaunchKernelGGL(gemv5_kernel<2>, dim3(grid), dim3(256), 0, st, p); }
+        else if (nc <= 4) { psk_note_kernel("gemv5_kernel<4>"); hipLaunchKernelGGL(gemv5_kernel<4>, dim3(grid), dim3(256), 0, st, p); }
+        else { psk_note_kernel("gemv5_kernel<8>"); hipLaunchKernelGGL(gemv5_kernel<8>, dim3(grid), dim3(256), 0, st, p); }
     }
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
@@ -268,10 +268,10 @@ int psk_gemv6(hipStream_t st, int n_cu, const psk_gemv6_args &a, ps_act act, int
         const int nc = (int)(bs - c0 < 8 ? bs - c0 : 8);
         p.aq = act.qs + c0 * K; p.ad = act.d + c0 * (K / 256);
         p.out = a.out + c0 * a.ldo; p.residual = a.residual ? a.residual + c0 * a.ldo : nullptr; p.nc = nc;
-        if (nc == 1) hipLaunchKernelGGL(gemv6_kernel<1>, dim3(grid), dim3(256), 0, st, p);
-        else if (nc == 2) hipLaunchKernelGGL(gemv6_kernel<2>, dim3(grid), dim3(256), 0, st, p);
-        else if (nc <= 4) hipLaunchKernelGGL(gemv6_kernel<4>, dim3(grid), dim3(256), 0, st, p);
-        else hipLaunchKernelGGL(gemv6_kernel<8>, dim3(grid), dim3(256), 0, st, p);
+        if (nc == 1) { psk_note_kernel("gemv6_kernel<1>"); hipLaunchKernelGGL(gemv6_kernel<1>, dim3(grid), dim3(256), 0, st, p); }
+        else if (nc == 2) { psk_note_kernel("gemv6_kernel<2>"); hipLaunchKernelGGL(gemv6_kernel<2>, dim3(grid), dim3(256), 0, st, p); }
+        else if (nc <= 4) { psk_note_kernel("gemv6_kernel<4>"); hipLaunchKernelGGL(gemv6_kernel<4>, dim3(grid), dim3(256), 0, st, p); }
+        else { psk_note_kernel("gemv6_kernel<8>"); hipLaunchKernelGGL(gemv6_kernel<8>, dim3(grid), dim3(256), 0, st, p); }
     }
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }

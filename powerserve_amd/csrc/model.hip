@@ -569,7 +569,12 @@ uint64_t ps_hip_model_weight_bytes_per_token(const ps_hip_model *m) { return m->
 // which = 1: only the gate/up launch of each layer (the dominant kernel).  Then the same number of empty launches to
 // expose the launch boundary.
 int ps_hip_model_bench_gemv(ps_hip_model *m, int reps, int which, double *seq_ms, double *null_ms, int *n_launches) {
+    return ps_hip_model_bench_matmul(m, reps, which, 1, seq_ms, null_ms, n_launches);
+}
+// the same replay with `bs` activation columns (bs = 128: the mat-muls of a prefill chunk, quantizer launches included)
+int ps_hip_model_bench_matmul(ps_hip_model *m, int reps, int which, int bs, double *seq_ms, double *null_ms, int *n_launches) {
     ps_hip_ctx *c = m->ctx;
+    if (bs < 1 || bs > m->max_batch) PS_FAIL(c, "bench_matmul: batch size out of range");
     const ps_llm_config &f = m->cfg;
     const int64_t dim = f.dim, kvd = f.kv_dim, hid = f.hidden_dim;
     hipEvent_t e0, e1;
@@ -586,28 +591,28 @@ int ps_hip_model_bench_gemv(ps_hip_model *m, int reps, int which, double *seq_ms
                 g.out[0] = m->q; g.out[1] = m->k; g.out[2] = m->v; g.ldo[0] = dim; g.ldo[1] = kvd; g.ldo[2] = kvd;
                 if (m->qwen2) { g.bias[0] = m->bq[L]; g.bias[1] = m->bk[L]; g.bias[2] = m->bv[L]; }
                 g.pro = 1; g.pro_x = m->x; g.pro_norm_w = m->attn_norm[L]; g.pro_eps = f.norm_eps;
-                if (mm(m, g, a1, dim, 1)) return 2;
+                if (mm(m, g, a1, dim, bs)) return 2;
                 if (count) launches += 1;
             }
             if (op) {
                 psk_gemv_args go{};
                 go.n_w = 1; go.w[0] = m->wo[L]; go.out[0] = m->hb; go.ldo[0] = dim; // (not into x: the replay must not drift)
                 go.pro = 2; go.pro_x = m->att;
-                if (mm(m, go, a1, dim, 1)) return 2;
+                if (mm(m, go, a1, dim, bs)) return 2;
                 if (count) launches += 1;
             }
             if (gu) {
                 psk_gemv_args gf{};
                 gf.n_w = 2; gf.w[0] = m->wg[L]; gf.w[1] = m->wu[L]; gf.out[0] = m->g1; gf.out[1] = m->g1; gf.ldo[0] = hid; gf.ldo[1] = hid; gf.silu_pair = 1;
                 gf.pro = 1; gf.pro_x = m->x; gf.pro_norm_w = m->ffn_norm[L]; gf.pro_eps = f.norm_eps;
-                if (mm(m, gf, a1, dim, 1)) return 2;
+                if (mm(m, gf, a1, dim, bs)) return 2;
                 if (count) launches += 1;
             }
             if (dn) {
                 psk_gemv_args gd{};
                 gd.n_w = 1; gd.w[0] = m->wd[L]; gd.out[0] = m->att; gd.ldo[0] = dim;
                 gd.pro = 2; gd.pro_x = m->g1;
-                if (mm(m, gd, a2, hid, 1)) return 2;
+                if (mm(m, gd, a2, hid, bs)) return 2;
                 if (count) launches += 1;
             }
         }
@@ -615,7 +620,7 @@ int ps_hip_model_bench_gemv(ps_hip_model *m, int reps, int which, double *seq_ms
             psk_gemv_args gl{};
             gl.n_w = 1; gl.w[0] = m->output ? m->output : m->token_embd; gl.out[0] = m->logits; gl.ldo[0] = f.vocab_size;
             gl.pro = 1; gl.pro_x = m->x; gl.pro_norm_w = m->output_norm; gl.pro_eps = f.norm_eps;
-            if (mm(m, gl, a1, dim, 1)) return 2;
+            if (mm(m, gl, a1, dim, bs)) return 2;
             if (count) launches += 1;
         }
         return 0;

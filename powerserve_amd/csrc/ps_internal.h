@@ -178,3 +178,7 @@ int psk_gemv(hipStream_t st, int n_cu, const psk_gemv_args &a, ps_act act, int v
 // second-generation single-column Q4_K mat-vec (k_gemv4.hip); -1: not covered, the caller falls back
 int psk_gemv4(hipStream_t st, int n_cu, const psk_gemv_args &a, ps_act act, int64_t K);
 unsigned long long *psk_gemv_dbg_buf(int epi, int pro); // timeline slot armed for this (epilogue, prologue) pair, or null
+// the template instance the last quantized mat-vec / mat-mul launch of this process used (rocprofv3's kernel name): bench.py's
+// roofline names the kernel that RAN, not the one it expects
+void psk_note_kernel(const char *fmt, ...);
+const char *psk_last_kernel();

@@ -25,6 +25,8 @@ PRESETS = {
     "llama-3.2-1b": ("llama", 2048, 8192, 16, 32, 8, 64, 128256, 5e5, 0, True, 1e-5),
     "llama-3.1-8b": ("llama", 4096, 14336, 32, 32, 8, 128, 128256, 5e5, 0, False, 1e-5),
     "llama-8b-dims-4l": ("llama", 4096, 14336, 4, 32, 8, 128, 4096, 5e5, 0, False, 1e-5),  # kernel diagnostics
+    "llama-1b-dims-2l": ("llama", 2048, 8192, 2, 32, 8, 64, 4096, 5e5, 0, True, 1e-5),      # config 2's layer shape (Q4_0), small vocabulary
+    "qwen2-0.5b-dims-2l": ("qwen2", 896, 4864, 2, 14, 2, 64, 4096, 1e6, 2, True, 1e-6),     # config 1's layer shape (Q8_0: 896 and 4864 are not multiples of 256)
     # small shapes for parity tests (finish in seconds on the CPU oracle)
     "tiny-llama": ("llama", 256, 512, 2, 4, 2, 64, 512, 1e4, 0, False, 1e-5),
     "tiny-qwen2": ("qwen2", 256, 512, 2, 4, 2, 64, 512, 1e6, 2, True, 1e-6),

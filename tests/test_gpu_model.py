@@ -176,6 +176,41 @@ def test_decode_attention_long_cache_matches_oracle(ctx, oracle, tmp_path, prese
     om.close()
 
 
+@pytest.mark.parametrize("preset,wt,P", [("llama-8b-dims-4l", 12, 161), ("llama-8b-dims-4l", 1015, 140), ("llama-1b-dims-2l", 2, 300), ("qwen2-0.5b-dims-2l", 8, 300)])
+def test_real_layer_shapes_match_oracle(ctx, oracle, tmp_path, preset, wt, P):
+    """The BASELINE.json configurations at their REAL layer dimensions (a few layers, a 4096-token vocabulary): Llama-3.1-8B
+    (4096 / 14336, 32 / 8 heads of 128; pure Q4_K and the Q4_K_M mix), Llama-3.2-1B (2048 / 8192, 32 / 8 heads of 64; Q4_0) and
+    Qwen2-0.5B (896 / 4864, 14 / 2 heads of 64, biases, NEOX; Q8_0) — prefill in chunks of 128 (a full chunk and a ragged one),
+    greedy ids through the captured step, and every step's logits through eager single-token forwards, bit-exact against
+    the oracle.  These are the shapes the production kernels are dispatched for (gemv4, gemm4k, attn_decode2, ...)."""
+    from oracle import binding as B
+    from powerserve_amd import hip, synth
+    d = str(tmp_path / "m")
+    mj = synth.write_model_dir(d, preset, wt, n_ctx=512, seed=77)
+    cfg = B.make_config(mj["llm_config"])
+    om = oracle.model(cfg, mj["model_arch"], load_tensors(os.path.join(d, "ggml/weights.gguf")), n_threads=min(32, os.cpu_count() or 8))
+    prompt = np.random.default_rng(4).integers(0, cfg.vocab_size, P)
+    steps = 8
+    want_ids, want_logits, *_ = om.generate(prompt, 128, steps, want_logits=True)
+    gm = hip.Model(ctx, d, max_batch=128, n_ctx=512)
+    assert np.array_equal(gm.generate(prompt, 128, steps), want_ids)
+    gm.kv_rollback(steps)
+    cur = int(prompt[-1])
+    for s in range(steps):
+        lg, am = gm.forward([cur], [gm.position], lm_head=True)
+        assert np.array_equal(np.asarray(lg[0]).view(np.uint32), np.asarray(want_logits[s]).view(np.uint32)), (s, rel_err(lg[0], want_logits[s]))
+        cur = int(want_ids[s])
+    # a batch with logits behind the prompt (the chunk kernels with lm_head)
+    om.rollback(steps)
+    gm.kv_rollback(steps)
+    toks = np.random.default_rng(5).integers(0, cfg.vocab_size, 9)
+    want = om.forward(toks, np.arange(P - 1, P + 8), True)
+    got, _ = gm.forward(toks, np.arange(P - 1, P + 8), lm_head=True)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), rel_err(got, want)
+    gm.close()
+    om.close()
+
+
 def test_tree_mask_plumbing(ctx, tmp_path):
     """The batch forward takes an optional [bs][bs] tree mask (speculative verify; the reference's CPU
     executor ignores mask objects, executor.cpp:210-224, so there is no CPU golden for a real tree).  A tree mask that
@@ -394,3 +429,21 @@ def test_fp16_kv_decode_mode_is_close_to_parity(ctx, tmp_path, preset, wt, n_pro
         assert int(am[0]) == int(got[s])
         cur = int(am[0])
     m.close()
+
+
+def test_bench_runs_under_rccl_world_of_one(tmp_path):
+    """bench.py --force-dist: torch.distributed / RCCL is initialised for a single rank and the prompt broadcast, the id
+    all-gather and the max-over-ranks reduction run on the GPU (the N > 1 code path, loaded under the driver
+    even where only one GPU is there).  A small model keeps it to seconds; the JSON line must carry the contract's fields."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TMPDIR=str(tmp_path), HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29671", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--force-dist", "--steps", "2", "--warmup", "1", "--preset", "small-llama-hs128", "--wtype", "Q4_K",
+                        "--prompt-len", "40", "--n-ctx", "128", "--batch", "32", "--no-cpu-baseline", "--no-kv-f16", "--no-graph-path"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["steps"] == 2 and line["replicas_agree"] is True and line["value"] > 0
+    assert line["roofline"]["kernel"] and "prefill_roofline" in line

@@ -122,6 +122,48 @@ def test_mul_mat_q4k_chunk_on_matrix_cores(ctx, oracle, hip, K, N, bs):
     W.free()
 
 
+def q4k_extreme_blocks(rng, N, K):
+    """Random Q4_K rows with the corner cases the random generator never draws (synth.random_blocks: scales 8..63, mins tied to
+    the scales) planted in every row: block_q4_K = d, dmin (fp16), scales[12] (6-bit scale / min pairs), qs[128]."""
+    from powerserve_amd import synth
+    w = synth.random_blocks(rng, 12, N, K).reshape(N, K // 256, 144)
+    f16 = lambda v: np.frombuffer(np.float16(v).tobytes(), dtype=np.uint8)
+    nb = K // 256
+    for r in range(N):
+        b = w[r]
+        b[(r + 0) % nb, 4:8] = 0x00; b[(r + 0) % nb, 8:12] = 0xFF; b[(r + 0) % nb, 12:16] = 0xF0   # every scale 0, every min 63
+        if nb > 1: b[(r + 1) % nb, 0:2] = f16(0.0)                                               # d = 0
+        if nb > 2: b[(r + 2) % nb, 2:4] = f16(0.0)                                               # dmin = 0
+        if nb > 3: b[(r + 3) % nb, 4:16] = 0xFF; b[(r + 3) % nb, 16:] = 0xFF                      # scales, mins 63, every nibble 15
+        if nb > 4: b[(r + 4) % nb, 4:16] = 0x00                                                  # every scale and min 0
+        if nb > 5: b[(r + 5) % nb, 0:2] = f16(-0.0); b[(r + 5) % nb, 2:4] = f16(-1.5)             # d = -0, negative dmin
+        if nb > 6: b[(r + 6) % nb, 0:2] = np.array([1, 0], dtype=np.uint8); b[(r + 6) % nb, 16:] = 0x00  # fp16 subnormal d, every nibble 0
+        if nb > 7: b[(r + 7) % nb, 0:2] = f16(-3.0); b[(r + 7) % nb, 4:8] = 0x3F                  # negative d, scales 63 / 0 mixed
+    return w.reshape(-1)
+
+
+@pytest.mark.parametrize("K,N,bs", [(4096, 512, 1), (14336, 64, 1), (1024, 2056, 1), (2048, 96, 1), (4096, 160, 2), (1024, 64, 5), (2048, 64, 12), (1024, 8224, 16),
+                                    (1024, 96, 40), (4096, 256, 128), (2048, 32, 130)])
+def test_mul_mat_q4k_extreme_blocks(ctx, oracle, hip, K, N, bs):
+    """Q4_K corner cases through the single-column producer / consumer mat-vec (gemv4, bs = 1), the narrow (2..16 columns) and
+    the wide matrix-core mat-muls: scale 0 with min 63, d = 0, dmin = 0, every field at its maximum, all zero, d = -0 and
+    negative dmin, an fp16 subnormal d — against quants at +-127, an all-zero super-block and a huge one. Bit for bit."""
+    rng = np.random.default_rng(K + N + bs + 44)
+    w = q4k_extreme_blocks(rng, N, K)
+    x = (rng.standard_normal((bs, K)) * rng.uniform(0.1, 30.0, (bs, 1))).astype(np.float32)
+    x[0, 0:512] = np.where(rng.random(512) < 0.5, 1.0, -1.0) * 7.0   # every quant of these super-blocks at +-127
+    x[bs - 1, 256:512] = 0.0                                          # an all-zero super-block (Q8_K d = 0)
+    x[bs // 2, 512:768] *= 1e4
+    want = oracle.mul_mat(12, w, K, N, x)
+    assert np.isfinite(want).all()
+    W = ctx.upload_weight(12, w, K, N)
+    dx, dy = ctx.to_device(x), ctx.empty((bs, N))
+    ctx.check(ctx.L.ps_hip_mul_mat(ctx.h, C.byref(dy.tensor()), C.byref(W.tensor()), C.byref(dx.tensor())))
+    got = dy.numpy()
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (rel_err(got, want), np.argwhere(got != want)[:8])
+    W.free()
+
+
 @pytest.mark.parametrize("K,N,bs", [(4096, 512, 128), (1024, 96, 120), (14336, 64, 113), (2048, 8224, 40), (1024, 64, 160), (1024, 32, 17), (2048, 160, 9)])
 def test_mul_mat_q6k_chunk_on_matrix_cores(ctx, oracle, hip, K, N, bs):
     """Q6_K weights (attn_v, ffn_down, output of the Q4_K_M / Q5_K_M mixes), batches from 9 columns: gemm6k_kernel in

@@ -134,3 +134,15 @@ def test_tree_forward_restatement_vs_reference_operators(oracle, ref, tmp_path, 
     assert np.array_equal(bits(causal[0]), bits(om.forward_tree(toks, rope, TREE, None, True, advance=False)[0]))
     assert not any(np.array_equal(causal[i], got[i]) for i in range(12))
     om.close()
+
+
+def test_q4k_corner_case_blocks(oracle, ref):
+    """scale 0 / min 63, d = 0, dmin = 0, every field at its maximum, -0, subnormal d (tests/test_gpu_ops.py plants them for the
+    GPU kernels): the restatement agrees with the reference on them, too"""
+    from test_gpu_ops import q4k_extreme_blocks
+    for K, N, bs in [(4096, 48, 1), (2048, 32, 5), (1024, 32, 3)]:
+        rng = np.random.default_rng(K + N + bs + 44)
+        w = q4k_extreme_blocks(rng, N, K)
+        x = (rng.standard_normal((bs, K)) * rng.uniform(0.1, 30.0, (bs, 1))).astype(np.float32)
+        x[0, 0:512] = np.where(rng.random(512) < 0.5, 1.0, -1.0) * 7.0
+        assert np.array_equal(bits(ref.mul_mat(12, w, K, N, x)), bits(oracle.mul_mat(12, w, K, N, x)))
