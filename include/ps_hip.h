@@ -159,6 +159,7 @@ int ps_hip_model_create(ps_hip_ctx *ctx, const ps_model_desc *desc, ps_hip_model
 void ps_hip_model_destroy(ps_hip_model *m);
 /* KVCacheInterface bookkeeping (core/kv_cache.hpp:97-163) */
 size_t ps_hip_model_kv_position(const ps_hip_model *m);
+int ps_hip_model_max_batch(const ps_hip_model *m); /* widest forward the model's buffers hold (ps_model_desc::max_batch) */
 int ps_hip_model_kv_truncate(ps_hip_model *m, size_t n_tokens);
 int ps_hip_model_kv_advance(ps_hip_model *m, size_t n_tokens); /* after an op-by-op forward through the ps_hip_* operators */
 int ps_hip_model_kv_rollback(ps_hip_model *m, size_t n_tokens);

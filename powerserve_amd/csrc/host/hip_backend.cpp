@@ -184,6 +184,8 @@ bool HIPBackend::match_canonical(std::vector<std::shared_ptr<OpNode>> &ops, Lowe
     const std::vector<int> *pos = nullptr;
     const CausalAttentionMask *mask = nullptr;
     const float want_scale = 1.0f / sqrtf((float)m_config.head_size);
+    const size_t hs = m_config.head_size, n_head = m_config.n_heads, n_head_kv = m_config.n_kv_heads, n_ctx = m_config.seq_len, kv_gqa = hs * n_head_kv, es = sizeof(float);
+    if (bs > (size_t)ps_hip_model_max_batch(m_model)) return false; // (run op by op: the lowered forward's buffers hold max_batch columns)
     auto mat_mul = [&](const void *w, TensorNode *act) -> TensorNode * { // MAT_MUL(weight w, activation act) -> its output node
         OpNode *o = c.take(OpType::MAT_MUL);
         return (o && handle_of(o->in[0]) == w && o->in[1] == act) ? o->out[0] : nullptr;
@@ -205,7 +207,8 @@ bool HIPBackend::match_canonical(std::vector<std::shared_ptr<OpNode>> &ops, Lowe
         TensorNode *q = mat_mul(W.wq, n1); if (!q || !(q = add_bias(q, W.bq))) return false;
         TensorNode *k = mat_mul(W.wk, n1); if (!k || !(k = add_bias(k, W.bk))) return false;
         TensorNode *v = mat_mul(W.wv, n1); if (!v || !(v = add_bias(v, W.bv))) return false;
-        for (int r = 0; r < 2; r++) { // rope(q view), rope(k view): same positions, the model's rope configuration
+        TensorNode *roped[2] = {nullptr, nullptr};
+        for (int r = 0; r < 2; r++) { // rope(q view), rope(k view): views of q / k split into heads, same positions, the model's rope configuration
             OpNode *o = c.take(OpType::ROPE);
             if (!o) return false;
             const auto &rp = o->get_params<RopeParams>();
@@ -213,21 +216,52 @@ bool HIPBackend::match_canonical(std::vector<std::shared_ptr<OpNode>> &ops, Lowe
             if (rp.pos != *pos || rp.pos.size() != bs || rp.rope_cfg.n_dims != m_config.rope_config.n_dims || rp.rope_cfg.rope_type != m_config.rope_config.rope_type ||
                 rp.rope_cfg.freq_base != m_config.rope_config.freq_base || rp.rope_cfg.freq_scale != m_config.rope_config.freq_scale)
                 return false;
+            const TensorNode *src = o->in[0];
+            if (!src || src->alias_of != (r == 0 ? q : k) || src->m_shape != Shape{hs, r == 0 ? n_head : n_head_kv, bs, 1}) return false;
+            roped[r] = o->out[0];
         }
-        // KV store: transpose(v), view(k cache), copy, view(v cache), copy
-        if (!c.take(OpType::TRANSPOSE) || !c.take(OpType::VIEW) || !c.take(OpType::COPY) || !c.take(OpType::VIEW) || !c.take(OpType::COPY)) return false;
+        // The attention core is lowered to the fused kernels, which hard-wire what NormAttention::build wires: every operand,
+        // view offset / stride, permutation and n_kv is compared — a graph that keeps the op order but reads another window of
+        // the cache, another n_kv or other strides runs op by op instead of being silently replaced by the stock forward.
+        const size_t cur_pos = (size_t)(*pos)[0], n_kv = (size_t)pos->back() + 1;
+        const void *kc_dev = ps_hip_model_k_cache(m_model, (int)L), *vc_dev = ps_hip_model_v_cache(m_model, (int)L);
+        auto view_of = [&](const void *cache, const Shape &shape, const Shape &stride, size_t offset) -> TensorNode * {
+            OpNode *o = c.take(OpType::VIEW);
+            if (!o) return nullptr;
+            const TensorNode *t = o->out[0];
+            const auto &vp = o->get_params<ViewParams>();
+            return (t->alias_of && handle_of(t->alias_of) == cache && t->m_shape == shape && vp.stride == stride && vp.offset == offset) ? o->out[0] : nullptr;
+        };
+        // KV store: transpose(v), view(k cache rows cur_pos ..), copy, view(v cache column cur_pos ..), copy
+        OpNode *tr = c.take(OpType::TRANSPOSE);
+        if (!tr || tr->in[0] != v) return false;
+        TensorNode *kc = view_of(kc_dev, Shape{bs * kv_gqa, 1, 1, 1}, Shape{es, es * bs * kv_gqa, es * bs * kv_gqa, es * bs * kv_gqa}, es * kv_gqa * cur_pos);
+        OpNode *cpk = kc ? c.take(OpType::COPY) : nullptr;
+        if (!cpk || cpk->in[0] != kc || cpk->in[1] != roped[1]) return false;
+        TensorNode *vc = view_of(vc_dev, Shape{bs, kv_gqa, 1, 1}, Shape{es, n_ctx * es, n_ctx * es * kv_gqa, n_ctx * es * kv_gqa}, es * cur_pos);
+        OpNode *cpv = vc ? c.take(OpType::COPY) : nullptr;
+        if (!cpv || cpv->in[0] != vc || cpv->in[1] != tr->out[0]) return false;
         // scores, mask, softmax, V.p, merge heads
-        if (!c.take(OpType::PERMUTE) || !c.take(OpType::VIEW) || !c.take(OpType::MAT_MUL)) return false;
+        const Shape heads_perm{0, 2, 1, 3};
+        OpNode *qp = c.take(OpType::PERMUTE);
+        if (!qp || qp->in[0] != roped[0] || qp->get_params<PermuteParams>().axes != heads_perm) return false;
+        TensorNode *kv = view_of(kc_dev, Shape{hs, n_kv, n_head_kv, 1}, Shape{es, es * kv_gqa, es * hs, es * hs * n_head_kv}, 0);
+        OpNode *kq = kv ? c.take(OpType::MAT_MUL) : nullptr;
+        if (!kq || kq->in[0] != kv || kq->in[1] != qp->out[0]) return false;
         OpNode *gm = c.take(OpType::GET_MASK);
         if (!gm) return false;
         const auto &mp = gm->get_params<GetMaskParams>();
-        if (mp.pos != *pos) return false;
+        if (mp.pos != *pos || gm->out[0]->m_shape != Shape{n_kv, bs, 1, 1}) return false;
         mask = mp.mask;
         OpNode *sm = c.take(OpType::SOFTMAX_EXT);
-        if (!sm || sm->get_params<SoftmaxExtParams>().scale != want_scale || sm->get_params<SoftmaxExtParams>().max_bias != 0.0f) return false;
-        if (!c.take(OpType::VIEW) || !c.take(OpType::MAT_MUL) || !c.take(OpType::PERMUTE)) return false;
+        if (!sm || sm->in[0] != kq->out[0] || sm->in[1] != gm->out[0] || sm->get_params<SoftmaxExtParams>().scale != want_scale || sm->get_params<SoftmaxExtParams>().max_bias != 0.0f) return false;
+        TensorNode *vv = view_of(vc_dev, Shape{n_kv, hs, n_head_kv, 1}, Shape{es, es * n_ctx, es * n_ctx * hs, es * n_ctx * hs * n_head_kv}, 0);
+        OpNode *pv = vv ? c.take(OpType::MAT_MUL) : nullptr;
+        if (!pv || pv->in[0] != vv || pv->in[1] != sm->out[0]) return false;
+        OpNode *mg = c.take(OpType::PERMUTE);
+        if (!mg || mg->in[0] != pv->out[0] || mg->get_params<PermuteParams>().axes != heads_perm) return false;
         OpNode *ct = c.take(OpType::CONT);
-        if (!ct) return false;
+        if (!ct || ct->in[0] != mg->out[0] || ct->out[0]->m_shape != Shape{hs * n_head, bs, 1, 1}) return false;
         TensorNode *o = mat_mul(W.wo, ct->out[0]);
         OpNode *res = c.take(OpType::ADD);
         if (!o || !res || res->in[0] != x || res->in[1] != o) return false;
@@ -254,6 +288,9 @@ bool HIPBackend::match_canonical(std::vector<std::shared_ptr<OpNode>> &ops, Lowe
     }
     if (!pos) return false;
     for (size_t i = 1; i < bs; i++) if ((*pos)[i] != (*pos)[0] + (int)i) return false; // the KV append is one contiguous block
+    // the lowered forward appends at slot pos[0] and HIPKV::advance then adds bs to the cache position: the two agree only when
+    // the graph was built for the current position (a re-run of an earlier position goes op by op, which writes where it is told)
+    if ((size_t)(*pos)[0] != m_kv->position()) return false;
     out.tokens.assign(tokens.begin(), tokens.end());
     out.pos.assign(pos->begin(), pos->end());
     out.tree.clear();

@@ -367,6 +367,7 @@ void ps_hip_model_destroy(ps_hip_model *m) {
 }
 
 size_t ps_hip_model_kv_position(const ps_hip_model *m) { return m->position; }
+int ps_hip_model_max_batch(const ps_hip_model *m) { return m->max_batch; }
 static void unmask_range(ps_hip_model *m, size_t from, size_t n);
 // slots at or behind the position are never consulted through the visibility table (the causal / tree mask governs them)
 // and KVCache::advance_tokens / append un-hides what it walks over (core/kv_cache.hpp:249-255): a rollback or truncate

@@ -28,7 +28,7 @@ EXPORTS = [
     "ps_hip_weight_dtype", "ps_hip_vec_dot_type", "ps_hip_row_size", "ps_hip_quantize_act", "ps_hip_mul_mat",
     "ps_hip_rms_norm", "ps_hip_rope", "ps_hip_softmax_ext", "ps_hip_add", "ps_hip_dup", "ps_hip_silu_hadamard",
     "ps_hip_get_embedding", "ps_hip_get_mask", "ps_hip_argmax", "ps_hip_model_create", "ps_hip_model_destroy",
-    "ps_hip_model_kv_position", "ps_hip_model_kv_truncate", "ps_hip_model_kv_advance", "ps_hip_model_kv_rollback", "ps_hip_model_kv_move",
+    "ps_hip_model_kv_position", "ps_hip_model_max_batch", "ps_hip_model_kv_truncate", "ps_hip_model_kv_advance", "ps_hip_model_kv_rollback", "ps_hip_model_kv_move",
     "ps_hip_model_forward", "ps_hip_model_decode_greedy", "ps_hip_model_logits", "ps_hip_model_scratch", "ps_hip_model_k_cache",
     "ps_hip_model_v_cache", "ps_hip_model_weight_bytes_per_token", "ps_hip_model_set_mode", "ps_hip_model_bench_gemv", "ps_hip_model_bench_matmul", "ps_hip_debug_timeline", "ps_hip_last_matmul_kernel", "ps_hip_debug_set", "ps_hip_model_forward_tree", "ps_hip_model_forward_lowered", "ps_hip_model_kv_mask",
 ]
