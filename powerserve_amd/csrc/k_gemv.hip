@@ -935,6 +935,17 @@ bool launch_g3_wt(hipStream_t st, int n_cu, const GemvParams &p, int epi, int pr
     if (n_units % 4 != 0) return false; // the consumer tests row boundaries once per four units
     const size_t rec = sizeof(typename RecOf<WT>::T) + 2; // (+ the Q8_0 / Q4_0 scale plane)
     if ((size_t)p.col_bytes + 2 * 56 * 64 * rec > 150 * 1024) return false;
+    if constexpr (WT != PS_Q4_K) { // (Q4_K single columns go to gemv4, k_gemv4.hip)
+        // eight-wave workgroups (seven producers + one chain wave) for the small matrices of the 1B / 0.5B shapes: a kernel
+        // boundary behind 512-thread workgroups is ~1.4 us shorter than behind 1024-thread ones and there are only a few units per CU
+        static const int small_wg = getenv("PS_G3_SMALL") ? atoi(getenv("PS_G3_SMALL")) : 1;
+        if (small_wg && p.K <= 8 * 4 * 256) {
+            if (p.K <= 8 * 1 * 256) launch_g3_ep<WT, 4, 7, 1>(st, n_cu, p, epi, pro);
+            else if (p.K <= 8 * 2 * 256) launch_g3_ep<WT, 4, 7, 2>(st, n_cu, p, epi, pro);
+            else launch_g3_ep<WT, 4, 7, 4>(st, n_cu, p, epi, pro);
+            return true;
+        }
+    }
     if (p.K <= 14 * 2 * 256) { launch_g3_ep<WT, 4, 14, 2>(st, n_cu, p, epi, pro); return true; } // prologue tiles on the 14 producers
     if (p.K <= 14 * 4 * 256) { launch_g3_ep<WT, 4, 14, 4>(st, n_cu, p, epi, pro); return true; }
     return false;

@@ -56,6 +56,38 @@ def test_graph_path_equals_fused_equals_oracle(oracle, tmp_path, preset, wt):
     hm.close(); om.close()
 
 
+def test_plan_does_not_lower_what_the_fused_forward_cannot_do(oracle, tmp_path):
+    """HIPBackend::plan lowers a graph only when the fused forward does exactly what the graph says (advisor, round 2): a
+    forward whose first position is NOT the cache position (an earlier position run again) keeps the canonical op order
+    but appends elsewhere than HIPKV::advance assumes — it must run op by op, write where it is told, and still equal the
+    oracle; a batch wider than the model's buffers must run op by op instead of aborting."""
+    from oracle import binding as B
+    from powerserve_amd import host, synth
+    d = str(tmp_path / "m")
+    mj = synth.write_model_dir(d, "tiny-llama", 12, n_ctx=96, seed=6)
+    cfg = B.make_config(mj["llm_config"])
+    om = oracle.model(cfg, mj["model_arch"], load_tensors(os.path.join(d, "ggml/weights.gguf")), n_threads=4)
+    hm = host.HostModel(d, 0, max_batch=8)
+    toks = np.random.default_rng(2).integers(0, cfg.vocab_size, 24)
+    a = hm.forward(toks[:8], np.arange(8), True)
+    b = om.forward(toks[:8], np.arange(8), True)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    low0 = hm.plan_stats()[1]
+    assert low0 == 1
+    # positions 2..4 once more while the cache stands at 8: same ops, different append slot
+    a = hm.forward(toks[8:11], np.arange(2, 5), True)
+    b = om.forward(toks[8:11], np.arange(2, 5), True)
+    assert hm.plan_stats()[1] == low0, "a graph for another cache position was lowered"
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    # wider than max_batch = 8
+    hm.reset(); om.reset()
+    a = hm.forward(toks[:12], np.arange(12), True)
+    b = om.forward(toks[:12], np.arange(12), True)
+    assert hm.plan_stats()[1] == low0, "a batch wider than the model's buffers was lowered"
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    hm.close(); om.close()
+
+
 def test_host_errors_surface(tmp_path):
     from powerserve_amd import host, synth
     d = str(tmp_path / "m")
