@@ -215,13 +215,14 @@ int ps_hip_debug_timeline(ps_hip_ctx *ctx, int key, uint64_t *host_out, int n_wo
  * tools/g4_variants.py).  Returns non-zero for an unknown key. */
 int ps_hip_debug_set(int key, int value);
 /* bit 0: 0 = hipGraph replay of the decode step (default), 1 = eager launches (rocprofv3 needs them);
- * bit 1: 1 = run the O / gate-up / down mat-vecs of a layer as ONE chained launch (device-wide barriers from relaxed
- * atomics between the phases; needs every CU for this process; same results bit for bit);
- * bit 2: 1 = single-token attention (scores, softmax, V.p) as ONE launch with a per-kv-head rendezvous instead of two
- * launches (same results bit for bit; measured equal in time; needs every workgroup of its grid resident);
+ * bits 1, 2: unused (round 1 / 2 experiments, removed);
  * bit 3: 1 = fp16-KV decode mode — NOT bit-exact: K and V are mirrored in fp16 as they are appended and the
  * single-token attention reads only the mirrors (half the KV bytes) with a split-KV online soft-max; prefill, batches and
- * tree verify keep reading the FP32 caches.  Must be switched on while the cache is empty (position 0). */
+ * tree verify keep reading the FP32 caches.  Must be switched on while the cache is empty (position 0).;
+ * bit 4: 1 = single-token attention as TWO launches (scores, then soft-max + V.p) instead of the one-launch form
+ * (attn_decode2_kernel: scores exchanged inside the launch; it needs every workgroup of its grid resident, its wait is bounded,
+ * and a wait that gives up is reported as an error by the forward that hit it and switches this bit on).  Same results bit for
+ * bit.  The environment variable PS_HIP_MODE_OR is OR-ed into every mode (A/B runs of unmodified drivers). */
 int ps_hip_model_set_mode(ps_hip_model *m, int mode);
 
 #ifdef __cplusplus

@@ -26,6 +26,13 @@ void HIPSpecBackend::forward_tree(const std::vector<int32_t> &tokens, const std:
     // advance = 0: the reference's forward followed by rollback_tokens(draft_batch_size) (spec_model.hpp:98-102)
     check(ps_hip_model_forward_tree(m.backend().m_model, tokens.data(), (int)tokens.size(), positions.data(), mask.data(), 1, argmax.data(), 0), "tree verify");
 }
+bool HIPSpecBackend::tree_logits(size_t n, std::vector<float> &logits) {
+    logits.resize(n * vocab_size());
+    check(ps_hip_memcpy_d2h(m.backend().m_ctx, logits.data(), ps_hip_model_logits(m.backend().m_model), logits.size() * 4), "tree logits copy");
+    return true;
+}
+size_t HIPSpecBackend::vocab_size() const { return m.m_config->llm.vocab_size; }
+size_t HIPSpecBackend::n_ctx() const { return m.m_config->llm.seq_len; }
 void HIPSpecBackend::kv_mask(size_t slot, bool visible) { check(ps_hip_model_kv_mask(m.backend().m_model, slot, visible ? 1 : 0), "kv mask"); }
 void HIPSpecBackend::kv_move(size_t dst, size_t src) { check(ps_hip_model_kv_move(m.backend().m_model, dst, src), "kv move"); }
 void HIPSpecBackend::kv_advance(size_t n) { check(ps_hip_model_kv_advance(m.backend().m_model, n), "kv advance"); }
@@ -161,6 +168,7 @@ void TokenTree::draft(SpecBackend &draft_model, size_t batch_size, Token root_to
         expanded_last = u;
 
         const auto next = draft_sample(logits, smp.top_k, smp.temperature);
+        POWERSERVE_ASSERT(!next.empty(), "the draft sampler returned no candidate (top_k = 0 or an empty vocabulary)");
         const float floor = next[0].prob * smp.p_base;
         for (size_t i = 0; i < next.size(); i++) {
             const bool fill_only = i >= shape.max_fan_out || next[i].prob < floor;
@@ -174,7 +182,7 @@ void TokenTree::draft(SpecBackend &draft_model, size_t batch_size, Token root_to
     draft_model.kv_rollback(n_forwards);
 }
 
-void TokenTree::verify(SpecBackend &target_model, SpecBackend &draft_model, const std::vector<int32_t> &target_argmax, const std::function<void(Token)> &enqueue) {
+void TokenTree::verify(SpecBackend &target_model, SpecBackend &draft_model, const std::function<Token(int)> &choose, const std::function<void(Token)> &enqueue) {
     POWERSERVE_ASSERT(target_model.kv_position() == draft_model.kv_position());
     m_stat.n_iterations++;
     const size_t staging = target_model.kv_position(); // the tree forward left node u's KV in target slot staging + u
@@ -193,7 +201,7 @@ void TokenTree::verify(SpecBackend &target_model, SpecBackend &draft_model, cons
             draft_model.kv_move((size_t)node.position, (size_t)node.cache_index);
             draft_model.kv_advance(1);
         }
-        const Token chosen = target_argmax[u];
+        const Token chosen = choose(u);
         enqueue(chosen);
         m_stat.n_generated_tokens++;
         const auto child = std::find_if(node.children.begin(), node.children.end(), [&](int v) { return m_nodes[v].token == chosen; });
@@ -203,11 +211,23 @@ void TokenTree::verify(SpecBackend &target_model, SpecBackend &draft_model, cons
     }
 }
 
-void TokenTree::iterate(SpecBackend &target_model, SpecBackend &draft_model, Token last, std::vector<Token> &out) {
-    draft(draft_model, m_config.draft_batch_size, last);
+void TokenTree::iterate(SpecBackend &target_model, SpecBackend &draft_model, Token last, std::vector<Token> &out, Sampler *sampler,
+                        const std::function<bool(Token)> &should_stop) {
+    draft(draft_model, m_config.draft_batch_size, last, should_stop);
     std::vector<int32_t> argmax;
     target_model.forward_tree(tokens(), positions(), attention_mask(), argmax);
-    verify(target_model, draft_model, argmax, [&](Token t) { out.push_back(t); });
+    if (!sampler) {
+        verify(target_model, draft_model, argmax, [&](Token t) { out.push_back(t); });
+        return;
+    }
+    std::vector<float> logits;
+    const size_t V = target_model.vocab_size();
+    if (V == 0 || !target_model.tree_logits(m_nodes.size(), logits)) POWERSERVE_ABORT("speculative verify with a sampler needs a target backend that returns the tree's logits");
+    verify(target_model, draft_model, [&](int u) {
+        ProbArray probs(std::span<const float>(logits.data() + (size_t)u * V, V)); // token_tree.cpp:214-216
+        sampler->apply(probs);
+        return probs.greedy_sample().token;
+    }, [&](Token t) { out.push_back(t); });
 }
 
 // ModelTokenIterator's prefill (model.hpp:117-150): everything but the last prompt token, no lm_head
@@ -222,18 +242,27 @@ static void prefill(Model &m, const std::vector<Token> &prompt, size_t batch_siz
     }
 }
 
-std::vector<Token> SpeculativeModel::generate(const std::vector<Token> &prompt, int steps, size_t batch_size) {
+std::vector<Token> SpeculativeModel::generate(const std::vector<Token> &prompt, int steps, size_t batch_size, Sampler *sampler,
+                                              const std::function<bool(Token)> &should_stop) {
     std::vector<Token> out;
     if (steps <= 0 || prompt.empty()) return out;
     prefill(*target_model, prompt, batch_size);
     prefill(*draft_model, prompt, batch_size);
     HIPSpecBackend target(*target_model), draft(*draft_model);
     Token last = prompt.back();
-    while ((int)out.size() < steps) {
-        token_tree.iterate(target, draft, last, out);
+    bool stopped = false;
+    while ((int)out.size() < steps && !stopped) {
+        // a tree needs draft_batch_size free slots behind the position in both caches: end the text instead of aborting
+        if (target.kv_position() + config.draft_batch_size > target.n_ctx() || draft.kv_position() + config.draft_batch_size > draft.n_ctx()) break;
+        const size_t from = out.size();
+        token_tree.iterate(target, draft, last, out, sampler, should_stop);
+        for (size_t i = from; i < out.size(); i++) {
+            if (sampler) sampler->accept(out[i]); // (the reference's iterator accepts each token as it is handed out)
+            if (should_stop && should_stop(out[i])) { out.resize(i + 1); stopped = true; break; }
+        }
         last = out.back();
     }
-    out.resize((size_t)steps);
+    if ((int)out.size() > steps) out.resize((size_t)steps);
     return out;
 }
 

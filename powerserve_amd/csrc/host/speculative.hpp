@@ -65,6 +65,11 @@ struct SpecBackend {
     virtual void kv_move(size_t dst_slot, size_t src_slot) = 0;
     virtual void kv_advance(size_t n) = 0;
     virtual void kv_rollback(size_t n) = 0;
+    // the logits [n][vocab] of the most recent forward_tree, for a verify that samples (token_tree.cpp:214-216); false: this
+    // backend only reports arg-max ids
+    virtual bool tree_logits(size_t n, std::vector<float> &logits) { (void)n; (void)logits; return false; }
+    virtual size_t vocab_size() const { return 0; }
+    virtual size_t n_ctx() const { return 0; } // 0: unknown
 };
 
 struct HIPSpecBackend final : SpecBackend {
@@ -78,6 +83,9 @@ struct HIPSpecBackend final : SpecBackend {
     void kv_move(size_t dst_slot, size_t src_slot) override;
     void kv_advance(size_t n) override;
     void kv_rollback(size_t n) override;
+    bool tree_logits(size_t n, std::vector<float> &logits) override;
+    size_t vocab_size() const override;
+    size_t n_ctx() const override;
 
 private:
     void check(int rc, const char *what);
@@ -126,10 +134,18 @@ struct TokenTree {
     std::vector<uint8_t> attention_mask() const; // [n][n]: node u sees its ancestors and itself
 
     void draft(SpecBackend &draft_model, size_t batch_size, Token root_token, const std::function<bool(Token)> &should_stop = {});
+    // choose(u): the token the target model's sampler picks from node u's logits (greedy: its arg-max)
+    void verify(SpecBackend &target_model, SpecBackend &draft_model, const std::function<Token(int)> &choose, const std::function<void(Token)> &enqueue);
     // target_argmax[u]: the target's greedy token after node u (from the tree forward)
-    void verify(SpecBackend &target_model, SpecBackend &draft_model, const std::vector<int32_t> &target_argmax, const std::function<void(Token)> &enqueue);
-    // one draft / tree-forward / verify round starting from `last`; emitted tokens are appended to `out`
-    void iterate(SpecBackend &target_model, SpecBackend &draft_model, Token last, std::vector<Token> &out);
+    void verify(SpecBackend &target_model, SpecBackend &draft_model, const std::vector<int32_t> &target_argmax, const std::function<void(Token)> &enqueue) {
+        verify(target_model, draft_model, [&](int u) { return (Token)target_argmax[(size_t)u]; }, enqueue);
+    }
+    // one draft / tree-forward / verify round starting from `last`; emitted tokens are appended to `out`.  sampler == nullptr:
+    // greedy through the device arg-max (4 bytes per node cross the bus).  Otherwise every node on the accepted path goes
+    // ProbArray -> sampler->apply -> greedy_sample exactly as token_tree.cpp:214-216 (the backend must provide tree_logits);
+    // the sampler's accept() is the caller's business, as in the reference (the iterator that pops the tokens calls it)
+    void iterate(SpecBackend &target_model, SpecBackend &draft_model, Token last, std::vector<Token> &out, Sampler *sampler = nullptr,
+                 const std::function<bool(Token)> &should_stop = {});
 
 private:
     int lca(int u, int v) const;
@@ -143,7 +159,11 @@ struct SpeculativeModel {
     SpeculativeModel(std::shared_ptr<Model> target, std::shared_ptr<Model> draft, const SpeculativeConfig &cfg = {})
         : target_model(std::move(target)), draft_model(std::move(draft)), config(cfg), token_tree(cfg) {}
     // prefill both models with all but the last prompt token, then draft / verify iterations until `steps` tokens exist
-    std::vector<Token> generate(const std::vector<Token> &prompt, int steps, size_t batch_size);
+    // sampler: the target's sampler chain (hparams); null or pure greedy (top_k = 1, no penalties): the device arg-max.  Generation
+    // ends early when the sampler's chain says so through should_stop (EOS without ignore_eos) or when the next tree would not
+    // fit the cache window (position + draft_batch_size > n_ctx): the tokens so far are returned
+    std::vector<Token> generate(const std::vector<Token> &prompt, int steps, size_t batch_size, Sampler *sampler = nullptr,
+                                const std::function<bool(Token)> &should_stop = {});
 };
 
 } // namespace powerserve

@@ -243,7 +243,6 @@ constexpr int PV_LPT  = (4 * PV_TILE / 4 + PV_NT - 1) / PV_NT; // float4 V loads
 // Exact softmax numerators of the r2 rows of (kv head kvh, column i) into LDS (pl[g][n_kv4]) and 1/sum per row (invs):
 // ggml_vec_soft_max_f32 (ggml.c:2831-2866).  All PV_NT threads; ends with the rows complete and invs visible after the
 // caller's next __syncthreads().
-template <bool COH = false>
 __device__ __forceinline__ void attn_softmax_rows(const psl_attn_args &a, const int i, const int kvh, const int r2, const int pos0, const int bs,
                                                   const int n_kv, float *pl, float (*redf)[PV_NW], double (*redd)[PV_NW], float *invs,
                                                   unsigned long long *dbg = nullptr) {
@@ -263,7 +262,7 @@ __device__ __forceinline__ void attn_softmax_rows(const psl_attn_args &a, const 
             for (int t = 0; t < EPT; t++) {
                 const int j = j0 + PV_NT * t;
                 const float *sp = a.scores + ((int64_t)i * a.n_heads + (int64_t)kvh * r2 + g) * a.n_ctx + j;
-                sv[g][t] = (g < r2 && j < n_kv) ? (COH ? coh_load_f(sp) : *sp) : 0.f;
+                sv[g][t] = (g < r2 && j < n_kv) ? *sp : 0.f;
             }
 #pragma unroll
         for (int t = 0; t < EPT; t++) {
@@ -415,137 +414,7 @@ __global__ __launch_bounds__(PV_NT) void attn_softmax_pv_kernel(psl_attn_args a)
     if (dbg) { dbg[10] = __builtin_amdgcn_s_memtime(); dbg[30] = __builtin_amdgcn_s_memrealtime(); }
 }
 
-// ---------------------------------------------------------------- single token: scores + softmax + V·p in ONE launch
-// The workgroups (channel group x, kv head) of attn_softmax_pv_kernel first compute the SCORES of a slice of the cached
-// positions (groups of 32 positions, group x + k * gridDim.x; a half-wave per position, ggml_vec_dot_f32's 32 chains and
-// GGML_F32x8_REDUCE exactly as attn_scores_kernel), publish them with write-through (sc1) stores, and meet the other
-// workgroups of their kv head at a ticket counter (relaxed agent-scope atomics; exactly gridDim.x arrivals per head and
-// launch, so a ticket's epoch is ticket / gridDim.x and nothing ever needs resetting).  Then every workgroup reads the
-// r2 score rows of its head with cache-bypassing loads and continues as attn_softmax_pv_kernel.  K, V and q are requested
-// together at t = 0: the V tile is in flight across the rendezvous.  One launch and one start-up instead of two; the
-// scores never make a kernel-boundary round trip.  Needs every workgroup of the grid resident (grid <= CUs, one 1024-thread
-// workgroup each): the spin is bounded and raises a flag (sync[31]) that the host turns into an error.
-constexpr int DA_RMAX = 4; // position groups per workgroup (n_ctx <= 32 * DA_RMAX * gridDim.x)
-template <int NV>
-__global__ __launch_bounds__(PV_NT) void attn_decode_kernel(psl_attn_args a) {
-    extern __shared__ __attribute__((aligned(16))) float pl[]; // [r2][n_ctx4] e_j, then [4][PV_VSTR] V tile
-    constexpr int hs = NV * 32;
-    const int dim = a.n_heads * hs, kvd = a.n_kv_heads * hs, r2 = a.n_heads / a.n_kv_heads;
-    const int kvh = blockIdx.y, pos0 = a.state->pos0;
-    const int n_kv = pos0 + 1, np = n_kv & ~31, n_kv4 = (n_kv + 3) & ~3;
-    float *vt = pl + (size_t)r2 * (((size_t)a.n_ctx + 3) & ~(size_t)3);
-    __shared__ float redf[R2MAX][PV_NW];
-    __shared__ double redd[R2MAX][PV_NW];
-    __shared__ float invs[R2MAX];
-
-    // ---- t = 0: q, this workgroup's K rows and the first V tile
-    const int c = threadIdx.x & 31, hw = threadIdx.x >> 5; // 32 half-waves: one cached position each per round
-    const float *qb = a.q + (int64_t)kvh * r2 * hs;
-    float qf[R2MAX][NV];
-#pragma unroll
-    for (int g = 0; g < R2MAX; g++)
-#pragma unroll
-        for (int m = 0; m < NV; m++) qf[g][m] = (g < r2) ? qb[g * hs + m * 32 + c] : 0.f;
-    float kf[DA_RMAX][NV];
-#pragma unroll
-    for (int rd = 0; rd < DA_RMAX; rd++) {
-        const int j     = ((int)blockIdx.x + rd * (int)gridDim.x) * 32 + hw;
-        const float *kr = a.k_cache + (int64_t)(j < n_kv ? j : 0) * kvd + kvh * hs;
-#pragma unroll
-        for (int m = 0; m < NV; m++) kf[rd][m] = kr[m * 32 + c];
-    }
-    const float *vbase = a.v_cache + ((int64_t)kvh * hs + blockIdx.x * 4) * a.n_ctx;
-    float4 ld[PV_LPT];
-    auto load_tile = [&](int t0) {
-#pragma unroll
-        for (int k = 0; k < PV_LPT; k++) {
-            const int f = threadIdx.x + PV_NT * k, row = f / (PV_TILE / 4), col = (f % (PV_TILE / 4)) * 4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row < 4 && t0 + col < n_kv4) v = *(const float4 *)(vbase + (int64_t)row * a.n_ctx + t0 + col);
-            ld[k] = v;
-        }
-    };
-    auto store_tile = [&]() {
-#pragma unroll
-        for (int k = 0; k < PV_LPT; k++) {
-            const int f = threadIdx.x + PV_NT * k, row = f / (PV_TILE / 4), col = (f % (PV_TILE / 4)) * 4;
-            if (row < 4) *(float4 *)(vt + row * PV_VSTR + col) = ld[k];
-        }
-    };
-    load_tile(0);
-
-    // ---- scores of this workgroup's positions, published write-through
-    float *sb = a.scores + (int64_t)kvh * r2 * a.n_ctx;
-#pragma unroll
-    for (int rd = 0; rd < DA_RMAX; rd++) {
-        const int j     = ((int)blockIdx.x + rd * (int)gridDim.x) * 32 + hw;
-        const bool live = j < n_kv;
-#pragma unroll
-        for (int g = 0; g < R2MAX; g++) {
-            if (g < r2) {
-                float s = 0.f;
-#pragma unroll
-                for (int m = 0; m < NV; m++) s = __fmaf_rn(kf[rd][m], qf[g][m], s); // sum = x*y + sum, x = K row (src0)
-                s = reduce_f32x8x4(s);
-                if (live && c == 0) coh_store_f(sb + (int64_t)g * a.n_ctx + j, s);
-            }
-        }
-    }
-    // ---- rendezvous of the gridDim.x workgroups of this kv head
-    __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): this wave's score stores have left (the V tile has landed, too)
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned *ctr = a.sync + 64 + kvh * 64; // one 256-byte stretch per kv head: the heads' tickets do not share a line
-        const unsigned G = gridDim.x;
-        const unsigned ticket = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned target = (ticket / G + 1u) * G;
-        int spins = 0;
-        while ((int)(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
-            __builtin_amdgcn_s_sleep(8);
-            if (++spins > (1 << 18)) { __hip_atomic_store(a.sync + 31, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; } // never hang the GPU
-        }
-    }
-    __syncthreads();
-
-    // ---- softmax numerators of the r2 rows (cache-bypassing score loads), then V·p as attn_softmax_pv_kernel
-    attn_softmax_rows<true>(a, 0, kvh, r2, pos0, 1, n_kv, pl, redf, redd, invs);
-    store_tile();
-    __syncthreads();
-    const int dl = (threadIdx.x >> 5) & 3, g = threadIdx.x >> 7;
-    const bool live = g < r2;
-    const float inv = live ? invs[g] : 0.f;
-    const float *pg = pl + (size_t)(live ? g : 0) * n_kv4;
-    const float *vr = vt + dl * PV_VSTR;
-    float acc = 0.f, out = 0.f;
-    for (int t0 = 0; t0 < n_kv; t0 += PV_TILE) {
-        const int tn = min(PV_TILE, np - t0);
-        if (t0 > 0) {
-            __syncthreads();
-            store_tile();
-            __syncthreads();
-        }
-        if (t0 + PV_TILE < n_kv) load_tile(t0 + PV_TILE);
-        if (live) {
-            int j = c;
-            for (; j + 7 * 32 < tn; j += 8 * 32) {
-                float v[8], e[8];
-#pragma unroll
-                for (int k = 0; k < 8; k++) { v[k] = vr[j + 32 * k]; e[k] = pg[t0 + j + 32 * k]; }
-#pragma unroll
-                for (int k = 0; k < 8; k++) acc = __fmaf_rn(v[k], __fmul_rn(e[k], inv), acc);
-            }
-            for (; j < tn; j += 32) acc = __fmaf_rn(vr[j], __fmul_rn(pg[t0 + j], inv), acc);
-            if (t0 + PV_TILE >= n_kv) {
-                float sres = reduce_f32x8x4(acc);
-                for (int jj = np; jj < n_kv; jj++) sres = __fadd_rn(sres, __fmul_rn(vr[jj - t0], __fmul_rn(pg[jj], inv)));
-                out = sres;
-            }
-        }
-    }
-    if (live && c == 0) a.att[((int64_t)kvh * r2 + g) * hs + blockIdx.x * 4 + dl] = out;
-}
-
-// ---------------------------------------------------------------- single token, ONE launch, second generation
+// ---------------------------------------------------------------- single token: scores + soft-max + V.p in ONE launch
 // attn_decode2_kernel: K·q, soft-max and V·p of one cached token in one launch whose critical path is
 //   q / K landed -> scores -> ONE exchange -> max -> exp -> sum -> 17 dependent matrix instructions -> reduce.
 // What the round-2 timeline of the two launches showed to be waste is gone (profiles/r02_attention_timeline.txt):
@@ -1490,26 +1359,7 @@ bool psl_attn_decode_f16(hipStream_t st, const psl_attn_args &a) {
     return true;
 }
 
-// single token, one launch (attn_decode_kernel); false: not covered, the caller launches scores + softmax/V·p
-bool psl_attn_decode(hipStream_t st, int n_cu, const psl_attn_args &a) {
-    const int gx = a.head_size / 4, r2 = a.n_heads / a.n_kv_heads;
-    if (!a.sync || a.tree || a.head_size % 32 || a.head_size > 128 || r2 > R2MAX) return false;
-    if (gx * a.n_kv_heads > n_cu || a.n_kv_heads > 30) return false;  // every workgroup resident; ticket lines per head
-    if ((a.n_ctx + 31) / 32 > DA_RMAX * gx) return false;              // position groups per workgroup
-    const size_t lds = psl_attn_softmax_pv_lds(a);
-    static unsigned long long attr = 0; // devices that have the attribute
-    if (ps_first_on_device(&attr)) {
-        (void)hipFuncSetAttribute((const void *)attn_decode_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
-        (void)hipFuncSetAttribute((const void *)attn_decode_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
-    }
-    dim3 g((unsigned)gx, (unsigned)a.n_kv_heads);
-    if (a.head_size == 128) hipLaunchKernelGGL(attn_decode_kernel<4>, g, dim3(PV_NT), lds, st, a);
-    else if (a.head_size == 64) hipLaunchKernelGGL(attn_decode_kernel<2>, g, dim3(PV_NT), lds, st, a);
-    else return false;
-    return true;
-}
-
-// single token, one launch, second generation (attn_decode2_kernel); false: not covered
+// single token, one launch (attn_decode2_kernel); false: not covered, the caller launches scores + softmax / V.p
 size_t psl_attn_decode2_xchg_bytes(int n_kv_heads, int n_ctx) { return (size_t)n_kv_heads * 4 * (((size_t)n_ctx + 31) & ~(size_t)31) * 4; }
 bool psl_attn_decode2(hipStream_t st, int n_cu, const psl_attn_args &a) {
     const int r2 = a.n_heads / a.n_kv_heads, gx = a.head_size / 4;

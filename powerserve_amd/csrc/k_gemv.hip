@@ -460,12 +460,12 @@ __device__ __forceinline__ void coh_store_f(float *p, float v) { __hip_atomic_st
 
 constexpr int g3_waves(int nw) { return nw + (nw >= 12 ? 2 : 1); } // producers + chain waves
 
-// One mat-vec phase of a workgroup.  HOOKED = false: a kernel of its own.  HOOKED = true: a phase of a chained kernel:
-// the weight loads go out first, then hook() (the device-wide barrier that makes the previous phase's results
-// visible), then the producers fetch the activation row with cache-bypassing loads (queued behind a chunk that has had
-// the whole barrier to land); COH: outputs and the residual are written / read cache-bypassing too.
-template <int WT, int UPW, int NW, int TPW, int EPI, int PRO, bool HOOKED, bool COH, typename Hook>
-__device__ __forceinline__ void g3_body(const GemvParams &p, char *smem, double *red, Hook hook) {
+// The mat-vec of one workgroup.  (Round 1 also ran it as a phase of a chained kernel — O -> gate/up -> down in one launch
+// behind device-wide barriers of relaxed atomics, 2.5 us each, tools/micro/gridbar2.hip: bit-identical, break-even at best
+// against separate launches, DESIGN.md 5 "Tried" — that variant and its HOOKED / COH paths are gone since round 3.)
+template <int WT, int UPW, int NW, int TPW, int EPI, int PRO>
+__device__ __forceinline__ void g3_body(const GemvParams &p, char *smem, double *red) {
+    constexpr bool HOOKED = false, COH = false;
     constexpr int NC = g3_waves(NW) - NW; // chain waves: rows alternate between them
     using TR  = WTraits<WT>;
     using Rec = typename RecOf<WT>::T;
@@ -798,85 +798,17 @@ __device__ __forceinline__ void g3_body(const GemvParams &p, char *smem, double 
             }
         }
     };
-    if constexpr (!HOOKED) { // one contiguous producer path (the register allocator treats it best that way)
-        if (wave < NW) { begin_producers(); run_producers(); } else run_chain();
-    } else {
-        if (wave < NW) begin_producers();
-        if constexpr (HOOKED) {
-            hook(); // every wave; afterwards the previous phase's results are visible to cache-bypassing loads
-            mark_at(24); // device-wide barrier passed
-            // chunk A has had the whole barrier to land, so the (cache-bypassing) activation loads queued behind it come
-            // back at once; chunk B goes out behind them
-            if (wave < NW) {
-                if (PRO != 0) ps_qrow_load_coh<TPW>(p.x, K, xv, nwl);
-                if (B_EARLY) issue(qB, hB, tB, uB, n_chunks > 1);
-            }
-            mark_at(25); // activation and second chunk requested
-        }
-        if (wave < NW) run_producers(); else run_chain();
-    }
+    if (wave < NW) { begin_producers(); run_producers(); } else run_chain(); // one contiguous producer path (the register allocator treats it best that way)
     if (COH && wave >= NW) __builtin_amdgcn_s_waitcnt(0x0070); // vmcnt(0) (expcnt/lgkmcnt untouched): this wave's output stores have landed
     if (dbg) { dbg[31] = __builtin_amdgcn_s_memtime(); dbg[30] = __builtin_amdgcn_s_memrealtime(); } // 31: done
 }
 
 
-struct G3NoHook { __device__ __forceinline__ void operator()() const {} };
-
 template <int WT, int UPW, int NW, int TPW, int EPI, int PRO>
 __global__ __launch_bounds__(g3_waves(NW) * 64, 4) void gemv3_kernel(const GemvParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ double red[16];
-    g3_body<WT, UPW, NW, TPW, EPI, PRO, false, false>(p, smem, red, G3NoHook{});
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// Three dependent mat-vecs in ONE launch: O projection -> gate/up -> down.  Between the phases the 256 resident
-// workgroups meet at a device-wide barrier built from RELAXED agent-scope atomics (two levels: 8 leaf counters, one
-// root, one generation word; 2.5 us measured, tools/micro/gridbar2.hip -- the release/acquire flavour costs 10-38 us
-// on 8 XCDs because every fence flushes / invalidates a whole L2).  What crosses a barrier (x, h) is written and read
-// with cache-bypassing accesses by the phases themselves (g3_body<.., HOOKED, COH>), so no fence is needed.  A phase
-// puts its first two chunks of weight loads in flight BEFORE it waits for the previous phase: start-up, first-byte
-// latency and the previous phase's chain tail overlap with HBM traffic instead of idling it.
-struct G3Bar { // per launch site, zeroed once: [0] generation base, [32] generation, [32*(2+leaf)] leaf counters, [32*10] root, [32*11] error flag
-    unsigned *w;
-};
-struct G3GridHook {
-    unsigned *w;
-    unsigned gen; // generation this barrier completes
-    int nw;       // first chain wave
-    __device__ __forceinline__ void operator()() const {
-        __syncthreads(); // the chain waves have waited for their own output stores (end of g3_body)
-        if ((int)(threadIdx.x >> 6) == nw && (threadIdx.x & 63) == 0) { // a chain wave: nothing of its own in the memory pipeline
-            const unsigned leaf = blockIdx.x & 7, per_leaf = gridDim.x >> 3;
-            const unsigned a = __hip_atomic_fetch_add(w + 32 * (2 + leaf), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (a == gen * per_leaf - 1) {
-                const unsigned b = __hip_atomic_fetch_add(w + 32 * 10, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (b == gen * 8 - 1) __hip_atomic_store(w + 32, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            int spins = 0;
-            while (__hip_atomic_load(w + 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gen) {
-                __builtin_amdgcn_s_sleep(1);
-                if (++spins > (1 << 22)) { __hip_atomic_store(w + 32 * 11, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; } // never hang the GPU
-            }
-        }
-        __syncthreads();
-    }
-};
-struct GemvChain3 {
-    GemvParams p[3];
-    G3Bar bar;
-};
-
-template <int WT, int TPW0, int TPW2>
-__global__ __launch_bounds__(1024, 4) void gemv3_chain3_kernel(const GemvChain3 c) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    __shared__ double red[16];
-    const unsigned base = __hip_atomic_load(c.bar.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // barriers completed by earlier launches
-    // (inlined on purpose: as out-of-line functions the phases read their parameters from a scratch copy -- 3x slower)
-    g3_body<WT, 4, 14, TPW0, 0, 2, false, true>(c.p[0], smem, red, G3NoHook{});                        // att -> x += Wo att
-    g3_body<WT, 4, 14, TPW0, 1, 1, true, true>(c.p[1], smem, red, G3GridHook{c.bar.w, base + 1, 14});  // h = silu(Wg n(x)) * (Wu n(x))
-    g3_body<WT, 4, 14, TPW2, 0, 2, true, true>(c.p[2], smem, red, G3GridHook{c.bar.w, base + 2, 14});  // x += Wd h
-    if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(c.bar.w, base + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    g3_body<WT, UPW, NW, TPW, EPI, PRO>(p, smem, red);
 }
 
 template <int WT, int UPW, int NW, int TPW, int EPI, int PRO>
@@ -929,23 +861,14 @@ void launch_g3_ep(hipStream_t st, int n_cu, const GemvParams &p, int epi, int pr
 // the prologue's register tiles or the row length is not a multiple of four units (falls back).
 template <int WT>
 bool launch_g3_wt(hipStream_t st, int n_cu, const GemvParams &p, int epi, int pro) {
+    static const bool no_g3 = getenv("PS_NO_G3") != nullptr;
+    if (no_g3 && WT != PS_Q4_K) return false;
     if (epi == 1 && pro == 2) return false;
     if (epi == 2 && pro != 1) return false;
     const int n_units = (int)((p.K + WTraits<WT>::UNIT - 1) / WTraits<WT>::UNIT);
     if (n_units % 4 != 0) return false; // the consumer tests row boundaries once per four units
     const size_t rec = sizeof(typename RecOf<WT>::T) + 2; // (+ the Q8_0 / Q4_0 scale plane)
     if ((size_t)p.col_bytes + 2 * 56 * 64 * rec > 150 * 1024) return false;
-    if constexpr (WT != PS_Q4_K) { // (Q4_K single columns go to gemv4, k_gemv4.hip)
-        // eight-wave workgroups (seven producers + one chain wave) for the small matrices of the 1B / 0.5B shapes: a kernel
-        // boundary behind 512-thread workgroups is ~1.4 us shorter than behind 1024-thread ones and there are only a few units per CU
-        static const int small_wg = getenv("PS_G3_SMALL") ? atoi(getenv("PS_G3_SMALL")) : 1;
-        if (small_wg && p.K <= 8 * 4 * 256) {
-            if (p.K <= 8 * 1 * 256) launch_g3_ep<WT, 4, 7, 1>(st, n_cu, p, epi, pro);
-            else if (p.K <= 8 * 2 * 256) launch_g3_ep<WT, 4, 7, 2>(st, n_cu, p, epi, pro);
-            else launch_g3_ep<WT, 4, 7, 4>(st, n_cu, p, epi, pro);
-            return true;
-        }
-    }
     if (p.K <= 14 * 2 * 256) { launch_g3_ep<WT, 4, 14, 2>(st, n_cu, p, epi, pro); return true; } // prologue tiles on the 14 producers
     if (p.K <= 14 * 4 * 256) { launch_g3_ep<WT, 4, 14, 4>(st, n_cu, p, epi, pro); return true; }
     return false;
@@ -997,6 +920,13 @@ int launch_epi(hipStream_t st, int n_cu, const GemvParams &p, int epi, int pro) 
 
 template <int WT>
 int launch_wt(hipStream_t st, int n_cu, const GemvParams &p, int epi, int pro) {
+    if constexpr (WT != PS_Q4_K) {
+        // short rows of Q4_0 / Q8_0 (<= 32 units per task: the O and gate/up launches of the 1B shape): the register-resident
+        // kernel measured faster than the 16-wave producer / consumer one (O 6.6 vs 9.3 us, gate/up 12.0 vs 13.2 us,
+        // profiles/r03_decode_kernel_stats_1b_q4_0.txt); the QKV launch keeps the latter for its fused RoPE + KV append
+        const int tot = (int)((p.K + WTraits<WT>::UNIT - 1) / WTraits<WT>::UNIT) * (epi == 1 ? 2 : 1);
+        if (p.bs == 1 && epi != 2 && tot <= 32 && launch_g1_wt<WT>(st, n_cu, p, epi, pro)) return 0;
+    }
     if (p.bs == 1 && launch_g3_wt<WT>(st, n_cu, p, epi, pro)) return 0;
     if (epi == 2) return 8; // the fused RoPE epilogue exists in the producer/consumer kernel only (psk_gemv_rope_ok)
     if (p.bs == 1 && launch_g1_wt<WT>(st, n_cu, p, epi, pro)) return 0;
@@ -1567,6 +1497,8 @@ unsigned long long *psk_gemv_dbg_buf(int epi, int pro) { // key = k1 + 100 * (k2
 }
 
 bool psk_gemv_rope_ok(int wt, int64_t K) { // mirrors launch_g3_wt
+    static const bool no_g3 = getenv("PS_NO_G3") != nullptr; // (A/B: the register-resident gemv1 instead)
+    if (no_g3 && wt != PS_Q4_K) return false;
     const int64_t unit = (wt == PS_Q4_K) ? 256 : 128, n_units = (K + unit - 1) / unit;
     const size_t rec = (wt == PS_Q4_K ? 8 : 16) + 2;
     return (wt == PS_Q4_K || wt == PS_Q8_0 || wt == PS_Q4_0) && n_units % 4 == 0 && K <= 14 * 4 * 256 &&
@@ -1578,49 +1510,6 @@ size_t psk_gemv_lds_col_bytes(int wt, int64_t K) {
     const int64_t Kp = (K + unit - 1) / unit * unit;
     const size_t b = (size_t)Kp + (size_t)(Kp / blk) * 4 + (size_t)(Kp / 32) * 4 + (size_t)(Kp / 16) * 2;
     return (b + 15) / 16 * 16;
-}
-
-// O projection -> gate/up -> down of one layer in one launch (single token, Q4_K).  a[0]: Wo (pro 2, residual);
-// a[1]: Wgate|Wup (pro 1, silu_pair); a[2]: Wdown (pro 2, residual).  bar: 12*32 zero-initialised uints owned by this
-// launch site.  Returns -1 when the shapes are not covered (the caller launches the three mat-vecs separately).
-int psk_gemv_chain3(hipStream_t st, int n_cu, const psk_gemv_args a[3], unsigned *bar) {
-    GemvChain3 c{};
-    const int want_pro[3] = {2, 1, 2}, want_epi[3] = {0, 1, 0};
-    size_t smem = 0;
-    int64_t grid = (int64_t)n_cu; // one 16-wave workgroup per CU: all resident, which the barrier relies on
-    if (grid % 8) return -1;
-    for (int ph = 0; ph < 3; ph++) {
-        const psk_gemv_args &g = a[ph];
-        const int64_t K = g.w[0]->K;
-        GemvParams &p = c.p[ph];
-        if (g.pro != want_pro[ph] || (g.silu_pair ? 1 : 0) != want_epi[ph] || g.rope || g.n_w != (ph == 1 ? 2 : 1)) return -1;
-        p.n_w = g.n_w; p.K = K; p.bs = 1; p.residual = g.residual; p.x = g.pro_x; p.nw = g.pro_norm_w; p.eps = g.pro_eps;
-        for (int i = 0; i < g.n_w; i++) {
-            if (g.w[i]->dtype != PS_Q4_K || g.w[i]->K != K || g.bias[i]) return -1;
-            const int64_t ng = (g.w[i]->N + 7) / 8;
-            p.w[i] = GemvW{g.w[i]->qs, g.w[i]->aux, g.out[i], nullptr, g.w[i]->N, g.ldo[i], ng};
-            p.groups_total += ng;
-        }
-        if (ph == 1 && g.w[0]->N != g.w[1]->N) return -1;
-        if (K % 1024) return -1;                                    // rows end on multiples of four units
-        if (ph < 2 ? K > 14 * 2 * 256 : K > 14 * 4 * 256) return -1; // prologue register tiles (TPW 2 / 4)
-        const int64_t n_tasks = ph == 1 ? p.w[0].n_groups : p.groups_total;
-        if (n_tasks < grid) return -1; // every workgroup needs at least one row group in every phase
-        p.split_q = (int)(n_tasks / grid);
-        p.split_r = (int)(n_tasks % grid);
-        p.col_bytes = (int64_t)psk_gemv_lds_col_bytes(PS_Q4_K, K);
-        if (g_dbg_buf && g_dbg_key % 100 == 20 + ph) p.dbg = g_dbg_buf; // timeline of one phase (tools/gpu_timeline.py 20 21 22)
-        const size_t need = (size_t)p.col_bytes + (size_t)2 * 56 * 64 * 8; // activation image + records
-        smem = need > smem ? need : smem;
-    }
-    if (smem > 156 * 1024) return -1;
-    c.bar.w = bar;
-    static unsigned long long attr = 0; // devices that have the attribute
-    if (ps_first_on_device(&attr)) {
-        (void)hipFuncSetAttribute((const void *)gemv3_chain3_kernel<PS_Q4_K, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
-    }
-    hipLaunchKernelGGL((gemv3_chain3_kernel<PS_Q4_K, 2, 4>), dim3((unsigned)grid), dim3(1024), smem, st, c);
-    return 0;
 }
 
 // Batched mat-mul from pre-quantized activations; returns -1 when the shape is not covered (caller falls back to

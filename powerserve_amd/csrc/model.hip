@@ -41,8 +41,7 @@ struct ps_hip_model {
     std::vector<const ps_weight *> wq, wk, wv, wo, wg, wu, wd;
     // arena
     float *x = nullptr, *q = nullptr, *k = nullptr, *v = nullptr, *att = nullptr, *hb = nullptr, *g1 = nullptr, *u1 = nullptr;
-    unsigned *bars = nullptr; // device-wide barrier words of the chained launches, [n_layers][12*32]
-    unsigned *attn_sync = nullptr; // [2048] words: [31] rendezvous-timeout flag of the one-launch attentions, [64 + 64 * kv head] tickets of the first one
+    unsigned *attn_sync = nullptr; // [2048] words: [31] the one-launch attention's rendezvous-timeout flag
     float *attn_xchg = nullptr;    // attn_decode2: scores in flight between workgroups (k_attn.hip)
     unsigned *attn_tick = nullptr; // attn_decode2: [64 * kv head] arrival counters
     size_t graph_hint = 0;                   // KV position the captured step was given as its prefetch hint (n_kv_lo)
@@ -77,6 +76,12 @@ static int dmalloc(ps_hip_model *m, void **p, size_t bytes) {
 }
 
 static int mm(ps_hip_model *m, psk_gemv_args &g, ps_act act, int64_t K, int64_t bs);
+// from this many columns on a launch quantizes its activation ONCE into `act` and goes to the batched kernels (2-4 columns: 4.8-4.9 ms
+// per 8B forward through the batched kernel, 5.4-6.3 ms through the 4-column mat-vec)
+static int gemm_min_bs() {
+    static const int v = getenv("PS_GEMM8_MIN_BS") ? atoi(getenv("PS_GEMM8_MIN_BS")) : 2;
+    return v;
+}
 // Launches whose matrices are not all of one lane-major type (stock Q4_K_M files: attn_v / ffn_down / output in Q6_K next
 // to Q4_K): one launch per matrix, exactly the reference's op sequence (mat-mul, + bias, silu_hadamard).
 static int mm_each(ps_hip_model *m, psk_gemv_args &g, ps_act act, int64_t K, int64_t bs) {
@@ -114,7 +119,7 @@ static int mm_each(ps_hip_model *m, psk_gemv_args &g, ps_act act, int64_t K, int
             s.n_w = run;
             if (mm(m, s, act, K, bs)) return 2;
             i += run - 1;
-            quantized = bs >= 2 && g.pro != 0 && ps_hip_vec_dot_type(g.w[i]->dtype) == PS_Q8_K; // (a batch leaves the same Q8_K image in `act`; a single-token launch quantizes in its own prologue, into LDS)
+            quantized = bs >= gemm_min_bs() && g.pro != 0 && ps_hip_vec_dot_type(g.w[i]->dtype) == PS_Q8_K; // (exactly when mm() quantized into `act`: a narrower launch quantizes in its own prologue, into LDS)
         }
     }
     if (g.silu_pair) psl_silu_hadamard(c->stream, g.out[0], tmp[0], tmp[1], (int64_t)g.ldo[0] * bs);
@@ -130,8 +135,7 @@ static int mm(ps_hip_model *m, psk_gemv_args &g, ps_act act, int64_t K, int64_t 
     const int64_t blk = vdt == PS_Q8_0 ? 32 : 256;
     psk_gemv_args gq = g;
     int64_t step = 4;
-    static const int gemm_min_bs = getenv("PS_GEMM8_MIN_BS") ? atoi(getenv("PS_GEMM8_MIN_BS")) : 2; // (2-4 columns: 4.8-4.9 ms per 8B forward through the batched kernel, 5.4-6.3 ms through the 4-column mat-vec)
-    if (bs >= gemm_min_bs) {
+    if (bs >= gemm_min_bs()) {
         // batches: the activation is quantized ONCE (with its RMSNorm when the launch carries one) and the weights are
         // streamed once per column group of up to 16 instead of once per 4 columns
         if (g.pro) {
@@ -181,8 +185,7 @@ static int enqueue_forward(ps_hip_model *m, int bs, bool lm_head, bool use_tree,
     aa.scale = 1.0f / sqrtf((float)f.head_size);
     aa.n_kv_host = m->n_kv_host;
     aa.sync = m->attn_sync;
-    const bool one_launch_v1 = (m->mode & 4) != 0;  // mode bit 2: the first one-launch decode attention (round 2; measured equal to the two launches)
-    const bool one_launch_v2 = (m->mode & 16) == 0; // default; mode bit 4 switches attn_decode2 off (two launches)
+    const bool one_launch = (m->mode & 16) == 0; // default; mode bit 4 switches attn_decode2 off (two launches)
     aa.xchg = m->attn_xchg; aa.tick = m->attn_tick;
     aa.n_kv_lo = m->n_kv_host > 0 ? m->n_kv_host : (int)m->position; // (a hint: rows below it are requested before the device-side position has arrived)
 
@@ -210,9 +213,9 @@ static int enqueue_forward(ps_hip_model *m, int bs, bool lm_head, bool use_tree,
         bool att_quantized = false;
         if (bs == 1 && !use_tree && kv16 && psl_attn_decode_f16(st, aa)) {
             // fp16-KV decode mode (not bit-exact): split-KV online soft-max over the fp16 mirrors
-        } else if (bs == 1 && !use_tree && one_launch_v2 && (aa.dbg = psk_gemv_dbg_buf(10, 2), psl_attn_decode2(st, c->n_cu, aa))) { // timeline key 42
+        } else if (bs == 1 && !use_tree && one_launch && (aa.dbg = psk_gemv_dbg_buf(10, 2), psl_attn_decode2(st, c->n_cu, aa))) { // timeline key 42
             aa.dbg = nullptr;
-        } else if (!(bs == 1 && !use_tree && one_launch_v1 && psl_attn_decode(st, c->n_cu, aa))) {
+        } else {
             aa.dbg = bs == 1 ? psk_gemv_dbg_buf(10, 0) : nullptr; // timeline key 40
             psl_attn_scores(st, aa, bs);
             aa.dbg = bs == 1 ? psk_gemv_dbg_buf(10, 1) : nullptr; // timeline key 41
@@ -242,14 +245,6 @@ static int enqueue_forward(ps_hip_model *m, int bs, bool lm_head, bool use_tree,
         gf.pro = 1; gf.pro_x = m->x; gf.pro_norm_w = m->ffn_norm[L]; gf.pro_eps = f.norm_eps;
         psk_gemv_args gd{};
         gd.n_w = 1; gd.w[0] = m->wd[L]; gd.out[0] = m->x; gd.ldo[0] = dim; gd.residual = m->x;
-        if (bs == 1 && (m->mode & 2)) { // opt-in: the three dependent mat-vecs of the layer in ONE launch (break-even today)
-            gd.pro = 2; gd.pro_x = m->hb;
-            const psk_gemv_args ch[3] = {go, gf, gd};
-            const int rc = psk_gemv_chain3(st, c->n_cu, ch, m->bars + (size_t)L * 12 * 32);
-            if (rc == 0) continue;
-            if (rc != -1) { c->err = "gemv chain launch rc=" + std::to_string(rc); return 2; }
-            gd.pro = 0; gd.pro_x = nullptr;
-        }
         if (mm(m, go, a1, dim, bs)) return 2;
         if (mm(m, gf, a1, dim, bs)) return 2;
         if (psk_gemv_lds_col_bytes(m->wd[L]->dtype, hid) * (bs == 1 ? 1 : 4) <= 64 * 1024 && (hid <= 8192 || bs == 1)) {
@@ -329,7 +324,7 @@ int ps_hip_model_create(ps_hip_ctx *c, const ps_model_desc *d, ps_hip_model **ou
         dmalloc(m, (void **)&m->k, mb * kvd * 4) || dmalloc(m, (void **)&m->v, mb * kvd * 4) ||
         dmalloc(m, (void **)&m->att, mb * dim * 4) || dmalloc(m, (void **)&m->hb, mb * hid * 4) ||
         dmalloc(m, (void **)&m->g1, mb * hid * 4) || dmalloc(m, (void **)&m->u1, mb * hid * 4) ||
-        dmalloc(m, (void **)&m->bars, (size_t)f.n_layers * 12 * 32 * 4) || dmalloc(m, (void **)&m->attn_sync, 2048 * 4) ||
+        dmalloc(m, (void **)&m->attn_sync, 2048 * 4) ||
         dmalloc(m, (void **)&m->attn_xchg, psl_attn_decode2_xchg_bytes((int)f.n_kv_heads, (int)nctx)) || dmalloc(m, (void **)&m->attn_tick, (size_t)f.n_kv_heads * 64 * 4) ||
         dmalloc(m, (void **)&m->scores, mb * f.n_heads * nctx * 4) || dmalloc(m, (void **)&m->logits, mb * f.vocab_size * 4) ||
         dmalloc(m, (void **)&m->rope_table, nctx * f.head_size * 4) ||
@@ -338,7 +333,6 @@ int ps_hip_model_create(ps_hip_ctx *c, const ps_model_desc *d, ps_hip_model **ou
         dmalloc(m, (void **)&m->argmax_dev, mb * 4) || dmalloc(m, (void **)&m->ids_dev, (nctx + 1) * 4) ||
         dmalloc(m, (void **)&m->tree_dev, mb * mb) || dmalloc(m, (void **)&m->rope_pos_dev, mb * 4) || dmalloc(m, (void **)&m->kv_vis_dev, nctx) || dmalloc(m, (void **)&m->am_v, mb * 64 * 4) || dmalloc(m, (void **)&m->am_i, mb * 64 * 4))
         return fail();
-    (void)hipMemsetAsync(m->bars, 0, (size_t)f.n_layers * 12 * 32 * 4, c->stream);
     (void)hipMemsetAsync(m->attn_sync, 0, 2048 * 4, c->stream);
     (void)hipMemsetAsync(m->attn_tick, 0, (size_t)f.n_kv_heads * 64 * 4, c->stream);
     (void)hipMemsetAsync(m->kv_vis_dev, 1, nctx, c->stream);
@@ -416,13 +410,13 @@ static int model_forward_impl(ps_hip_model *m, const int32_t *tokens, int n, con
 // from here on (mode bit 4): the forward that timed out has no valid result.  Expects the stream to be idle.
 static int check_attn_timeout(ps_hip_model *m, const char *who) {
     ps_hip_ctx *c = m->ctx;
-    if ((m->mode & 16) && !(m->mode & 4)) return 0; // neither one-launch form is in use
+    if (m->mode & 16) return 0; // the one-launch form is not in use
     unsigned stuck = 0;
     PS_CHECK(c, hipMemcpy(&stuck, m->attn_sync + 31, 4, hipMemcpyDeviceToHost));
     if (!stuck) return 0;
     PS_CHECK(c, hipMemset(m->attn_sync + 31, 0, 4));
     if (m->step_graph) { (void)hipGraphExecDestroy(m->step_graph); m->step_graph = nullptr; }
-    m->mode = (m->mode | 16) & ~4;
+    m->mode |= 16;
     c->err = std::string(who) + ": the one-launch attention timed out at its score exchange (GPU shared or partitioned?); this forward has no valid "
              "result, the cache position is unchanged, and the model now uses the two-launch attention (mode bit 4)";
     return 2;
@@ -535,16 +529,7 @@ int ps_hip_model_decode_greedy(ps_hip_model *m, int32_t token, int steps, int32_
         }
     }
     PS_CHECK(c, hipMemcpyAsync(out_ids, m->ids_dev, (size_t)steps * 4, hipMemcpyDeviceToHost, c->stream));
-    unsigned bar_err = 0;
-    if (m->mode & 2) // chained launches: a device-wide barrier that gave up raises word 32 * 11 of its launch site
-        for (uint32_t L = 0; L < m->cfg.n_layers && !bar_err; L++) {
-            unsigned e = 0;
-            PS_CHECK(c, hipMemcpyAsync(&e, m->bars + (size_t)L * 12 * 32 + 32 * 11, 4, hipMemcpyDeviceToHost, c->stream));
-            PS_CHECK(c, hipStreamSynchronize(c->stream));
-            bar_err |= e;
-        }
     PS_CHECK(c, hipStreamSynchronize(c->stream));
-    if (bar_err) PS_FAIL(c, "decode_greedy: a device-wide barrier of the chained launch timed out (mode bit 1 needs every CU for this process); results are not valid");
     if (int rc = check_attn_timeout(m, "decode_greedy")) return rc;
     m->position += (size_t)steps;
     return 0;

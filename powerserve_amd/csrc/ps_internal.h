@@ -157,7 +157,6 @@ size_t psk_gemv_lds_col_bytes(int wt, int64_t K);
 int psk_gemm8(hipStream_t st, int n_cu, const psk_gemv_args &a, ps_act act, int64_t K, int64_t bs); // -1: not covered
 int psk_gemm4k(hipStream_t st, int n_cu, const psk_gemv_args &a, ps_act act, int64_t K, int64_t bs);
 bool psk_gemm4k_rope_ok(const psk_gemv_args &a, int64_t K, int64_t bs); // a Q / K / V batch whose RoPE + KV append the mat-mul epilogue will do (set a.rope) // Q4_K batches on v_mfma_f32_16x16x32_f16, exact integers (k_gemm4k.hip); -1: not covered
-int psk_gemv_chain3(hipStream_t st, int n_cu, const psk_gemv_args a[3], unsigned *bar); // O -> gate/up -> down, one launch; -1: not covered
 int psk_gemv_max_cols(int wt, int64_t K); // widest column group one launch takes (16, 8 or 4; > 4 needs pro == 0)
 static inline int64_t ps_w_rg(int dtype) { return dtype == PS_Q4_0 ? 16 : 8; }
 static inline int64_t ps_w_unit(int dtype) { return dtype == PS_Q4_K ? 256 : 128; }

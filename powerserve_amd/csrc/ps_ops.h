@@ -42,7 +42,7 @@ struct psl_attn_args {
     _Float16 *k16, *v16;     // optional fp16 mirrors of the caches, both [n_ctx][kv_dim] (fp16-KV decode mode: ps_hip_model_set_mode bit 3)
     float *part;             // [n_heads][FL_SPLITS][head_size + 2] partial (o, m, l) of the split-KV decode attention
     unsigned long long *dbg; // timeline buffer of the single-token kernels (ps_hip_debug_timeline keys 40 / 41), or null
-    unsigned *sync;          // [2048] words, zeroed once: [31] spin-timeout flag, [64 + 64 * kv head] ticket counter of the one-launch decode attention
+    unsigned *sync;          // [2048] words, zeroed once: [31] the one-launch decode attention's spin-timeout flag
     float *xchg;             // attn_decode2: raw scores in flight between the workgroups of a kv head, [n_kv_heads][4][n_ctx rounded up to 32]; null: not used
     unsigned *tick;          // attn_decode2: [64 * kv head] arrival counters, zeroed once (epoch = ticket / workgroups per head)
     int n_kv_lo;             // attn_decode2: a lower bound of pos0 + 1 known to the host at enqueue time (a prefetch HINT only)
@@ -52,8 +52,7 @@ void psl_attn_scores(hipStream_t st, const psl_attn_args &a, int bs);
 void psl_attn_softmax_pv(hipStream_t st, const psl_attn_args &a, int bs);
 bool psl_attn_pv_quantizes(const psl_attn_args &a, int bs); // whether psl_attn_softmax_pv(a, bs) would fill a.qact (shape conditions of the fused epilogue)
 bool psl_attn_decode_f16(hipStream_t st, const psl_attn_args &a); // single token over the fp16 mirrors: split-KV online soft-max + combine (NOT bit-exact); false: not covered
-bool psl_attn_decode(hipStream_t st, int n_cu, const psl_attn_args &a); // single token, scores + softmax + V.p in one launch; false: not covered
-bool psl_attn_decode2(hipStream_t st, int n_cu, const psl_attn_args &a); // the same, second generation (tagged score granules, V.p on the matrix cores); false: not covered
+bool psl_attn_decode2(hipStream_t st, int n_cu, const psl_attn_args &a); // single token: scores + soft-max + V.p in one launch (counter exchange of the scores, V.p on the matrix cores); false: not covered
 size_t psl_attn_decode2_xchg_bytes(int n_kv_heads, int n_ctx);
 size_t psl_attn_softmax_pv_lds(const psl_attn_args &a); // dynamic LDS bytes (grows with n_ctx)
 // two-stage arg-max (64 partials per row).  With state != NULL the final stage also does the greedy-decode

@@ -69,37 +69,10 @@ def test_generate_matches_oracle(ctx, oracle, tmp_path, preset, wt):
     om.close()
 
 
-def test_chained_launch_is_bit_identical(ctx, oracle, tmp_path):
-    """Opt-in mode bit 1: the O / gate-up / down mat-vecs of a layer as ONE launch with device-wide barriers between
-    the phases (relaxed atomics + cache-bypassing activation traffic).  Same ids and logits as the default launch
-    plan and as the oracle, eager and hipGraph replay."""
-    from oracle import binding as B
-    from powerserve_amd import hip, synth
-    d = str(tmp_path / "m")
-    mj = synth.write_model_dir(d, "wide-llama", 12, n_ctx=64, seed=9)
-    cfg = B.make_config(mj["llm_config"])
-    om = oracle.model(cfg, mj["model_arch"], load_tensors(os.path.join(d, "ggml/weights.gguf")), n_threads=8)
-    prompt = np.random.default_rng(3).integers(0, cfg.vocab_size, 9)
-    want_ids, want_logits, *_ = om.generate(prompt, 8, 12, want_logits=True)
-    for mode in (2, 3, 0):
-        gm = hip.Model(ctx, d, max_batch=8)
-        gm.set_mode(mode)
-        assert np.array_equal(gm.generate(prompt, 8, 12), want_ids), mode
-        gm.reset()  # logits of every decode step, teacher-forced
-        gm.forward(prompt[:-1], np.arange(8), lm_head=False)
-        cur = int(prompt[-1])
-        for s in range(12):
-            lg, am = gm.forward([cur], [gm.position], lm_head=True)
-            assert np.array_equal(np.asarray(lg[0]).view(np.uint32), np.asarray(want_logits[s]).view(np.uint32)), (mode, s)
-            cur = int(want_ids[s])
-        gm.close()
-    om.close()
-
-
 def test_one_launch_attention_is_bit_identical(ctx, oracle, tmp_path):
-    """Opt-in mode bit 2: single-token attention as ONE launch (scores published write-through, per-kv-head ticket
-    rendezvous, cache-bypassing score loads) — the same ids and logits as the two-launch plan and as the oracle, eager
-    and hipGraph replay, past a few position groups so that several workgroups contribute scores."""
+    """Single-token attention as ONE launch (attn_decode2: scores stored write-through, per-kv-head ticket rendezvous; the
+    default) and as two launches (mode bit 4): the same ids and logits as the oracle, eager and hipGraph replay, past a few
+    position groups so that several workgroups contribute scores."""
     from oracle import binding as B
     from powerserve_amd import hip, synth
     d = str(tmp_path / "m")
@@ -108,7 +81,7 @@ def test_one_launch_attention_is_bit_identical(ctx, oracle, tmp_path):
     om = oracle.model(cfg, mj["model_arch"], load_tensors(os.path.join(d, "ggml/weights.gguf")), n_threads=8)
     prompt = np.random.default_rng(5).integers(0, cfg.vocab_size, 150)
     want_ids, want_logits, *_ = om.generate(prompt, 32, 10, want_logits=True)
-    for mode in (0, 1, 16, 17, 20, 21):  # default = the second one-launch form (attn_decode2); 16: two launches; 20: the first one-launch form; +1: eager
+    for mode in (0, 1, 16, 17):  # default = one launch (attn_decode2); 16: two launches; +1: eager
         gm = hip.Model(ctx, d, max_batch=32)
         gm.set_mode(mode)
         assert np.array_equal(gm.generate(prompt, 32, 10), want_ids), mode

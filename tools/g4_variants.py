@@ -39,7 +39,7 @@ for cfg in cfgs:
     # a real decode (graph replay): 32 tokens from the same state
     m.set_mode(0)
     ctx.check(L.ps_hip_model_kv_truncate(m.h, pos0))
-    m.set_mode(2); m.set_mode(0)  # drop the captured graph: the launch plan changed
+    m.set_mode(16); m.set_mode(0)  # drop the captured graph: the launch plan changed
     m.decode_greedy(int(prompt[-1]), 4)
     ctx.check(L.ps_hip_model_kv_truncate(m.h, pos0))
     ctx.sync()

@@ -8,7 +8,7 @@ rm -rf $GRAFT_REPO_ROOT/gpurun_out/prof_kt $GRAFT_REPO_ROOT/gpurun_out/prof_pmc
 timeout 400 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof_kt -o kt -- python $GRAFT_REPO_ROOT/bench.py --eager --steps 32 --warmup 4 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/prof_kt.log 2>&1; tail -1 $GRAFT_REPO_ROOT/gpurun_out/prof_kt.log | cut -c1-200
 timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_pmc -o pmc -- python $GRAFT_REPO_ROOT/bench.py --eager --steps 8 --warmup 2 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/prof_pmc.log 2>&1; tail -1 $GRAFT_REPO_ROOT/gpurun_out/prof_pmc.log | cut -c1-200
 cd $GRAFT_REPO_ROOT
-python tools/prof_summary.py $(ls gpurun_out/prof_kt/*.db | head -1) --decode > gpurun_out/r02_decode_kernel_stats_8b_q4k.txt 2>&1
-python tools/prof_summary.py $(ls gpurun_out/prof_kt/*.db | head -1) > gpurun_out/r02_all_kernel_stats_8b_q4k.txt 2>&1
-python tools/pmc_summary.py $(find gpurun_out/prof_pmc -name "*counter_collection.csv" | head -1) --json gpurun_out/r02_pmc_traffic.json > gpurun_out/r02_pmc_fetch_size_8b_q4k.txt 2>&1
-head -12 gpurun_out/r02_decode_kernel_stats_8b_q4k.txt; head -8 gpurun_out/r02_pmc_fetch_size_8b_q4k.txt
+python tools/prof_summary.py $(ls gpurun_out/prof_kt/*.db | head -1) --decode > gpurun_out/r03_decode_kernel_stats_8b_q4k.txt 2>&1
+python tools/prof_summary.py $(ls gpurun_out/prof_kt/*.db | head -1) > gpurun_out/r03_all_kernel_stats_8b_q4k.txt 2>&1
+python tools/pmc_summary.py $(find gpurun_out/prof_pmc -name "*counter_collection.csv" | head -1) --json gpurun_out/r03_pmc_traffic.json > gpurun_out/r03_pmc_fetch_size_8b_q4k.txt 2>&1
+head -12 gpurun_out/r03_decode_kernel_stats_8b_q4k.txt; head -8 gpurun_out/r03_pmc_fetch_size_8b_q4k.txt
