@@ -1,6 +1,7 @@
 #include "json_gguf.hpp"
 
 #include <cctype>
+#include <cerrno>
 #include <cstring>
 #include <fcntl.h>
 #include <algorithm>
@@ -57,7 +58,14 @@ struct JP {
             size_t e = p;
             while (e < s.size() && (std::isdigit((unsigned char)s[e]) || strchr("+-.eE", s[e]))) e++;
             if (e == p) bad("value");
-            v.kind = JsonValue::NUM; v.num = std::stod(s.substr(p, e - p)); p = e;
+            const std::string lit = s.substr(p, e - p);
+            v.kind = JsonValue::NUM; v.num = std::stod(lit); p = e;
+            if (lit.find_first_of(".eE") == std::string::npos) { // integer literal: keep all 64 bits (seed 18446744073709551615 = "pick one")
+                errno = 0;
+                const bool neg = lit[0] == '-';
+                const unsigned long long mag = std::strtoull(lit.c_str() + (neg || lit[0] == '+'), nullptr, 10);
+                if (errno == 0) { v.is_int = true; v.u64 = neg ? (uint64_t)0 - mag : (uint64_t)mag; }
+            }
         }
         return v;
     }
@@ -90,7 +98,7 @@ HyperParams::HyperParams(const std::string &params_file) {
         if (j.contains("sampler") && j.at("sampler").kind == JsonValue::OBJ && !j.at("sampler").obj.empty()) {
             const JsonValue &s = j.at("sampler");
             auto &c = sampler_config;
-            if (s.contains("seed")) c.seed = s.at("seed").num < 0 ? (uint64_t)(int64_t)s.at("seed").num : (uint64_t)s.at("seed").num;
+            if (s.contains("seed")) { const JsonValue &sd = s.at("seed"); c.seed = sd.is_int ? sd.u64 : (sd.num < 0 ? (uint64_t)(int64_t)sd.num : (uint64_t)sd.num); }
             c.temperature = (float)num(s, "temperature", c.temperature);
             c.top_p = (float)num(s, "top_p", c.top_p);
             c.top_k = (size_t)num(s, "top_k", (double)c.top_k);

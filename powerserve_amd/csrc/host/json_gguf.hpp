@@ -11,6 +11,8 @@ namespace powerserve {
 struct JsonValue {
     enum Kind { NUL, NUM, STR, BOOL, OBJ, ARR } kind = NUL;
     double num = 0;
+    uint64_t u64 = 0;      // NUM written as a plain integer: its exact value (negative ones wrapped), which a double cannot hold above 2^53
+    bool is_int = false;
     bool b = false;
     std::string str;
     std::map<std::string, JsonValue> obj;

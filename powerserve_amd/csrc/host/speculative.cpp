@@ -310,6 +310,28 @@ int psh_spec_generate(void *target, void *draft, const int32_t *prompt, int n_pr
     } catch (const std::exception &e) { psh_set_error(e.what()); return 1; }
 }
 
+// the same with the verify going through a sampler chain (handle of psh_sampler_create; spec_model.hpp:105) and an optional
+// stop token (eos < 0: none).  The text ends early at the stop token or when the caches cannot hold another tree: *n_out <= steps.
+int psh_spec_generate_sampled(void *target, void *draft, const int32_t *prompt, int n_prompt, int batch_size, int steps, int draft_batch_size,
+                              void *sampler, int32_t eos, int32_t *out, int32_t *n_out, uint64_t *stats) {
+    try {
+        SpeculativeConfig cfg;
+        if (draft_batch_size > 0) cfg.draft_batch_size = (size_t)draft_batch_size;
+        SpeculativeModel sm(((psh_model *)target)->model, ((psh_model *)draft)->model, cfg);
+        std::vector<Token> p(prompt, prompt + n_prompt);
+        std::function<bool(Token)> stop;
+        if (eos >= 0) stop = [eos](Token t) { return t == eos; };
+        const auto r = sm.generate(p, steps, (size_t)batch_size, (SamplerChain *)sampler, stop);
+        if (!r.empty()) memcpy(out, r.data(), r.size() * 4);
+        *n_out = (int32_t)r.size();
+        if (stats) {
+            const auto &s = sm.token_tree.m_stat;
+            stats[0] = s.n_draft_times; stats[1] = s.n_draft_tokens; stats[2] = s.n_accepted_tokens; stats[3] = s.n_iterations; stats[4] = s.n_generated_tokens;
+        }
+        return 0;
+    } catch (const std::exception &e) { psh_set_error(e.what()); return 1; }
+}
+
 // The token tree over caller-supplied models: n_iterations rounds of draft / tree forward / verify starting from
 // root_token (both caches already hold the same prefix).  out_tokens: capacity n_iterations * draft_batch_size,
 // *n_out = tokens emitted.  tree (optional): per iteration draft_batch_size rows of

@@ -10,7 +10,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libps_host.so")
 EXPORTS = ["psh_last_error", "psh_model_load", "psh_model_free", "psh_model_set_fused", "psh_model_plan_stats", "psh_model_kv_position", "psh_model_reset",
-           "psh_model_vocab", "psh_model_forward", "psh_model_generate", "psh_spec_generate", "psh_draft_sample", "psh_sampler_create", "psh_sampler_free", "psh_sampler_sample",
+           "psh_model_vocab", "psh_model_forward", "psh_model_generate", "psh_spec_generate", "psh_spec_generate_sampled", "psh_draft_sample", "psh_sampler_create", "psh_sampler_free", "psh_sampler_sample",
            "psh_model_generate_sampled", "psh_token_tree_run", "psh_gguf_summary", "psh_config_summary"]
 _LIB = None
 
@@ -35,6 +35,7 @@ def lib() -> C.CDLL:
         L.psh_model_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
         L.psh_model_generate.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.psh_spec_generate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.psh_spec_generate_sampled.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
         L.psh_draft_sample.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]
         L.psh_sampler_create.restype = C.c_void_p
         L.psh_sampler_create.argtypes = [C.c_void_p]
@@ -178,6 +179,19 @@ def spec_generate(target: HostModel, draft: HostModel, prompt, batch_size: int, 
     return out, {k: int(v) for k, v in zip(keys, st)}
 
 
+def spec_generate_sampled(target: HostModel, draft: HostModel, prompt, batch_size: int, steps: int, sampler: "Sampler", eos: int = -1, draft_batch_size: int = 12):
+    """SpeculativeModel::generate with the verify going through a sampler chain (sampler.apply + greedy pick per tree node,
+    src/speculative/token_tree.cpp:214-216; accept per emitted token) and an optional stop token.  Returns (ids, stats); ids may
+    be shorter than `steps` (stop token emitted, or no room left in the caches for another tree)."""
+    L = lib()
+    p = np.ascontiguousarray(prompt, dtype=np.int32)
+    out, n_out, st = np.empty(max(steps, 1), dtype=np.int32), np.zeros(1, dtype=np.int32), np.zeros(5, dtype=np.uint64)
+    if L.psh_spec_generate_sampled(target.h, draft.h, p.ctypes.data, p.size, batch_size, steps, draft_batch_size, sampler.h, eos, out.ctypes.data, n_out.ctypes.data, st.ctypes.data):
+        raise HostError(L.psh_last_error().decode())
+    keys = ("n_draft_times", "n_draft_tokens", "n_accepted_tokens", "n_iterations", "n_generated_tokens")
+    return out[:int(n_out[0])].copy(), {k: int(v) for k, v in zip(keys, st)}
+
+
 class SpecConfig(C.Structure):
     """psh_spec_config: plain-C view of SpeculativeConfig (csrc/host/speculative.hpp); defaults = the reference's."""
     _fields_ = [("draft_batch_size", C.c_int32), ("top_k", C.c_int32), ("max_fan_out", C.c_int32), ("early_stop", C.c_int32),
@@ -283,8 +297,8 @@ def generate_sampled(model: HostModel, prompt, batch_size: int, steps: int, cfg:
 class Workspace:
     """A PowerServe work folder (workspace.json -> hparams file, main and optional draft model directories;
     src/core/config.cpp:121-152) opened on the HIP backend: what `powerserve-run --work-folder` sets up, ids in / ids out.
-    generate(): speculative (greedy, token tree) when a draft model is configured, otherwise through the sampler chain
-    the hparams describe (top_k = 1 is plain greedy)."""
+    generate(): through the sampler chain the hparams describe (top_k = 1 is plain greedy); with a draft model configured
+    the text is produced by the token tree and the chain picks at every verified node."""
 
     def __init__(self, work_folder: str, device: int = 0, n_ctx: int = 0):
         self.config = config_summary(work_folder)
@@ -301,10 +315,16 @@ class Workspace:
                                penalty_present=float(c["penalty_present"]), penalize_nl=c["penalize_nl"] == "1", ignore_eos=c["ignore_eos"] == "1",
                                special_eos_id=special_eos_id, linefeed_id=linefeed_id)
 
-    def generate(self, prompt, steps: int):
-        if self.draft is not None:
-            return spec_generate(self.main, self.draft, prompt, self.batch_size, steps)[0]
-        return generate_sampled(self.main, prompt, self.batch_size, steps, self.sampler_cfg())
+    def generate(self, prompt, steps: int, special_eos_id: int = -1):
+        cfg = self.sampler_cfg(special_eos_id=special_eos_id)
+        if self.draft is not None:  # the verify samples through the same chain a plain run would use (spec_model.hpp:105)
+            sampler = Sampler(cfg)
+            try:
+                eos = special_eos_id if self.config["ignore_eos"] != "1" else -1
+                return spec_generate_sampled(self.main, self.draft, prompt, self.batch_size, steps, sampler, eos=eos)[0]
+            finally:
+                sampler.close()
+        return generate_sampled(self.main, prompt, self.batch_size, steps, cfg)
 
     def close(self):
         self.main.close()

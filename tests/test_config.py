@@ -52,6 +52,15 @@ def test_partial_sampler_section_keeps_the_other_defaults(tmp_path):
     assert c["top_k"] == "1" and float(c["temperature"]) == pytest.approx(0.8) and c["batch_size"] == "128"
 
 
+@pytest.mark.parametrize("seed", [2**64 - 1, 2**64 - 2, 2**53 + 1, -1, 0, 7])
+def test_seed_keeps_all_64_bits(tmp_path, seed):
+    """hparams "seed" is a uint64 in the reference (nlohmann reads it exactly; 2^64-1 = "pick one"): not through a double."""
+    from powerserve_amd import host
+    d = str(tmp_path / "w")
+    write(d, {"hparams_config": "hparams.json", "model_main": "m"}, {"sampler": {"seed": seed}})
+    assert host.config_summary(d)["seed"] == str(seed % 2**64)
+
+
 def test_errors_are_reported(tmp_path):
     from powerserve_amd import host
     with pytest.raises(host.HostError):

@@ -1,7 +1,9 @@
 """Speculative token-tree decoding (src/speculative/token_tree.cpp, spec_model.hpp) on the HIP backend.
 
-The reference's CPU executor ignores mask objects (executor.cpp:210-224), so there is no CPU golden for the tree forward;
-the domain offers a size-independent property instead: with a greedy target sampler the speculative output IS the target
+The reference's CPU executor ignores mask objects (executor.cpp:210-224), so the reference cannot run a tree forward as
+a whole; its compiled operators can (oracle/ref_ops_forward.py sequences them with a caller-supplied mask), and that is
+what test_tree_forward_all_nodes_match_reference_operators pins every tree node's logits to, bit for bit.  The drivers
+are checked through a size-independent property: with a greedy target sampler the speculative output IS the target
 model's own greedy output, whatever the draft model proposes.  Checked with an unrelated draft model (nearly nothing
 accepted: exercises catch-up forwards, branch switching with hidden cache slots, KV moves) and with the target as its own
 draft (long accepted paths)."""
@@ -61,6 +63,41 @@ def test_speculative_output_follows_target_greedy(tmp_path, draft, draft_seed, w
     assert np.array_equal(dm.generate(prompt, 8, 12), ref_d)
     target.close()
     dm.close()
+
+
+def test_speculative_verify_through_the_sampler_chain(tmp_path):
+    """spec_model.hpp:105 hands the SAMPLER to TokenTree::verify (token_tree.cpp:214-216: sampler.apply on the node's logits,
+    then the top candidate): a top_k = 1 chain reproduces the greedy text, a stop token ends the text where it is emitted, a
+    cache too small for another tree ends it early instead of aborting, and a penalised chain is reproducible."""
+    from powerserve_amd import host, synth
+    td = str(tmp_path / "t")
+    synth.write_model_dir(td, "small-llama-hs128", 12, n_ctx=96, seed=5)
+    target, dm = host.HostModel(td, max_batch=16), host.HostModel(td, max_batch=16)
+    prompt = np.random.default_rng(11).integers(0, target.vocab, 13)
+    steps = 40
+    want = target.generate(prompt, 8, steps)
+    smp = host.Sampler(host.SamplerCfg.make(target.vocab, top_k=1))
+    got, st = host.spec_generate_sampled(target, dm, prompt, 8, steps, smp)
+    assert np.array_equal(got, want) and st["n_generated_tokens"] / st["n_iterations"] > 2.0, (got, want, st)
+    # stop token: the first emitted occurrence ends the text (inclusive)
+    eos = int(want[9])
+    first = int(np.nonzero(want == eos)[0][0])
+    got, _ = host.spec_generate_sampled(target, dm, prompt, 8, steps, smp, eos=eos)
+    assert np.array_equal(got, want[:first + 1])
+    # capacity: 96 slots hold the 13-token prompt and at most 96 - 12 - 12 further tokens before a 12-node tree no longer fits
+    got, _ = host.spec_generate_sampled(target, dm, prompt, 8, 500, smp)
+    assert 40 <= got.size <= 96 - 12 and np.array_equal(got[:steps], want)
+    smp.close()
+    # a chain with penalties: deterministic, and not the greedy text
+    kw = dict(top_k=1, penalty_repeat=1.8, penalty_last_n=16, penalty_freq=0.3)
+    a, b = host.Sampler(host.SamplerCfg.make(target.vocab, **kw)), host.Sampler(host.SamplerCfg.make(target.vocab, **kw))
+    ga, _ = host.spec_generate_sampled(target, dm, prompt, 8, steps, a)
+    gb, _ = host.spec_generate_sampled(target, dm, prompt, 8, steps, b)
+    assert np.array_equal(ga, gb) and ga.size == steps
+    a.close(); b.close()
+    assert np.array_equal(target.generate(prompt, 8, steps), want)  # both models are left usable
+    target.close(); dm.close()
+
 
 
 def test_tree_forward_positions_and_masks(ctx, tmp_path):
