@@ -1496,7 +1496,8 @@ unsigned long long *psk_gemv_dbg_buf(int epi, int pro) { // key = k1 + 100 * (k2
     return nullptr;
 }
 
-bool psk_gemv_rope_ok(int wt, int64_t K) { // mirrors launch_g3_wt
+bool psk_gemv_rope_ok(int wt, int64_t K) { // mirrors psk_gemvb / launch_g3_wt
+    if (psk_gemvb_covers(wt, K)) return true;
     static const bool no_g3 = getenv("PS_NO_G3") != nullptr; // (A/B: the register-resident gemv1 instead)
     if (no_g3 && wt != PS_Q4_K) return false;
     const int64_t unit = (wt == PS_Q4_K) ? 256 : 128, n_units = (K + unit - 1) / unit;
@@ -1641,6 +1642,10 @@ int psk_gemv(hipStream_t st, int n_cu, const psk_gemv_args &a, ps_act act, int v
     if (epi == 1 && (a.n_w != 2 || a.w[0]->N != a.w[1]->N)) return 5;
     if (bs == 1 && wt == PS_Q4_K) { // second-generation decode kernel (k_gemv4.hip)
         const int rc = psk_gemv4(st, n_cu, a, act, K);
+        if (rc != -1) return rc;
+    }
+    if (bs == 1 && (wt == PS_Q4_0 || wt == PS_Q8_0)) { // producer / chain-wave kernel of the 32-element block formats (k_gemvb.hip)
+        const int rc = psk_gemvb(st, n_cu, a, act, K);
         if (rc != -1) return rc;
     }
     switch (wt) {

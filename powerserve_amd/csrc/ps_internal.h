@@ -176,6 +176,9 @@ int psk_gemv_debug(int key, uint64_t *host_out, int n_words); // timeline buffer
 int psk_gemv(hipStream_t st, int n_cu, const psk_gemv_args &a, ps_act act, int vdt, int64_t K, int64_t bs);
 // second-generation single-column Q4_K mat-vec (k_gemv4.hip); -1: not covered, the caller falls back
 int psk_gemv4(hipStream_t st, int n_cu, const psk_gemv_args &a, ps_act act, int64_t K);
+// single-column Q4_0 / Q8_0 mat-vec, producer / chain-wave form (k_gemvb.hip); -1: not covered, the caller falls back
+int psk_gemvb(hipStream_t st, int n_cu, const psk_gemv_args &a, ps_act act, int64_t K);
+bool psk_gemvb_covers(int wt, int64_t K);
 unsigned long long *psk_gemv_dbg_buf(int epi, int pro); // timeline slot armed for this (epilogue, prologue) pair, or null
 // the template instance the last quantized mat-vec / mat-mul launch of this process used (rocprofv3's kernel name): bench.py's
 // roofline names the kernel that RAN, not the one it expects
