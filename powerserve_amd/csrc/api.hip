@@ -265,6 +265,14 @@ int ps_hip_mul_mat(ps_hip_ctx *c, const ps_tensor *dst, const ps_tensor *src0, c
         const int vdt = ps_hip_vec_dot_type(w->dtype);
         if (ensure(c, &c->act_buf, &c->act_cap, ps_act_bytes(K, bs))) return 1;
         ps_act a = ps_act_carve(c->act_buf, K, bs);
+        if (is_row_wave(w->dtype) && bs == 1) { // single column: producer / chain-wave kernel, quantizer in its prologue (k_gemvk.hip)
+            psk_gemv_args g{};
+            g.n_w = 1; g.w[0] = w; g.out[0] = (float *)dst->data; g.ldo[0] = w->N;
+            g.pro = 2; g.pro_x = (const float *)src1->data;
+            const int rc = psk_gemvk(c->stream, c->n_cu, g, a, K);
+            if (rc == 0) { PS_CHECK(c, hipGetLastError()); return 0; }
+            if (rc != -1) { c->err = "mul_mat: Q5_K / Q6_K mat-vec launch rc=" + std::to_string(rc); return 2; }
+        }
         if (is_row_wave(w->dtype)) { // one wave per row (k_gemv6.hip)
             psk_quantize_act(c->stream, vdt, 0, (const float *)src1->data, nullptr, nullptr, 0.f, K, bs, a);
             psk_gemv6_args g6{w, (float *)dst->data, w->N, nullptr, nullptr};

@@ -1498,6 +1498,7 @@ unsigned long long *psk_gemv_dbg_buf(int epi, int pro) { // key = k1 + 100 * (k2
 
 bool psk_gemv_rope_ok(int wt, int64_t K) { // mirrors psk_gemvb / launch_g3_wt
     if (psk_gemvb_covers(wt, K)) return true;
+    if (wt == PS_Q5_K && psk_gemvk_covers(wt, K)) return true; // (Q / K / V all Q5_K: k_gemvk.hip)
     static const bool no_g3 = getenv("PS_NO_G3") != nullptr; // (A/B: the register-resident gemv1 instead)
     if (no_g3 && wt != PS_Q4_K) return false;
     const int64_t unit = (wt == PS_Q4_K) ? 256 : 128, n_units = (K + unit - 1) / unit;
@@ -1635,8 +1636,9 @@ int psk_gemv(hipStream_t st, int n_cu, const psk_gemv_args &a, ps_act act, int v
     p.col_bytes = (int64_t)psk_gemv_lds_col_bytes(wt, K);
     if ((size_t)p.col_bytes * (bs == 1 ? 1 : 4) > 158 * 1024) return 7;
     const int epi = a.silu_pair ? 1 : (a.rope ? 2 : 0);
+    const bool rope_part = a.rope && (a.n_w != 3 || a.rope_wi0 != 0); // a part of the Q / K / V triple: gemv4 only
     if (a.rope) {
-        if (a.n_w != 3 || bs != 1 || a.pro != 1) return 9;
+        if (a.n_w + a.rope_wi0 > 3 || bs != 1 || a.pro != 1) return 9;
         p.rope = *a.rope;
     }
     if (epi == 1 && (a.n_w != 2 || a.w[0]->N != a.w[1]->N)) return 5;
@@ -1644,6 +1646,7 @@ int psk_gemv(hipStream_t st, int n_cu, const psk_gemv_args &a, ps_act act, int v
         const int rc = psk_gemv4(st, n_cu, a, act, K);
         if (rc != -1) return rc;
     }
+    if (rope_part) return 9;
     if (bs == 1 && (wt == PS_Q4_0 || wt == PS_Q8_0)) { // producer / chain-wave kernel of the 32-element block formats (k_gemvb.hip)
         const int rc = psk_gemvb(st, n_cu, a, act, K);
         if (rc != -1) return rc;

@@ -18,43 +18,6 @@
 namespace {
 constexpr int G4_PAIR = 0; // units of a chunk the scheduler may interleave (0: one at a time)
 
-// silu_hadamard (src/backend/ggml/ggml.cpp:115-129) with glibc's expf table read from LDS: a table lookup in global /
-// constant memory is a vector-memory round trip (> 1 us behind the weight stream) on the chain wave's critical path
-__device__ __forceinline__ float g4_silu_mul(float g, float u, const uint64_t *tab) {
-    float val = g;
-    val       = __fmul_rn(val, __fdiv_rn(1.0f, __fadd_rn(1.0f, ps_expf_glibc(-val, tab))));
-    return __fmul_rn(val, u);
-}
-
-// Q8_K quantization of one 256-element tile held 4 values per lane (quantize_row_q8_K_ref, ggml-quants.c:3799-3835), the
-// prologue's version of ps_quantize_tile: every tile is full (K % 256 == 0), no 16-sums, and the scale / 32-sums are
-// written by every lane of their group (same value, same address) instead of behind exec-mask branches -- the prologue is
-// issue-bound on a single wave per tile, so instructions are what it costs.
-__device__ __forceinline__ void g4_quantize_tile(const float v[4], const int e, const int t, int8_t *qs, float *d, int *bs32, const bool live = true) {
-    // straight-line on purpose (no branch on the all-zero tile, `live` guards only the stores): a wave quantizes several
-    // independent tiles back to back and the scheduler can only interleave their dependent chains inside one basic block
-    int q[4];
-    const float am   = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
-    const float amax = wave_max_dpp(am); // max is order-independent: exact
-    // the first element (index order) with the largest |x| decides the sign of iscale
-    const unsigned long long hits = __ballot(am == amax);
-    const float mine = fabsf(v[0]) == amax ? v[0] : fabsf(v[1]) == amax ? v[1] : fabsf(v[2]) == amax ? v[2] : v[3];
-    const float mx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine), __ffsll((long long)hits) - 1));
-    const bool zero = amax == 0.f; // (an all-zero tile: quants 0, d 0 — quantize_row_q8_K's early-out)
-    const float iscale = zero ? 0.f : __fdiv_rn(-127.f, mx);
-#pragma unroll
-    for (int i = 0; i < 4; i++) q[i] = min(127, __float2int_rn(__fmul_rn(iscale, v[i])));
-    const float dd = zero ? 0.f : __fdiv_rn(1.0f, iscale);
-    int s = q[0] + q[1] + q[2] + q[3];
-    s += dpp_i<0xB1>(s); s += dpp_i<0x4E>(s); s += dpp_i<0x141>(s); // all 8 lanes of a 32-element group hold its sum
-    if (live) { // quad-major inside the tile (unit_rec<.., QT>): dword (e / 4) % 64 = g * 8 + u goes to u * 8 + g
-        const int dw = (e >> 2) & 63, eq = (e & ~255) + (((dw & 7) << 3) | (dw >> 3)) * 4;
-        *(uint32_t *)(qs + eq) = (uint32_t)(q[0] & 0xff) | ((uint32_t)(q[1] & 0xff) << 8) | ((uint32_t)(q[2] & 0xff) << 16) | ((uint32_t)(q[3] & 0xff) << 24);
-        d[t] = dd;
-        bs32[e >> 5] = s;
-    }
-}
-
 // A row's header of one super-block, expanded ONCE per chunk (by the lane that loaded it) into what the eight lanes of the
 // row need for each unit, so that they do not all unpack the same 6-bit fields again (the producers are VALU-bound:
 // ~62 instructions per unit and lane, a third of them header work).  64 bytes in LDS:
@@ -115,6 +78,7 @@ struct G4Params {
     const int16_t *abs16;
     unsigned long long *dbg;
     psk_rope_kv rope;           // EPI 2
+    int rope_wi0;               // EPI 2: w[0]'s place in the Q / K / V triple (a launch may carry a part of it)
 };
 
 // NW producer waves, DC chunks of weight loads in flight per wave (register ring), TPW activation tiles per producer,
@@ -343,7 +307,7 @@ __global__ __launch_bounds__((NW + 1) * 64) void gemv4_kernel(const G4Params p) 
                     if (b) vc = b[row];
                     if (EPI == 0) {
                         if (p.residual && wi == 0) va = p.residual[row];
-                    } else if (wi != 2) { // (cos, sin) of the rotation pair this row belongs to
+                    } else if (wi + p.rope_wi0 != 2) { // (cos, sin) of the rotation pair this row belongs to
                         const int e = (int)(row % p.rope.head_size);
                         if (e < p.rope.n_dims) {
                             const int64_t i0 = (int64_t)rpos * p.rope.head_size + (e & ~1);
@@ -378,8 +342,9 @@ __global__ __launch_bounds__((NW + 1) * 64) void gemv4_kernel(const G4Params p) 
                 if (b && row < Nw) v = __fadd_rn(v, ec);
                 const float vp = dpp_f<0x128>(v); // partner row (row_ror:8 swaps the two row groups of 8 lanes)
                 const psk_rope_kv &R = p.rope;
+                const int role = wi + p.rope_wi0; // 0 q, 1 k, 2 v
                 if (u == 0 && row < Nw) {
-                    if (wi == 2) {
+                    if (role == 2) {
                         R.v_cache[row * R.n_ctx + kv_pos] = v;
                         if (R.v16) R.v16[(int64_t)kv_pos * R.kv_dim + row] = (_Float16)v;
                     } else {
@@ -390,7 +355,7 @@ __global__ __launch_bounds__((NW + 1) * 64) void gemv4_kernel(const G4Params p) 
                             const float x0 = (e & 1) ? vp : v, x1 = (e & 1) ? v : vp;
                             res = (e & 1) ? __fadd_rn(__fmul_rn(x0, sn), __fmul_rn(x1, c)) : __fsub_rn(__fmul_rn(x0, c), __fmul_rn(x1, sn));
                         }
-                        if (wi == 0) o[row] = res; else { R.k_cache[(int64_t)kv_pos * R.kv_dim + row] = res; if (R.k16) R.k16[(int64_t)kv_pos * R.kv_dim + row] = (_Float16)res; }
+                        if (role == 0) o[row] = res; else { R.k_cache[(int64_t)kv_pos * R.kv_dim + row] = res; if (R.k16) R.k16[(int64_t)kv_pos * R.kv_dim + row] = (_Float16)res; }
                     }
                 }
             } else if (u == 0 && row < Nw) {
@@ -485,11 +450,14 @@ int launch_g4_kc(hipStream_t st, int grid, const G4Params &p, int epi, int pro) 
 int g_g4_cfg = 0;   // ps_hip_debug_set(1, cfg)
 int g_g4_flags = 0; // ps_hip_debug_set(2, flags): reserved for what-if switches
 
+bool psk_gemv4_covers(int64_t K) { // rows end on multiples of four units
+    static const bool off = getenv("PS_NO_GEMV4") != nullptr; // (A/B switch for measurements)
+    return !off && K % 1024 == 0 && K <= 16384;
+}
+
 // Single-column Q4_K mat-vec.  Returns -1 when the launch is not covered (the caller falls back to gemv3 / gemv1).
 int psk_gemv4(hipStream_t st, int n_cu, const psk_gemv_args &a, ps_act act, int64_t K) {
-    static const bool off = getenv("PS_NO_GEMV4") != nullptr; // (A/B switch for measurements)
-    if (off) return -1;
-    if (a.n_w < 1 || a.n_w > 3 || K % 1024 || K > 16384) return -1; // rows end on multiples of four units
+    if (a.n_w < 1 || a.n_w > 3 || !psk_gemv4_covers(K)) return -1;
     G4Params p{};
     int groups_total = 0;
     for (int i = 0; i < a.n_w; i++) {
@@ -501,8 +469,8 @@ int psk_gemv4(hipStream_t st, int n_cu, const psk_gemv_args &a, ps_act act, int6
     const int epi = a.silu_pair ? 1 : (a.rope ? 2 : 0);
     if (epi == 1 && (a.n_w != 2 || a.w[0]->N != a.w[1]->N)) return -1;
     if (epi == 2) {
-        if (a.n_w != 3 || a.pro != 1) return -1;
-        p.rope = *a.rope;
+        if (a.n_w + a.rope_wi0 > 3 || a.rope_wi0 < 0 || a.pro != 1) return -1;
+        p.rope = *a.rope; p.rope_wi0 = a.rope_wi0;
     }
     p.n_w = a.n_w; p.n_units = (int)(K / 256); p.K = (int)K;
     p.n_tasks = epi == 1 ? p.w[0].n_groups : groups_total;

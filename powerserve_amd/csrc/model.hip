@@ -94,7 +94,7 @@ static int mm_each(ps_hip_model *m, psk_gemv_args &g, ps_act act, int64_t K, int
     };
     bool all5 = g.n_w > 1;
     for (int i = 0; i < g.n_w; i++) all5 = all5 && g.w[i]->dtype == PS_Q5_K;
-    if (all5 && bs == 1) { // Q5_K_M: Q / K / V and gate / up as one launch each
+    if (all5 && bs == 1 && !g.rope) { // Q5_K_M: Q / K / V and gate / up as one launch each (when k_gemvk.hip did not take them)
         quantize_once();
         psk_gemv6_args a5[3];
         for (int i = 0; i < g.n_w; i++) a5[i] = psk_gemv6_args{g.w[i], g.silu_pair ? tmp[i] : g.out[i], g.ldo[i], g.bias[i], (i == 0 && !g.silu_pair) ? g.residual : nullptr};
@@ -107,7 +107,13 @@ static int mm_each(ps_hip_model *m, psk_gemv_args &g, ps_act act, int64_t K, int
         s.n_w = 1; s.w[0] = g.w[i]; s.out[0] = g.silu_pair ? tmp[i] : g.out[i]; s.bias[0] = g.bias[i];
         s.ldo[0] = g.ldo[i]; s.residual = (i == 0 && !g.silu_pair) ? g.residual : nullptr;
         s.pro = g.pro; s.pro_x = g.pro_x; s.pro_norm_w = g.pro_norm_w; s.pro_eps = g.pro_eps;
+        s.rope = g.rope; s.rope_wi0 = g.rope_wi0 + i; // (a Q / K / V group split by type: every launch does its part of RoPE + KV append)
         if (g.w[i]->dtype == PS_Q6_K || g.w[i]->dtype == PS_Q5_K) {
+            if (bs == 1) { // one matrix of a mixed group (Q4_K_M: a Q6_K V next to Q4_K Q and K): its own prologue
+                const int rc = psk_gemvk(c->stream, c->n_cu, s, act, K);
+                if (rc == 0) continue;
+                if (rc != -1 || g.rope) { c->err = "Q5_K / Q6_K mat-vec launch rc=" + std::to_string(rc); return 2; }
+            }
             quantize_once();
             psk_gemv6_args a6{g.w[i], s.out[0], s.ldo[0], s.bias[0], s.residual};
             if (int rc = psk_gemv6(c->stream, c->n_cu, a6, act, K, bs)) { c->err = "Q5_K / Q6_K mat-vec launch rc=" + std::to_string(rc); return 2; }
@@ -128,6 +134,11 @@ static int mm_each(ps_hip_model *m, psk_gemv_args &g, ps_act act, int64_t K, int
 
 static int mm(ps_hip_model *m, psk_gemv_args &g, ps_act act, int64_t K, int64_t bs) {
     ps_hip_ctx *c = m->ctx;
+    if (bs == 1 && (g.w[0]->dtype == PS_Q6_K || g.w[0]->dtype == PS_Q5_K)) { // single token: the launch with its fused prologue / epilogue (k_gemvk.hip)
+        const int rc = psk_gemvk(c->stream, c->n_cu, g, act, K); // (-1: mixed types, a pair it does not take, ...)
+        if (rc == 0) return 0;
+        if (rc != -1) { c->err = "Q5_K / Q6_K mat-vec launch rc=" + std::to_string(rc); return 2; }
+    }
     bool each = g.w[0]->dtype == PS_Q6_K || g.w[0]->dtype == PS_Q5_K;
     for (int i = 1; i < g.n_w; i++) each = each || g.w[i]->dtype != g.w[0]->dtype;
     if (each) return mm_each(m, g, act, K, bs);
@@ -202,7 +213,13 @@ static int enqueue_forward(ps_hip_model *m, int bs, bool lm_head, bool use_tree,
         const bool kv16 = (m->mode & 8) && !m->k16.empty();
         aa.k16 = kv16 ? m->k16[L] : nullptr; aa.v16 = kv16 ? m->v16[L] : nullptr; aa.part = m->attn_part;
         // single token, adjacent-pair RoPE: rotation and the KV append ride in the mat-vec epilogue
-        const bool fuse_rope = bs == 1 && !aa.neox && psk_gemv_rope_ok(m->wq[L]->dtype, dim) && m->wk[L]->dtype == m->wq[L]->dtype && m->wv[L]->dtype == m->wq[L]->dtype;
+        // (mixed types -- Q4_K_M's Q6_K V next to Q4_K Q and K -- and pure Q6_K: one launch per run of a type, each with its part
+        //  of the epilogue, psk_gemv_args::rope_wi0)
+        auto rope_part_ok = [&](const ps_weight *w) {
+            return (w->dtype == PS_Q4_K && psk_gemv4_covers(dim)) || ((w->dtype == PS_Q5_K || w->dtype == PS_Q6_K) && psk_gemvk_covers(w->dtype, dim) && w->N % 8 == 0);
+        };
+        const bool qkv_same = m->wk[L]->dtype == m->wq[L]->dtype && m->wv[L]->dtype == m->wq[L]->dtype;
+        const bool fuse_rope = bs == 1 && !aa.neox && ((qkv_same && psk_gemv_rope_ok(m->wq[L]->dtype, dim)) || (rope_part_ok(m->wq[L]) && rope_part_ok(m->wk[L]) && rope_part_ok(m->wv[L])));
         psk_rope_kv rk{m->state, m->rope_table, aa.k_cache, aa.v_cache, (int)f.head_size, (int)f.rope.n_dims, (int)f.seq_len, (int)kvd, aa.rope_pos, aa.k16, aa.v16};
         // batches of Q4_K weights: the same, in the chunk mat-mul's epilogue (k_gemm4k.hip)
         const bool fuse_rope_b = bs > 1 && !aa.neox && psk_gemm4k_rope_ok(g, dim, bs);

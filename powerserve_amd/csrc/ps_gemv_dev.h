@@ -194,4 +194,42 @@ __device__ __forceinline__ void rec_chain(const typename RecOf<WT>::T rc, const 
     }
 }
 
+// ---- shared by the producer / chain-wave kernels with a Q8_K activation (k_gemv4.hip, k_gemvk.hip)
+// silu_hadamard (src/backend/ggml/ggml.cpp:115-129) with glibc's expf table read from LDS: a table lookup in global /
+// constant memory is a vector-memory round trip (> 1 us behind the weight stream) on the chain wave's critical path
+__device__ __forceinline__ float g4_silu_mul(float g, float u, const uint64_t *tab) {
+    float val = g;
+    val       = __fmul_rn(val, __fdiv_rn(1.0f, __fadd_rn(1.0f, ps_expf_glibc(-val, tab))));
+    return __fmul_rn(val, u);
+}
+
+// Q8_K quantization of one 256-element tile held 4 values per lane (quantize_row_q8_K_ref, ggml-quants.c:3799-3835), the
+// prologue's version of ps_quantize_tile: every tile is full (K % 256 == 0), no 16-sums, and the scale / 32-sums are
+// written by every lane of their group (same value, same address) instead of behind exec-mask branches -- the prologue is
+// issue-bound on a single wave per tile, so instructions are what it costs.
+__device__ __forceinline__ void g4_quantize_tile(const float v[4], const int e, const int t, int8_t *qs, float *d, int *bs32, const bool live = true) {
+    // straight-line on purpose (no branch on the all-zero tile, `live` guards only the stores): a wave quantizes several
+    // independent tiles back to back and the scheduler can only interleave their dependent chains inside one basic block
+    int q[4];
+    const float am   = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    const float amax = wave_max_dpp(am); // max is order-independent: exact
+    // the first element (index order) with the largest |x| decides the sign of iscale
+    const unsigned long long hits = __ballot(am == amax);
+    const float mine = fabsf(v[0]) == amax ? v[0] : fabsf(v[1]) == amax ? v[1] : fabsf(v[2]) == amax ? v[2] : v[3];
+    const float mx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine), __ffsll((long long)hits) - 1));
+    const bool zero = amax == 0.f; // (an all-zero tile: quants 0, d 0 — quantize_row_q8_K's early-out)
+    const float iscale = zero ? 0.f : __fdiv_rn(-127.f, mx);
+#pragma unroll
+    for (int i = 0; i < 4; i++) q[i] = min(127, __float2int_rn(__fmul_rn(iscale, v[i])));
+    const float dd = zero ? 0.f : __fdiv_rn(1.0f, iscale);
+    int s = q[0] + q[1] + q[2] + q[3];
+    s += dpp_i<0xB1>(s); s += dpp_i<0x4E>(s); s += dpp_i<0x141>(s); // all 8 lanes of a 32-element group hold its sum
+    if (live) { // quad-major inside the tile (unit_rec<.., QT>): dword (e / 4) % 64 = g * 8 + u goes to u * 8 + g
+        const int dw = (e >> 2) & 63, eq = (e & ~255) + (((dw & 7) << 3) | (dw >> 3)) * 4;
+        *(uint32_t *)(qs + eq) = (uint32_t)(q[0] & 0xff) | ((uint32_t)(q[1] & 0xff) << 8) | ((uint32_t)(q[2] & 0xff) << 16) | ((uint32_t)(q[3] & 0xff) << 24);
+        d[t] = dd;
+        bs32[e >> 5] = s;
+    }
+}
+
 } // namespace

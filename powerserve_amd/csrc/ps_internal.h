@@ -151,6 +151,8 @@ struct psk_gemv_args {
     // optional (n_w == 3, one column): out[0] receives the rotated q, k goes rotated to the K cache row pos0, v to the
     // V cache column pos0 (norm_attention.cpp:76-113); out[1] / out[2] are not written
     const psk_rope_kv *rope;
+    int rope_wi0;            // with `rope`: which of Q / K / V w[0] is (0 .. 2) when the triple is split over launches by weight type
+                             // (Q4_K_M: Q and K in Q4_K, V in Q6_K); n_w + rope_wi0 <= 3.  Taken by gemv4 / gemvk only.
 };
 bool psk_gemv_rope_ok(int wt, int64_t K); // the fused epilogue exists for this weight type / row length
 size_t psk_gemv_lds_col_bytes(int wt, int64_t K);
@@ -176,9 +178,13 @@ int psk_gemv_debug(int key, uint64_t *host_out, int n_words); // timeline buffer
 int psk_gemv(hipStream_t st, int n_cu, const psk_gemv_args &a, ps_act act, int vdt, int64_t K, int64_t bs);
 // second-generation single-column Q4_K mat-vec (k_gemv4.hip); -1: not covered, the caller falls back
 int psk_gemv4(hipStream_t st, int n_cu, const psk_gemv_args &a, ps_act act, int64_t K);
+bool psk_gemv4_covers(int64_t K);
 // single-column Q4_0 / Q8_0 mat-vec, producer / chain-wave form (k_gemvb.hip); -1: not covered, the caller falls back
 int psk_gemvb(hipStream_t st, int n_cu, const psk_gemv_args &a, ps_act act, int64_t K);
 bool psk_gemvb_covers(int wt, int64_t K);
+// single-column Q6_K / Q5_K mat-vec with the fused prologues / epilogues (k_gemvk.hip); -1: not covered
+int psk_gemvk(hipStream_t st, int n_cu, const psk_gemv_args &a, ps_act act, int64_t K);
+bool psk_gemvk_covers(int wt, int64_t K);
 unsigned long long *psk_gemv_dbg_buf(int epi, int pro); // timeline slot armed for this (epilogue, prologue) pair, or null
 // the template instance the last quantized mat-vec / mat-mul launch of this process used (rocprofv3's kernel name): bench.py's
 // roofline names the kernel that RAN, not the one it expects
