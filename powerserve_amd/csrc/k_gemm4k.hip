@@ -933,6 +933,360 @@ __global__ __launch_bounds__((G4K_NC + G4K_NP) * 64) void gemm6k_kernel(const G6
 } // namespace
 
 // grid, persistence and the wide / narrow choice for a filled-in G4KParams (tasks, pointers, wt)
+// ---- narrow batches, wave-autonomous form (round 3): at most 16 columns, Q4_K.  The producer / consumer kernels above pay a
+// fixed ~0.45 us per super-block step (barriers, LDS round trips) whatever the width, and a K walk is sequential: 12 columns cost
+// 39.6 us for the gate / up launch (1.7 TB/s) and 31 us for down, where 128 tasks leave half the chip idle
+// (profiles/r03_tree12_kernel_stats.txt).  Here ONE WAVE owns one 16-row tile -- all eight accumulator lanes and all four mins
+// lanes -- for the whole K walk: no stage shared with other waves, no barrier.  Lane (row m, k-group kb) needs dword kb of the
+// 16 bytes the lane-major layout keeps for (row, u); fetched as dwords that is eight loads per super-block over the same sixteen
+// 128-byte lines, every one of them served by L2 (measured: 17 TB/s of L2 reads, slower than the staged kernel).  So a wave fetches
+// each line ONCE -- lane (r, u) its 16 bytes, two fully coalesced 1 KiB loads per super-block -- and turns the 2 KiB around in
+// a private LDS buffer (padded rows: conflict-free both ways; one wave's LDS operations are ordered).  The wave builds its fp16 A operands in registers (g4k_produce's arithmetic),
+// fetches the B fragments from L2 as it goes, runs its 48 fp32 chains and finishes hsum_float_8 in its own registers; a
+// register ring RA super-blocks deep covers the weight latency.  EPI 1: two waves per workgroup (gate tile, up tile), one
+// exchange through LDS at the end.
+template <int EPI, int RA, int MB> // MB: waves per SIMD the register allocation leaves room for
+__global__ __launch_bounds__(EPI == 1 ? 128 : 64, MB) void gemm4k_wav_kernel(const G4KParams p) {
+    const int wave = EPI == 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0, lane = threadIdx.x & 63;
+    const int m = lane & 15, kb = lane >> 4;
+    __shared__ float xup[EPI == 1 ? 64 * 4 : 1];
+    __shared__ uint64_t tab[EPI == 1 ? PS_EXP2F_N : 1];
+    if (EPI == 1 && threadIdx.x < PS_EXP2F_N) tab[threadIdx.x] = ps_exp2f_tab[threadIdx.x];
+    const int nsb = p.nsb;
+    int wi, pair;
+    const int task = EPI == 1 ? (int)blockIdx.x : (int)(blockIdx.x >> 1);
+    const G4KRows R = g4k_rows<EPI>(p, task, wi, pair);
+    const G4KMat &W = wi == 0 ? p.w[0] : (wi == 1 ? p.w[1] : p.w[2]);
+    const int tt = EPI == 1 ? wave : (int)(blockIdx.x & 1);
+    const int tile = tt ? R.tile[1] : R.tile[0];
+    const size_t g8 = (size_t)2 * tile + (m >> 3); // the 8-row group of this lane's row
+    const uint8_t *qb = (tt ? R.qs[1] : R.qs[0]) + ((size_t)2 * tile * nsb << 10) + (size_t)lane * 16; // the tile's two 1 KiB units of a super-block, 16 B per lane
+    const uint8_t *hb = (tt ? R.aux[1] : R.aux[0]) + g8 * nsb * 128 + (size_t)(m & 7) * 16;
+    // the wave's transposition buffer: row (16) x (8 u x 4 dwords), rows padded to 36 dwords (conflict-free both ways)
+    __shared__ uint32_t trb[EPI == 1 ? 2 : 1][16 * 36];
+    uint32_t *const trw = trb[wave];
+    const int col = m, colc = col < p.bs ? col : p.bs - 1;
+    const char *qfp = (const char *)p.qf + lane * 16; // (one column tile: ct = 0)
+    const uint8_t *ydp = p.mf + colc * 4, *b16p = p.mf + 64 + colc * 32;
+
+    ps_u32x4 rq[RA][2], rh[RA], rb[8], rs[2][2]; // weights and headers RA steps ahead; fragments one step ahead; the column's 16-sums two
+    float ryd[2];
+    auto load_a = [&](const int s, const int sb) { // every line of the tile ONCE: lane (r, u) takes its 16 bytes of both 8-row groups
+        rq[s][0] = __builtin_nontemporal_load((const ps_u32x4 *)(qb + ((size_t)sb << 10)));
+        rq[s][1] = __builtin_nontemporal_load((const ps_u32x4 *)(qb + ((size_t)(nsb + sb) << 10)));
+        rh[s] = *(const ps_u32x4 *)(hb + (size_t)sb * 128);
+    };
+    auto load_m = [&](const int s, const int sb) {
+        ryd[s]   = *(const float *)(ydp + (size_t)sb * 576);
+        rs[s][0] = *(const ps_u32x4 *)(b16p + (size_t)sb * 576);
+        rs[s][1] = *(const ps_u32x4 *)(b16p + (size_t)sb * 576 + 16);
+    };
+#pragma unroll
+    for (int s = 0; s < RA; s++) load_a(s, s < nsb ? s : nsb - 1);
+    load_m(0, 0); load_m(1, 1 < nsb ? 1 : 0);
+#pragma unroll
+    for (int u = 0; u < 8; u++) rb[u] = *(const ps_u32x4 *)(qfp + u * 1024);
+
+    float acc[4][8], accm[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+#pragma unroll
+        for (int u = 0; u < 8; u++) acc[r][u] = 0.f;
+#pragma unroll
+        for (int v = 0; v < 4; v++) accm[r][v] = 0.f;
+    }
+    const g4k_f4 zf = {0.f, 0.f, 0.f, 0.f};
+    const g4k_h2 k1024 = {(_Float16)1024.f, (_Float16)1024.f}, km1024 = {(_Float16)-1024.f, (_Float16)-1024.f};
+    const uint32_t sel0 = 0x04000400u | ((uint32_t)(2 * (kb & 1)) * 0x00010001u), sel1 = sel0 + 0x00010001u; // scales 2 (kb & 1), + 1 of the four
+    static_assert(RA % 2 == 0, "the 16-sum ring is two deep");
+#pragma clang loop unroll(disable)
+    for (int sb0 = 0; sb0 < nsb; sb0 += RA) { // (nsb % RA == 0: the host checks)
+#pragma unroll
+        for (int s = 0; s < RA; s++) {
+            const int sb = sb0 + s, nx = sb + 1 < nsb ? sb + 1 : sb; // nx: the super-block whose fragments are requested now
+            const float yd = ryd[s & 1];
+            const ps_u32x4 h = rh[s];
+            // the scales of sub-blocks 2 kb, 2 kb + 1 (get_scale_min_k4) as fp16 pairs (s, s) and (-1024 s, -1024 s)
+            const uint32_t scb = (kb & 2) ? ((h.w & 0x0f0f0f0fu) | (((h.y >> 6) & 0x03030303u) << 4)) : (h.y & 0x3f3f3f3fu);
+            const uint32_t t0 = __builtin_amdgcn_perm(0x64646464u, scb, sel0), t1 = __builtin_amdgcn_perm(0x64646464u, scb, sel1);
+            g4k_h2 s0, s1;
+            __builtin_memcpy(&s0, &t0, 4); __builtin_memcpy(&s1, &t1, 4);
+            s0 = s0 - k1024; s1 = s1 - k1024; // (bytes (s, 0x64) = fp16 1024 + s)
+            const g4k_h2 n0 = s0 * km1024, n1 = s1 * km1024;
+            // d, dmin of the rows this lane's results belong to (rows 4 kb + r: their headers sit in lanes 4 kb + r)
+            float dr[4], dmn[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const uint32_t hx = (uint32_t)__shfl((int)h.x, 4 * kb + r, 64);
+                dr[r]  = __fmul_rn(yd, ps_h2f((uint16_t)(hx & 0xffff)));
+                dmn[r] = __fmul_rn(-yd, ps_h2f((uint16_t)(hx >> 16)));
+            }
+            // lane (r, u) parks its 16 bytes (dwords kb = 0 .. 3); lane (m, kb) picks dword kb of (row m, u) for the eight u.  One
+            // wave, LDS operations in order: no barrier
+            *(ps_u32x4 *)(trw + (lane >> 3) * 36 + (lane & 7) * 4) = rq[s][0];
+            *(ps_u32x4 *)(trw + (8 + (lane >> 3)) * 36 + (lane & 7) * 4) = rq[s][1];
+            uint32_t wq[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) wq[u] = trw[m * 36 + u * 4 + kb];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const uint32_t w = wq[u];
+                // nibble pairs as fp16 (1024 + n): (e0, e2), (e1, e3) of sub-block 2 kb, then of 2 kb + 1;  fma(1024 + n, s, -1024 s) = n s, exact
+                const uint32_t tq[4] = {(w & 0x000F000Fu) | 0x64006400u, ((w >> 8) & 0x000F000Fu) | 0x64006400u,
+                                        ((w >> 4) & 0x000F000Fu) | 0x64006400u, ((w >> 12) & 0x000F000Fu) | 0x64006400u};
+                uint32_t o[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    g4k_h2 v;
+                    __builtin_memcpy(&v, &tq[k], 4);
+                    v = __builtin_elementwise_fma(v, k < 2 ? s0 : s1, k < 2 ? n0 : n1);
+                    __builtin_memcpy(&o[k], &v, 4);
+                }
+                const ps_u32x4 ao = {o[0], o[1], o[2], o[3]};
+                g4k_h8 av, bv;
+                __builtin_memcpy(&av, &ao, 16); __builtin_memcpy(&bv, &rb[u], 16);
+                const g4k_f4 si = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bv, zf, 0, 0, 0); // (float)sumi[u] of rows 4 kb + r, this lane's column
+                rb[u] = *(const ps_u32x4 *)(qfp + ((size_t)nx << 13) + u * 1024);
+#pragma unroll
+                for (int r = 0; r < 4; r++) acc[r][u] = __fmaf_rn(dr[r], si[r], acc[r][u]);
+                if (u & 1) __builtin_amdgcn_sched_barrier(0); // two accumulator lanes at a time: interleaving all eight costs registers, hides nothing other waves do not
+            }
+            { // the four mins lanes: A = (m[2v], m[2v], m[2v+1], m[2v+1]) in the lanes of k-group 0, zero elsewhere; B = the column's 16-sums
+                const uint32_t mn[2] = {h.z & 0x3f3f3f3fu, ((h.w >> 4) & 0x0f0f0f0fu) | (((h.z >> 6) & 0x03030303u) << 4)};
+                const uint32_t bw[8] = {rs[s & 1][0].x, rs[s & 1][0].y, rs[s & 1][0].z, rs[s & 1][0].w, rs[s & 1][1].x, rs[s & 1][1].y, rs[s & 1][1].z, rs[s & 1][1].w};
+                const g4k_h2 z2 = {(_Float16)0.f, (_Float16)0.f};
+#pragma unroll
+                for (int v = 0; v < 4; v++) {
+                    const uint32_t p0 = __builtin_amdgcn_perm(0x64646464u, mn[v >> 1], 0x04000400u | (uint32_t)(((2 * v) & 3) * 0x00010001u));
+                    const uint32_t p1 = __builtin_amdgcn_perm(0x64646464u, mn[v >> 1], 0x04000400u | (uint32_t)((((2 * v) & 3) + 1) * 0x00010001u));
+                    g4k_h2 h0, h1;
+                    __builtin_memcpy(&h0, &p0, 4); __builtin_memcpy(&h1, &p1, 4);
+                    h0 = h0 - k1024; h1 = h1 - k1024;
+                    if (kb != 0) { h0 = z2; h1 = z2; }
+                    const g4k_h4 am = {h0[0], h0[1], h1[0], h1[1]};
+                    g4k_h4 bm;
+                    { const ps_u32x2 b2 = {bw[2 * v], bw[2 * v + 1]}; __builtin_memcpy(&bm, &b2, 8); }
+                    const g4k_f4 pr = __builtin_amdgcn_mfma_f32_16x16x16f16(am, bm, zf, 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < 4; r++) accm[r][v] = __fmaf_rn(dmn[r], pr[r], accm[r][v]);
+                }
+            }
+            // the slots just used take the loads of RA (2) steps ahead; past the end they re-read the last super-block
+            load_a(s, sb + RA < nsb ? sb + RA : nsb - 1);
+            load_m(s & 1, sb + 2 < nsb ? sb + 2 : nsb - 1);
+        }
+    }
+    // ---- hsum_float_8 (+ the mins chains) of rows 4 kb + r, in registers
+    float y[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const float s0 = __fadd_rn(acc[r][0], acc[r][4]), s1 = __fadd_rn(acc[r][1], acc[r][5]), s2 = __fadd_rn(acc[r][2], acc[r][6]), s3 = __fadd_rn(acc[r][3], acc[r][7]);
+        const float res = __fadd_rn(__fadd_rn(s0, s2), __fadd_rn(s1, s3));
+        const float mm = __fadd_rn(__fadd_rn(accm[r][0], accm[r][2]), __fadd_rn(accm[r][1], accm[r][3]));
+        y[r] = __fadd_rn(res, mm);
+    }
+    if constexpr (EPI == 1) { // wave 1 (the up tile) hands its rows to wave 0 (the gate tile)
+        if (wave == 1) *(float4 *)(xup + lane * 4) = make_float4(y[0], y[1], y[2], y[3]);
+        __syncthreads();
+        if (wave == 0 && col < p.bs) {
+            const float4 up = *(const float4 *)(xup + lane * 4);
+            const float uv[4] = {up.x, up.y, up.z, up.w};
+            const int64_t row0 = (int64_t)task * 16 + kb * 4;
+            float o[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) // ps_silu_mul with the table in LDS
+                o[r] = __fmul_rn(__fmul_rn(y[r], __fdiv_rn(1.0f, __fadd_rn(1.0f, ps_expf_glibc(-y[r], tab)))), uv[r]);
+            *(float4 *)(W.out + (int64_t)col * W.ldo + row0) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    } else if (col < p.bs) {
+        const int64_t row0 = (int64_t)tile * 16 + kb * 4;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            v[r] = y[r];
+            if (W.bias) v[r] = __fadd_rn(v[r], W.bias[row0 + r]);
+            if (p.residual && wi == 0) v[r] = __fadd_rn(p.residual[(int64_t)col * W.ldo + row0 + r], v[r]);
+        }
+        g4k_store_pair<2>(p, wi, W, col, row0, v[0], v[1]);
+        g4k_store_pair<2>(p, wi, W, col, row0 + 2, v[2], v[3]);
+    }
+}
+
+// The same for launches with few row tiles (N = 4096: 256 tiles; Q / K / V: 384): one wave per tile would leave three SIMDs in
+// four idle and walk K at one wave's pace (24.9 us per launch against 19 for the staged kernel).  FOUR waves share a tile: wave q
+// owns the accumulator lanes 2q, 2q + 1 and the mins lane q.  The weights still arrive once: wave q fetches the whole tile
+// (2 KiB + 16 headers) of the super-blocks sb = q (mod 4), RA of its own steps ahead, and parks them in LDS stage sb % 4 two steps
+// before they are consumed; one workgroup barrier (four waves) per super-block.
+template <int RA, int SPB> // RA groups of SPB super-blocks in flight per wave; one barrier per group
+__global__ __launch_bounds__(256) void gemm4k_wav4_kernel(const G4KParams p) {
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int m = lane & 15, kb = lane >> 4;
+    constexpr int STG = 16 * 36 + 16 * 4; // dwords of a stage: the transposition rows, then the 16 row headers
+    __shared__ __attribute__((aligned(16))) uint32_t stg[4 * SPB][STG];
+    __shared__ float xall[4][64][16]; // [wave][lane][4 rows][2 accumulator chains, the mins chain, -]
+    const int nsb = p.nsb;
+    int wi, pair;
+    const G4KRows R = g4k_rows<0>(p, (int)(blockIdx.x >> 1), wi, pair);
+    const G4KMat &W = wi == 0 ? p.w[0] : (wi == 1 ? p.w[1] : p.w[2]);
+    const int tt = (int)(blockIdx.x & 1), tile = tt ? R.tile[1] : R.tile[0];
+    const uint8_t *qb = R.qs[0] + ((size_t)2 * tile * nsb << 10) + (size_t)lane * 16;
+    const uint8_t *hb = R.aux[0] + ((size_t)2 * tile + (m >> 3)) * nsb * 128 + (size_t)(m & 7) * 16; // row m's header (the four kb lanes of a row ask for the same 16 bytes)
+    const int col = m, colc = col < p.bs ? col : p.bs - 1;
+    const char *qfp = (const char *)p.qf + (size_t)(2 * wave) * 1024 + lane * 16;
+    const uint8_t *ydp = p.mf + colc * 4, *b16p = p.mf + 64 + colc * 32 + wave * 8;
+
+    ps_u32x4 rq[RA][SPB][2], rh[RA][SPB]; // this wave's own groups wave, wave + 4, ...: RA of them in flight
+    auto load_a = [&](const int s, const int g) { // group g = super-blocks g * SPB ..
+#pragma unroll
+        for (int i = 0; i < SPB; i++) {
+            const int sbx = g * SPB + i, sb = sbx < nsb ? sbx : nsb - 1;
+            rq[s][i][0] = __builtin_nontemporal_load((const ps_u32x4 *)(qb + ((size_t)sb << 10)));
+            rq[s][i][1] = __builtin_nontemporal_load((const ps_u32x4 *)(qb + ((size_t)(nsb + sb) << 10)));
+            rh[s][i] = *(const ps_u32x4 *)(hb + (size_t)sb * 128);
+        }
+    };
+    auto park = [&](const int s, const int gs) { // into the stages of group slot gs (0 .. 3)
+#pragma unroll
+        for (int i = 0; i < SPB; i++) {
+            uint32_t *st = stg[gs * SPB + i];
+            *(ps_u32x4 *)(st + (lane >> 3) * 36 + (lane & 7) * 4) = rq[s][i][0];
+            *(ps_u32x4 *)(st + (8 + (lane >> 3)) * 36 + (lane & 7) * 4) = rq[s][i][1];
+            if (kb == 0) *(ps_u32x4 *)(st + 16 * 36 + m * 4) = rh[s][i];
+        }
+    };
+#pragma unroll
+    for (int s = 0; s < RA; s++) load_a(s, wave + 4 * s);
+    ps_u32x4 rb[2][2]; // fragments, 16-sums and column scale two steps ahead
+    float ryd[2];
+    ps_u32x2 rs[2];
+    auto load_b = [&](const int s, const int sb) {
+        rb[s][0] = *(const ps_u32x4 *)(qfp + ((size_t)sb << 13));
+        rb[s][1] = *(const ps_u32x4 *)(qfp + ((size_t)sb << 13) + 1024);
+        ryd[s] = *(const float *)(ydp + (size_t)sb * 576);
+        rs[s]  = *(const ps_u32x2 *)(b16p + (size_t)sb * 576);
+    };
+    load_b(0, 0); load_b(1, 1 < nsb ? 1 : 0);
+    float acc[4][2], accm[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) { acc[r][0] = acc[r][1] = 0.f; accm[r] = 0.f; }
+    const g4k_f4 zf = {0.f, 0.f, 0.f, 0.f};
+    const g4k_h2 k1024 = {(_Float16)1024.f, (_Float16)1024.f}, km1024 = {(_Float16)-1024.f, (_Float16)-1024.f};
+    const uint32_t sel0 = 0x04000400u | ((uint32_t)(2 * (kb & 1)) * 0x00010001u), sel1 = sel0 + 0x00010001u;
+    const uint32_t msel0 = 0x04000400u | ((uint32_t)((2 * wave) & 3) * 0x00010001u), msel1 = msel0 + 0x00010001u;
+    const int ng = nsb / SPB; // (nsb % (4 * SPB) == 0: the host checks)
+    // groups 0 and 1 before the loop (waves 0 and 1 own them), then every round parks the group two ahead
+    if (wave < 2) park(0, wave);
+    int own = wave < 2 ? 1 % RA : 0; // ring slot of this wave's next group to park
+    if (wave < 2) load_a(0, wave + 4 * RA);
+#pragma clang loop unroll(disable)
+    for (int g0 = 0; g0 < ng; g0 += 4) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int g = g0 + k;
+            if (wave == ((k + 2) & 3) && g + 2 < ng) { // this wave's group g + 2 goes to its stages; the slot takes the group RA rounds later
+#pragma unroll
+                for (int s = 0; s < RA; s++)
+                    if (s == own) {
+                        park(s, (k + 2) & 3);
+                        load_a(s, g + 2 + 4 * RA);
+                    }
+                own = own + 1 == RA ? 0 : own + 1;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < SPB; i++) {
+            const int sb = g * SPB + i, bi = (SPB * k + i) & 1;
+            const uint32_t *st = stg[k * SPB + i];
+            const float yd = ryd[bi];
+            const ps_u32x4 h = *(const ps_u32x4 *)(st + 16 * 36 + m * 4);
+            const uint32_t scb = (kb & 2) ? ((h.w & 0x0f0f0f0fu) | (((h.y >> 6) & 0x03030303u) << 4)) : (h.y & 0x3f3f3f3fu);
+            const uint32_t t0 = __builtin_amdgcn_perm(0x64646464u, scb, sel0), t1 = __builtin_amdgcn_perm(0x64646464u, scb, sel1);
+            g4k_h2 s0, s1;
+            __builtin_memcpy(&s0, &t0, 4); __builtin_memcpy(&s1, &t1, 4);
+            s0 = s0 - k1024; s1 = s1 - k1024;
+            const g4k_h2 n0 = s0 * km1024, n1 = s1 * km1024;
+            float dr[4], dmn[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) { // d | dmin of rows 4 kb + r
+                const uint32_t hx = st[16 * 36 + (4 * kb + r) * 4];
+                dr[r]  = __fmul_rn(yd, ps_h2f((uint16_t)(hx & 0xffff)));
+                dmn[r] = __fmul_rn(-yd, ps_h2f((uint16_t)(hx >> 16)));
+            }
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const uint32_t w = st[m * 36 + (2 * wave + j) * 4 + kb];
+                const uint32_t tq[4] = {(w & 0x000F000Fu) | 0x64006400u, ((w >> 8) & 0x000F000Fu) | 0x64006400u,
+                                        ((w >> 4) & 0x000F000Fu) | 0x64006400u, ((w >> 12) & 0x000F000Fu) | 0x64006400u};
+                uint32_t o[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    g4k_h2 v;
+                    __builtin_memcpy(&v, &tq[q], 4);
+                    v = __builtin_elementwise_fma(v, q < 2 ? s0 : s1, q < 2 ? n0 : n1);
+                    __builtin_memcpy(&o[q], &v, 4);
+                }
+                const ps_u32x4 ao = {o[0], o[1], o[2], o[3]};
+                g4k_h8 av, bv;
+                __builtin_memcpy(&av, &ao, 16); __builtin_memcpy(&bv, &rb[bi][j], 16);
+                const g4k_f4 si = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bv, zf, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; r++) acc[r][j] = __fmaf_rn(dr[r], si[r], acc[r][j]);
+            }
+            {
+                const uint32_t mp = wave < 2 ? (h.z & 0x3f3f3f3fu) : (((h.w >> 4) & 0x0f0f0f0fu) | (((h.z >> 6) & 0x03030303u) << 4));
+                const uint32_t p0 = __builtin_amdgcn_perm(0x64646464u, mp, msel0), p1 = __builtin_amdgcn_perm(0x64646464u, mp, msel1);
+                g4k_h2 h0, h1;
+                __builtin_memcpy(&h0, &p0, 4); __builtin_memcpy(&h1, &p1, 4);
+                h0 = h0 - k1024; h1 = h1 - k1024;
+                const g4k_h2 z2 = {(_Float16)0.f, (_Float16)0.f};
+                if (kb != 0) { h0 = z2; h1 = z2; }
+                const g4k_h4 am = {h0[0], h0[1], h1[0], h1[1]};
+                g4k_h4 bm;
+                { const ps_u32x2 b2 = rs[bi]; __builtin_memcpy(&bm, &b2, 8); }
+                const g4k_f4 pr = __builtin_amdgcn_mfma_f32_16x16x16f16(am, bm, zf, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; r++) accm[r] = __fmaf_rn(dmn[r], pr[r], accm[r]);
+            }
+            load_b(bi, sb + 2 < nsb ? sb + 2 : nsb - 1);
+            }
+        }
+    }
+    // ---- the four waves meet: waves 0 and 1 finish rows 4 kb + 2 wave, + 1 (hsum_float_8's order)
+#pragma unroll
+    for (int r = 0; r < 4; r++) *(float4 *)(&xall[wave][lane][r * 4]) = make_float4(acc[r][0], acc[r][1], accm[r], 0.f);
+    __syncthreads();
+    if (wave < 2 && col < p.bs) {
+        float v[2];
+#pragma unroll
+        for (int rr = 0; rr < 2; rr++) {
+            const int r = 2 * wave + rr;
+            float au[8], mv[4];
+#pragma unroll
+            for (int u = 0; u < 8; u++) au[u] = xall[u >> 1][lane][r * 4 + (u & 1)];
+#pragma unroll
+            for (int q = 0; q < 4; q++) mv[q] = xall[q][lane][r * 4 + 2];
+            const float s0 = __fadd_rn(au[0], au[4]), s1 = __fadd_rn(au[1], au[5]), s2 = __fadd_rn(au[2], au[6]), s3 = __fadd_rn(au[3], au[7]);
+            const float res = __fadd_rn(__fadd_rn(s0, s2), __fadd_rn(s1, s3));
+            const float mm = __fadd_rn(__fadd_rn(mv[0], mv[2]), __fadd_rn(mv[1], mv[3]));
+            v[rr] = __fadd_rn(res, mm);
+        }
+        const int64_t row0 = (int64_t)tile * 16 + kb * 4 + 2 * wave;
+#pragma unroll
+        for (int rr = 0; rr < 2; rr++) {
+            if (W.bias) v[rr] = __fadd_rn(v[rr], W.bias[row0 + rr]);
+            if (p.residual && wi == 0) v[rr] = __fadd_rn(p.residual[(int64_t)col * W.ldo + row0 + rr], v[rr]);
+        }
+        g4k_store_pair<2>(p, wi, W, col, row0, v[0], v[1]);
+    }
+}
+
+template <int EPI, int RA, int MB>
+static void g4k_launch_wav(hipStream_t st, const G4KParams &p) {
+    const unsigned grid = (unsigned)(EPI == 1 ? p.n_tasks : 2 * p.n_tasks);
+    psk_note_kernel("gemm4k_wav_kernel<%d, %d, %d>", EPI, RA, MB);
+    hipLaunchKernelGGL((gemm4k_wav_kernel<EPI, RA, MB>), dim3(grid), dim3(EPI == 1 ? 128 : 64), 0, st, p);
+}
+
 static int g4k_launch(hipStream_t st, int n_cu, G4KParams &p, const int epi, const int64_t bs) {
     const int n_ct = (int)((bs + 15) / 16);
     // (Measured, not kept.  (1) 64 rows x 32 columns per workgroup for batches of at most 32 columns -- every prepared weight
@@ -946,6 +1300,8 @@ static int g4k_launch(hipStream_t st, int n_cu, G4KParams &p, const int epi, con
     // 32: 5.9, 64: 6.3, 128: 8.4 (wide); the round-1 kernels that spread a row group's integer work over producer waves
     // (gemm8): 2: 4.9, 8: 5.0, 12: 6.1, 16: 6.2, 32: 8.8, 64: 12.8, 96: 19.9.  PS_GEMM4K_MIN_COLS moves the switch (default 2).
     if (bs < ps_gemm4k_min_cols() || p.nsb % 4) return -1;
+    static const bool no_wav = getenv("PS_NO_GEMM4K_WAV") != nullptr;                                     // (A/B switches for measurements)
+    static const int wav_cfg = getenv("PS_GEMM4K_WAV_CFG") ? atoi(getenv("PS_GEMM4K_WAV_CFG")) : 0;
     const int ctw = n_ct <= 1 ? 1 : 4; // column tiles per workgroup: the narrow kernel for at most 16 columns (its two-tile form, CT = 2, spills: 13.7 ms per 8B forward against 5.9 ms, not instantiated)
     p.n_cb = (n_ct + ctw - 1) / ctw;
     p.n_items = (p.n_tasks + 7) / 8 * 8 * p.n_cb;
@@ -969,6 +1325,18 @@ static int g4k_launch(hipStream_t st, int n_cu, G4KParams &p, const int epi, con
         if (epi != 0) return -1;
         if (ctw == 1) { psk_note_kernel("gemm4k_narrow_kernel<0, 1, 13>"); hipLaunchKernelGGL((gemm4k_narrow_kernel<0, 1, PS_Q5_K>), grid, blkn, LDS1, st, p); }
         else { psk_note_kernel("gemm4k_kernel<0, 13>"); hipLaunchKernelGGL((gemm4k_kernel<0, PS_Q5_K>), grid, blk, G4K_LDS, st, p); }
+    } else if (ctw == 1 && n_ct == 1 && !no_wav && p.nsb % 8 == 0) { // at most 16 columns: the wave-autonomous form
+        // 8B tree forward 12 wide, us per launch, staged narrow kernel -> these (profiles/r03_tree12_kernel_stats*.txt): gate / up 39.6 -> 23.6,
+        // Q / K / V and O 13 -> 11, down 31 -> 31, lm_head 151 -> 88; the forward 4.59 -> 3.68 ms.  Measured and not kept: the accumulator
+        // lanes of a tile split over four unsynchronised waves with dword loads (every 128-byte line fetched from L2 eight times: 46 us
+        // for gate / up); one wave per tile for the few-tile launches (24.9 us on average: one wave per four SIMDs walks K alone); two
+        // super-blocks per barrier in the four-wave form (SPB = 2: down 30 us, Q / K / V and O 14.7).
+        if (epi == 1) g4k_launch_wav<1, 2, 2>(st, p);
+        else if (2 * p.n_tasks >= 4 * n_cu || wav_cfg == 1) g4k_launch_wav<0, 2, 2>(st, p); // many tiles (lm_head): a wave per tile, occupancy hides the latency
+        else { // few tiles: four waves per tile
+            psk_note_kernel("gemm4k_wav4_kernel<2, 1>");
+            hipLaunchKernelGGL((gemm4k_wav4_kernel<2, 1>), dim3((unsigned)(2 * p.n_tasks)), dim3(256), 0, st, p);
+        }
     } else if (ctw == 1) {
         if (epi == 1) { psk_note_kernel("gemm4k_narrow_kernel<1, 1, 12>"); hipLaunchKernelGGL((gemm4k_narrow_kernel<1, 1, PS_Q4_K>), grid, blkn, LDS1, st, p); }
         else { psk_note_kernel("gemm4k_narrow_kernel<0, 1, 12>"); hipLaunchKernelGGL((gemm4k_narrow_kernel<0, 1, PS_Q4_K>), grid, blkn, LDS1, st, p); }
