@@ -1117,12 +1117,12 @@ __global__ __launch_bounds__(EPI == 1 ? 128 : 64, MB) void gemm4k_wav_kernel(con
 // owns the accumulator lanes 2q, 2q + 1 and the mins lane q.  The weights still arrive once: wave q fetches the whole tile
 // (2 KiB + 16 headers) of the super-blocks sb = q (mod 4), RA of its own steps ahead, and parks them in LDS stage sb % 4 two steps
 // before they are consumed; one workgroup barrier (four waves) per super-block.
-template <int RA, int SPB> // RA groups of SPB super-blocks in flight per wave; one barrier per group
+template <int RA> // RA of a wave's own super-blocks in flight
 __global__ __launch_bounds__(256) void gemm4k_wav4_kernel(const G4KParams p) {
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int m = lane & 15, kb = lane >> 4;
     constexpr int STG = 16 * 36 + 16 * 4; // dwords of a stage: the transposition rows, then the 16 row headers
-    __shared__ __attribute__((aligned(16))) uint32_t stg[4 * SPB][STG];
+    __shared__ __attribute__((aligned(16))) uint32_t stg[4][STG];
     __shared__ float xall[4][64][16]; // [wave][lane][4 rows][2 accumulator chains, the mins chain, -]
     const int nsb = p.nsb;
     int wi, pair;
@@ -1135,24 +1135,18 @@ __global__ __launch_bounds__(256) void gemm4k_wav4_kernel(const G4KParams p) {
     const char *qfp = (const char *)p.qf + (size_t)(2 * wave) * 1024 + lane * 16;
     const uint8_t *ydp = p.mf + colc * 4, *b16p = p.mf + 64 + colc * 32 + wave * 8;
 
-    ps_u32x4 rq[RA][SPB][2], rh[RA][SPB]; // this wave's own groups wave, wave + 4, ...: RA of them in flight
-    auto load_a = [&](const int s, const int g) { // group g = super-blocks g * SPB ..
-#pragma unroll
-        for (int i = 0; i < SPB; i++) {
-            const int sbx = g * SPB + i, sb = sbx < nsb ? sbx : nsb - 1;
-            rq[s][i][0] = __builtin_nontemporal_load((const ps_u32x4 *)(qb + ((size_t)sb << 10)));
-            rq[s][i][1] = __builtin_nontemporal_load((const ps_u32x4 *)(qb + ((size_t)(nsb + sb) << 10)));
-            rh[s][i] = *(const ps_u32x4 *)(hb + (size_t)sb * 128);
-        }
+    ps_u32x4 rq[RA][2], rh[RA]; // this wave's own super-blocks wave, wave + 4, ...: RA of them in flight
+    auto load_a = [&](const int s, const int sbx) {
+        const int sb = sbx < nsb ? sbx : nsb - 1;
+        rq[s][0] = __builtin_nontemporal_load((const ps_u32x4 *)(qb + ((size_t)sb << 10)));
+        rq[s][1] = __builtin_nontemporal_load((const ps_u32x4 *)(qb + ((size_t)(nsb + sb) << 10)));
+        rh[s] = *(const ps_u32x4 *)(hb + (size_t)sb * 128);
     };
-    auto park = [&](const int s, const int gs) { // into the stages of group slot gs (0 .. 3)
-#pragma unroll
-        for (int i = 0; i < SPB; i++) {
-            uint32_t *st = stg[gs * SPB + i];
-            *(ps_u32x4 *)(st + (lane >> 3) * 36 + (lane & 7) * 4) = rq[s][i][0];
-            *(ps_u32x4 *)(st + (8 + (lane >> 3)) * 36 + (lane & 7) * 4) = rq[s][i][1];
-            if (kb == 0) *(ps_u32x4 *)(st + 16 * 36 + m * 4) = rh[s][i];
-        }
+    auto park = [&](const int s, const int stage) {
+        uint32_t *st = stg[stage];
+        *(ps_u32x4 *)(st + (lane >> 3) * 36 + (lane & 7) * 4) = rq[s][0];
+        *(ps_u32x4 *)(st + (8 + (lane >> 3)) * 36 + (lane & 7) * 4) = rq[s][1];
+        if (kb == 0) *(ps_u32x4 *)(st + 16 * 36 + m * 4) = rh[s];
     };
 #pragma unroll
     for (int s = 0; s < RA; s++) load_a(s, wave + 4 * s);
@@ -1173,32 +1167,44 @@ __global__ __launch_bounds__(256) void gemm4k_wav4_kernel(const G4KParams p) {
     const g4k_h2 k1024 = {(_Float16)1024.f, (_Float16)1024.f}, km1024 = {(_Float16)-1024.f, (_Float16)-1024.f};
     const uint32_t sel0 = 0x04000400u | ((uint32_t)(2 * (kb & 1)) * 0x00010001u), sel1 = sel0 + 0x00010001u;
     const uint32_t msel0 = 0x04000400u | ((uint32_t)((2 * wave) & 3) * 0x00010001u), msel1 = msel0 + 0x00010001u;
-    const int ng = nsb / SPB; // (nsb % (4 * SPB) == 0: the host checks)
-    // groups 0 and 1 before the loop (waves 0 and 1 own them), then every round parks the group two ahead
+    // what a step reads from its stage: the row header, d | dmin of the four result rows, the two weight dwords.  Fetched one
+    // step AHEAD (the stage of step sb + 1 has been complete since the barrier of step sb - 1): at one wave per SIMD an LDS round
+    // trip in front of every dependent instruction chain is what a step costs
+    struct Ops { ps_u32x4 h; uint32_t hx[4], w[2]; };
+    auto fetch = [&](const int stage) {
+        const uint32_t *st = stg[stage];
+        Ops o;
+        o.h = *(const ps_u32x4 *)(st + 16 * 36 + m * 4);
+#pragma unroll
+        for (int r = 0; r < 4; r++) o.hx[r] = st[16 * 36 + (4 * kb + r) * 4];
+#pragma unroll
+        for (int j = 0; j < 2; j++) o.w[j] = st[m * 36 + (2 * wave + j) * 4 + kb];
+        return o;
+    };
+    // super-blocks 0 and 1 before the loop (waves 0 and 1 own them), then every step parks the one two ahead
     if (wave < 2) park(0, wave);
-    int own = wave < 2 ? 1 % RA : 0; // ring slot of this wave's next group to park
+    int own = wave < 2 ? 1 % RA : 0; // ring slot of this wave's next super-block to park
     if (wave < 2) load_a(0, wave + 4 * RA);
+    __syncthreads();
+    Ops cur = fetch(0);
 #pragma clang loop unroll(disable)
-    for (int g0 = 0; g0 < ng; g0 += 4) {
+    for (int sb0 = 0; sb0 < nsb; sb0 += 4) { // (nsb % 4 == 0)
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const int g = g0 + k;
-            if (wave == ((k + 2) & 3) && g + 2 < ng) { // this wave's group g + 2 goes to its stages; the slot takes the group RA rounds later
+            const int sb = sb0 + k;
+            if (wave == ((k + 2) & 3) && sb + 2 < nsb) { // this wave's super-block sb + 2 goes to its stage; the slot takes the one RA rounds later
 #pragma unroll
                 for (int s = 0; s < RA; s++)
                     if (s == own) {
                         park(s, (k + 2) & 3);
-                        load_a(s, g + 2 + 4 * RA);
+                        load_a(s, sb + 2 + 4 * RA);
                     }
                 own = own + 1 == RA ? 0 : own + 1;
             }
             __syncthreads();
-#pragma unroll
-            for (int i = 0; i < SPB; i++) {
-            const int sb = g * SPB + i, bi = (SPB * k + i) & 1;
-            const uint32_t *st = stg[k * SPB + i];
-            const float yd = ryd[bi];
-            const ps_u32x4 h = *(const ps_u32x4 *)(st + 16 * 36 + m * 4);
+            const Ops nxt = fetch((k + 1) & 3);
+            const float yd = ryd[k & 1];
+            const ps_u32x4 h = cur.h;
             const uint32_t scb = (kb & 2) ? ((h.w & 0x0f0f0f0fu) | (((h.y >> 6) & 0x03030303u) << 4)) : (h.y & 0x3f3f3f3fu);
             const uint32_t t0 = __builtin_amdgcn_perm(0x64646464u, scb, sel0), t1 = __builtin_amdgcn_perm(0x64646464u, scb, sel1);
             g4k_h2 s0, s1;
@@ -1208,13 +1214,13 @@ __global__ __launch_bounds__(256) void gemm4k_wav4_kernel(const G4KParams p) {
             float dr[4], dmn[4];
 #pragma unroll
             for (int r = 0; r < 4; r++) { // d | dmin of rows 4 kb + r
-                const uint32_t hx = st[16 * 36 + (4 * kb + r) * 4];
+                const uint32_t hx = cur.hx[r];
                 dr[r]  = __fmul_rn(yd, ps_h2f((uint16_t)(hx & 0xffff)));
                 dmn[r] = __fmul_rn(-yd, ps_h2f((uint16_t)(hx >> 16)));
             }
 #pragma unroll
             for (int j = 0; j < 2; j++) {
-                const uint32_t w = st[m * 36 + (2 * wave + j) * 4 + kb];
+                const uint32_t w = cur.w[j];
                 const uint32_t tq[4] = {(w & 0x000F000Fu) | 0x64006400u, ((w >> 8) & 0x000F000Fu) | 0x64006400u,
                                         ((w >> 4) & 0x000F000Fu) | 0x64006400u, ((w >> 12) & 0x000F000Fu) | 0x64006400u};
                 uint32_t o[4];
@@ -1227,7 +1233,7 @@ __global__ __launch_bounds__(256) void gemm4k_wav4_kernel(const G4KParams p) {
                 }
                 const ps_u32x4 ao = {o[0], o[1], o[2], o[3]};
                 g4k_h8 av, bv;
-                __builtin_memcpy(&av, &ao, 16); __builtin_memcpy(&bv, &rb[bi][j], 16);
+                __builtin_memcpy(&av, &ao, 16); __builtin_memcpy(&bv, &rb[k & 1][j], 16);
                 const g4k_f4 si = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bv, zf, 0, 0, 0);
 #pragma unroll
                 for (int r = 0; r < 4; r++) acc[r][j] = __fmaf_rn(dr[r], si[r], acc[r][j]);
@@ -1242,13 +1248,13 @@ __global__ __launch_bounds__(256) void gemm4k_wav4_kernel(const G4KParams p) {
                 if (kb != 0) { h0 = z2; h1 = z2; }
                 const g4k_h4 am = {h0[0], h0[1], h1[0], h1[1]};
                 g4k_h4 bm;
-                { const ps_u32x2 b2 = rs[bi]; __builtin_memcpy(&bm, &b2, 8); }
+                { const ps_u32x2 b2 = rs[k & 1]; __builtin_memcpy(&bm, &b2, 8); }
                 const g4k_f4 pr = __builtin_amdgcn_mfma_f32_16x16x16f16(am, bm, zf, 0, 0, 0);
 #pragma unroll
                 for (int r = 0; r < 4; r++) accm[r] = __fmaf_rn(dmn[r], pr[r], accm[r]);
             }
-            load_b(bi, sb + 2 < nsb ? sb + 2 : nsb - 1);
-            }
+            load_b(k & 1, sb + 2 < nsb ? sb + 2 : nsb - 1);
+            cur = nxt;
         }
     }
     // ---- the four waves meet: waves 0 and 1 finish rows 4 kb + 2 wave, + 1 (hsum_float_8's order)
@@ -1330,12 +1336,12 @@ static int g4k_launch(hipStream_t st, int n_cu, G4KParams &p, const int epi, con
         // Q / K / V and O 13 -> 11, down 31 -> 31, lm_head 151 -> 88; the forward 4.59 -> 3.68 ms.  Measured and not kept: the accumulator
         // lanes of a tile split over four unsynchronised waves with dword loads (every 128-byte line fetched from L2 eight times: 46 us
         // for gate / up); one wave per tile for the few-tile launches (24.9 us on average: one wave per four SIMDs walks K alone); two
-        // super-blocks per barrier in the four-wave form (SPB = 2: down 30 us, Q / K / V and O 14.7).
+        // super-blocks per barrier in the four-wave form (down 30 us, Q / K / V and O 14.7).
         if (epi == 1) g4k_launch_wav<1, 2, 2>(st, p);
         else if (2 * p.n_tasks >= 4 * n_cu || wav_cfg == 1) g4k_launch_wav<0, 2, 2>(st, p); // many tiles (lm_head): a wave per tile, occupancy hides the latency
         else { // few tiles: four waves per tile
-            psk_note_kernel("gemm4k_wav4_kernel<2, 1>");
-            hipLaunchKernelGGL((gemm4k_wav4_kernel<2, 1>), dim3((unsigned)(2 * p.n_tasks)), dim3(256), 0, st, p);
+            psk_note_kernel("gemm4k_wav4_kernel<2>");
+            hipLaunchKernelGGL((gemm4k_wav4_kernel<2>), dim3((unsigned)(2 * p.n_tasks)), dim3(256), 0, st, p);
         }
     } else if (ctw == 1) {
         if (epi == 1) { psk_note_kernel("gemm4k_narrow_kernel<1, 1, 12>"); hipLaunchKernelGGL((gemm4k_narrow_kernel<1, 1, PS_Q4_K>), grid, blkn, LDS1, st, p); }

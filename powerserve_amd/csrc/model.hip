@@ -45,6 +45,7 @@ struct ps_hip_model {
     float *attn_xchg = nullptr;    // attn_decode2: scores in flight between workgroups (k_attn.hip)
     unsigned *attn_tick = nullptr; // attn_decode2: [64 * kv head] arrival counters
     size_t graph_hint = 0;                   // KV position the captured step was given as its prefetch hint (n_kv_lo)
+    int n_kv_hint = 0;             // capture of a single-token forward: the lower bound of n_kv its prefetch hint is baked with
     int n_kv_host = 0;             // pos0 + bs of the forward being enqueued eagerly (0 while a graph is captured / replayed)
     float *scores = nullptr, *logits = nullptr, *rope_table = nullptr;
     void *act_mem = nullptr;
@@ -63,11 +64,14 @@ struct ps_hip_model {
     size_t position = 0;
     int mode = 0;
     hipGraphExec_t step_graph = nullptr;
+    hipGraphExec_t fwd1_graph[2] = {nullptr, nullptr}; // single-token forward without / with lm_head (the lowered op-API path)
+    size_t fwd1_hint[2] = {0, 0};
     uint64_t weight_bytes = 0;
     std::vector<void *> owned;
 };
 
 static int mode_env_or();
+static void drop_graphs(ps_hip_model *m);
 static int dmalloc(ps_hip_model *m, void **p, size_t bytes) {
     ps_hip_ctx *c = m->ctx;
     PS_CHECK(c, hipMalloc(p, bytes ? bytes : 16));
@@ -198,7 +202,7 @@ static int enqueue_forward(ps_hip_model *m, int bs, bool lm_head, bool use_tree,
     aa.sync = m->attn_sync;
     const bool one_launch = (m->mode & 16) == 0; // default; mode bit 4 switches attn_decode2 off (two launches)
     aa.xchg = m->attn_xchg; aa.tick = m->attn_tick;
-    aa.n_kv_lo = m->n_kv_host > 0 ? m->n_kv_host : (int)m->position; // (a hint: rows below it are requested before the device-side position has arrived)
+    aa.n_kv_lo = m->n_kv_host > 0 ? m->n_kv_host : (m->n_kv_hint > 0 ? m->n_kv_hint : (int)m->position); // (a hint: rows below it are requested before the device-side position has arrived)
 
     for (uint32_t L = 0; L < f.n_layers; L++) {
         ps_act a1 = act_for(dim);
@@ -372,7 +376,7 @@ int ps_hip_model_create(ps_hip_ctx *c, const ps_model_desc *d, ps_hip_model **ou
 void ps_hip_model_destroy(ps_hip_model *m) {
     if (!m) return;
     (void)hipStreamSynchronize(m->ctx->stream);
-    if (m->step_graph) (void)hipGraphExecDestroy(m->step_graph);
+    drop_graphs(m);
     for (void *p : m->owned) (void)hipFree(p);
     delete m;
 }
@@ -425,6 +429,10 @@ static int model_forward_impl(ps_hip_model *m, const int32_t *tokens, int n, con
 // The one-launch attentions wait for each other's workgroups inside the launch (bounded); a wait that gave up raises
 // attn_sync[31].  Read it behind every synchronised single-token forward, clear it, and fall back to the two launches
 // from here on (mode bit 4): the forward that timed out has no valid result.  Expects the stream to be idle.
+static void drop_graphs(ps_hip_model *m) { // every captured launch plan (they bake the mode, the prefetch hint and the visibility pointers in)
+    if (m->step_graph) { (void)hipGraphExecDestroy(m->step_graph); m->step_graph = nullptr; }
+    for (auto &g : m->fwd1_graph) if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
+}
 static int check_attn_timeout(ps_hip_model *m, const char *who) {
     ps_hip_ctx *c = m->ctx;
     if (m->mode & 16) return 0; // the one-launch form is not in use
@@ -432,7 +440,7 @@ static int check_attn_timeout(ps_hip_model *m, const char *who) {
     PS_CHECK(c, hipMemcpy(&stuck, m->attn_sync + 31, 4, hipMemcpyDeviceToHost));
     if (!stuck) return 0;
     PS_CHECK(c, hipMemset(m->attn_sync + 31, 0, 4));
-    if (m->step_graph) { (void)hipGraphExecDestroy(m->step_graph); m->step_graph = nullptr; }
+    drop_graphs(m);
     m->mode |= 16;
     c->err = std::string(who) + ": the one-launch attention timed out at its score exchange (GPU shared or partitioned?); this forward has no valid "
              "result, the cache position is unchanged, and the model now uses the two-launch attention (mode bit 4)";
@@ -459,10 +467,33 @@ static int model_forward_impl(ps_hip_model *m, const int32_t *tokens, int n, con
     if (tree) PS_CHECK(c, hipMemcpyAsync(m->tree_dev, tree, (size_t)n * n, hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(1), 0, c->stream, m->state, pos[0], n, 0);
     PS_CHECK(c, hipStreamSynchronize(c->stream)); // tokens/tree may be host temporaries
-    m->n_kv_host = pos[0] + n;
-    const int rc_fw = enqueue_forward(m, n, lm_head != 0, tree != nullptr);
-    m->n_kv_host = 0;
-    if (rc_fw) return rc_fw;
+    // A single token through this entry (ModelTokenIterator::decode over the op API, HIPBackend::plan's lowered graph) replays
+    // a captured launch plan like ps_hip_model_decode_greedy does: the first call at a position range runs eagerly and captures.
+    const int gk = lm_head ? 1 : 0;
+    const bool graphable = n == 1 && !tree && (m->mode & 1) == 0 && m->n_hidden == 0;
+    if (graphable && m->fwd1_graph[gk] && ((size_t)pos[0] < m->fwd1_hint[gk] || (size_t)pos[0] >= m->fwd1_hint[gk] + 1024)) {
+        (void)hipGraphExecDestroy(m->fwd1_graph[gk]); m->fwd1_graph[gk] = nullptr;
+    }
+    if (graphable && m->fwd1_graph[gk]) {
+        PS_CHECK(c, hipGraphLaunch(m->fwd1_graph[gk], c->stream));
+    } else {
+        m->n_kv_host = pos[0] + n;
+        const int rc_fw = enqueue_forward(m, n, lm_head != 0, tree != nullptr);
+        if (rc_fw) { m->n_kv_host = 0; return rc_fw; }
+        if (graphable) { // capture the same launches (nothing executes); the hint stays a lower bound of n_kv for 1024 positions
+            hipGraph_t g = nullptr;
+            PS_CHECK(c, hipStreamSynchronize(c->stream));
+            m->n_kv_host = 0; m->n_kv_hint = pos[0]; // (no host-side n_kv inside a graph: the score grids cover n_ctx)
+            PS_CHECK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+            const int rc = enqueue_forward(m, 1, lm_head != 0, false);
+            const hipError_t e = hipStreamEndCapture(c->stream, &g);
+            m->n_kv_hint = 0;
+            if (!rc && e == hipSuccess && hipGraphInstantiate(&m->fwd1_graph[gk], g, nullptr, nullptr, 0) == hipSuccess) m->fwd1_hint[gk] = (size_t)pos[0];
+            else m->fwd1_graph[gk] = nullptr; // (stay eager)
+            if (g) (void)hipGraphDestroy(g);
+        }
+        m->n_kv_host = 0;
+    }
     if (lm_head && argmax_host) PS_CHECK(c, hipMemcpyAsync(argmax_host, m->argmax_dev, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
     if (!advance) return 0; // lowered graph: the executor's caller syncs when it reads the logits and advances the cache itself
     PS_CHECK(c, hipStreamSynchronize(c->stream));
@@ -667,10 +698,7 @@ int ps_hip_model_set_mode(ps_hip_model *m, int mode) {
         if (dmalloc(m, (void **)&m->attn_part, (size_t)m->cfg.n_heads * 32 * (m->cfg.head_size + 2) * 4)) return 2;
     }
     if ((mode & 8) && !(m->mode & 8) && m->position != 0) { m->ctx->err = "set_mode: the fp16-KV decode mode must be switched on while the cache is empty"; return 2; }
-    if (((m->mode ^ mode) & 30) && m->step_graph) { // the captured step bakes the launch plan in
-        (void)hipGraphExecDestroy(m->step_graph);
-        m->step_graph = nullptr;
-    }
+    if ((m->mode ^ mode) & 30) drop_graphs(m); // the captured steps bake the launch plan in
     m->mode = mode;
     return 0;
 }
