@@ -113,9 +113,14 @@ static int mm_each(ps_hip_model *m, psk_gemv_args &g, ps_act act, int64_t K, int
         s.pro = g.pro; s.pro_x = g.pro_x; s.pro_norm_w = g.pro_norm_w; s.pro_eps = g.pro_eps;
         s.rope = g.rope; s.rope_wi0 = g.rope_wi0 + i; // (a Q / K / V group split by type: every launch does its part of RoPE + KV append)
         if (g.w[i]->dtype == PS_Q6_K || g.w[i]->dtype == PS_Q5_K) {
-            if (bs == 1) { // one matrix of a mixed group (Q4_K_M: a Q6_K V next to Q4_K Q and K): its own prologue
+            if (bs == 1) { // one matrix of a mixed group (Q4_K_M: a Q6_K V next to Q4_K Q and K), or a run of Q5_K ones (Q5_K_M: Q and K next to a Q6_K V): its own prologue
+                int run = 1;
+                while (g.w[i]->dtype == PS_Q5_K && !g.silu_pair && i + run < g.n_w && g.w[i + run]->dtype == PS_Q5_K) run++;
+                for (int j = 1; j < run; j++) { s.w[j] = g.w[i + j]; s.out[j] = g.out[i + j]; s.bias[j] = g.bias[i + j]; s.ldo[j] = g.ldo[i + j]; }
+                s.n_w = run;
                 const int rc = psk_gemvk(c->stream, c->n_cu, s, act, K);
-                if (rc == 0) continue;
+                if (rc == 0) { i += run - 1; continue; }
+                s.n_w = 1;
                 if (rc != -1 || g.rope) { c->err = "Q5_K / Q6_K mat-vec launch rc=" + std::to_string(rc); return 2; }
             }
             quantize_once();
