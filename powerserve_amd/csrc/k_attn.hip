@@ -1118,7 +1118,9 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_pv_mfma_lds_kernel(psl_attn_a
 //                         loads (the lanes of a position share it), q in registers as fp16 pairs, v_dot2_f32_f16 with fp32
 //                         accumulation.  Then per q head one wave: chunk max, p = exp(s - max), chunk sum, and
 //                         o[d] = sum_j p_j V[j][d] with lane = channel pair (coalesced V rows).  Writes (o, max, sum).
-//   attn_flash16_combine_kernel   one workgroup per q head merges the FL_SPLITS partials the usual way.
+//                         The workgroup that arrives LAST at its kv head's counter (a relaxed agent-scope fetch_add behind
+//                         its drained write-through stores; round 3: the separate combine launch is gone) merges the
+//                         FL_SPLITS partials of the group's q heads the usual way.
 // Differences from the parity path: fp16 rounding of K, V and q; exp via __expf; fp32 sums in split order.
 constexpr int FL_SPLITS = 32, FL_NT = 512;
 typedef _Float16 fl_h2 __attribute__((ext_vector_type(2)));
@@ -1173,7 +1175,7 @@ __global__ __launch_bounds__(FL_NT) void attn_flash16_kernel(psl_attn_args a) {
     __syncthreads();
     // ---- per head: wave g (r2 <= 8 waves)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (wave >= r2) return;
+    if (wave < r2) {
     const int g = wave, h = kvh * r2 + g;
     float *out = a.part + ((int64_t)h * FL_SPLITS + split) * (HS + 2);
     float s0 = lane < nj ? sc[g][lane] : -INFINITY, s1 = lane + 64 < nj ? sc[g][lane + 64] : -INFINITY;
@@ -1199,26 +1201,35 @@ __global__ __launch_bounds__(FL_NT) void attn_flash16_kernel(psl_attn_args a) {
             o1 = fmaf(pj, (float)vv[t].y, o1);
         }
     }
-    if (own) { out[2 * lane] = o0; out[2 * lane + 1] = o1; }
-    if (lane == 0) { out[HS] = m; out[HS + 1] = l; }
-}
-
-template <int HS>
-__global__ __launch_bounds__(HS) void attn_flash16_combine_kernel(psl_attn_args a) {
-    const int h = blockIdx.x, d = threadIdx.x;
-    const float *pp = a.part + (int64_t)h * FL_SPLITS * (HS + 2);
-    float M = -INFINITY;
-#pragma unroll
-    for (int s = 0; s < FL_SPLITS; s++) M = fmaxf(M, pp[s * (HS + 2) + HS]);
-    float L = 0.f, o = 0.f;
-#pragma unroll
-    for (int s = 0; s < FL_SPLITS; s++) {
-        const float ms = pp[s * (HS + 2) + HS];
-        const float w = ms > -INFINITY ? __expf(ms - M) : 0.f;
-        L = fmaf(w, pp[s * (HS + 2) + HS + 1], L);
-        o = fmaf(w, pp[s * (HS + 2) + d], o);
+    // (write-through: the merging workgroup may sit on another XCD, whose L2 never sees this one's plain stores)
+    if (own) { coh_store_f(out + 2 * lane, o0); coh_store_f(out + 2 * lane + 1, o1); }
+    if (lane == 0) { coh_store_f(out + HS, m); coh_store_f(out + HS + 1, l); }
     }
-    a.att[(int64_t)h * HS + d] = o / L;
+    // ---- the last workgroup of this kv head to get here merges the partials of its q heads
+    __shared__ int is_last;
+    __builtin_amdgcn_s_waitcnt(0x0070); // vmcnt(0): this wave's partials have landed
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned t = __hip_atomic_fetch_add(a.tick + kvh * 64 + 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        is_last = ((t + 1) % FL_SPLITS) == 0;
+    }
+    __syncthreads();
+    if (!is_last) return;
+    for (int idx = threadIdx.x; idx < r2 * HS; idx += FL_NT) {
+        const int h = kvh * r2 + idx / HS, d = idx % HS;
+        const float *pp = a.part + (int64_t)h * FL_SPLITS * (HS + 2);
+        float ms[FL_SPLITS], M = -INFINITY;
+#pragma unroll
+        for (int s = 0; s < FL_SPLITS; s++) { ms[s] = coh_load_f(pp + s * (HS + 2) + HS); M = fmaxf(M, ms[s]); }
+        float L = 0.f, o = 0.f;
+#pragma unroll
+        for (int s = 0; s < FL_SPLITS; s++) {
+            const float w = ms[s] > -INFINITY ? __expf(ms[s] - M) : 0.f;
+            L = fmaf(w, coh_load_f(pp + s * (HS + 2) + HS + 1), L);
+            o = fmaf(w, coh_load_f(pp + s * (HS + 2) + d), o);
+        }
+        a.att[(int64_t)h * HS + d] = o / L;
+    }
 }
 
 // ---------------------------------------------------------------- arg-max, first maximum (prob_array.cpp:65-67)
@@ -1345,17 +1356,12 @@ void psl_attn_softmax_pv(hipStream_t st, const psl_attn_args &a, int bs) {
 }
 
 bool psl_attn_decode_f16(hipStream_t st, const psl_attn_args &a) {
-    if (!a.k16 || !a.v16 || !a.part || a.tree || a.n_ctx > 128 * FL_SPLITS) return false;
+    if (!a.k16 || !a.v16 || !a.part || !a.tick || a.tree || a.n_ctx > 128 * FL_SPLITS) return false;
     const int r2 = a.n_heads / a.n_kv_heads;
     if ((r2 != 1 && r2 != 2 && r2 != 4 && r2 != 8) || (a.head_size != 128 && a.head_size != 64)) return false;
     const dim3 g(FL_SPLITS, (unsigned)a.n_kv_heads);
-    if (a.head_size == 128) {
-        hipLaunchKernelGGL(attn_flash16_kernel<128>, g, dim3(FL_NT), 0, st, a);
-        hipLaunchKernelGGL(attn_flash16_combine_kernel<128>, dim3((unsigned)a.n_heads), dim3(128), 0, st, a);
-    } else {
-        hipLaunchKernelGGL(attn_flash16_kernel<64>, g, dim3(FL_NT), 0, st, a);
-        hipLaunchKernelGGL(attn_flash16_combine_kernel<64>, dim3((unsigned)a.n_heads), dim3(64), 0, st, a);
-    }
+    if (a.head_size == 128) hipLaunchKernelGGL(attn_flash16_kernel<128>, g, dim3(FL_NT), 0, st, a);
+    else hipLaunchKernelGGL(attn_flash16_kernel<64>, g, dim3(FL_NT), 0, st, a);
     return true;
 }
 
