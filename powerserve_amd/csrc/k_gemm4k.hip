@@ -1336,7 +1336,10 @@ static int g4k_launch(hipStream_t st, int n_cu, G4KParams &p, const int epi, con
         // Q / K / V and O 13 -> 11, down 31 -> 31, lm_head 151 -> 88; the forward 4.59 -> 3.68 ms.  Measured and not kept: the accumulator
         // lanes of a tile split over four unsynchronised waves with dword loads (every 128-byte line fetched from L2 eight times: 46 us
         // for gate / up); one wave per tile for the few-tile launches (24.9 us on average: one wave per four SIMDs walks K alone); two
-        // super-blocks per barrier in the four-wave form (down 30 us, Q / K / V and O 14.7).
+        // super-blocks per barrier in the four-wave form (down 30 us, Q / K / V and O 14.7).  The four-wave form stays at ~0.43 us per
+        // super-block step whatever was tried on it: its LDS operands fetched a step ahead (16.7 us average per launch, as before), the
+        // header operands derived once by the parking wave instead of by all four (170 -> ~110 instructions per step: 16.6 us), a fifth
+        // wave that owns the HBM stream with an eight-deep fragment ring in the others (22.9 us).
         if (epi == 1) g4k_launch_wav<1, 2, 2>(st, p);
         else if (2 * p.n_tasks >= 4 * n_cu || wav_cfg == 1) g4k_launch_wav<0, 2, 2>(st, p); // many tiles (lm_head): a wave per tile, occupancy hides the latency
         else { // few tiles: four waves per tile
