@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--no-kv-f16", action="store_true", help="skip the fp16-KV decode mode leg")
     ap.add_argument("--no-graph-path", action="store_true", help="skip the Graph -> Executor -> HIPBackend::plan leg (libps_host.so)")
     ap.add_argument("--graph-steps", type=int, default=96)
+    ap.add_argument("--wide-chunk", type=int, default=512, help="side leg: prefill in chunks of this many tokens (0: skip)")
     return ap.parse_args()
 
 
@@ -187,6 +188,29 @@ def graph_path(model_dir, device, args, prompt):
             "graphs_planned": n_plans, "graphs_lowered": n_low, "first_ids": ids[:8],
             "what": "Graph -> Executor::run -> HIPBackend::plan (lowered to the fused launches; a single token replays a captured launch plan), "
                     "logits to the host and arg-max there every step"}
+
+
+def prefill_wide_leg(ctx, model_dir, args, prompt):
+    """Reported next to the headline, never in it: the same prompt prefilled in chunks of --wide-chunk tokens (hparams batch_size; the
+    headline uses the reference's default of 128, src/core/config.hpp).  Per-chunk fixed costs (quantizer, RoPE, attention launches,
+    the QKV launch's uneven last round) are paid a quarter as often; every column is still the reference's arithmetic for that
+    chunking (tests/test_gpu_model.py::test_wide_prefill_chunks_match_oracle)."""
+    from powerserve_amd import hip
+    m = hip.Model(ctx, model_dir, max_batch=args.wide_chunk, n_ctx=args.n_ctx)
+    res = []
+    for _ in range(2):
+        ctx.sync()
+        t0 = time.perf_counter()
+        m.reset()
+        done = 0
+        while done < prompt.size - 1:
+            bs = min(args.wide_chunk, prompt.size - 1 - done)
+            m.forward(prompt[done:done + bs], np.arange(done, done + bs), lm_head=False)
+            done += bs
+        ctx.sync()
+        res.append((prompt.size - 1) / (time.perf_counter() - t0))
+    m.close()
+    return {"chunk": args.wide_chunk, "prefill_tokens_per_s": res[0], "prefill_tokens_per_s_warm": res[1]}
 
 
 def fp16_kv_leg(ctx, model, args, prompt, ids_parity):
@@ -399,6 +423,11 @@ def main():
                 out["fp16_kv_mode"] = fp16_kv_leg(ctx, model, args, prompt, np.concatenate([ids_w, ids]))
             except Exception as e:  # noqa: BLE001 — a failing side leg must not take the headline line with it
                 out["fp16_kv_mode"] = {"error": repr(e)}
+        if args.wide_chunk > args.batch and dist is None:
+            try:
+                out["prefill_wide_chunks"] = prefill_wide_leg(ctx, model_dir, args, prompt)
+            except Exception as e:  # noqa: BLE001
+                out["prefill_wide_chunks"] = {"error": repr(e)}
         if not args.no_graph_path and dist is None:
             try:
                 out["graph_path"] = graph_path(model_dir, local, args, prompt)

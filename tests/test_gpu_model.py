@@ -220,6 +220,39 @@ def test_tree_mask_plumbing(ctx, tmp_path):
     gm.close()
 
 
+@pytest.mark.parametrize("preset,wt,chunk", [("small-llama-hs128", 12, 256), ("small-llama-hs128", 12, 512), ("small-llama-hs128", 1015, 384), ("tiny-llama", 8, 256), ("tiny-qwen2", 2, 320)])
+def test_wide_prefill_chunks_match_oracle(ctx, oracle, tmp_path, preset, wt, chunk):
+    """hparams batch_size above the reference's default of 128 (bench.py reports a 512-token-chunk prefill next to the headline):
+    chunks of 256 .. 512 columns, a ragged last one, logits of every column of the last chunk bit-equal to the oracle run with the
+    same chunking (the soft-max row length n_kv = end of the chunk depends on it, in the reference too)."""
+    from oracle import binding as B
+    from powerserve_amd import hip, synth
+    d = str(tmp_path / "m")
+    mj = synth.write_model_dir(d, preset, wt, n_ctx=1024, seed=9)
+    cfg = B.make_config(mj["llm_config"])
+    om = oracle.model(cfg, mj["model_arch"], load_tensors(os.path.join(d, "ggml/weights.gguf")), n_threads=16)
+    gm = hip.Model(ctx, d, max_batch=chunk, n_ctx=1024)
+    P = 2 * chunk - 37 if chunk > 256 else 2 * chunk + 91
+    prompt = np.random.default_rng(7).integers(0, cfg.vocab_size, P)
+    done = 0
+    while done < P:
+        bs = min(chunk, P - done)
+        last = done + bs == P
+        want = om.forward(prompt[done:done + bs], np.arange(done, done + bs), last)
+        got = gm.forward(prompt[done:done + bs], np.arange(done, done + bs), last)
+        if last:
+            assert np.array_equal(got[0].view(np.uint32), want.view(np.uint32)), rel_err(got[0], want)
+        done += bs
+    cur = int(got[1][-1])
+    for s in range(3):  # and single tokens behind it
+        want1 = om.forward([cur], [P + s], True)
+        got1, am1 = gm.forward([cur], [P + s], True)
+        assert np.array_equal(got1.view(np.uint32), want1.view(np.uint32)), (s, rel_err(got1, want1))
+        cur = int(am1[0])
+    gm.close()
+    om.close()
+
+
 @pytest.mark.parametrize("wt", [12, 1015, 1017])  # pure Q4_K; the Q4_K_M mix (Q6_K attn_v / ffn_down / output: the prefill chunks take gemm6k); Q5_K_M (Q5_K producer + gemm6k)
 def test_long_context_batches_match_oracle(ctx, oracle, tmp_path, wt):
     """Batches appended behind a long KV prefix (n_kv > 256: several 32-column chain rounds, leftovers, softmax tails):
