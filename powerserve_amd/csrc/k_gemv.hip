@@ -45,7 +45,7 @@ struct GemvParams {
     const float *ad;
     const int16_t *abs16;
     unsigned long long *dbg; // timeline buffer or null (ps_hip_debug_timeline)
-    int split_q, split_r;    // gemv3: row groups per workgroup = split_q (+1 for the first split_r workgroups)
+    int split_q, split_r;    // (unused by the kernels of this file since gemv3 went)
     psk_rope_kv rope;        // EPI 2
 };
 
@@ -420,459 +420,14 @@ void launch_g1_ep(hipStream_t st, int n_cu, const GemvParams &p, int epi, int pr
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Decode kernel, producer/consumer form.  NW producer waves turn 1 KiB units into exact INTEGER partials and
-// drop them in LDS (8-16 B per lane and unit); one consumer wave runs the reference's fp32 fma chains over them
-// in unit order, one chunk (NW*UPW units) behind the producers, and writes the rows.  One barrier per chunk,
-// nobody waits for the chain.  A workgroup owns a contiguous range of row groups and treats their units as one
-// stream, so chunks may straddle row groups (K = 14336: 56 units, chunks of 28).  Producers keep two chunks of
-// weight loads in flight (register double buffer).
-// out of line on purpose: inlined, the double-precision expf inflates the register allocation of the whole kernel
-__device__ __attribute__((noinline)) float silu_mul_call(float g, float u) { return ps_silu_mul(g, u); }
-
-constexpr int G3_DBG_WGS = 1024; // workgroups with a timeline slot
+// (The first producer / consumer decode kernel, gemv3 -- 14 producer waves + 2 chain waves per 1024-thread workgroup, integer
+//  records, the chain waves deriving every block scale -- lived here through round 2.  Every shape it took now goes to its
+//  successors: Q4_K to gemv4 (k_gemv4.hip), Q4_0 / Q8_0 to gemvb (k_gemvb.hip), Q6_K / Q5_K to gemvk (k_gemvk.hip); what they do
+//  not cover -- row lengths that are not whole units of four, very short rows, the long single-matrix stream of a Q4_0 / Q8_0
+//  lm_head -- was never gemv3's either and takes gemv1 / gemv_kernel below.  Deleted in round 3; DESIGN.md 5 keeps its history.)
+constexpr int G3_DBG_WGS = 1024; // workgroups with a timeline slot (ps_hip_debug_timeline: gemv4, gemm4k, the attention kernels)
 unsigned long long *g_dbg_buf = nullptr;
 int g_dbg_key = -1;
-struct G3Mats {
-    const uint8_t *qs0, *qs1, *qs2, *ax0, *ax1, *ax2;
-    int ng0, ng1, n_w, n_units;
-};
-// (row-group task, unit) -> quant plane / header plane of the owning matrix; everything wave-uniform (SALU)
-template <int EPI, int AUXU>
-__device__ __forceinline__ void g3_locate(const G3Mats m, int task, int un, const uint8_t *&qg, const uint8_t *&ag, int &ul) {
-    int grp = task;
-    const uint8_t *qb = m.qs0, *ab = m.ax0;
-    ul = un;
-    if (EPI != 1) {
-        if (m.n_w > 1 && grp >= m.ng0) {
-            grp -= m.ng0; qb = m.qs1; ab = m.ax1;
-            if (m.n_w > 2 && grp >= m.ng1) { grp -= m.ng1; qb = m.qs2; ab = m.ax2; }
-        }
-    } else if (un >= m.n_units) {
-        ul = un - m.n_units; qb = m.qs1; ab = m.ax1;
-    }
-    const uint32_t idx = (uint32_t)(grp * m.n_units + ul); // unit index inside the matrix: N*K/2048 < 2^31
-    qg = qb + ((uint64_t)idx << 10);
-    ag = ab + (uint64_t)idx * AUXU;
-}
-
-__device__ __forceinline__ float coh_load_f(const float *p) { return __uint_as_float(__hip_atomic_load((const uint32_t *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
-__device__ __forceinline__ void coh_store_f(float *p, float v) { __hip_atomic_store((uint32_t *)p, __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
-constexpr int g3_waves(int nw) { return nw + (nw >= 12 ? 2 : 1); } // producers + chain waves
-
-// The mat-vec of one workgroup.  (Round 1 also ran it as a phase of a chained kernel — O -> gate/up -> down in one launch
-// behind device-wide barriers of relaxed atomics, 2.5 us each, tools/micro/gridbar2.hip: bit-identical, break-even at best
-// against separate launches, DESIGN.md 5 "Tried" — that variant and its HOOKED / COH paths are gone since round 3.)
-template <int WT, int UPW, int NW, int TPW, int EPI, int PRO>
-__device__ __forceinline__ void g3_body(const GemvParams &p, char *smem, double *red) {
-    constexpr bool HOOKED = false, COH = false;
-    constexpr int NC = g3_waves(NW) - NW; // chain waves: rows alternate between them
-    using TR  = WTraits<WT>;
-    using Rec = typename RecOf<WT>::T;
-    constexpr int UPB = NW * UPW; // units per chunk
-    // TPW: prologue tiles per wave, K <= g3_waves(NW)*TPW*256
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int64_t K = p.K;
-    const int Kp   = (int)((K + TR::UNIT - 1) / TR::UNIT * TR::UNIT);
-    const int nblk = Kp / TR::BLK, nb32 = Kp / 32, nb16 = Kp / 16;
-    const int nblk_k = (int)(K / TR::BLK), nb16_k = (int)(K / 16);
-    int8_t *lq   = (int8_t *)smem;
-    float *ld    = (float *)(smem + Kp);
-    int *lb      = (int *)(ld + nblk);
-    int16_t *l16 = (int16_t *)(lb + nb32);
-    Rec *recs    = (Rec *)(smem + p.col_bytes); // [2][UPB][64]
-    uint2 *hdl   = (uint2 *)(recs + 2 * UPB * 64); // Q8_0 / Q4_0: the units' fp16 block scales, [2][UPB][RG]
-    LAct A;
-    A.q32 = (const int *)lq; A.d = ld; A.bs32 = lb;
-
-    const int r = (WT == PS_Q4_0) ? (lane >> 2) : (lane >> 3);
-    const int u = (WT == PS_Q4_0) ? (lane & 3) : (lane & 7);
-    const int n_units = Kp / TR::UNIT;
-    const int tot     = (EPI == 1) ? 2 * n_units : n_units; // EPI 1: gate units then up units of the same row group
-    constexpr int AUXR = (WT == PS_Q4_K) ? 16 : 8;          // header bytes per row and unit
-    constexpr int AUXU = TR::RG * AUXR;                     // header bytes per unit
-    const int n_tasks  = (int)((EPI == 1) ? p.w[0].n_groups : p.groups_total);
-    // contiguous range of row groups of this workgroup: the first split_r workgroups take split_q + 1 groups
-    const int g0 = (int)blockIdx.x * p.split_q + min((int)blockIdx.x, p.split_r);
-    const int g1 = g0 + p.split_q + ((int)blockIdx.x < p.split_r ? 1 : 0);
-    const int n_chunks = (int)(((int64_t)(g1 - g0) * tot + UPB - 1) / UPB);
-    const int n_rounds = (n_chunks + 1) / 2;
-    int step_g = 0, step_u = 2 * UPB; // a slot moves 2*UPB stream units per round (a few subtractions beat a division)
-    while (step_u >= tot) { step_u -= tot; step_g++; }
-    const uint32_t lane16 = (uint32_t)lane * 16u, raux = (uint32_t)r * AUXR;
-    unsigned long long *const dbg = (p.dbg && blockIdx.x < G3_DBG_WGS && lane == 0 && (wave == 0 || wave == NW)) ? p.dbg + ((size_t)blockIdx.x * 2 + (wave == NW)) * 32 : nullptr;
-    int dbg_n = 0;
-    auto mark = [&]() { if (dbg && dbg_n < 20) dbg[dbg_n++] = __builtin_amdgcn_s_memtime(); };
-    auto mark_at = [&](int i) { if (dbg && wave == 0) dbg[i] = __builtin_amdgcn_s_memtime(); }; // 20..28: start-up detail
-    mark(); // 0: entry
-    if (dbg) dbg[29] = __builtin_amdgcn_s_memrealtime(); // 29/30: 100 MHz reference at entry / exit
-    if (n_chunks > 0) mark_at(20); // kernel arguments have arrived
-
-    // activation row first: its address needs nothing but the arguments, and the prologue (not the weight stream) is what
-    // the short launches (QKV, O) wait for
-    float4 xv[TPW], wv[TPW];
-    const int nwl = min(NW, (int)((K + 255) / 256 + TPW - 1) / TPW); // the tiles go to as few (= the earliest started) waves as TPW allows
-    if (!HOOKED && PRO != 0 && wave < NW) ps_qrow_load<(PRO == 1 ? 1 : 0), TPW>(p.x, p.nw, K, xv, wv, nwl);
-    mark_at(28); // activation loads issued
-
-    // matrices of the launch, in scalar registers
-    const G3Mats mats{p.w[0].qs, p.w[1].qs, p.w[2].qs, p.w[0].aux, p.w[1].aux, p.w[2].aux,
-                      (int)p.w[0].n_groups, (int)p.w[1].n_groups, p.n_w, n_units};
-    const int ng0 = mats.ng0, ng1 = mats.ng1, n_w = mats.n_w;
-    auto locate = [&](int task, int un, const uint8_t *&qg, const uint8_t *&ag, int &ul) { g3_locate<EPI, AUXU>(mats, task, un, qg, ag, ul); };
-
-    static_assert(UPW == 4, "four units per producer wave and chunk");
-    using HT = typename std::conditional<WT == PS_Q4_K, ps_u32x4, ps_u32x2>::type;
-    constexpr int LPC = 2 * UPW; // loads per chunk and lane
-    ps_u32x4 qA[UPW], qB[UPW];
-    HT hA[UPW], hB[UPW];
-    int tA[UPW], tB[UPW], uA[UPW], uB[UPW];
-    // Loads and partials are UNCONDITIONAL (slots past the end of the range are clamped to its last row group and
-    // their records are never read) and the loads are explicitly scheduled (ps_dev.h): a chunk is consumed while
-    // the next one is still in flight.
-    // `live` (wave-uniform): the chunk lies inside this workgroup's range.  Chunks past it are still "loaded", from
-    // the first KiB of the first matrix (L2-resident after the first touch), so that the loop stays free of
-    // conditional loads and the compiler can count vmcnt exactly.
-    auto issue = [&](ps_u32x4 (&q)[UPW], HT (&h)[UPW], const int (&t)[UPW], const int (&un)[UPW], bool live) {
-#pragma unroll
-        for (int i = 0; i < UPW; i++) {
-            const uint8_t *qg, *ag;
-            int ul;
-            locate(min(t[i], g1 - 1), un[i], qg, ag, ul);
-            if (!live) { qg = mats.qs0; ag = mats.ax0; }
-            const ps_u32x4 *qp = (const ps_u32x4 *)(qg + (live ? lane16 : 0u)); // not live: every lane the same 16 bytes
-            q[i] = __builtin_nontemporal_load(qp);
-            h[i] = *(const HT *)(ag + (live ? raux : 0u));
-        }
-    };
-    // unit i of a chunk is waited for on its own: the partials start when the first KiB lands, and the compiler
-    // cannot hoist the unpacking of all four units above one wait (register pressure)
-    auto produce = [&](const ps_u32x4 (&q)[UPW], const HT (&h)[UPW], const int (&un)[UPW], int buf) {
-#pragma unroll
-        for (int i = 0; i < UPW; i++) {
-            const int ul = (EPI == 1 && un[i] >= n_units) ? un[i] - n_units : un[i];
-            uint4 hv;
-            if constexpr (WT == PS_Q4_K) hv = make_uint4(h[i].x, h[i].y, h[i].z, h[i].w); else hv = make_uint4(h[i].x, h[i].y, 0, 0);
-            recs[(buf * UPB + wave * UPW + i) * 64 + lane] = unit_rec<WT>(make_uint4(q[i].x, q[i].y, q[i].z, q[i].w), hv, ul, u, A);
-            if constexpr (WT != PS_Q4_K) { if (u == 0) hdl[(buf * UPB + wave * UPW + i) * TR::RG + r] = make_uint2(h[i].x, h[i].y); }
-            __builtin_amdgcn_sched_barrier(0); // one unit at a time: interleaving four of them costs more registers than it hides
-        }
-    };
-    auto advance = [&](int (&t)[UPW], int (&un)[UPW]) {
-#pragma unroll
-        for (int i = 0; i < UPW; i++) {
-            t[i] += step_g;
-            un[i] += step_u;
-            if (un[i] >= tot) { un[i] -= tot; t[i]++; }
-        }
-    };
-
-    // When does the second chunk go out?  The CU's vector-memory path holds about one chunk of outstanding requests: a
-    // wave that issues more stalls IN the issue until earlier data returns, and so arrives late at the prologue's
-    // barriers (measured: all of A + B before the prologue -> last producer wave at the first barrier after 4.8 us
-    // instead of 2.4 us).  So B follows the first prologue barrier (RMSNorm: B_MID) or the prologue (plain quantize);
-    // only a launch without a prologue sends it at once.
-    constexpr bool B_EARLY = !HOOKED && (PRO == 0);
-    constexpr bool B_MID   = !HOOKED && (PRO == 1) && (TPW <= 2); // (long rows keep the registers for the prologue)
-    constexpr bool B_TAIL  = !HOOKED && (PRO != 0) && !B_MID;      // once this wave's tiles are quantized (their registers are free) // RMSNorm over long rows / chained phase: the prologue needs the registers
-    auto begin_producers = [&]() { // the chain waves never touch the vector-memory queue before their stores
-        // activation row first, the first chunks of weights right behind it (vmcnt retires in order: the prologue
-        // only waits for the L2-resident activation while the weights stream in)
-        if (HOOKED && PRO == 1) { // only the (read-only) norm weights can be asked for before the barrier
-            float4 dummy[TPW];
-            ps_qrow_load<1, TPW>(p.nw, p.nw, K, dummy, wv, nwl);
-        }
-        mark_at(21); // activation loads issued
-#pragma unroll
-        for (int i = 0; i < UPW; i++) {
-            int sa = wave * UPW + i, ta = g0;
-            while (sa >= tot) { sa -= tot; ta++; }
-            int sb = sa + UPB, tb = ta;
-            while (sb >= tot) { sb -= tot; tb++; }
-            tA[i] = ta; uA[i] = sa;
-            tB[i] = tb; uB[i] = sb;
-        }
-        mark_at(22); // slots placed
-        issue(qA, hA, tA, uA, true); // (g1 > g0 always: the grid never exceeds the number of row groups)
-        mark_at(23); // chunk A issued
-        if (B_EARLY && !HOOKED) issue(qB, hB, tB, uB, n_chunks > 1); // (chained phase: one chunk across the barrier, the second right behind it)
-        mark(); // 1: loads issued
-    };
-    auto run_producers = [&]() {
-        // activation -> LDS once per workgroup
-        if (Kp != K) {
-            for (int i = (int)K + threadIdx.x * 4; i < Kp; i += NW * 64 * 4) *(int *)(lq + i) = 0;
-            for (int i = nblk_k + threadIdx.x; i < nblk; i += NW * 64) ld[i] = 0.f;
-            for (int i = nb16_k + threadIdx.x; i < nb16; i += NW * 64) l16[i] = 0;
-            for (int i = nb16_k / 2 + threadIdx.x; i < nb32; i += NW * 64) lb[i] = 0;
-        }
-        // (the int sums of 32 are written together with the quants: no second pass, no second barrier)
-        if (PRO == 0) {
-            for (int64_t i = threadIdx.x * 16; i < K; i += NW * 64 * 16) *(int4 *)(lq + i) = *(const int4 *)(p.aq + i);
-            for (int i = threadIdx.x; i < nblk_k; i += NW * 64) ld[i] = p.ad[i];
-            for (int i = threadIdx.x; i < nb16_k; i += NW * 64) l16[i] = p.abs16[i];
-            for (int i = threadIdx.x; i < nb16_k / 2; i += NW * 64) lb[i] = (int)p.abs16[2 * i] + (int)p.abs16[2 * i + 1];
-            __syncthreads();
-        } else {
-            ps_qrow_compute<TR::VDT, (PRO == 1 ? 1 : 0), TPW>(xv, wv, p.eps, K, lq, ld, l16, red, nwl, [&](int k, float dep) {
-                asm volatile("" ::"v"(dep));
-                mark_at(k);
-                if (B_MID && k == 25) issue(qB, hB, tB, uB, n_chunks > 1); // behind the sum-of-squares barrier
-                if (B_TAIL && k == 27) issue(qB, hB, tB, uB, n_chunks > 1);
-                // (diagnostic) arrival of every producer wave at the first prologue barrier: chain-role slots 12 + wave
-                if (k == 24 && p.dbg && blockIdx.x < G3_DBG_WGS && lane == 0) p.dbg[((size_t)blockIdx.x * 2 + 1) * 32 + 12 + wave] = __builtin_amdgcn_s_memtime();
-            }, lb);
-        }
-        mark(); // 2: activation in LDS
-        if (!B_EARLY && !B_MID && !B_TAIL) issue(qB, hB, tB, uB, n_chunks > 1);
-        for (int rd = 0; rd < n_rounds; rd++) { // chunk 2rd from A, 2rd+1 from B
-            produce(qA, hA, uA, 0);
-            mark(); // producers: 3, 5, ...: chunk A done
-            advance(tA, uA);
-            issue(qA, hA, tA, uA, 2 * rd + 2 < n_chunks);
-            __syncthreads();
-            if (2 * rd + 1 < n_chunks) produce(qB, hB, uB, 1); // (the loads stay unconditional, the arithmetic need not)
-            mark(); // 4, 6, ...: chunk B done
-            advance(tB, uB);
-            issue(qB, hB, tB, uB, 2 * rd + 3 < n_chunks);
-            __syncthreads();
-        }
-    };
-    auto run_chain = [&]() { // ---------------- chain waves: fp32 chains in unit order, one chunk behind the producers
-        // the prologue's barriers, nothing else (ps_qrow_compute: one after the sum of squares, one at its end)
-        if (PRO == 1) {
-            if (lane == 0) red[wave] = 0.0;
-            __syncthreads();
-        }
-        __syncthreads();
-        mark();
-        mark();
-        __builtin_amdgcn_s_setprio(3); // few waves serve NW producers: they get the issue slots first
-        const int cid = wave - NW;      // this chain wave owns the rows with (task - g0) % NC == cid
-        float acc0 = 0.f, acc1 = 0.f, accm = 0.f, ygate = 0.f;
-        int task = g0, un = 0;
-        auto mine = [&]() { return NC == 1 || ((task - g0) % NC) == cid; };
-        auto gate_done = [&]() { // gate row finished: reduce it, restart the chains for the up row
-            ygate = row_reduce<WT>(acc0, acc1, accm);
-            acc0 = 0.f; acc1 = 0.f; accm = 0.f;
-        };
-        auto row_done = [&]() {
-            const float y = row_reduce<WT>(acc0, acc1, accm);
-            int wi = 0, grp = task;
-            if (EPI != 1) {
-                if (n_w > 1 && grp >= ng0) { grp -= ng0; wi = 1; }
-                if (n_w > 2 && wi == 1 && grp >= ng1) { grp -= ng1; wi = 2; }
-            }
-            int64_t Nw = p.w[0].N;
-            float *o = p.w[0].out;
-            const float *b = p.w[0].bias;
-            if (wi == 1) { Nw = p.w[1].N; o = p.w[1].out; b = p.w[1].bias; }
-            if (wi == 2) { Nw = p.w[2].N; o = p.w[2].out; b = p.w[2].bias; }
-            const int64_t row = (int64_t)grp * TR::RG + r;
-            if constexpr (EPI == 2) { // q / k: rotate adjacent pairs (rows 2i, 2i+1 sit in neighbouring lane groups); v: transpose-append
-                float v = y;
-                if (b && row < Nw) v = __fadd_rn(v, b[row]);
-                constexpr int LPR = 64 / TR::RG; // lanes per row
-                const float vp = (LPR == 8) ? dpp_f<0x128>(v) : __shfl_xor(v, LPR, 64); // partner row (row_ror:8 swaps the two row groups of 8 lanes)
-                const psk_rope_kv &R = p.rope;
-                const int pos = R.state->pos0;                         // cache slot
-                const int rpos = R.rope_pos ? R.rope_pos[0] : pos;     // RoPE position (differs inside a token tree)
-                if (u == 0 && row < Nw) {
-                    if (wi == 2) {
-                        R.v_cache[row * R.n_ctx + pos] = v;
-                        if (R.v16) R.v16[(int64_t)pos * R.kv_dim + row] = (_Float16)v;
-                    } else {
-                        const int e = (int)(row % R.head_size);
-                        float res = v;
-                        if (e < R.n_dims) {
-                            const int i0 = e & ~1;
-                            const float c = R.rope_table[(int64_t)rpos * R.head_size + i0], sn = R.rope_table[(int64_t)rpos * R.head_size + i0 + 1];
-                            const float x0 = (e & 1) ? vp : v, x1 = (e & 1) ? v : vp;
-                            res = (e & 1) ? __fadd_rn(__fmul_rn(x0, sn), __fmul_rn(x1, c)) : __fsub_rn(__fmul_rn(x0, c), __fmul_rn(x1, sn));
-                        }
-                        if (wi == 0) o[row] = res; else { R.k_cache[(int64_t)pos * R.kv_dim + row] = res; if (R.k16) R.k16[(int64_t)pos * R.kv_dim + row] = (_Float16)res; }
-                    }
-                }
-            } else if (u == 0 && row < Nw) {
-                if (EPI == 1) {
-                    if (COH) coh_store_f(o + row, ps_silu_mul(ygate, y)); else o[row] = ps_silu_mul(ygate, y);
-                } else {
-                    float v = y;
-                    if (b) v = __fadd_rn(v, b[row]);
-                    if (p.residual && wi == 0) v = __fadd_rn(COH ? coh_load_f(p.residual + row) : p.residual[row], v);
-                    if (COH) coh_store_f(o + row, v); else o[row] = v;
-                }
-            }
-            acc0 = 0.f; acc1 = 0.f; accm = 0.f;
-            un = 0;
-            task++;
-        };
-        // whole chunks inside one row (and inside one half of a gate/up pair): the common shapes
-        const bool chunk_in_row = (WT == PS_Q4_K) && (tot % UPB == 0) && (EPI != 1 || n_units % UPB == 0);
-        for (int c = 0; c < 2 * n_rounds; c++) {
-            mark(); // chain wave: 3, 5, ...: waiting for chunk c
-            __syncthreads();
-            mark(); // 4, 6, ...: chunk c handed over
-            const Rec *rb = recs + (size_t)(c & 1) * UPB * 64 + lane;
-            if constexpr (WT == PS_Q4_K) {
-                if (chunk_in_row) { // every record and activation scale of the chunk in one LDS round trip, then a branch-free chain
-                    if (task < g1 && !mine()) { // the other chain wave's row
-                        un += UPB;
-                        if (un == tot) { un = 0; task++; }
-                    } else if (task < g1) {
-                        if (EPI == 1 && un == n_units) gate_done();
-                        const int ul = (EPI == 1 && un >= n_units) ? un - n_units : un;
-                        constexpr int KB = UPB <= 16 ? UPB : (UPB % 16 == 0 ? 16 : (UPB % 14 == 0 ? 14 : 4)); // records per LDS round trip (register budget)
-#pragma unroll
-                        for (int kb = 0; kb < UPB; kb += KB) {
-                            Rec rc[KB];
-                            float yd[KB];
-#pragma unroll
-                            for (int k = 0; k < KB; k++) rc[k] = rb[(kb + k) * 64];
-#pragma unroll
-                            for (int k = 0; k < KB; k++) yd[k] = A.d[ul + kb + k];
-#pragma unroll
-                            for (int k = 0; k < KB; k++) { // d|dmin sits in the record of lane u + 4 (row_shl:4 within the row of 16)
-                                const int up       = __builtin_amdgcn_update_dpp(0, rc[k].y, 0x104, 0xf, 0xf, false);
-                                const uint32_t hdx = (uint32_t)(u < 4 ? up : rc[k].y);
-                                const float d      = __fmul_rn(yd[k], ps_h2f((uint16_t)(hdx & 0xffff)));
-                                const float dmin   = __fmul_rn(-yd[k], ps_h2f((uint16_t)(hdx >> 16)));
-                                acc0 = __fmaf_rn(d, (float)rc[k].x, acc0);
-                                accm = __fmaf_rn(dmin, (float)rc[k].y, accm); // lanes u >= 4: not an acc_m lane, never read
-                            }
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
-                        un += UPB;
-                        if (un == tot) row_done();
-                    }
-                    continue;
-                }
-            }
-            // generic: rows (and the gate half of a gate/up pair) end on multiples of four units (host-checked).  The chunk
-            // is walked in runs (units of one row, one gate/up half); a run of the other chain wave is skipped whole,
-            // an own run is chained in batches of 8 / 4 records per LDS round trip (the producers keep the LDS queue
-            // long: round trips, not instructions, are what this wave waits for).
-            auto batch = [&](auto nconst, const int k0, const int ul) {
-                constexpr int N = decltype(nconst)::value;
-                Rec rc[N];
-                uint2 hh[N];
-#pragma unroll
-                for (int k = 0; k < N; k++) rc[k] = rb[(k0 + k) * 64];
-#pragma unroll
-                for (int k = 0; k < N; k++) {
-                    if constexpr (WT == PS_Q4_K) hh[k] = make_uint2(0u, __float_as_uint(A.d[ul + k]));
-                    else hh[k] = hdl[((c & 1) * UPB + k0 + k) * TR::RG + r];
-                }
-#pragma unroll
-                for (int k = 0; k < N; k++) {
-                    uint2 hk = hh[k];
-                    if constexpr (WT == PS_Q4_K) { // d|dmin sits in the record of lane u + 4 (row_shl:4 within the row of 16)
-                        const int up = __builtin_amdgcn_update_dpp(0, rc[k].y, 0x104, 0xf, 0xf, false);
-                        hk.x = (uint32_t)(u < 4 ? up : rc[k].y);
-                    }
-                    rec_chain<WT>(rc[k], hk, ul + k, A, acc0, acc1, accm);
-                }
-            };
-            for (int k0 = 0; k0 < UPB && task < g1;) {
-                const bool own = mine();
-                if (EPI == 1 && un == n_units && own) gate_done();
-                const int bound = (EPI == 1 && un < n_units) ? n_units : tot;
-                int len = min(bound - un, UPB - k0); // multiple of 4
-                if (own) {
-                    int ul = (EPI == 1 && un >= n_units) ? un - n_units : un, kk = k0;
-                    if constexpr (WT == PS_Q4_K) { // (16-byte records: four at a time is what the registers hold)
-                        int rem = len;
-                        for (; rem >= 16; rem -= 16, kk += 16, ul += 16) batch(std::integral_constant<int, 16>{}, kk, ul);
-                        if (rem >= 8) { batch(std::integral_constant<int, 8>{}, kk, ul); rem -= 8; kk += 8; ul += 8; }
-                        if (rem >= 4) batch(std::integral_constant<int, 4>{}, kk, ul);
-                    } else {
-                        for (int rem = len; rem >= 4; rem -= 4, kk += 4, ul += 4) batch(std::integral_constant<int, 4>{}, kk, ul);
-                    }
-                }
-                un += len;
-                k0 += len;
-                if (un == tot) {
-                    if (own) row_done(); else { un = 0; task++; }
-                }
-            }
-        }
-    };
-    if (wave < NW) { begin_producers(); run_producers(); } else run_chain(); // one contiguous producer path (the register allocator treats it best that way)
-    if (COH && wave >= NW) __builtin_amdgcn_s_waitcnt(0x0070); // vmcnt(0) (expcnt/lgkmcnt untouched): this wave's output stores have landed
-    if (dbg) { dbg[31] = __builtin_amdgcn_s_memtime(); dbg[30] = __builtin_amdgcn_s_memrealtime(); } // 31: done
-}
-
-
-template <int WT, int UPW, int NW, int TPW, int EPI, int PRO>
-__global__ __launch_bounds__(g3_waves(NW) * 64, 4) void gemv3_kernel(const GemvParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    __shared__ double red[16];
-    g3_body<WT, UPW, NW, TPW, EPI, PRO>(p, smem, red);
-}
-
-template <int WT, int UPW, int NW, int TPW, int EPI, int PRO>
-void launch_g3(hipStream_t st, int n_cu, const GemvParams &p) {
-    const int64_t n_tasks = (EPI == 1) ? p.w[0].n_groups : p.groups_total;
-    const size_t smem     = (size_t)p.col_bytes + (size_t)2 * NW * UPW * (64 * sizeof(typename RecOf<WT>::T) + (WT == PS_Q4_K ? 0 : WTraits<WT>::RG * 8));
-    static int occ = 0;
-    if (occ == 0) { // resident workgroups per CU for this instantiation (registers / LDS), queried once
-        (void)hipFuncSetAttribute((const void *)gemv3_kernel<WT, UPW, NW, TPW, EPI, PRO>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)gemv3_kernel<WT, UPW, NW, TPW, EPI, PRO>, g3_waves(NW) * 64, smem) != hipSuccess || nb < 1) nb = 1;
-        // a workgroup's waves are dealt to the four SIMDs starting from the same one: only whole multiples of
-        // four waves pack to the register-file limit (measured: 5-wave groups at 108 VGPRs ran 2 per CU, not 3)
-        const int by_waves = 16 / (((g3_waves(NW) + 3) / 4) * 4);
-        occ = nb > by_waves ? by_waves : nb;
-        if (occ < 1) occ = 1;
-    }
-    int64_t grid      = n_tasks;
-    const int64_t cap = (int64_t)n_cu * occ;
-    if (grid > cap) grid = cap;
-    if (grid < 1) grid = 1;
-    GemvParams pd = p;
-    pd.split_q = (int)(n_tasks / grid);
-    pd.split_r = (int)(n_tasks % grid);
-    pd.dbg = nullptr; // key = k1 + 100 * (k2 + 1): launches matching k1 record into the first half, k2 into the second
-    if (g_dbg_buf && g_dbg_key >= 0) {
-        const int k1 = g_dbg_key % 100, k2 = g_dbg_key / 100 - 1;
-        if (k1 == EPI * 4 + PRO) pd.dbg = g_dbg_buf;
-        else if (k2 == EPI * 4 + PRO) pd.dbg = g_dbg_buf + (size_t)G3_DBG_WGS * 64;
-    }
-    psk_note_kernel("gemv3_kernel<%d, %d, %d, %d, %d, %d>", WT, UPW, NW, TPW, EPI, PRO);
-    hipLaunchKernelGGL((gemv3_kernel<WT, UPW, NW, TPW, EPI, PRO>), dim3((unsigned)grid), dim3(g3_waves(NW) * 64), smem, st, pd);
-}
-
-template <int WT, int UPW, int NW, int TPW>
-void launch_g3_ep(hipStream_t st, int n_cu, const GemvParams &p, int epi, int pro) {
-    if (epi == 2) {
-        launch_g3<WT, UPW, NW, TPW, 2, 1>(st, n_cu, p);
-    } else if (epi == 1) {
-        if (pro == 1) launch_g3<WT, UPW, NW, TPW, 1, 1>(st, n_cu, p); else launch_g3<WT, UPW, NW, TPW, 1, 0>(st, n_cu, p);
-    } else {
-        if (pro == 0) launch_g3<WT, UPW, NW, TPW, 0, 0>(st, n_cu, p);
-        else if (pro == 1) launch_g3<WT, UPW, NW, TPW, 0, 1>(st, n_cu, p);
-        else launch_g3<WT, UPW, NW, TPW, 0, 2>(st, n_cu, p);
-    }
-}
-
-// Sixteen-wave workgroups (fourteen producers + two chain waves), one per CU: the activation prologue runs once per
-// CU, and 256 workgroups split the usual row counts evenly.  Returns false when the activation row does not fit
-// the prologue's register tiles or the row length is not a multiple of four units (falls back).
-template <int WT>
-bool launch_g3_wt(hipStream_t st, int n_cu, const GemvParams &p, int epi, int pro) {
-    static const bool no_g3 = getenv("PS_NO_G3") != nullptr;
-    if (no_g3 && WT != PS_Q4_K) return false;
-    if (epi == 1 && pro == 2) return false;
-    if (epi == 2 && pro != 1) return false;
-    const int n_units = (int)((p.K + WTraits<WT>::UNIT - 1) / WTraits<WT>::UNIT);
-    if (n_units % 4 != 0) return false; // the consumer tests row boundaries once per four units
-    const size_t rec = sizeof(typename RecOf<WT>::T) + 2; // (+ the Q8_0 / Q4_0 scale plane)
-    if ((size_t)p.col_bytes + 2 * 56 * 64 * rec > 150 * 1024) return false;
-    if (p.K <= 14 * 2 * 256) { launch_g3_ep<WT, 4, 14, 2>(st, n_cu, p, epi, pro); return true; } // prologue tiles on the 14 producers
-    if (p.K <= 14 * 4 * 256) { launch_g3_ep<WT, 4, 14, 4>(st, n_cu, p, epi, pro); return true; }
-    return false;
-}
 
 // returns false when the row is too long for the register-resident kernel (falls back to gemv_kernel)
 template <int WT>
@@ -920,15 +475,7 @@ int launch_epi(hipStream_t st, int n_cu, const GemvParams &p, int epi, int pro) 
 
 template <int WT>
 int launch_wt(hipStream_t st, int n_cu, const GemvParams &p, int epi, int pro) {
-    if constexpr (WT != PS_Q4_K) {
-        // short rows of Q4_0 / Q8_0 (<= 32 units per task: the O and gate/up launches of the 1B shape): the register-resident
-        // kernel measured faster than the 16-wave producer / consumer one (O 6.6 vs 9.3 us, gate/up 12.0 vs 13.2 us,
-        // profiles/r03_decode_kernel_stats_1b_q4_0.txt); the QKV launch keeps the latter for its fused RoPE + KV append
-        const int tot = (int)((p.K + WTraits<WT>::UNIT - 1) / WTraits<WT>::UNIT) * (epi == 1 ? 2 : 1);
-        if (p.bs == 1 && epi != 2 && tot <= 32 && launch_g1_wt<WT>(st, n_cu, p, epi, pro)) return 0;
-    }
-    if (p.bs == 1 && launch_g3_wt<WT>(st, n_cu, p, epi, pro)) return 0;
-    if (epi == 2) return 8; // the fused RoPE epilogue exists in the producer/consumer kernel only (psk_gemv_rope_ok)
+    if (epi == 2) return 8; // the fused RoPE epilogue exists in the producer / chain-wave kernels only (psk_gemv_rope_ok)
     if (p.bs == 1 && launch_g1_wt<WT>(st, n_cu, p, epi, pro)) return 0;
     if (p.bs == 1) return launch_epi<WT, 1>(st, n_cu, p, epi, pro);
     if (p.bs <= 4) return launch_epi<WT, 4>(st, n_cu, p, epi, pro);
@@ -1496,15 +1043,10 @@ unsigned long long *psk_gemv_dbg_buf(int epi, int pro) { // key = k1 + 100 * (k2
     return nullptr;
 }
 
-bool psk_gemv_rope_ok(int wt, int64_t K) { // mirrors psk_gemvb / launch_g3_wt
+bool psk_gemv_rope_ok(int wt, int64_t K) { // a Q / K / V launch of ONE type whose epilogue rotates and appends: mirrors psk_gemv4 / psk_gemvb / psk_gemvk
+    if (wt == PS_Q4_K) return psk_gemv4_covers(K);
     if (psk_gemvb_covers(wt, K)) return true;
-    if (wt == PS_Q5_K && psk_gemvk_covers(wt, K)) return true; // (Q / K / V all Q5_K: k_gemvk.hip)
-    static const bool no_g3 = getenv("PS_NO_G3") != nullptr; // (A/B: the register-resident gemv1 instead)
-    if (no_g3 && wt != PS_Q4_K) return false;
-    const int64_t unit = (wt == PS_Q4_K) ? 256 : 128, n_units = (K + unit - 1) / unit;
-    const size_t rec = (wt == PS_Q4_K ? 8 : 16) + 2;
-    return (wt == PS_Q4_K || wt == PS_Q8_0 || wt == PS_Q4_0) && n_units % 4 == 0 && K <= 14 * 4 * 256 &&
-           psk_gemv_lds_col_bytes(wt, K) + 2 * 56 * 64 * rec <= 150 * 1024;
+    return wt == PS_Q5_K && psk_gemvk_covers(wt, K); // (Q / K / V all Q5_K: k_gemvk.hip)
 }
 
 size_t psk_gemv_lds_col_bytes(int wt, int64_t K) {

@@ -1,5 +1,5 @@
 // Decode mat-vec, second generation (single activation column, Q4_K weights): the same bit-exact arithmetic as
-// gemv3_kernel (k_gemv.hip: producers turn 1 KiB units into the reference's integer partials, a chain wave runs the
+// round 1's gemv3_kernel (deleted in round 3: producers turn 1 KiB units into the reference's integer partials, a chain wave runs the
 // fp32 fma chains of ggml_vec_dot_q4_K_q8_K in unit order, libs/ggml/src/ggml-quants.c:7809-7873), restructured around
 // what the launch-boundary micro-benchmark (tools/micro/overlap.hip, profiles/r02_micro_boundary.txt) showed on MI355X:
 //   * a dependent kernel boundary costs 2.8-3.1 us behind 1024-thread workgroups but 1.3-1.6 us behind 512-thread ones,
@@ -12,7 +12,7 @@
 //     instructions per chunk instead of ~60 per unit;
 //   * chunks are sized so that whole rows fit (K = 4096: 8 producers, 32 units = 2 row groups; K = 14336: 7 producers,
 //     28 units = half a row group).
-// Epilogues as gemv3: EPI 0 bias / residual, EPI 1 SiLU(gate)*up, EPI 2 RoPE + KV-cache append (QKV).
+// Epilogues: EPI 0 bias / residual, EPI 1 SiLU(gate)*up, EPI 2 RoPE + KV-cache append (QKV).
 #include "ps_gemv_dev.h"
 
 namespace {
@@ -455,7 +455,7 @@ bool psk_gemv4_covers(int64_t K) { // rows end on multiples of four units
     return !off && K % 1024 == 0 && K <= 16384;
 }
 
-// Single-column Q4_K mat-vec.  Returns -1 when the launch is not covered (the caller falls back to gemv3 / gemv1).
+// Single-column Q4_K mat-vec.  Returns -1 when the launch is not covered (the caller falls back to gemv1 / gemv_kernel).
 int psk_gemv4(hipStream_t st, int n_cu, const psk_gemv_args &a, ps_act act, int64_t K) {
     if (a.n_w < 1 || a.n_w > 3 || !psk_gemv4_covers(K)) return -1;
     G4Params p{};

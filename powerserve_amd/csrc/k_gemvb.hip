@@ -415,7 +415,7 @@ bool psk_gemvb_covers(int wt, int64_t K) {
     return !off && (wt == PS_Q4_0 || wt == PS_Q8_0) && K >= 128 && K % 128 == 0 && K <= 16384;
 }
 
-// Single-column Q4_0 / Q8_0 mat-vec.  Returns -1 when the launch is not covered (the caller falls back to gemv3 / gemv1).
+// Single-column Q4_0 / Q8_0 mat-vec.  Returns -1 when the launch is not covered (the caller falls back to gemv1 / gemv_kernel).
 int psk_gemvb(hipStream_t st, int n_cu, const psk_gemv_args &a, ps_act act, int64_t K) {
     if (a.n_w < 1 || a.n_w > 3) return -1;
     const int wt = a.w[0]->dtype;

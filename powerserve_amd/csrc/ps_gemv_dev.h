@@ -1,6 +1,5 @@
-// Device code shared by the quantized mat-vec kernels (k_gemv.hip: gemv / gemv1 / gemv3 / gemm8*, k_gemv4.hip: gemv4):
-// weight-type traits, the LDS image of an activation column, the per-unit integer work (unit_dot, unit_rec), the fp32
-// chain step (rec_chain) and hsum_float_8 (row_reduce).  See k_gemv.hip's header for the numerics contract.
+// Device code shared by the quantized mat-vec kernels (k_gemv.hip: gemv / gemv1 / gemm8*, k_gemv4.hip, k_gemvb.hip, k_gemvk.hip):
+// weight-type traits, the LDS image of an activation column, the per-unit integer work (unit_dot) and hsum_float_8 (row_reduce).  See k_gemv.hip's header for the numerics contract.
 #pragma once
 #include <type_traits>
 #include "ps_dev.h"
@@ -101,98 +100,6 @@ __device__ __forceinline__ float row_reduce(float acc0, float acc1, float accm) 
     return r;
 }
 
-
-template <int WT> struct RecOf { using T = int4; };
-template <> struct RecOf<PS_Q4_K> { using T = int2; };
-
-// Q4_K record: {s, u < 4 ? prod : d|dmin}: the four acc_m lanes need prod, the other four carry the fp16 pair
-// QT (Q4_K, k_gemv4.hip): the quants of a 256-element tile are stored quad-major in LDS — dword u * 8 + g instead of
-// g * 8 + u (g = sub-block, u = AVX lane) — so that lane u fetches its eight dwords with two ds_read_b128 instead of
-// eight ds_read_b32
-template <int WT, bool QT = false>
-__device__ __forceinline__ typename RecOf<WT>::T unit_rec(const uint4 q, const uint4 h, const int unit, const int u, const LAct a) {
-    constexpr uint32_t M = 0x0F0F0F0Fu;
-    const uint32_t wq[4] = {q.x, q.y, q.z, q.w};
-    if constexpr (WT == PS_Q4_K) {
-        const uint32_t sc03 = h.y & 0x3f3f3f3fu;
-        const uint32_t sc47 = (h.w & 0x0f0f0f0fu) | (((h.y >> 6) & 0x03030303u) << 4);
-        const uint32_t mn03 = h.z & 0x3f3f3f3fu;
-        const uint32_t mn47 = ((h.w >> 4) & 0x0f0f0f0fu) | (((h.z >> 6) & 0x03030303u) << 4);
-        const int base = unit * 64 + u;
-        int s = 0;
-        int ylv[4], yhv[4]; // every LDS read of the unit first: one wait instead of one per 64-element group
-        const int v = u & 3;
-        int bsa, bsb;
-        if constexpr (QT) {
-            const int4 y0 = *(const int4 *)(a.q32 + unit * 64 + u * 8), y1 = *(const int4 *)(a.q32 + unit * 64 + u * 8 + 4);
-            ylv[0] = y0.x; yhv[0] = y0.y; ylv[1] = y0.z; yhv[1] = y0.w; ylv[2] = y1.x; yhv[2] = y1.y; ylv[3] = y1.z; yhv[3] = y1.w;
-            const int2 bs = *(const int2 *)(a.bs32 + unit * 8 + 2 * v);
-            bsa = bs.x; bsb = bs.y;
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; j++) { ylv[j] = a.q32[base + j * 16]; yhv[j] = a.q32[base + j * 16 + 8]; }
-            bsa = a.bs32[unit * 8 + 2 * v]; bsb = a.bs32[unit * 8 + 2 * v + 1];
-        }
-        int dlo[4], dhi[4]; // the eight quad dots as plain v_dot4 (no zeroed accumulators)
-        dot4x4(dlo, (int)(wq[0] & M), (int)(wq[1] & M), (int)(wq[2] & M), (int)(wq[3] & M), ylv[0], ylv[1], ylv[2], ylv[3]);
-        dot4x4(dhi, (int)((wq[0] >> 4) & M), (int)((wq[1] >> 4) & M), (int)((wq[2] >> 4) & M), (int)((wq[3] >> 4) & M), yhv[0], yhv[1], yhv[2], yhv[3]);
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            // |dot4| <= 4*15*127 fits int16, the 6-bit scales too: the two quad dots of a 64-element group are packed into
-            // one dword and meet their scale pair in a single v_dot2_i32_i16 (exact integer arithmetic, 32-bit accumulate)
-            const uint32_t scp  = (j < 2) ? sc03 : sc47;
-            const uint32_t sc16 = __builtin_amdgcn_perm(0u, scp, (j & 1) ? 0x0c030c02u : 0x0c010c00u); // {scale[2j], scale[2j+1]} as int16
-            const uint32_t d16 = __builtin_amdgcn_perm((uint32_t)dhi[j], (uint32_t)dlo[j], 0x05040100u); // {dl, dh} as int16
-            s = dot2_i16(d16, sc16, s);
-        }
-        const uint32_t mp = (v < 2) ? mn03 : mn47;
-        const int pr = __mul24(bfe8(mp, (2 * v) & 3), bsa) + __mul24(bfe8(mp, (2 * v + 1) & 3), bsb);
-        return make_int2(s, u < 4 ? pr : (int)h.x);
-    } else if constexpr (WT == PS_Q8_0) {
-        int s[4], y[4];
-#pragma unroll
-        for (int b = 0; b < 4; b++) y[b] = a.q32[(unit * 4 + b) * 8 + u];
-        dot4x4(s, (int)wq[0], (int)wq[1], (int)wq[2], (int)wq[3], y[0], y[1], y[2], y[3]);
-        return make_int4(s[0], s[1], s[2], s[3]);
-    } else { // |sum (q-8)*y| over a quad <= 4*8*127: the low/high partials travel as an int16 pair
-        int s[4];
-#pragma unroll
-        for (int b = 0; b < 4; b++) {
-            const int blk = unit * 4 + b;
-            const int yl = a.q32[blk * 8 + u], yh = a.q32[blk * 8 + 4 + u];
-            const int sl = dot4((int)(wq[b] & M), yl, 0) - 8 * dot4(0x01010101, yl, 0);
-            const int sh = dot4((int)((wq[b] >> 4) & M), yh, 0) - 8 * dot4(0x01010101, yh, 0);
-            s[b] = (sl & 0xffff) | (sh << 16);
-        }
-        return make_int4(s[0], s[1], s[2], s[3]);
-    }
-}
-
-// hd: Q4_K d|dmin, Q8_0 / Q4_0 the four fp16 block scales of the unit
-template <int WT>
-__device__ __forceinline__ void rec_chain(const typename RecOf<WT>::T rc, const uint2 hd, const int unit, const LAct a,
-                                          float &acc0, float &acc1, float &accm) {
-    if constexpr (WT == PS_Q4_K) {
-        const float yd   = __uint_as_float(hd.y); // == a.d[unit], read by the caller together with the records
-        const float d    = __fmul_rn(yd, ps_h2f((uint16_t)(hd.x & 0xffff)));
-        const float dmin = __fmul_rn(-yd, ps_h2f((uint16_t)(hd.x >> 16)));
-        acc0 = __fmaf_rn(d, (float)rc.x, acc0);
-        accm = __fmaf_rn(dmin, (float)rc.y, accm); // lanes u >= 4: not an acc_m lane, never read
-    } else {
-        const int sv[4] = {rc.x, rc.y, rc.z, rc.w};
-        const uint16_t dh[4] = {(uint16_t)(hd.x & 0xffff), (uint16_t)(hd.x >> 16), (uint16_t)(hd.y & 0xffff), (uint16_t)(hd.y >> 16)};
-#pragma unroll
-        for (int b = 0; b < 4; b++) {
-            const float d = __fmul_rn(ps_h2f(dh[b]), a.d[unit * 4 + b]);
-            if constexpr (WT == PS_Q8_0) {
-                acc0 = __fmaf_rn(d, (float)sv[b], acc0);
-            } else {
-                acc0 = __fmaf_rn(d, (float)(int)(int16_t)(sv[b] & 0xffff), acc0);
-                acc1 = __fmaf_rn(d, (float)(sv[b] >> 16), acc1);
-            }
-        }
-    }
-}
 
 // ---- shared by the producer / chain-wave kernels with a Q8_K activation (k_gemv4.hip, k_gemvk.hip)
 // silu_hadamard (src/backend/ggml/ggml.cpp:115-129) with glibc's expf table read from LDS: a table lookup in global /

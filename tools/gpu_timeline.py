@@ -60,7 +60,7 @@ for key in keys:
     if (arr > 0).any():
         rel = (arr - ev[:, 0, 0][:, None]) / mhz
         rel[arr <= 0] = np.nan
-        print("  waves 0..15: entry (gemv4) / arrival at the first prologue barrier (gemv3), us since workgroup entry, mean:", np.nanmean(rel, axis=0).round(2))
+        print("  waves 0..15: entry (gemv4), us since workgroup entry, mean:", np.nanmean(rel, axis=0).round(2))
 # boundary between two consecutive kernels: gate/up (5) then down (2) of the same layer
 if os.environ.get('TL_BOUNDARY', '0') != '1':
     sys.exit(0)
