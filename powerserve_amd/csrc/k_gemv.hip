@@ -482,7 +482,7 @@ int launch_wt(hipStream_t st, int n_cu, const GemvParams &p, int epi, int pro) {
     return 3;
 }
 
-// Activation image of 8 pre-quantized columns in LDS, shared by gemm8_kernel and gemm8m_kernel.
+// Activation image of 8 / 16 pre-quantized columns in LDS, shared by gemm8m_kernel and gemm8b_kernel.
 template <int WT, int NT, int C = 8>
 __device__ __forceinline__ void gemm8_stage(const int8_t *aq, const float *ad, const int16_t *abs16, const int K, char *smem, const int c0,
                                             const int nc) {
@@ -534,178 +534,12 @@ __device__ __forceinline__ void gemm8_stage(const int8_t *aq, const float *ad, c
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Batched mat-mul (prefill chunks, tree verify): 8 activation columns per workgroup, in-lane chains.
-// grid = (row-group tiles of 16, column groups of 8); a workgroup stages its 8 pre-quantized columns in LDS once
-// (quants transposed so that the bytes a lane needs per unit are contiguous: ds_read_b128), every wave then owns one
-// row group: the weights of a unit are unpacked ONCE and meet the 8 columns, each column keeping the reference's fma
-// chains in this lane's registers.  Same arithmetic, same order as the mat-vec.
-template <int WT, int EPI, int NWV>
-__global__ __launch_bounds__(NWV * 64) void gemm8_kernel(const GemvParams p) {
-    constexpr int NT = NWV * 64;
-    using TR = WTraits<WT>;
-    constexpr int C = 8;
-    constexpr uint32_t M = 0x0F0F0F0Fu;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int K = (int)p.K, n_units = K / TR::UNIT, nblk = K / TR::BLK, c0 = blockIdx.y * C, nc = min(C, (int)p.bs - c0);
-    constexpr int REC = (WT == PS_Q4_K) ? 304 : 144; // (gemm8_stage)
-    gemm8_stage<WT, NT>(p.aq, p.ad, p.abs16, K, smem, c0, nc);
-    __syncthreads();
-
-    const int r = (WT == PS_Q4_0) ? (lane >> 2) : (lane >> 3);
-    const int u = (WT == PS_Q4_0) ? (lane & 3) : (lane & 7);
-    const int v = u & 3;
-    constexpr int AUXR = (WT == PS_Q4_K) ? 16 : 8;
-    const int64_t n_tasks = (EPI == 1) ? p.w[0].n_groups : p.groups_total;
-    const int64_t task = (int64_t)blockIdx.x * NWV + wave;
-    if (task >= n_tasks) return;
-    float yg[C];
-#pragma unroll
-    for (int pass = 0; pass < (EPI == 1 ? 2 : 1); pass++) {
-        int wi = 0;
-        int64_t grp = task;
-        if (EPI == 1) {
-            wi = pass;
-        } else {
-            if (p.n_w > 1 && grp >= p.w[0].n_groups) { grp -= p.w[0].n_groups; wi = 1; }
-            if (p.n_w > 2 && wi == 1 && grp >= p.w[1].n_groups) { grp -= p.w[1].n_groups; wi = 2; }
-        }
-        const uint8_t *qs = p.w[0].qs, *ax = p.w[0].aux;
-        if (wi == 1) { qs = p.w[1].qs; ax = p.w[1].aux; }
-        if (wi == 2) { qs = p.w[2].qs; ax = p.w[2].aux; }
-        const uint8_t *qg = qs + grp * n_units * 1024 + lane * 16;
-        const uint8_t *ag = ax + grp * n_units * (TR::RG * AUXR) + r * AUXR;
-        float acc0[C], acc1[C];
-#pragma unroll
-        for (int c = 0; c < C; c++) { acc0[c] = 0.f; acc1[c] = 0.f; }
-        auto load_h = [&](int un) {
-            uint4 h = make_uint4(0, 0, 0, 0);
-            if (WT == PS_Q4_K) h = *(const uint4 *)(ag + (int64_t)un * (TR::RG * AUXR));
-            else { const uint2 t2 = *(const uint2 *)(ag + (int64_t)un * (TR::RG * AUXR)); h.x = t2.x; h.y = t2.y; }
-            return h;
-        };
-        auto unit = [&](const int un, const uint4 q, const uint4 h) {
-            const uint32_t wq[4] = {q.x, q.y, q.z, q.w};
-            if constexpr (WT == PS_Q4_K) {
-                // ---- this unit's weights, unpacked once for the 8 columns (acc1 plays acc_m)
-                const uint32_t sc03 = h.y & 0x3f3f3f3fu, sc47 = (h.w & 0x0f0f0f0fu) | (((h.y >> 6) & 0x03030303u) << 4);
-                const uint32_t mn03 = h.z & 0x3f3f3f3fu, mn47 = ((h.w >> 4) & 0x0f0f0f0fu) | (((h.z >> 6) & 0x03030303u) << 4);
-                const uint32_t sc16[4] = {__builtin_amdgcn_perm(0u, sc03, 0x0c010c00u), __builtin_amdgcn_perm(0u, sc03, 0x0c030c02u),
-                                          __builtin_amdgcn_perm(0u, sc47, 0x0c010c00u), __builtin_amdgcn_perm(0u, sc47, 0x0c030c02u)};
-                int wl[4], wh[4];
-#pragma unroll
-                for (int j = 0; j < 4; j++) { wl[j] = (int)(wq[j] & M); wh[j] = (int)((wq[j] >> 4) & M); }
-                const uint32_t mp = (v < 2) ? mn03 : mn47;
-                const int mna = bfe8(mp, (2 * v) & 3), mnb = bfe8(mp, (2 * v + 1) & 3);
-                const float dw = ps_h2f((uint16_t)(h.x & 0xffff)), dmw = ps_h2f((uint16_t)(h.x >> 16));
-#pragma unroll
-                for (int c = 0; c < C; c++) {
-                    const char *rec = smem + (un * C + c) * REC;
-                    const int4 y0 = *(const int4 *)(rec + u * 32), y1 = *(const int4 *)(rec + u * 32 + 16);
-                    const int2 bs = *(const int2 *)(rec + 256 + v * 8);
-                    const float yd = *(const float *)(rec + 288);
-                    const int yl[4] = {y0.x, y0.z, y1.x, y1.z}, yh[4] = {y0.y, y0.w, y1.y, y1.w};
-                    int s = 0, dlo[4], dhi[4];
-                    dot4x4(dlo, wl[0], wl[1], wl[2], wl[3], yl[0], yl[1], yl[2], yl[3]);
-                    dot4x4(dhi, wh[0], wh[1], wh[2], wh[3], yh[0], yh[1], yh[2], yh[3]);
-#pragma unroll
-                    for (int j = 0; j < 4; j++)
-                        s = dot2_i16(__builtin_amdgcn_perm((uint32_t)dhi[j], (uint32_t)dlo[j], 0x05040100u), sc16[j], s);
-                    const int pr   = __mul24(mna, bs.x) + __mul24(mnb, bs.y);
-                    const float d  = __fmul_rn(yd, dw), dmin = __fmul_rn(-yd, dmw);
-                    acc0[c] = __fmaf_rn(d, (float)s, acc0[c]);
-                    acc1[c] = __fmaf_rn(dmin, (float)pr, acc1[c]);
-                }
-            } else {
-                const float dh[4] = {ps_h2f((uint16_t)(h.x & 0xffff)), ps_h2f((uint16_t)(h.x >> 16)), ps_h2f((uint16_t)(h.y & 0xffff)), ps_h2f((uint16_t)(h.y >> 16))};
-                int wl[4], wh[4];
-#pragma unroll
-                for (int b = 0; b < 4; b++) {
-                    if (WT == PS_Q8_0) { wl[b] = (int)wq[b]; wh[b] = 0; }
-                    else { // nibble - 8 as signed bytes, once: dot4(n - 8, y) == dot4(n, y) - 8 * sum(y), the reference's integer
-                        wl[b] = (int)((((wq[b] & M) | 0x80808080u) - 0x08080808u) ^ 0x80808080u);
-                        wh[b] = (int)(((((wq[b] >> 4) & M) | 0x80808080u) - 0x08080808u) ^ 0x80808080u);
-                    }
-                }
-#pragma unroll
-                for (int c = 0; c < C; c++) {
-                    const char *rec = smem + (un * C + c) * REC;
-                    const float4 yd = *(const float4 *)(rec + 128);
-                    const float ydv[4] = {yd.x, yd.y, yd.z, yd.w};
-                    if constexpr (WT == PS_Q8_0) {
-                        const int4 y = *(const int4 *)(rec + u * 16);
-                        const int yv[4] = {y.x, y.y, y.z, y.w};
-                        int sd[4];
-                        dot4x4(sd, wl[0], wl[1], wl[2], wl[3], yv[0], yv[1], yv[2], yv[3]);
-#pragma unroll
-                        for (int b = 0; b < 4; b++) acc0[c] = __fmaf_rn(__fmul_rn(dh[b], ydv[b]), (float)sd[b], acc0[c]);
-                    } else {
-                        const int4 y0 = *(const int4 *)(rec + u * 32), y1 = *(const int4 *)(rec + u * 32 + 16);
-                        const int yl[4] = {y0.x, y0.z, y1.x, y1.z}, yh[4] = {y0.y, y0.w, y1.y, y1.w};
-                        int sl[4], sh[4];
-                        dot4x4(sl, wl[0], wl[1], wl[2], wl[3], yl[0], yl[1], yl[2], yl[3]);
-                        dot4x4(sh, wh[0], wh[1], wh[2], wh[3], yh[0], yh[1], yh[2], yh[3]);
-#pragma unroll
-                        for (int b = 0; b < 4; b++) {
-                            const float d = __fmul_rn(dh[b], ydv[b]);
-                            acc0[c] = __fmaf_rn(d, (float)sl[b], acc0[c]);
-                            acc1[c] = __fmaf_rn(d, (float)sh[b], acc1[c]);
-                        }
-                    }
-                }
-            }
-        };
-        if constexpr (NWV == 16) { // 128 VGPRs per lane: one unit ahead
-            uint4 q = ld_stream16(qg), h = load_h(0);
-            for (int un = 0; un < n_units; un++) {
-                uint4 qn = q, hn = h;
-                if (un + 1 < n_units) { qn = ld_stream16(qg + (int64_t)(un + 1) * 1024); hn = load_h(un + 1); }
-                unit(un, q, h);
-                q = qn; h = hn;
-            }
-        } else {
-            // small launches leave less than one wave per SIMD, so the walk is latency-bound: PF units in flight per
-            // wave; loads are unconditional (index clamped to the last unit) so that the compiler counts them exactly
-            constexpr int PF = 4;
-            uint4 qb[PF], hb[PF];
-#pragma unroll
-            for (int s = 0; s < PF; s++) { const int uc = min(s, n_units - 1); qb[s] = ld_stream16(qg + (int64_t)uc * 1024); hb[s] = load_h(uc); }
-            for (int un0 = 0; un0 < n_units; un0 += PF) {
-#pragma unroll
-                for (int s = 0; s < PF; s++) {
-                    const int un = un0 + s;
-                    if (un >= n_units) break;
-                    const uint4 q = qb[s], h = hb[s];
-                    const int nx = min(un + PF, n_units - 1);
-                    qb[s] = ld_stream16(qg + (int64_t)nx * 1024); hb[s] = load_h(nx);
-                    unit(un, q, h);
-                }
-            }
-        }
-        // ---- epilogue: lane with u == 0 owns row grp*RG + r
-        int64_t Nw = p.w[0].N, ldo = p.w[0].ldo;
-        float *o = p.w[0].out;
-        const float *b = p.w[0].bias;
-        if (wi == 1) { Nw = p.w[1].N; ldo = p.w[1].ldo; o = p.w[1].out; b = p.w[1].bias; }
-        if (wi == 2) { Nw = p.w[2].N; ldo = p.w[2].ldo; o = p.w[2].out; b = p.w[2].bias; }
-        const int64_t row = grp * TR::RG + r;
-#pragma unroll
-        for (int c = 0; c < C; c++) {
-            const float y = (WT == PS_Q4_K) ? row_reduce<WT>(acc0[c], 0.f, acc1[c]) : row_reduce<WT>(acc0[c], acc1[c], 0.f);
-            if (EPI == 1 && pass == 0) { yg[c] = y; continue; }
-            if (u == 0 && row < Nw && c < nc) {
-                if (EPI == 1) {
-                    p.w[0].out[(int64_t)(c0 + c) * p.w[0].ldo + row] = ps_silu_mul(yg[c], y);
-                } else {
-                    float val = y;
-                    if (b) val = __fadd_rn(val, b[row]);
-                    if (p.residual && wi == 0) val = __fadd_rn(p.residual[(int64_t)(c0 + c) * ldo + row], val);
-                    o[(int64_t)(c0 + c) * ldo + row] = val;
-                }
-            }
-        }
-    }
-}
+// Batched mat-mul (prefill chunks, tree verify) for the shapes the fp16 matrix-core kernels of k_gemm4k.hip do not take: 8 or 16
+// activation columns per workgroup.  grid = (row-group tiles, column groups); a workgroup stages its pre-quantized columns in LDS
+// once (gemm8_stage: quants transposed so that the bytes a lane needs per unit are contiguous, ds_read_b128), every wave then owns
+// one row group: the weights of a unit are unpacked ONCE and meet the columns, each column keeping the reference's fma chains in
+// this lane's registers.  Same arithmetic, same order as the mat-vec.  (Round 1's v_dot4 form, gemm8_kernel, was deleted in round
+// 3: the two kernels below -- the same lane roles with the quad dots on v_mfma_i32_4x4x4_16B_i8 -- took every launch.)
 
 // ---------------------------------------------------------------------------------------------------------
 // Q4_K batched mat-mul with the quad dots on the matrix cores (exact: everything before the fp32 chain is integer).
@@ -1058,13 +892,6 @@ size_t psk_gemv_lds_col_bytes(int wt, int64_t K) {
 
 // Batched mat-mul from pre-quantized activations; returns -1 when the shape is not covered (caller falls back to
 // column groups through the mat-vec).
-template <int WT, int EPI, int NWV>
-static void launch_gemm8_k(hipStream_t st, const GemvParams &p, const dim3 grid, size_t smem) {
-    static unsigned long long attr = 0; // devices that have the attribute
-    if (ps_first_on_device(&attr)) { (void)hipFuncSetAttribute((const void *)gemm8_kernel<WT, EPI, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024); }
-    psk_note_kernel("gemm8_kernel<%d, %d, %d>", WT, EPI, NWV);
-    hipLaunchKernelGGL((gemm8_kernel<WT, EPI, NWV>), grid, dim3(NWV * 64), smem, st, p);
-}
 template <int EPI, int NWV, int C>
 static void launch_gemm8m_k(hipStream_t st, const GemvParams &p, const dim3 grid, size_t smem) {
     static unsigned long long attr = 0; // devices that have the attribute
@@ -1081,23 +908,15 @@ static void launch_gemm8b_k(hipStream_t st, const GemvParams &p, const dim3 grid
 }
 template <int WT>
 static int launch_gemm8(hipStream_t st, const GemvParams &p, int epi, int nwv, const dim3 grid, size_t smem) {
-    static const bool valu_only = getenv("PS_GEMM8_VALU") != nullptr; // (A/B switch for measurements)
-    if constexpr (WT != PS_Q4_K) {
-        if (!valu_only) { // quad dots on the matrix cores
-            if (nwv == 8) launch_gemm8b_k<WT, 1, 8>(st, p, grid, smem); // (Q4_0 gate/up: see psk_gemm8)
-            else if (nwv == 16) { if (epi) launch_gemm8b_k<WT, 1, 16>(st, p, grid, smem); else launch_gemm8b_k<WT, 0, 16>(st, p, grid, smem); }
-            else { if (epi) launch_gemm8b_k<WT, 1, 4>(st, p, grid, smem); else launch_gemm8b_k<WT, 0, 4>(st, p, grid, smem); }
-            return 0;
-        }
-    }
-    if (WT == PS_Q4_K && !valu_only) { // quad dots on the matrix cores
+    if constexpr (WT != PS_Q4_K) { // quad dots on the matrix cores
+        if (nwv == 8) launch_gemm8b_k<WT, 1, 8>(st, p, grid, smem); // (Q4_0 gate/up: see psk_gemm8)
+        else if (nwv == 16) { if (epi) launch_gemm8b_k<WT, 1, 16>(st, p, grid, smem); else launch_gemm8b_k<WT, 0, 16>(st, p, grid, smem); }
+        else { if (epi) launch_gemm8b_k<WT, 1, 4>(st, p, grid, smem); else launch_gemm8b_k<WT, 0, 4>(st, p, grid, smem); }
+    } else {
         if (nwv == 8) { if (epi) launch_gemm8m_k<1, 8, 16>(st, p, grid, smem); else launch_gemm8m_k<0, 8, 16>(st, p, grid, smem); } // 16 columns
         else if (nwv == 16) { if (epi) launch_gemm8m_k<1, 16, 8>(st, p, grid, smem); else launch_gemm8m_k<0, 16, 8>(st, p, grid, smem); }
         else { if (epi) launch_gemm8m_k<1, 4, 8>(st, p, grid, smem); else launch_gemm8m_k<0, 4, 8>(st, p, grid, smem); }
-        return 0;
     }
-    if (nwv == 16) { if (epi) launch_gemm8_k<WT, 1, 16>(st, p, grid, smem); else launch_gemm8_k<WT, 0, 16>(st, p, grid, smem); }
-    else { if (epi) launch_gemm8_k<WT, 1, 4>(st, p, grid, smem); else launch_gemm8_k<WT, 0, 4>(st, p, grid, smem); }
     return 0;
 }
 int psk_gemm8(hipStream_t st, int n_cu, const psk_gemv_args &a, ps_act act, int64_t K, int64_t bs) {
@@ -1123,7 +942,7 @@ int psk_gemm8(hipStream_t st, int n_cu, const psk_gemv_args &a, ps_act act, int6
     }
     const int epi = a.silu_pair ? 1 : 0;
     if (epi == 1 && (a.n_w != 2 || a.w[0]->N != a.w[1]->N)) return -1;
-    const size_t smem = (size_t)(K / unit) * 8 * (wt == PS_Q4_K ? 304 : 144); // [unit][column] records (gemm8_kernel)
+    const size_t smem = (size_t)(K / unit) * 8 * (wt == PS_Q4_K ? 304 : 144); // [unit][column] records (gemm8_stage)
     if (smem > 158 * 1024) return -1;
     const int64_t n_tasks = epi == 1 ? p.w[0].n_groups : p.groups_total;
     // one wave per row group; 16-wave workgroups amortise the LDS staging of the 8 columns, 4-wave workgroups spread a
@@ -1135,8 +954,7 @@ int psk_gemm8(hipStream_t st, int n_cu, const psk_gemv_args &a, ps_act act, int6
     // twice the columns; the image of 16 columns has to fit the LDS)
     static const bool no16 = getenv("PS_GEMM8_C8") != nullptr;
     if (wt == PS_Q4_K && !no16 && nwv == 16 && bs > 8 && 2 * smem <= 80 * 1024) { nwv = 8; ncg = (bs + 15) / 16; smem_l = 2 * smem; }
-    static const bool valu_q40 = getenv("PS_GEMM8_VALU") != nullptr;
-    if (wt == PS_Q4_0 && epi == 1 && nwv == 16 && !valu_q40) nwv = 8; // two column sets + the held gate rows need more than the 128 VGPRs of a 16-wave workgroup
+    if (wt == PS_Q4_0 && epi == 1 && nwv == 16) nwv = 8; // two column sets + the held gate rows need more than the 128 VGPRs of a 16-wave workgroup
     const dim3 grid((unsigned)((n_tasks + nwv - 1) / nwv), (unsigned)ncg);
     switch (wt) {
     case PS_Q4_K: return launch_gemm8<PS_Q4_K>(st, p, epi, nwv, grid, smem_l);
