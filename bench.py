@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--no-graph-path", action="store_true", help="skip the Graph -> Executor -> HIPBackend::plan leg (libps_host.so)")
     ap.add_argument("--graph-steps", type=int, default=96)
     ap.add_argument("--wide-chunk", type=int, default=512, help="side leg: prefill in chunks of this many tokens (0: skip)")
+    ap.add_argument("--super-chunks", type=int, default=4, help="reference-sized prefill chunks (--batch tokens each) per launch sequence "
+                    "(ps_hip_model_prefill: same bits as chunk-by-chunk forwards; 1: one forward per chunk)")
     return ap.parse_args()
 
 
@@ -336,7 +338,7 @@ def main():
     model_dir = ensure_model(args, rank, barrier)
     ctx = hip.Ctx(local)
     t0 = time.time()
-    model = hip.Model(ctx, model_dir, max_batch=max(args.batch, 1), n_ctx=args.n_ctx)
+    model = hip.Model(ctx, model_dir, max_batch=max(args.batch, 1) * max(args.super_chunks, 1), n_ctx=args.n_ctx)
     load_s = time.time() - t0
     cfg = model.cfg
     if args.eager:
@@ -349,24 +351,28 @@ def main():
 
     # ---- prefill (all but the last prompt token, lm_head skipped: src/model/model.hpp:147-163)
     barrier(); ctx.sync()
+    def prefill():
+        # the reference's loop: forward(chunk of --batch tokens, lm_head = false) + advance, chunk after chunk.  ps_hip_model_prefill runs
+        # exactly that (bit-identical cache, tests/test_gpu_model.py::test_prefill_in_super_chunks_keeps_the_reference_chunking) with
+        # --super-chunks reference chunks per launch sequence: mat-muls over all their columns, attention per reference chunk
+        model.reset()
+        if args.super_chunks > 1:
+            model.prefill(prompt[:-1], args.batch)
+            return
+        done = 0
+        while done < prompt.size - 1:
+            bs = min(args.batch, prompt.size - 1 - done)
+            model.forward(prompt[done:done + bs], np.arange(done, done + bs), lm_head=False)
+            done += bs
+
     t0 = time.perf_counter()
-    model.reset()
-    done = 0
-    while done < prompt.size - 1:
-        bs = min(args.batch, prompt.size - 1 - done)
-        model.forward(prompt[done:done + bs], np.arange(done, done + bs), lm_head=False)
-        done += bs
+    prefill()
     ctx.sync(); barrier()
     prefill_s = time.perf_counter() - t0
     # (the pass above is the first use of every prefill kernel in this process; the same prompt once more, warm, is reported next to it)
     barrier(); ctx.sync()
     t0 = time.perf_counter()
-    model.reset()
-    done = 0
-    while done < prompt.size - 1:
-        bs = min(args.batch, prompt.size - 1 - done)
-        model.forward(prompt[done:done + bs], np.arange(done, done + bs), lm_head=False)
-        done += bs
+    prefill()
     ctx.sync(); barrier()
     prefill_warm_s = time.perf_counter() - t0
 
@@ -407,7 +413,7 @@ def main():
             "dtype": "int8 x int4 block dot, fp32 accumulate (ggml Q4_K x Q8_K semantics)" if args.wtype == "Q4_K" else "int8 block dot, fp32 accumulate",
             "data": "synthetic (random-init weights generated in the quantized domain; random prompt ids, seed 42)",
             "config": {"workload": f"{args.preset} {'mixed' if args.wtype in ('Q4_K_M', 'Q5_K_M') else 'pure'} {args.wtype}, prefill {args.prompt_len} + decode {args.steps}, n_ctx {args.n_ctx}, FP32 KV",
-                       "prefill_chunk": args.batch, "replicas": world, "collectives": "RCCL broadcast(prompt) + all_gather(ids)" if world > 1 else "none"},
+                       "prefill_chunk": args.batch, "prefill_chunks_per_launch_sequence": max(args.super_chunks, 1), "replicas": world, "collectives": "RCCL broadcast(prompt) + all_gather(ids)" if world > 1 else "none"},
             "prefill_tokens_per_s": world * (args.prompt_len - 1) / prefill_s, "prefill_s": prefill_s,
             "prefill_tokens_per_s_warm": world * (args.prompt_len - 1) / prefill_warm_s, "prefill_warm_s": prefill_warm_s,
             "decode_device_ms_per_step": dev_ms / args.steps, "model_load_s": load_s,
@@ -415,7 +421,7 @@ def main():
             "decode_effective_GBps": (wbytes + kv_bytes) / (dt / args.steps) / 1e9,
             "replicas_agree": replicas_agree, "first_ids": [int(i) for i in ids[:8]],
             "roofline": rf,
-            "prefill_roofline": prefill_roofline(ctx, model, cfg, args.prompt_len - 1, prefill_s, prefill_warm_s, args.batch,
+            "prefill_roofline": prefill_roofline(ctx, model, cfg, args.prompt_len - 1, prefill_s, prefill_warm_s, min(args.batch * max(args.super_chunks, 1), args.prompt_len - 1),
                                                  args.preset == "llama-3.1-8b" and args.wtype == "Q4_K"),
         }
         if not args.no_kv_f16 and dist is None:

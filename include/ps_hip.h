@@ -180,6 +180,11 @@ int ps_hip_model_forward_lowered(ps_hip_model *m, const int32_t *tokens, int n, 
  * not its slot) and sees the cached prefix (minus slots hidden with ps_hip_model_kv_mask) plus the batch columns j with
  * tree[i*n + j] != 0 (NULL: causal).  advance = 0 leaves kv_position where it was: the caller keeps the accepted path
  * with ps_hip_model_kv_move(dst, src) + ps_hip_model_kv_advance(1) per node, as TokenTree::verify does. */
+/* ModelTokenIterator's prefill loop (src/model/model.hpp:147-163: forward(chunk, lm_head = false) + advance, chunk after chunk of
+ * `chunk` tokens = hparams batch_size) for tokens appended at the current cache position -- bit-identical to calling
+ * ps_hip_model_forward per chunk, but up to max_batch / chunk chunks share one launch sequence: the mat-muls take all their columns at
+ * once, only the attention is evaluated per reference chunk (its sums depend on where a chunk ends). */
+int ps_hip_model_prefill(ps_hip_model *m, const int32_t *tokens, int n, int chunk);
 int ps_hip_model_forward_tree(ps_hip_model *m, const int32_t *tokens, int n, const int32_t *rope_pos, const uint8_t *tree,
                               int lm_head, int32_t *argmax_host, int advance);
 /* KVCacheInterface::mask / unmask (core/kv_cache.hpp:97-163): hide / show one cached slot in every later forward */

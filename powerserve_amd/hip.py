@@ -30,7 +30,7 @@ EXPORTS = [
     "ps_hip_get_embedding", "ps_hip_get_mask", "ps_hip_argmax", "ps_hip_model_create", "ps_hip_model_destroy",
     "ps_hip_model_kv_position", "ps_hip_model_max_batch", "ps_hip_model_kv_truncate", "ps_hip_model_kv_advance", "ps_hip_model_kv_rollback", "ps_hip_model_kv_move",
     "ps_hip_model_forward", "ps_hip_model_decode_greedy", "ps_hip_model_logits", "ps_hip_model_scratch", "ps_hip_model_k_cache",
-    "ps_hip_model_v_cache", "ps_hip_model_weight_bytes_per_token", "ps_hip_model_set_mode", "ps_hip_model_bench_gemv", "ps_hip_model_bench_matmul", "ps_hip_debug_timeline", "ps_hip_last_matmul_kernel", "ps_hip_debug_set", "ps_hip_model_forward_tree", "ps_hip_model_forward_lowered", "ps_hip_model_kv_mask",
+    "ps_hip_model_v_cache", "ps_hip_model_weight_bytes_per_token", "ps_hip_model_set_mode", "ps_hip_model_bench_gemv", "ps_hip_model_bench_matmul", "ps_hip_debug_timeline", "ps_hip_last_matmul_kernel", "ps_hip_debug_set", "ps_hip_model_forward_tree", "ps_hip_model_prefill", "ps_hip_model_forward_lowered", "ps_hip_model_kv_mask",
 ]
 
 
@@ -111,7 +111,7 @@ def lib() -> C.CDLL:
         "ps_hip_model_kv_rollback": (i32, [vp, sz]), "ps_hip_model_kv_move": (i32, [vp, sz, sz]),
         "ps_hip_model_forward": (i32, [vp, vp, i32, vp, vp, i32, vp]),
         "ps_hip_model_forward_lowered": (i32, [vp, vp, i32, vp, vp, i32]),
-        "ps_hip_model_forward_tree": (i32, [vp, vp, i32, vp, vp, i32, vp, i32]), "ps_hip_model_kv_mask": (i32, [vp, sz, i32]),
+        "ps_hip_model_forward_tree": (i32, [vp, vp, i32, vp, vp, i32, vp, i32]), "ps_hip_model_prefill": (i32, [vp, vp, i32, i32]), "ps_hip_model_kv_mask": (i32, [vp, sz, i32]),
         "ps_hip_model_decode_greedy": (i32, [vp, i32, i32, vp]), "ps_hip_model_logits": (vp, [vp]), "ps_hip_model_scratch": (vp, [vp, i32]),
         "ps_hip_model_k_cache": (vp, [vp, i32]), "ps_hip_model_v_cache": (vp, [vp, i32]),
         "ps_hip_model_weight_bytes_per_token": (C.c_uint64, [vp]), "ps_hip_model_set_mode": (i32, [vp, i32]),
@@ -343,6 +343,12 @@ class Model:
             logits = np.empty((n, self.cfg.vocab_size), dtype=np.float32)
             self.ctx.check(self.ctx.L.ps_hip_memcpy_d2h(self.ctx.h, _ptr(logits), self.ctx.L.ps_hip_model_logits(self.h), logits.nbytes))
         return logits, am
+
+    def prefill(self, tokens, chunk: int):
+        """ModelTokenIterator's prefill: the tokens appended at the cache position in reference chunks of `chunk`, no logits
+        (ps_hip_model_prefill: same bits as forward() per chunk, several chunks per launch sequence when max_batch allows)."""
+        tokens = np.ascontiguousarray(tokens, dtype=np.int32)
+        self.ctx.check(self.ctx.L.ps_hip_model_prefill(self.h, _ptr(tokens), tokens.size, int(chunk)))
 
     def forward_tree(self, tokens, rope_pos, tree=None, lm_head=True, want_logits=False, advance=False):
         """Token-tree forward (src/speculative/token_tree.cpp): tokens appended at the current KV position, column i rotated

@@ -220,6 +220,48 @@ def test_tree_mask_plumbing(ctx, tmp_path):
     gm.close()
 
 
+@pytest.mark.parametrize("preset,wt,chunk,max_batch", [("small-llama-hs128", 12, 128, 512), ("small-llama-hs128", 1015, 64, 256), ("small-llama-hs128", 12, 96, 500),
+                                                       ("tiny-llama", 8, 128, 384), ("tiny-qwen2", 2, 32, 128), ("small-llama-hs128", 12, 128, 128)])
+def test_prefill_in_super_chunks_keeps_the_reference_chunking(ctx, oracle, tmp_path, preset, wt, chunk, max_batch):
+    """ps_hip_model_prefill: several reference-sized chunks per launch sequence (mat-muls over all their columns, attention per chunk)
+    must leave exactly the cache the reference's chunk-by-chunk prefill leaves: K rows and V columns bit-equal to the oracle run
+    chunk by chunk, and so are the logits of the steps that follow (ragged last chunk, a prefix already in the cache, a chunk size that
+    does not divide max_batch, max_batch == chunk)."""
+    from oracle import binding as B
+    from powerserve_amd import hip, synth
+    d = str(tmp_path / "m")
+    mj = synth.write_model_dir(d, preset, wt, n_ctx=1536, seed=11)
+    cfg = B.make_config(mj["llm_config"])
+    om = oracle.model(cfg, mj["model_arch"], load_tensors(os.path.join(d, "ggml/weights.gguf")), n_threads=16)
+    gm = hip.Model(ctx, d, max_batch=max_batch, n_ctx=1536)
+    rng = np.random.default_rng(3)
+    pre = rng.integers(0, cfg.vocab_size, 5)  # a few tokens already in the cache
+    om.forward(pre, np.arange(5), False); gm.forward(pre, np.arange(5), lm_head=False)
+    P = 3 * max(chunk, max_batch // 2) + 2 * chunk + 17
+    prompt = rng.integers(0, cfg.vocab_size, P)
+    done = 0
+    while done < P:
+        bs = min(chunk, P - done)
+        om.forward(prompt[done:done + bs], np.arange(5 + done, 5 + done + bs), False)
+        done += bs
+    gm.prefill(prompt, chunk)
+    assert gm.position == om.position == 5 + P
+    kv = cfg.kv_dim
+    for L in (0, cfg.n_layers - 1):
+        gk, gv = gm.k_cache(L), gm.v_cache(L)
+        ok, ov = om.k_cache(L), om.v_cache(L)
+        assert np.array_equal(gk[:5 + P].view(np.uint32), ok[:5 + P].view(np.uint32)), L
+        assert np.array_equal(gv[:, :5 + P].view(np.uint32), ov[:, :5 + P].view(np.uint32)), L
+    cur = int(prompt[-1])
+    for s in range(3):
+        want1 = om.forward([cur], [5 + P + s], True)
+        got1, am1 = gm.forward([cur], [5 + P + s], True)
+        assert np.array_equal(got1.view(np.uint32), want1.view(np.uint32)), (s, rel_err(got1, want1))
+        cur = int(am1[0])
+    gm.close()
+    om.close()
+
+
 @pytest.mark.parametrize("preset,wt,chunk", [("small-llama-hs128", 12, 256), ("small-llama-hs128", 12, 512), ("small-llama-hs128", 1015, 384), ("tiny-llama", 8, 256), ("tiny-qwen2", 2, 320)])
 def test_wide_prefill_chunks_match_oracle(ctx, oracle, tmp_path, preset, wt, chunk):
     """hparams batch_size above the reference's default of 128 (bench.py reports a 512-token-chunk prefill next to the headline):
