@@ -215,6 +215,31 @@ def prefill_wide_leg(ctx, model_dir, args, prompt):
     return {"chunk": args.wide_chunk, "prefill_tokens_per_s": res[0], "prefill_tokens_per_s_warm": res[1]}
 
 
+def fp16_prefill_leg(ctx, model, args, prompt, ids_parity):
+    """SURVEY 8 f4 (second half), reported next to the headline and never mixed into it: the same prefill with the fp16 perf mode on
+    (ps_hip_model_set_mode bit 5: the layer mat-muls as dense fp16 GEMMs on dequantized fp16 copies of the weights, rocBLAS; RoPE, KV
+    append and attention stay the parity kernels on the FP32 cache).  NOT bit-exact: the greedy ids that follow (parity decode on the
+    perf-mode cache) are compared with the parity run's."""
+    model.reset()
+    model.set_mode((1 if args.eager else 0) | 32)
+    model.prefill(prompt[:8], args.batch)  # first use: dequantizes the weights, loads the GEMM library (not timed)
+    res = []
+    for _ in range(2):
+        ctx.sync()
+        t0 = time.perf_counter()
+        model.reset()
+        model.prefill(prompt[:-1], args.batch)
+        ctx.sync()
+        res.append((prompt.size - 1) / (time.perf_counter() - t0))
+    ids = model.decode_greedy(int(prompt[-1]), min(16, ids_parity.size))
+    model.set_mode(1 if args.eager else 0)
+    same = 0
+    while same < ids.size and ids[same] == ids_parity[same]:
+        same += 1
+    return {"prefill_tokens_per_s": res[0], "prefill_tokens_per_s_warm": res[1], "ids_matching_prefix_vs_parity": int(same), "ids_compared": int(ids.size),
+            "note": "layer mat-muls of the prefill as dense fp16 GEMMs (fp32 accumulation) on dequantized weights; decode stays on the parity kernels; not bit-exact by design"}
+
+
 def fp16_kv_leg(ctx, model, args, prompt, ids_parity):
     """SURVEY 8 f4, reported next to the headline and never mixed into it: the same prefill + decode with the fp16-KV
     decode mode on (ps_hip_model_set_mode bit 3: fp16 mirrors of K and V, split-KV online soft-max for the single-token
@@ -429,6 +454,10 @@ def main():
                 out["fp16_kv_mode"] = fp16_kv_leg(ctx, model, args, prompt, np.concatenate([ids_w, ids]))
             except Exception as e:  # noqa: BLE001 — a failing side leg must not take the headline line with it
                 out["fp16_kv_mode"] = {"error": repr(e)}
+            try:
+                out["fp16_prefill_mode"] = fp16_prefill_leg(ctx, model, args, prompt, np.concatenate([ids_w, ids]))
+            except Exception as e:  # noqa: BLE001
+                out["fp16_prefill_mode"] = {"error": repr(e)}
         if args.wide_chunk > args.batch and dist is None:
             try:
                 out["prefill_wide_chunks"] = prefill_wide_leg(ctx, model_dir, args, prompt)

@@ -227,7 +227,12 @@ int ps_hip_debug_set(int key, int value);
  * bit 4: 1 = single-token attention as TWO launches (scores, then soft-max + V.p) instead of the one-launch form
  * (attn_decode2_kernel: scores exchanged inside the launch; it needs every workgroup of its grid resident, its wait is bounded,
  * and a wait that gives up is reported as an error by the forward that hit it and switches this bit on).  Same results bit for
- * bit.  The environment variable PS_HIP_MODE_OR is OR-ed into every mode (A/B runs of unmodified drivers). */
+ * bit;
+ * bit 5: 1 = fp16 prefill perf mode — NOT bit-exact: the layer mat-muls of batches without logits (prefill chunks) run
+ * as dense fp16 GEMMs (fp32 accumulation) on dequantized fp16 copies of the matrices made at first use (+2 bytes per weight), through
+ * rocBLAS loaded with dlopen (an error, not a fallback, when it is missing); RoPE, KV append and attention stay the parity kernels on
+ * the FP32 cache, single tokens and tree forwards stay entirely on the parity path.
+ * The environment variable PS_HIP_MODE_OR is OR-ed into every mode (A/B runs of unmodified drivers). */
 int ps_hip_model_set_mode(ps_hip_model *m, int mode);
 
 #ifdef __cplusplus

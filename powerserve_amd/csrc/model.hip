@@ -68,6 +68,9 @@ struct ps_hip_model {
     size_t n_hidden = 0;
     size_t position = 0;
     int mode = 0;
+    psf16 *pf = nullptr;                // fp16 prefill perf mode (mode bit 5): rocBLAS handle, fp16 copies of the layer matrices, fp16 activation scratch
+    std::vector<_Float16 *> hq, hk, hv, ho, hg, hu, hd;
+    _Float16 *xh = nullptr;
     ps_step_state *state_sub = nullptr; // [64] per-chunk states of a super-chunk prefill (ps_hip_model_prefill)
     int attn_chunk = 0;                 // > 0 while such a forward is enqueued: the attention runs chunk by chunk
     hipGraphExec_t step_graph = nullptr;
@@ -189,6 +192,35 @@ static int mm(ps_hip_model *m, psk_gemv_args &g, ps_act act, int64_t K, int64_t 
     return 0;
 }
 
+// fp16 prefill perf mode: the first use dequantizes every layer matrix into an fp16 copy (rows through get_rows, the logits buffer as
+// fp32 scratch) and loads rocBLAS
+static int ensure_perf16(ps_hip_model *m) {
+    if (m->pf) return 0;
+    ps_hip_ctx *c = m->ctx;
+    const ps_llm_config &f = m->cfg;
+    const int64_t dim = f.dim, hid = f.hidden_dim;
+    if (dim % 4 || hid % 4) PS_FAIL(c, "fp16 perf mode: dim and hidden_dim must be multiples of 4");
+    psf16 *pf = nullptr;
+    if (int rc = psf16_create(c, &pf)) return rc;
+    const int64_t kmax = dim > hid ? dim : hid;
+    int cap = (int)((int64_t)m->max_batch * f.vocab_size / kmax);
+    if (cap > m->max_batch) cap = m->max_batch;
+    if (cap < 1) { psf16_destroy(pf); PS_FAIL(c, "fp16 perf mode: no scratch for the dequantizer"); }
+    auto copy = [&](const ps_weight *w, std::vector<_Float16 *> &dst) -> int {
+        _Float16 *h = nullptr;
+        if (dmalloc(m, (void **)&h, (size_t)w->N * w->K * 2)) return 2;
+        dst.push_back(h);
+        return psf16_dequantize(c, w, m->logits, m->tokens_dev, cap, h);
+    };
+    for (uint32_t L = 0; L < f.n_layers; L++)
+        if (copy(m->wq[L], m->hq) || copy(m->wk[L], m->hk) || copy(m->wv[L], m->hv) || copy(m->wo[L], m->ho) || copy(m->wg[L], m->hg) ||
+            copy(m->wu[L], m->hu) || copy(m->wd[L], m->hd)) { psf16_destroy(pf); return 2; }
+    if (dmalloc(m, (void **)&m->xh, (size_t)m->max_batch * kmax * 2)) { psf16_destroy(pf); return 2; }
+    PS_CHECK(c, hipStreamSynchronize(c->stream));
+    m->pf = pf;
+    return 0;
+}
+
 // enqueue one forward over `bs` tokens whose ids are in tokens_dev and whose state is in m->state
 static int enqueue_forward(ps_hip_model *m, int bs, bool lm_head, bool use_tree, bool advance = false, bool use_rope_pos = false) {
     ps_hip_ctx *c = m->ctx;
@@ -212,6 +244,10 @@ static int enqueue_forward(ps_hip_model *m, int bs, bool lm_head, bool use_tree,
     aa.scale = 1.0f / sqrtf((float)f.head_size);
     aa.n_kv_host = m->n_kv_host;
     aa.sync = m->attn_sync;
+    // fp16 perf mode (NOT bit-exact, mode bit 5): the layer mat-muls of a prefill batch as dense fp16 GEMMs (perf16.hip); single tokens,
+    // tree forwards and anything that produces logits stay on the parity kernels
+    const bool f16 = (m->mode & 32) && bs >= 2 && !lm_head && !use_tree && !use_rope_pos;
+    if (f16) if (int rc = ensure_perf16(m)) return rc;
     const bool one_launch = (m->mode & 16) == 0; // default; mode bit 4 switches attn_decode2 off (two launches)
     aa.xchg = m->attn_xchg; aa.tick = m->attn_tick;
     aa.n_kv_lo = m->n_kv_host > 0 ? m->n_kv_host : (m->n_kv_hint > 0 ? m->n_kv_hint : (int)m->position); // (a hint: rows below it are requested before the device-side position has arrived)
@@ -239,10 +275,15 @@ static int enqueue_forward(ps_hip_model *m, int bs, bool lm_head, bool use_tree,
         psk_rope_kv rk{m->state, m->rope_table, aa.k_cache, aa.v_cache, (int)f.head_size, (int)f.rope.n_dims, (int)f.seq_len, (int)kvd, aa.rope_pos, aa.k16, aa.v16};
         // batches of Q4_K weights: the same, in the chunk mat-mul's epilogue (k_gemm4k.hip)
         const bool fuse_rope_b = bs > 1 && !aa.neox && psk_gemm4k_rope_ok(g, dim, bs);
-        if (fuse_rope || fuse_rope_b) g.rope = &rk;
-        if (mm(m, g, a1, dim, bs)) return 2;
+        if ((fuse_rope || fuse_rope_b) && !f16) g.rope = &rk;
+        if (f16) {
+            psf16_rmsnorm_to_h(st, m->x, m->attn_norm[L], f.norm_eps, dim, bs, m->xh);
+            if (psf16_gemm(c, m->pf, m->hq[L], dim, dim, m->xh, bs, m->q, dim, 0.f) || psf16_gemm(c, m->pf, m->hk[L], kvd, dim, m->xh, bs, m->k, kvd, 0.f) ||
+                psf16_gemm(c, m->pf, m->hv[L], kvd, dim, m->xh, bs, m->v, kvd, 0.f)) return 2;
+            if (m->qwen2) { psf16_add_bias(st, m->q, m->bq[L], dim, bs); psf16_add_bias(st, m->k, m->bk[L], kvd, bs); psf16_add_bias(st, m->v, m->bv[L], kvd, bs); }
+        } else if (mm(m, g, a1, dim, bs)) return 2;
 
-        if (!fuse_rope && !fuse_rope_b) psl_rope_append(st, aa, bs);
+        if (f16 || (!fuse_rope && !fuse_rope_b)) psl_rope_append(st, aa, bs);
         bool att_quantized = false;
         if (bs == 1 && !use_tree && kv16 && psl_attn_decode_f16(st, aa)) {
             // fp16-KV decode mode (not bit-exact): split-KV online soft-max over the fp16 mirrors
@@ -269,7 +310,7 @@ static int enqueue_forward(ps_hip_model *m, int bs, bool lm_head, bool use_tree,
             // batches: the V.p kernel can leave `att` quantized for the O projection (one launch less per layer) when the O weight
             // takes Q8_K activations through the batched path
             aa.qact = ps_act{}; aa.qact_K = dim;
-            if (bs >= 2 && ps_hip_vec_dot_type(m->wo[L]->dtype) == PS_Q8_K && dim % 256 == 0) {
+            if (!f16 && bs >= 2 && ps_hip_vec_dot_type(m->wo[L]->dtype) == PS_Q8_K && dim % 256 == 0) {
                 aa.qact = a1;
                 if (!(bs >= ps_gemm4k_min_cols() && dim % 1024 == 0)) { aa.qact.qf = nullptr; aa.qact.mf = nullptr; } // (as psk_quantize_act decides)
                 if (!psl_attn_pv_quantizes(aa, bs)) aa.qact = ps_act{};
@@ -292,6 +333,15 @@ static int enqueue_forward(ps_hip_model *m, int bs, bool lm_head, bool use_tree,
         gf.pro = 1; gf.pro_x = m->x; gf.pro_norm_w = m->ffn_norm[L]; gf.pro_eps = f.norm_eps;
         psk_gemv_args gd{};
         gd.n_w = 1; gd.w[0] = m->wd[L]; gd.out[0] = m->x; gd.ldo[0] = dim; gd.residual = m->x;
+        if (f16) { // x += O att;  x += down(silu(gate x') * up x'),  x' = rmsnorm(x): residuals through beta = 1
+            psf16_to_h(st, m->att, (int64_t)bs * dim, m->xh);
+            if (psf16_gemm(c, m->pf, m->ho[L], dim, dim, m->xh, bs, m->x, dim, 1.f)) return 2;
+            psf16_rmsnorm_to_h(st, m->x, m->ffn_norm[L], f.norm_eps, dim, bs, m->xh);
+            if (psf16_gemm(c, m->pf, m->hg[L], hid, dim, m->xh, bs, m->g1, hid, 0.f) || psf16_gemm(c, m->pf, m->hu[L], hid, dim, m->xh, bs, m->u1, hid, 0.f)) return 2;
+            psf16_silu_mul_to_h(st, m->g1, m->u1, (int64_t)bs * hid, m->xh);
+            if (psf16_gemm(c, m->pf, m->hd[L], dim, hid, m->xh, bs, m->x, dim, 1.f)) return 2;
+            continue;
+        }
         if (mm(m, go, a1, dim, bs)) return 2;
         if (mm(m, gf, a1, dim, bs)) return 2;
         if (psk_gemv_lds_col_bytes(m->wd[L]->dtype, hid) * (bs == 1 ? 1 : 4) <= 64 * 1024 && (hid <= 8192 || bs == 1)) {
@@ -403,6 +453,7 @@ void ps_hip_model_destroy(ps_hip_model *m) {
     if (!m) return;
     (void)hipStreamSynchronize(m->ctx->stream);
     drop_graphs(m);
+    psf16_destroy(m->pf);
     for (void *p : m->owned) (void)hipFree(p);
     delete m;
 }
@@ -757,7 +808,7 @@ int ps_hip_model_set_mode(ps_hip_model *m, int mode) {
         if (dmalloc(m, (void **)&m->attn_part, (size_t)m->cfg.n_heads * 32 * (m->cfg.head_size + 2) * 4)) return 2;
     }
     if ((mode & 8) && !(m->mode & 8) && m->position != 0) { m->ctx->err = "set_mode: the fp16-KV decode mode must be switched on while the cache is empty"; return 2; }
-    if ((m->mode ^ mode) & 30) drop_graphs(m); // the captured steps bake the launch plan in
+    if ((m->mode ^ mode) & 62) drop_graphs(m); // the captured steps bake the launch plan in
     m->mode = mode;
     return 0;
 }

@@ -119,6 +119,17 @@ static inline ps_act ps_act_carve(void *base, int64_t K, int64_t rows) {
     return a;
 }
 
+// ---- fp16 prefill perf mode (perf16.hip): dense GEMMs on dequantized fp16 copies of the layer matrices, NOT bit-exact
+struct psf16;
+int psf16_create(ps_hip_ctx *c, psf16 **out); // dlopen of rocBLAS + a handle on the backend's stream
+void psf16_destroy(psf16 *f);
+int psf16_dequantize(ps_hip_ctx *c, const ps_weight *w, float *rows_buf, int32_t *ids_buf, int rows_cap, _Float16 *out); // out [N][K]
+int psf16_gemm(ps_hip_ctx *c, psf16 *f, const _Float16 *W, int64_t N, int64_t K, const _Float16 *x, int bs, float *out, int64_t ldo, float beta);
+void psf16_rmsnorm_to_h(hipStream_t st, const float *x, const float *w, float eps, int64_t K, int bs, _Float16 *y);
+void psf16_to_h(hipStream_t st, const float *x, int64_t n, _Float16 *y);
+void psf16_silu_mul_to_h(hipStream_t st, const float *g, const float *u, int64_t n, _Float16 *y);
+void psf16_add_bias(hipStream_t st, float *y, const float *b, int64_t N, int bs);
+
 // ---- kernel launchers (defined in k_*.hip); all enqueue on `st`
 // activation quantization.  mode: 0 plain, 1 rmsnorm(x, w, eps) first, 2 silu(x)*x2 first
 void psk_quantize_act(hipStream_t st, int vdt, int mode, const float *x, const float *x2, const float *w, float eps,
