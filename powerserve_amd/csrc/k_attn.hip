@@ -203,10 +203,19 @@ __global__ __launch_bounds__(256, 2) void attn_scores_mfma_kernel(psl_attn_args 
                 const ps_f32x4 tc = d[1] + d[5], td = d[3] + d[7]; // (c+4, c+20), (c+12, c+28)
                 return (ta + tb) + (tc + td);
             };
+            // (an empty asm ties the B operands of group g to the folded sum of group g - 2: the products are pure values with no
+            // chain edge, and without the tie all 32 are issued up front -- 128 live accumulator registers -- whatever the barriers say)
+            auto tie = [&](int g, const ps_f32x4 &t) {
+                asm volatile("" : "+v"(qb[g]), "+v"(qb[g + 4]), "+v"(qb[g + 8]), "+v"(qb[g + 12]), "+v"(qb[g + 16]), "+v"(qb[g + 20]), "+v"(qb[g + 24]), "+v"(qb[g + 28])
+                             : "v"(t[0]), "v"(t[2]));
+            };
             issue(pr[0], 0);
 #pragma unroll
             for (int c = 0; c < 4; c++) {
-                if (c < 3) issue(pr[(c + 1) & 1], c + 1);
+                if (c < 3) {
+                    if (c >= 1) tie(c + 1, t3[c - 1]);
+                    issue(pr[(c + 1) & 1], c + 1);
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 t3[c] = fold(pr[c & 1]);
                 __builtin_amdgcn_sched_barrier(0);
