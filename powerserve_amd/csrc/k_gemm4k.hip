@@ -62,6 +62,7 @@ struct G4KParams {
     const _Float16 *qf; // fragment-major fp16 quants
     const uint8_t *mf;  // tile-major column metadata (ps_act::mf)
     unsigned long long *dbg; // timeline slots (ps_hip_debug_timeline keys 48..50, 52), or null
+    int whatif;              // ps_hip_debug_set(2, v), timing experiments only (results wrong): 1 = producers park nothing, 2 = consumers skip the super-block work
     psk_rope_kv rope;        // rope_on (Q / K / V launches, adjacent-pair RoPE): the epilogue rotates Q and K and appends K, V to the caches
     int rope_on;
 };
@@ -260,7 +261,7 @@ __device__ __forceinline__ void g4k_producer_wave(const G4KParams &p, int item, 
                 for (int j = 0; j < UPP; j++) { a[j] = rq[k][j]; f[j] = rf[k][j]; }
                 const uint4 h = rh[k];
                 load(c_g + k, rq[k], rf[k], rh[k]);
-                g4k_produce<UPP, WT>(a, f, h, lds + ((g0 + k) & (G4K_NST - 1)) * G4K_STAGE, row, hw, pp);
+                if (!(p.whatif & 1)) g4k_produce<UPP, WT>(a, f, h, lds + ((g0 + k) & (G4K_NST - 1)) * G4K_STAGE, row, hw, pp);
                 if (k & 1) {
                     if (g0 == 0 && k == 1 && !first) __syncthreads(); // X of the previous item: its consumers have exchanged
                     __syncthreads(); // one barrier per PAIR of stages: stages g0 + k - 1, g0 + k are parked
@@ -286,18 +287,25 @@ __device__ __forceinline__ G4KMeta g4k_meta(const uint8_t *mf_ct, const int sb, 
 }
 
 // the fp32 chains this wave keeps: for both row tiles, rows 4 kb + r, accumulator lanes 4 uh + k and mins lanes 2 uh + vv
+// (kept as PAIRS OVER ROWS: a matrix instruction returns rows 4 kb .. 4 kb + 3 of one accumulator lane in four consecutive registers,
+// so (row r, row r + 1) of lane k is a register pair as it comes and one v_pk_fma_f32 advances two chains with no copies.  As scalars
+// the compiler paired lanes k, k + 1 of one row instead -- results of two different matrix instructions -- and spent two v_mov per
+// packed fma putting them side by side: 28 of a step's 145 instructions.)
+typedef float g4k_f2 __attribute__((ext_vector_type(2)));
 struct G4KAcc {
-    float acc[2][4][4], accm[2][4][2];
+    g4k_f2 acc[2][4][2], accm[2][2][2]; // acc[t][k][r >> 1][r & 1], accm[t][vv][r >> 1][r & 1]
     __device__ __forceinline__ void clear() {
 #pragma unroll
         for (int t = 0; t < 2; t++)
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
+            for (int h = 0; h < 2; h++) {
 #pragma unroll
-                for (int k = 0; k < 4; k++) acc[t][r][k] = 0.f;
-                accm[t][r][0] = accm[t][r][1] = 0.f;
+                for (int k = 0; k < 4; k++) acc[t][k][h] = g4k_f2{0.f, 0.f};
+                accm[t][0][h] = accm[t][1][h] = g4k_f2{0.f, 0.f};
             }
     }
+    __device__ __forceinline__ float a(int t, int r, int k) const { return acc[t][k][r >> 1][r & 1]; }
+    __device__ __forceinline__ float am(int t, int r, int vv) const { return accm[t][vv][r >> 1][r & 1]; }
 };
 
 // one super-block.  B[k] = this lane's B operand for accumulator lane 4 uh + k (loaded a step ago); as soon as both row
@@ -306,12 +314,12 @@ template <int WT>
 __device__ __forceinline__ void g4k_superblock(G4KAcc &T, const char *st, const char *zero, ps_u32x4 (&B)[4], const char *nq, const G4KMeta M,
                                                const int m, const int kb, const int uh) {
     const g4k_f4 zf = {0.f, 0.f, 0.f, 0.f};
-    float dr[2][4], dmin[2][4];
+    g4k_f2 dr[2][2], dmin[2][2]; // [t][r >> 1] = (row r, row r + 1)
 #pragma unroll
     for (int t = 0; t < 2; t++) {
         const g4k_f4 dda = *(const g4k_f4 *)(st + G4K_DD + (16 * t + 4 * kb) * 8), ddb = *(const g4k_f4 *)(st + G4K_DD + (16 * t + 4 * kb) * 8 + 16); // (d, dmin) of rows 4 kb + r
-        dr[t][0] = __fmul_rn(M.yd, dda[0]); dr[t][1] = __fmul_rn(M.yd, dda[2]); dr[t][2] = __fmul_rn(M.yd, ddb[0]); dr[t][3] = __fmul_rn(M.yd, ddb[2]);
-        dmin[t][0] = __fmul_rn(-M.yd, dda[1]); dmin[t][1] = __fmul_rn(-M.yd, dda[3]); dmin[t][2] = __fmul_rn(-M.yd, ddb[1]); dmin[t][3] = __fmul_rn(-M.yd, ddb[3]);
+        dr[t][0] = g4k_f2{__fmul_rn(M.yd, dda[0]), __fmul_rn(M.yd, dda[2])}; dr[t][1] = g4k_f2{__fmul_rn(M.yd, ddb[0]), __fmul_rn(M.yd, ddb[2])};
+        dmin[t][0] = g4k_f2{__fmul_rn(-M.yd, dda[1]), __fmul_rn(-M.yd, dda[3])}; dmin[t][1] = g4k_f2{__fmul_rn(-M.yd, ddb[1]), __fmul_rn(-M.yd, ddb[3])};
     }
     const char *ap = st + kb * G4K_KB + m * G4K_RS + (4 * uh) * 16;
 #pragma unroll
@@ -324,8 +332,8 @@ __device__ __forceinline__ void g4k_superblock(G4KAcc &T, const char *st, const 
             g4k_h8 av;
             __builtin_memcpy(&av, &ao, 16);
             const g4k_f4 si = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bv, zf, 0, 0, 0); // (float)sumi[4 uh + k] of rows 4 kb + r, this lane's column
-#pragma unroll
-            for (int r = 0; r < 4; r++) T.acc[t][r][k] = __fmaf_rn(dr[t][r], si[r], T.acc[t][r][k]);
+            T.acc[t][k][0] = __builtin_elementwise_fma(dr[t][0], __builtin_shufflevector(si, si, 0, 1), T.acc[t][k][0]); // acc = fma(d, (float)sumi, acc), rows r, r + 1
+            T.acc[t][k][1] = __builtin_elementwise_fma(dr[t][1], __builtin_shufflevector(si, si, 2, 3), T.acc[t][k][1]);
         }
         B[k] = *(const ps_u32x4 *)(nq + k * 1024);
     }
@@ -345,8 +353,8 @@ __device__ __forceinline__ void g4k_superblock(G4KAcc &T, const char *st, const 
                 __builtin_memcpy(&a0, &ma.x, 4); __builtin_memcpy(&a1, &ma.y, 4);
                 const g4k_h4 am = {a0[0], a0[1], a1[0], a1[1]};
                 const g4k_f4 pr = __builtin_amdgcn_mfma_f32_16x16x16f16(am, bm, zf, 0, 0, 0);
-#pragma unroll
-                for (int r = 0; r < 4; r++) T.accm[t][r][0] = __fadd_rn(T.accm[t][r][0], __fmul_rn(dmin[t][r], pr[r]));
+                T.accm[t][0][0] = T.accm[t][0][0] + dmin[t][0] * __builtin_shufflevector(pr, pr, 0, 1); // multiply, then add: two roundings (-ffp-contract=off)
+                T.accm[t][0][1] = T.accm[t][0][1] + dmin[t][1] * __builtin_shufflevector(pr, pr, 2, 3);
             }
         }
         return;
@@ -363,8 +371,8 @@ __device__ __forceinline__ void g4k_superblock(G4KAcc &T, const char *st, const 
             __builtin_memcpy(&a0, &ax, 4); __builtin_memcpy(&a1, &ay, 4); __builtin_memcpy(&g0, &bx, 4); __builtin_memcpy(&g1, &by, 4);
             const g4k_h4 am = {a0[0], a0[1], a1[0], a1[1]}, bm = {g0[0], g0[1], g1[0], g1[1]};
             const g4k_f4 pr = __builtin_amdgcn_mfma_f32_16x16x16f16(am, bm, zf, 0, 0, 0);
-#pragma unroll
-            for (int r = 0; r < 4; r++) T.accm[t][r][vv] = __fmaf_rn(dmin[t][r], pr[r], T.accm[t][r][vv]);
+            T.accm[t][vv][0] = __builtin_elementwise_fma(dmin[t][0], __builtin_shufflevector(pr, pr, 0, 1), T.accm[t][vv][0]);
+            T.accm[t][vv][1] = __builtin_elementwise_fma(dmin[t][1], __builtin_shufflevector(pr, pr, 2, 3), T.accm[t][vv][1]);
         }
     }
 }
@@ -423,7 +431,7 @@ __global__ __launch_bounds__((G4K_NC + G4K_NP) * 64) void gemm4k_kernel(const G4
             const G4KMeta Mn = g4k_meta(mf_ct, nb, mc, boff); // a step ahead, like B
             if (!(sb & 1)) __syncthreads(); // the producers have parked this step and the next
             mark(sb);
-            g4k_superblock<WT>(T, lds + (sb & (G4K_NST - 1)) * G4K_STAGE, zero, B, qf_ct + ((size_t)nb << 13), M, m, kb, uh);
+            if (!(p.whatif & 2)) g4k_superblock<WT>(T, lds + (sb & (G4K_NST - 1)) * G4K_STAGE, zero, B, qf_ct + ((size_t)nb << 13), M, m, kb, uh);
             M = Mn;
         };
         for (int sb = 0; sb < p.nsb - 1; sb++) step(sb);
@@ -450,9 +458,9 @@ __global__ __launch_bounds__((G4K_NC + G4K_NP) * 64) void gemm4k_kernel(const G4
 #pragma unroll
                 for (int rr = 0; rr < 2; rr++) {
                     // the other half's rows: 2 (1 - uh) + rr (selects, not a runtime index: the chains stay in registers)
-#define G4K_SEL(arr, k) (uh ? arr[t][rr][k] : arr[t][2 + rr][k])
-                    *(float4 *)(mine + (t * 2 + rr) * 4) = make_float4(G4K_SEL(T.acc, 0), G4K_SEL(T.acc, 1), G4K_SEL(T.acc, 2), G4K_SEL(T.acc, 3));
-                    *(float2 *)(mine + 16 + (t * 2 + rr) * 2) = make_float2(G4K_SEL(T.accm, 0), G4K_SEL(T.accm, 1));
+#define G4K_SEL(fn, k) (uh ? T.fn(t, rr, k) : T.fn(t, 2 + rr, k))
+                    *(float4 *)(mine + (t * 2 + rr) * 4) = make_float4(G4K_SEL(a, 0), G4K_SEL(a, 1), G4K_SEL(a, 2), G4K_SEL(a, 3));
+                    *(float2 *)(mine + 16 + (t * 2 + rr) * 2) = make_float2(G4K_SEL(am, 0), G4K_SEL(am, 1));
 #undef G4K_SEL
                 }
         }
@@ -465,13 +473,13 @@ __global__ __launch_bounds__((G4K_NC + G4K_NP) * 64) void gemm4k_kernel(const G4
             for (int t = 0; t < 2; t++)
 #pragma unroll
                 for (int rr = 0; rr < 2; rr++) {
-#define G4K_OWN(arr, k) (uh ? arr[t][2 + rr][k] : arr[t][rr][k])
+#define G4K_OWN(fn, k) (uh ? T.fn(t, 2 + rr, k) : T.fn(t, rr, k))
                     const float4 o4 = *(const float4 *)(theirs + (t * 2 + rr) * 4);
                     const float2 o2 = *(const float2 *)(theirs + 16 + (t * 2 + rr) * 2);
                     // lanes u < 4 (and mins lanes 0, 1) are half 0's, lanes u + 4 (mins 2, 3) half 1's
-                    const float s0 = __fadd_rn(G4K_OWN(T.acc, 0), o4.x), s1 = __fadd_rn(G4K_OWN(T.acc, 1), o4.y), s2 = __fadd_rn(G4K_OWN(T.acc, 2), o4.z), s3 = __fadd_rn(G4K_OWN(T.acc, 3), o4.w);
+                    const float s0 = __fadd_rn(G4K_OWN(a, 0), o4.x), s1 = __fadd_rn(G4K_OWN(a, 1), o4.y), s2 = __fadd_rn(G4K_OWN(a, 2), o4.z), s3 = __fadd_rn(G4K_OWN(a, 3), o4.w);
                     const float res = __fadd_rn(__fadd_rn(s0, s2), __fadd_rn(s1, s3));
-                    const float w0 = G4K_OWN(T.accm, 0), w1 = G4K_OWN(T.accm, 1);
+                    const float w0 = G4K_OWN(am, 0), w1 = G4K_OWN(am, 1);
                     const float ma = uh ? o2.x : w0, mb = uh ? o2.y : w1;   // acc_m lanes 0, 1
                     const float mc2 = uh ? w0 : o2.x, md = uh ? w1 : o2.y;  // acc_m lanes 2, 3
 #undef G4K_OWN
@@ -1372,6 +1380,7 @@ int psk_gemm4k(hipStream_t st, int n_cu, const psk_gemv_args &a, ps_act act, int
     p.n_tasks = epi == 1 ? p.w[0].n_tiles : pairs_total;
     p.residual = a.residual; p.qf = act.qf; p.mf = act.mf;
     p.dbg = psk_gemv_dbg_buf(12 + epi, epi ? 0 : (a.n_w == 3 ? 0 : (K <= 8192 ? 1 : 2))); // keys 48 QKV, 49 O, 50 down, 52 gate/up
+    { extern int g_g4_flags; p.whatif = g_g4_flags; }
     p.wt = PS_Q4_K;
     if (a.rope) { p.rope = *a.rope; p.rope_on = 1; }
     return g4k_launch(st, n_cu, p, epi, bs);
