@@ -62,7 +62,6 @@ struct G4KParams {
     const _Float16 *qf; // fragment-major fp16 quants
     const uint8_t *mf;  // tile-major column metadata (ps_act::mf)
     unsigned long long *dbg; // timeline slots (ps_hip_debug_timeline keys 48..50, 52), or null
-    int whatif;              // ps_hip_debug_set(2, v), timing experiments only (results wrong): 1 = producers park nothing, 2 = consumers skip the super-block work
     psk_rope_kv rope;        // rope_on (Q / K / V launches, adjacent-pair RoPE): the epilogue rotates Q and K and appends K, V to the caches
     int rope_on;
 };
@@ -261,7 +260,7 @@ __device__ __forceinline__ void g4k_producer_wave(const G4KParams &p, int item, 
                 for (int j = 0; j < UPP; j++) { a[j] = rq[k][j]; f[j] = rf[k][j]; }
                 const uint4 h = rh[k];
                 load(c_g + k, rq[k], rf[k], rh[k]);
-                if (!(p.whatif & 1)) g4k_produce<UPP, WT>(a, f, h, lds + ((g0 + k) & (G4K_NST - 1)) * G4K_STAGE, row, hw, pp);
+                g4k_produce<UPP, WT>(a, f, h, lds + ((g0 + k) & (G4K_NST - 1)) * G4K_STAGE, row, hw, pp);
                 if (k & 1) {
                     if (g0 == 0 && k == 1 && !first) __syncthreads(); // X of the previous item: its consumers have exchanged
                     __syncthreads(); // one barrier per PAIR of stages: stages g0 + k - 1, g0 + k are parked
@@ -431,7 +430,7 @@ __global__ __launch_bounds__((G4K_NC + G4K_NP) * 64) void gemm4k_kernel(const G4
             const G4KMeta Mn = g4k_meta(mf_ct, nb, mc, boff); // a step ahead, like B
             if (!(sb & 1)) __syncthreads(); // the producers have parked this step and the next
             mark(sb);
-            if (!(p.whatif & 2)) g4k_superblock<WT>(T, lds + (sb & (G4K_NST - 1)) * G4K_STAGE, zero, B, qf_ct + ((size_t)nb << 13), M, m, kb, uh);
+            g4k_superblock<WT>(T, lds + (sb & (G4K_NST - 1)) * G4K_STAGE, zero, B, qf_ct + ((size_t)nb << 13), M, m, kb, uh);
             M = Mn;
         };
         for (int sb = 0; sb < p.nsb - 1; sb++) step(sb);
@@ -1380,7 +1379,6 @@ int psk_gemm4k(hipStream_t st, int n_cu, const psk_gemv_args &a, ps_act act, int
     p.n_tasks = epi == 1 ? p.w[0].n_tiles : pairs_total;
     p.residual = a.residual; p.qf = act.qf; p.mf = act.mf;
     p.dbg = psk_gemv_dbg_buf(12 + epi, epi ? 0 : (a.n_w == 3 ? 0 : (K <= 8192 ? 1 : 2))); // keys 48 QKV, 49 O, 50 down, 52 gate/up
-    { extern int g_g4_flags; p.whatif = g_g4_flags; }
     p.wt = PS_Q4_K;
     if (a.rope) { p.rope = *a.rope; p.rope_on = 1; }
     return g4k_launch(st, n_cu, p, epi, bs);
