@@ -72,7 +72,14 @@ struct G4KParams {
 //                       quads apart, so each 16-lane group of a ds_read_b128 (which mixes lanes of two kb) is conflict-free
 //   [row] 32 B   = the mins as the four fp16 A operands (m[2v], m[2v], m[2v+1], m[2v+1]), v = 0..3
 //   [row] 8 B    = (d, dmin) as fp32
-constexpr int G4K_RS = 144, G4K_KB = 32 * G4K_RS, G4K_MINS = 4 * G4K_KB, G4K_DD = G4K_MINS + 32 * 32, G4K_STAGE = G4K_DD + 32 * 8;
+// (G4K_PAD: the operand planes of k-groups 2, 3 sit 16 B = four banks further on than those of k-groups 0, 1.  A plane is 4608 B = 18
+// x 256 B, so without it the two lanes of a producer row -- k-groups (e, 2 + e), the same row offset -- store to the SAME banks at
+// different addresses: every ds_write_b128 of the producers took two passes (SQ_LDS_BANK_CONFLICT = 28 % of SQ_LDS_IDX_ACTIVE,
+// profiles/r03_pmc_sq_prefill.txt).  A consumer read never mixes k-groups {0, 1} with {2, 3} in one 16-lane bank group, so its
+// conflict-free row stride survives the shift.)
+constexpr int G4K_PAD = 16;
+constexpr int G4K_RS = 144, G4K_KB = 32 * G4K_RS, G4K_MINS = 4 * G4K_KB + G4K_PAD, G4K_DD = G4K_MINS + 32 * 32, G4K_STAGE = G4K_DD + 32 * 8;
+__device__ __forceinline__ int g4k_plane(const int kb) { return kb * G4K_KB + (kb >> 1) * G4K_PAD; } // byte offset of k-group kb's operand plane in a stage
 constexpr int G4K_NC = 8, G4K_NP = 4, G4K_RING = 4; // computing waves, producing waves, super-blocks in flight per producer
 constexpr int G4K_NST = 4;                          // LDS stages
 constexpr int G4K_XCH = G4K_NST * G4K_STAGE + 32;   // after the stages and the 32 zero bytes: the end-of-tile exchange, [ct][lane][48 floats]
@@ -124,7 +131,7 @@ __device__ __forceinline__ void g4k_produce(const uint2 (&qq)[UPP], const uint32
                 v = __builtin_elementwise_fma(v, sc[2 * e + (k >> 1)], nc[2 * e + (k >> 1)]);
                 __builtin_memcpy(&o[k], &v, 4);
             }
-            *(uint4 *)(st + (2 * p + e) * G4K_KB + row * G4K_RS + (UPP * hw + j) * 16) = make_uint4(o[0], o[1], o[2], o[3]);
+            *(uint4 *)(st + g4k_plane(2 * p + e) + row * G4K_RS + (UPP * hw + j) * 16) = make_uint4(o[0], o[1], o[2], o[3]);
         }
     }
     if (hw == 0 && p == 0) { // once per row: the mins operands
@@ -320,7 +327,7 @@ __device__ __forceinline__ void g4k_superblock(G4KAcc &T, const char *st, const 
         dr[t][0] = g4k_f2{__fmul_rn(M.yd, dda[0]), __fmul_rn(M.yd, dda[2])}; dr[t][1] = g4k_f2{__fmul_rn(M.yd, ddb[0]), __fmul_rn(M.yd, ddb[2])};
         dmin[t][0] = g4k_f2{__fmul_rn(-M.yd, dda[1]), __fmul_rn(-M.yd, dda[3])}; dmin[t][1] = g4k_f2{__fmul_rn(-M.yd, ddb[1]), __fmul_rn(-M.yd, ddb[3])};
     }
-    const char *ap = st + kb * G4K_KB + m * G4K_RS + (4 * uh) * 16;
+    const char *ap = st + g4k_plane(kb) + m * G4K_RS + (4 * uh) * 16;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         g4k_h8 bv;
@@ -605,7 +612,7 @@ __global__ __launch_bounds__((G4K_NC + G4K_NPN) * 64) void gemm4k_narrow_kernel(
                     dr[t][0] = __fmul_rn(yd[j], dda[0]); dr[t][1] = __fmul_rn(yd[j], dda[2]); dr[t][2] = __fmul_rn(yd[j], ddb[0]); dr[t][3] = __fmul_rn(yd[j], ddb[2]);
                     dmin[t][0] = __fmul_rn(-yd[j], dda[1]); dmin[t][1] = __fmul_rn(-yd[j], dda[3]); dmin[t][2] = __fmul_rn(-yd[j], ddb[1]); dmin[t][3] = __fmul_rn(-yd[j], ddb[3]);
                 }
-                const char *ap = st + kb * G4K_KB + m * G4K_RS + (NU * ug) * 16;
+                const char *ap = st + g4k_plane(kb) + m * G4K_RS + (NU * ug) * 16;
 #pragma unroll
                 for (int k = 0; k < NU; k++) {
                     g4k_h8 bv;
@@ -722,7 +729,7 @@ struct G6KParams {
     const _Float16 *qf;
     const uint8_t *mf;
 };
-constexpr int G6K_PLANE = 4 * G4K_KB, G6K_DD = 2 * G6K_PLANE, G6K_STAGE = G6K_DD + 32 * 4, G6K_NST = 2;
+constexpr int G6K_PLANE = 4 * G4K_KB + G4K_PAD, G6K_DD = 2 * G6K_PLANE, G6K_STAGE = G6K_DD + 32 * 4, G6K_NST = 2;
 constexpr int G6K_XCH = G6K_NST * G6K_STAGE, G6K_LDS = G6K_XCH + 2 * 4 * 64 * 16 * 4; // exchange: [half][column tile][lane][16 floats]
 
 __device__ __forceinline__ void g6k_item(const G6KParams &p, const int i, int &task, int &cb) {
@@ -771,7 +778,7 @@ __device__ __forceinline__ void g6k_produce(const uint2 (&q)[2], const uint32_t 
                 v = v * (k < 2 ? ev0 : ev1); // (even, |.| <= 4096: exact)
                 __builtin_memcpy(&hi[k], &v, 4);
             }
-            char *dst = st + (2 * p + e) * G4K_KB + row * G4K_RS + (2 * hw + j) * 16;
+            char *dst = st + g4k_plane(2 * p + e) + row * G4K_RS + (2 * hw + j) * 16;
             *(uint4 *)dst = make_uint4(hi[0], hi[1], hi[2], hi[3]);
             *(uint4 *)(dst + G6K_PLANE) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
         }
@@ -880,7 +887,7 @@ __global__ __launch_bounds__((G4K_NC + G4K_NP) * 64) void gemm6k_kernel(const G6
 #pragma unroll
                 for (int r = 0; r < 4; r++) dr[t][r] = __fmul_rn(yd, dd[r]);
             }
-            const char *ap = st + kb * G4K_KB + m * G4K_RS + (4 * uh) * 16;
+            const char *ap = st + g4k_plane(kb) + m * G4K_RS + (4 * uh) * 16;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 g4k_h8 bv;
