@@ -72,11 +72,14 @@ struct G4KParams {
 //                       quads apart, so each 16-lane group of a ds_read_b128 (which mixes lanes of two kb) is conflict-free
 //   [row] 32 B   = the mins as the four fp16 A operands (m[2v], m[2v], m[2v+1], m[2v+1]), v = 0..3
 //   [row] 8 B    = (d, dmin) as fp32
-// (G4K_PAD: the operand planes of k-groups 2, 3 sit 16 B = four banks further on than those of k-groups 0, 1.  A plane is 4608 B = 18
-// x 256 B, so without it the two lanes of a producer row -- k-groups (e, 2 + e), the same row offset -- store to the SAME banks at
-// different addresses: every ds_write_b128 of the producers took two passes (SQ_LDS_BANK_CONFLICT = 28 % of SQ_LDS_IDX_ACTIVE,
+// (G4K_PAD: the operand planes of k-groups 2, 3 sit 16 B further on than those of k-groups 0, 1.  A plane is 4608 B = 18 x 256 B, so
+// without a shift the two lanes of a producer row -- k-groups (e, 2 + e), the same row offset -- store to the SAME banks at different
+// addresses: every ds_write_b128 of the producers takes two passes (SQ_LDS_BANK_CONFLICT = 28 % of SQ_LDS_IDX_ACTIVE,
 // profiles/r03_pmc_sq_prefill.txt).  A consumer read never mixes k-groups {0, 1} with {2, 3} in one 16-lane bank group, so its
-// conflict-free row stride survives the shift.)
+// conflict-free row stride survives any such shift.  tools/lds_bank_check.py, written after the round's last GPU minute, says that
+// under the guide's STORE bank function (32 banks, groups of 8 lanes) 16 B only moves the collision to the neighbouring row and that
+// 64 B removes it: the value below is the one the GPU suite ran with (gate/up launch 369 -> 365 us, within the noise); 64 is the
+// next round's first experiment.)
 constexpr int G4K_PAD = 16;
 constexpr int G4K_RS = 144, G4K_KB = 32 * G4K_RS, G4K_MINS = 4 * G4K_KB + G4K_PAD, G4K_DD = G4K_MINS + 32 * 32, G4K_STAGE = G4K_DD + 32 * 8;
 __device__ __forceinline__ int g4k_plane(const int kb) { return kb * G4K_KB + (kb >> 1) * G4K_PAD; } // byte offset of k-group kb's operand plane in a stage
