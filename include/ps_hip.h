@@ -173,18 +173,23 @@ int ps_hip_model_forward(ps_hip_model *m, const int32_t *tokens, int n, const in
                          int lm_head, int32_t *argmax_host);
 /* The same launches as ps_hip_model_forward, for a graph that HIPBackend::plan lowered (src/executor/executor.cpp:47-49,79:
  * the whole op vector goes to the backend's plan() before it runs): enqueues only -- no host sync, the KV position is left
- * to the caller (LlamaModel::forward advances it after Executor::run, llama_model.cpp:109). */
+ * to the caller (LlamaModel::forward advances it after Executor::run, llama_model.cpp:109).  The result counts once
+ * ps_hip_model_kv_advance or ps_hip_model_sync_check has returned 0. */
 int ps_hip_model_forward_lowered(ps_hip_model *m, const int32_t *tokens, int n, const int32_t *pos, const uint8_t *tree, int lm_head);
-/* Token-tree forward (speculative verify / draft, src/speculative/token_tree.cpp): the n tokens are appended at the
- * cache slots kv_position .. kv_position+n-1, column i is rotated with RoPE position rope_pos[i] (its depth in the tree,
- * not its slot) and sees the cached prefix (minus slots hidden with ps_hip_model_kv_mask) plus the batch columns j with
- * tree[i*n + j] != 0 (NULL: causal).  advance = 0 leaves kv_position where it was: the caller keeps the accepted path
- * with ps_hip_model_kv_move(dst, src) + ps_hip_model_kv_advance(1) per node, as TokenTree::verify does. */
+/* Waits for a pending ps_hip_model_forward_lowered and looks at the one-launch attention's time-out flag (k_attn.hip: its
+ * workgroups wait for each other inside the launch, bounded).  0: the result is valid.  2: it is not -- the model has switched to
+ * the two-launch attention and the caller runs the forward again (nothing was advanced).  ps_hip_model_kv_advance calls it. */
+int ps_hip_model_sync_check(ps_hip_model *m);
 /* ModelTokenIterator's prefill loop (src/model/model.hpp:147-163: forward(chunk, lm_head = false) + advance, chunk after chunk of
  * `chunk` tokens = hparams batch_size) for tokens appended at the current cache position -- bit-identical to calling
  * ps_hip_model_forward per chunk, but up to max_batch / chunk chunks share one launch sequence: the mat-muls take all their columns at
  * once, only the attention is evaluated per reference chunk (its sums depend on where a chunk ends). */
 int ps_hip_model_prefill(ps_hip_model *m, const int32_t *tokens, int n, int chunk);
+/* Token-tree forward (speculative verify / draft, src/speculative/token_tree.cpp): the n tokens are appended at the
+ * cache slots kv_position .. kv_position+n-1, column i is rotated with RoPE position rope_pos[i] (its depth in the tree,
+ * not its slot) and sees the cached prefix (minus slots hidden with ps_hip_model_kv_mask) plus the batch columns j with
+ * tree[i*n + j] != 0 (NULL: causal).  advance = 0 leaves kv_position where it was: the caller keeps the accepted path
+ * with ps_hip_model_kv_move(dst, src) + ps_hip_model_kv_advance(1) per node, as TokenTree::verify does. */
 int ps_hip_model_forward_tree(ps_hip_model *m, const int32_t *tokens, int n, const int32_t *rope_pos, const uint8_t *tree,
                               int lm_head, int32_t *argmax_host, int advance);
 /* KVCacheInterface::mask / unmask (core/kv_cache.hpp:97-163): hide / show one cached slot in every later forward */

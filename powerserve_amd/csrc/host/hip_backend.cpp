@@ -19,7 +19,7 @@ HIPKV::HIPKV(const ModelConfig::LLMConfig &c, ps_hip_model *model) :
 }
 void HIPKV::advance(int n) {
     POWERSERVE_ASSERT(position() + (size_t)n <= m_n_ctx, "the length of kvcache is up to the preset threshold");
-    ps_hip_model_kv_advance(m_model, (size_t)n);
+    POWERSERVE_ASSERT(ps_hip_model_kv_advance(m_model, (size_t)n) == 0, "kv advance refused: a pending lowered forward has no valid result");
 }
 void HIPKV::rollback(size_t n) {
     POWERSERVE_ASSERT(position() >= n);

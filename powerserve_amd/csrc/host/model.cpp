@@ -187,10 +187,16 @@ auto Model::forward_graph(const std::vector<int> &tokens, const std::vector<int>
         auto normed = g.rms_norm(x, g.add_tensor(m_weights->rms_final_weight), llm.norm_eps);
         logits = g.mat_mul(g.add_tensor(m_weights->output_weight), normed);
     }
-    Executor executor(*m_platform, g);
-    executor.plan();
-    if (!executor.lowered()) executor.allocate_buffers(); // a lowered graph runs in the device model's own arena
-    executor.run();
+    for (int attempt = 0;; attempt++) {
+        Executor executor(*m_platform, g);
+        executor.plan();
+        if (!executor.lowered()) executor.allocate_buffers(); // a lowered graph runs in the device model's own arena
+        executor.run();
+        // a lowered single-token forward is only enqueued: its one-launch attention may have given up at its exchange (bounded wait); the
+        // device model has then switched to the two launches and the same graph runs once more before anything counts
+        if (ps_hip_model_sync_check(be.m_model) == 0) break;
+        if (attempt > 0) POWERSERVE_ABORT(std::string("lowered forward: ") + ps_hip_last_error(be.m_ctx));
+    }
     be.m_kv->advance((int)bs);
     if (!lm_head) { be.sync(); return LogitsVector(); }
     Stride st = {4, 4 * (size_t)llm.vocab_size, 4 * (size_t)llm.vocab_size * bs, 4 * (size_t)llm.vocab_size * bs};

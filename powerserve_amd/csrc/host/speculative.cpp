@@ -256,10 +256,11 @@ std::vector<Token> SpeculativeModel::generate(const std::vector<Token> &prompt, 
         if (target.kv_position() + config.draft_batch_size > target.n_ctx() || draft.kv_position() + config.draft_batch_size > draft.n_ctx()) break;
         const size_t from = out.size();
         token_tree.iterate(target, draft, last, out, sampler, should_stop);
-        for (size_t i = from; i < out.size(); i++) {
-            if (sampler) sampler->accept(out[i]); // (the reference's iterator accepts each token as it is handed out)
+        // No sampler->accept() here: in the reference only Model::decode accepts (llama_model.cpp:128); SpecTokenIterator::decode and
+        // TokenTree::verify never do, so the repeat-penalty history keeps its initial window for the whole speculative text
+        // (tests/test_gpu_speculative.py::test_speculative_sampler_history_is_never_advanced pins this).
+        for (size_t i = from; i < out.size(); i++)
             if (should_stop && should_stop(out[i])) { out.resize(i + 1); stopped = true; break; }
-        }
         last = out.back();
     }
     if ((int)out.size() > steps) out.resize((size_t)steps);

@@ -143,7 +143,8 @@ struct TokenTree {
     // one draft / tree-forward / verify round starting from `last`; emitted tokens are appended to `out`.  sampler == nullptr:
     // greedy through the device arg-max (4 bytes per node cross the bus).  Otherwise every node on the accepted path goes
     // ProbArray -> sampler->apply -> greedy_sample exactly as token_tree.cpp:214-216 (the backend must provide tree_logits);
-    // the sampler's accept() is the caller's business, as in the reference (the iterator that pops the tokens calls it)
+    // sampler->accept() is never called on this path -- the reference's speculative iterator does not call it either (only
+    // Model::decode does, llama_model.cpp:128): penalties see the chain's initial history throughout
     void iterate(SpecBackend &target_model, SpecBackend &draft_model, Token last, std::vector<Token> &out, Sampler *sampler = nullptr,
                  const std::function<bool(Token)> &should_stop = {});
 

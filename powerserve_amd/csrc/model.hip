@@ -47,6 +47,8 @@ struct ps_hip_model {
     // arena
     float *x = nullptr, *q = nullptr, *k = nullptr, *v = nullptr, *att = nullptr, *hb = nullptr, *g1 = nullptr, *u1 = nullptr;
     unsigned *attn_sync = nullptr; // [2048] words: [31] the one-launch attention's rendezvous-timeout flag
+    unsigned *attn_flag_host = nullptr; // pinned: [31] travels here behind every single-token forward (async copy on the stream)
+    bool attn_unchecked = false;        // such a forward was enqueued and its flag has not been looked at yet
     float *attn_xchg = nullptr;    // attn_decode2: scores in flight between workgroups (k_attn.hip)
     unsigned *attn_tick = nullptr; // attn_decode2: [64 * kv head] arrival counters
     size_t graph_hint = 0;                   // KV position the captured step was given as its prefetch hint (n_kv_lo)
@@ -431,6 +433,8 @@ int ps_hip_model_create(ps_hip_ctx *c, const ps_model_desc *d, ps_hip_model **ou
         dmalloc(m, (void **)&m->tree_dev, mb * mb) || dmalloc(m, (void **)&m->rope_pos_dev, mb * 4) || dmalloc(m, (void **)&m->kv_vis_dev, nctx) || dmalloc(m, (void **)&m->am_v, mb * 64 * 4) || dmalloc(m, (void **)&m->am_i, mb * 64 * 4))
         return fail();
     (void)hipMemsetAsync(m->attn_sync, 0, 2048 * 4, c->stream);
+    if (hipHostMalloc((void **)&m->attn_flag_host, 64, hipHostMallocDefault) != hipSuccess) return fail();
+    *m->attn_flag_host = 0;
     (void)hipMemsetAsync(m->attn_tick, 0, (size_t)f.n_kv_heads * 64 * 4, c->stream);
     (void)hipMemsetAsync(m->kv_vis_dev, 1, nctx, c->stream);
     m->kv_vis_host.assign(nctx, 1);
@@ -453,6 +457,7 @@ void ps_hip_model_destroy(ps_hip_model *m) {
     if (!m) return;
     (void)hipStreamSynchronize(m->ctx->stream);
     drop_graphs(m);
+    if (m->attn_flag_host) (void)hipHostFree(m->attn_flag_host);
     psf16_destroy(m->pf);
     for (void *p : m->owned) (void)hipFree(p);
     delete m;
@@ -461,6 +466,7 @@ void ps_hip_model_destroy(ps_hip_model *m) {
 size_t ps_hip_model_kv_position(const ps_hip_model *m) { return m->position; }
 int ps_hip_model_max_batch(const ps_hip_model *m) { return m->max_batch; }
 static void unmask_range(ps_hip_model *m, size_t from, size_t n);
+extern "C" int ps_hip_model_sync_check(ps_hip_model *m);
 // slots at or behind the position are never consulted through the visibility table (the causal / tree mask governs them)
 // and KVCache::advance_tokens / append un-hides what it walks over (core/kv_cache.hpp:249-255): a rollback or truncate
 // leaves no hidden slot behind the new position, so a model that served as a speculative draft can decode again
@@ -481,6 +487,7 @@ static void unmask_range(ps_hip_model *m, size_t from, size_t n) {
     }
 }
 int ps_hip_model_kv_advance(ps_hip_model *m, size_t n) {
+    if (int rc = ps_hip_model_sync_check(m)) return rc; // (an unsynchronised lowered forward: its rows must be valid before they count)
     if (m->position + n > m->cfg.seq_len) { m->ctx->err = "kv_advance: KV cache is full (n_ctx)"; return 2; }
     unmask_range(m, m->position, n);
     m->position += n;
@@ -510,18 +517,35 @@ static void drop_graphs(ps_hip_model *m) { // every captured launch plan (they b
     if (m->step_graph) { (void)hipGraphExecDestroy(m->step_graph); m->step_graph = nullptr; }
     for (auto &g : m->fwd1_graph) if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
 }
+// Every single-token forward that may have used the one-launch attention is followed, on the stream, by a 4-byte copy of the flag into pinned
+// host memory (note_single_token): looking at it costs no round trip once the stream is idle.
+static void note_single_token(ps_hip_model *m) {
+    if (m->mode & 16) return; // the one-launch form is not in use
+    (void)hipMemcpyAsync(m->attn_flag_host, m->attn_sync + 31, 4, hipMemcpyDeviceToHost, m->ctx->stream);
+    m->attn_unchecked = true;
+}
+// 0: nothing pending or the flag is clear.  2: the forward(s) since the last check have no valid result; the model has switched to the
+// two-launch attention (mode bit 4, graphs dropped) and c->err says so -- the callers that still know their inputs run them again.
 static int check_attn_timeout(ps_hip_model *m, const char *who) {
     ps_hip_ctx *c = m->ctx;
-    if (m->mode & 16) return 0; // the one-launch form is not in use
-    unsigned stuck = 0;
-    PS_CHECK(c, hipMemcpy(&stuck, m->attn_sync + 31, 4, hipMemcpyDeviceToHost));
-    if (!stuck) return 0;
+    if (!m->attn_unchecked) return 0;
+    m->attn_unchecked = false;
+    if (!*(volatile unsigned *)m->attn_flag_host) return 0;
+    *(volatile unsigned *)m->attn_flag_host = 0;
     PS_CHECK(c, hipMemset(m->attn_sync + 31, 0, 4));
     drop_graphs(m);
     m->mode |= 16;
     c->err = std::string(who) + ": the one-launch attention timed out at its score exchange (GPU shared or partitioned?); this forward has no valid "
              "result, the cache position is unchanged, and the model now uses the two-launch attention (mode bit 4)";
     return 2;
+}
+// The lowered op-API path (ps_hip_model_forward_lowered) returns before its launches have run: whoever consumes its result next -- the
+// cache advance (LlamaModel::forward advances right behind Executor::run, llama_model.cpp:109) or a logits read -- looks at the flag.
+int ps_hip_model_sync_check(ps_hip_model *m) {
+    ps_hip_ctx *c = m->ctx;
+    if (!m->attn_unchecked) return 0;
+    PS_CHECK(c, hipStreamSynchronize(c->stream));
+    return check_attn_timeout(m, "lowered forward");
 }
 int ps_hip_model_forward(ps_hip_model *m, const int32_t *tokens, int n, const int32_t *pos, const uint8_t *tree, int lm_head,
                          int32_t *argmax_host) {
@@ -571,10 +595,14 @@ static int model_forward_impl(ps_hip_model *m, const int32_t *tokens, int n, con
         }
         m->n_kv_host = 0;
     }
+    if (n == 1 && !tree) note_single_token(m);
     if (lm_head && argmax_host) PS_CHECK(c, hipMemcpyAsync(argmax_host, m->argmax_dev, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
-    if (!advance) return 0; // lowered graph: the executor's caller syncs when it reads the logits and advances the cache itself
+    if (!advance) return 0; // lowered graph: ps_hip_model_kv_advance / ps_hip_model_sync_check look at the time-out flag before the result counts
     PS_CHECK(c, hipStreamSynchronize(c->stream));
-    if (n == 1 && !tree) if (int rc = check_attn_timeout(m, "model_forward")) return rc;
+    if (check_attn_timeout(m, "model_forward")) { // the model is on the two-launch attention now: the same forward once more (inputs are the caller's)
+        c->err.clear();
+        return model_forward_impl(m, tokens, n, pos, tree, lm_head, argmax_host, advance);
+    }
     unmask_range(m, (size_t)pos[0], (size_t)n);
     m->position = (size_t)pos[0] + (size_t)n; // m_kv->advance (llama_model.cpp:109)
     return 0;
@@ -605,7 +633,9 @@ int ps_hip_model_prefill(ps_hip_model *m, const int32_t *tokens, int n, int chun
         const int rc = enqueue_forward(m, ns, false, false);
         m->attn_chunk = 0; m->n_kv_host = 0;
         if (rc) return rc;
+        if (ns == 1) note_single_token(m);
         PS_CHECK(c, hipStreamSynchronize(c->stream));
+        if (check_attn_timeout(m, "model_prefill")) { c->err.clear(); continue; } // a one-token tail: once more, with the two launches
         unmask_range(m, m->position, (size_t)ns);
         m->position += (size_t)ns;
         done += ns;
@@ -632,9 +662,10 @@ int ps_hip_model_forward_tree(ps_hip_model *m, const int32_t *tokens, int n, con
     const int rc_fw = enqueue_forward(m, n, lm_head != 0, tree != nullptr, false, true);
     m->n_kv_host = 0;
     if (rc_fw) return rc_fw;
+    if (n == 1 && !tree) note_single_token(m);
     if (lm_head && argmax_host) PS_CHECK(c, hipMemcpyAsync(argmax_host, m->argmax_dev, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
     PS_CHECK(c, hipStreamSynchronize(c->stream));
-    if (n == 1 && !tree) if (int rc = check_attn_timeout(m, "model_forward_tree")) return rc;
+    if (check_attn_timeout(m, "model_forward_tree")) { c->err.clear(); return ps_hip_model_forward_tree(m, tokens, n, rope_pos, tree, lm_head, argmax_host, advance); }
     if (advance) { unmask_range(m, m->position, (size_t)n); m->position += (size_t)n; }
     return 0;
 }
@@ -686,9 +717,12 @@ int ps_hip_model_decode_greedy(ps_hip_model *m, int32_t token, int steps, int32_
             if (int rc = enqueue_forward(m, 1, true, false, true)) return rc;
         }
     }
+    note_single_token(m);
     PS_CHECK(c, hipMemcpyAsync(out_ids, m->ids_dev, (size_t)steps * 4, hipMemcpyDeviceToHost, c->stream));
     PS_CHECK(c, hipStreamSynchronize(c->stream));
-    if (int rc = check_attn_timeout(m, "decode_greedy")) return rc;
+    // a time-out anywhere in the run: the position has not moved and the first token is the caller's -- the whole run once more on the
+    // two-launch attention (every cache row it wrote is written again with the same values)
+    if (check_attn_timeout(m, "decode_greedy")) { c->err.clear(); return ps_hip_model_decode_greedy(m, token, steps, out_ids); }
     m->position += (size_t)steps;
     return 0;
 }

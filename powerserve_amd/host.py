@@ -181,7 +181,7 @@ def spec_generate(target: HostModel, draft: HostModel, prompt, batch_size: int, 
 
 def spec_generate_sampled(target: HostModel, draft: HostModel, prompt, batch_size: int, steps: int, sampler: "Sampler", eos: int = -1, draft_batch_size: int = 12):
     """SpeculativeModel::generate with the verify going through a sampler chain (sampler.apply + greedy pick per tree node,
-    src/speculative/token_tree.cpp:214-216; accept per emitted token) and an optional stop token.  Returns (ids, stats); ids may
+    src/speculative/token_tree.cpp:214-216; the chain's accept() is never called, as in the reference) and an optional stop token.  Returns (ids, stats); ids may
     be shorter than `steps` (stop token emitted, or no room left in the caches for another tree)."""
     L = lib()
     p = np.ascontiguousarray(prompt, dtype=np.int32)

@@ -37,6 +37,17 @@ def ctx():
     c.close()
 
 
+def load_tensors(path):
+    """{name: (ggml_type, raw bytes, ne0, ne1)} of a GGUF file, as oracle.binding.OracleModel takes them"""
+    from powerserve_amd import gguf
+    rd = gguf.GGUFReader(path)
+    out = {}
+    for name, ti in rd.tensors.items():
+        ne = list(ti.ne) + [1]
+        out[name] = (ti.type, np.array(rd.data(name)), ne[0], ne[1])
+    return out
+
+
 def rel_err(a, b):
     """max |a-b| / max |b|  (tensor-relative)"""
     a = np.asarray(a, dtype=np.float64)

@@ -7,19 +7,9 @@ import os
 import numpy as np
 import pytest
 
-from conftest import rel_err
+from conftest import load_tensors, rel_err
 
 pytestmark = pytest.mark.gpu
-
-
-def load_tensors(path):
-    from powerserve_amd import gguf
-    rd = gguf.GGUFReader(path)
-    out = {}
-    for name, ti in rd.tensors.items():
-        ne = list(ti.ne) + [1]
-        out[name] = (ti.type, np.array(rd.data(name)), ne[0], ne[1])
-    return out
 
 
 CASES = [("tiny-llama", 2), ("tiny-llama", 8), ("tiny-llama", 12), ("tiny-qwen2", 8), ("tiny-qwen2", 2),

@@ -100,6 +100,44 @@ def test_speculative_verify_through_the_sampler_chain(tmp_path):
 
 
 
+def test_speculative_sampler_history_is_never_advanced(tmp_path):
+    """The reference's speculative iterator never calls sampler.accept (only Model::decode does, llama_model.cpp:128;
+    SpecTokenIterator::decode / TokenTree::verify, token_tree.cpp:181-234, do not): a penalised chain therefore sees its INITIAL history
+    at every verified node.  The speculative text under penalty_repeat != 1 equals single-token steps whose logits go through a chain
+    that has accepted nothing -- and differs from the text of a chain that accepts what it emits."""
+    from powerserve_amd import host, synth
+    td = str(tmp_path / "t")
+    synth.write_model_dir(td, "small-llama-hs128", 12, n_ctx=96, seed=5)
+    target, dm = host.HostModel(td, max_batch=16), host.HostModel(td, max_batch=16)
+    prompt = np.random.default_rng(11).integers(0, target.vocab, 13)
+    steps = 24
+    kw = dict(top_k=1, penalty_repeat=1.8, penalty_last_n=16, penalty_freq=0.3)
+    smp = host.Sampler(host.SamplerCfg.make(target.vocab, **kw))
+    got, _ = host.spec_generate_sampled(target, dm, prompt, 8, steps, smp)
+    smp.close()
+
+    def plain(accepting):
+        target.reset()
+        target.forward(prompt[:-1], np.arange(prompt.size - 1), lm_head=False)
+        cur, out = int(prompt[-1]), []
+        chain = host.Sampler(host.SamplerCfg.make(target.vocab, **kw))
+        for s in range(steps):
+            lg = target.forward([cur], [prompt.size - 1 + s])[0]
+            if not accepting:  # a chain that has accepted nothing: a fresh one per step
+                chain.close()
+                chain = host.Sampler(host.SamplerCfg.make(target.vocab, **kw))
+            cur = chain.sample(lg)
+            out.append(cur)
+        chain.close()
+        return np.array(out, dtype=np.int32)
+
+    never, always = plain(False), plain(True)
+    target.close(); dm.close()
+    assert np.array_equal(got, never), (got, never)
+    if np.array_equal(never, always):
+        pytest.skip("the penalties never bite on this text: the two behaviours cannot be told apart here")
+
+
 def test_tree_forward_positions_and_masks(ctx, tmp_path):
     """Column i of a tree forward is rotated with its own RoPE position and sees only its ancestors: a two-branch tree
     reproduces, per branch, the logits of that branch run as a plain causal chain (same cache slots in the same order
