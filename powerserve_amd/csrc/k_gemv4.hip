@@ -58,6 +58,25 @@ __device__ __forceinline__ float4 g4_unit(const ps_u32x4 q, const char *hx, cons
     return make_float4(__fmul_rn(yd, dd.x), (float)s, __fmul_rn(-yd, dd.y), (float)pr);
 }
 
+// the same with the activation operands already in registers (gemv4_kernel's YS): y0 / y1 the lane's 32 quants, bs its pair of 32-sums
+__device__ __forceinline__ float4 g4_unit_y(const ps_u32x4 q, const char *hx, const int u, const int4 y0, const int4 y1, const int2 bs, const float yd) {
+    constexpr uint32_t M = 0x0F0F0F0Fu;
+    const uint32_t wq[4] = {q.x, q.y, q.z, q.w};
+    const int v = u & 3;
+    const uint4 sc16 = *(const uint4 *)hx;
+    const int2 mp = *(const int2 *)(hx + 16 + v * 8);
+    const float2 dd = *(const float2 *)(hx + 48);
+    int dlo[4], dhi[4];
+    dot4x4(dlo, (int)(wq[0] & M), (int)(wq[1] & M), (int)(wq[2] & M), (int)(wq[3] & M), y0.x, y0.z, y1.x, y1.z);
+    dot4x4(dhi, (int)((wq[0] >> 4) & M), (int)((wq[1] >> 4) & M), (int)((wq[2] >> 4) & M), (int)((wq[3] >> 4) & M), y0.y, y0.w, y1.y, y1.w);
+    const uint32_t scv[4] = {sc16.x, sc16.y, sc16.z, sc16.w};
+    int s = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) s = dot2_i16(__builtin_amdgcn_perm((uint32_t)dhi[j], (uint32_t)dlo[j], 0x05040100u), scv[j], s);
+    const int pr = __mul24(mp.x, bs.x) + __mul24(mp.y, bs.y);
+    return make_float4(__fmul_rn(yd, dd.x), (float)s, __fmul_rn(-yd, dd.y), (float)pr);
+}
+
 struct G4Mat {
     const uint8_t *qs, *aux;
     float *out;
@@ -84,7 +103,9 @@ struct G4Params {
 // NW producer waves, DC chunks of weight loads in flight per wave (register ring), TPW activation tiles per producer,
 // XW: wait for the activation row before the first weight request goes out (short launches: the row does not queue
 // behind the whole chip's first burst of weights)
-template <int NW, int DC, int TPW, int XW, int EPI, int PRO>
+// YS: the activation operands of a wave's units stay in registers (1: the wave meets the same four super-blocks in every chunk,
+// UPB % tot == 0; 2: two alternating sets, one per ring slot, 2 UPB % tot == 0 and DC == 2; 0: fetched from LDS per unit)
+template <int NW, int DC, int TPW, int XW, int EPI, int PRO, int YS = 0>
 __global__ __launch_bounds__((NW + 1) * 64) void gemv4_kernel(const G4Params p) {
     constexpr int WT = PS_Q4_K;
     using TR  = WTraits<WT>;
@@ -165,6 +186,11 @@ __global__ __launch_bounds__((NW + 1) * 64) void gemv4_kernel(const G4Params p) 
                 if (i >= i_lo && i < i_hi) q[i] = __builtin_nontemporal_load((const ps_u32x4 *)(qg + i * (1024 * st) + lo));
             if (i_lo == 0) h = *(const ps_u32x4 *)(ag + (live ? (uint32_t)(lane & 31) * 16u : 0u));
         };
+        constexpr int YN = YS ? YS : 1;
+        int4 Y0[YN][UPW], Y1[YN][UPW];
+        int2 YB[YN][UPW];
+        float YD[YN][UPW];
+        int yset = 0; // (a constant once the ring loop is unrolled)
         auto produce = [&](const ps_u32x4 (&q)[UPW], const ps_u32x4 &hc, int tl, int un, int buf, int i_lo = 0, int i_hi = UPW) {
             if (tl >= nt) return; // wave-uniform: nothing of this chunk belongs to the wave
             const int ul = (EPI == 1 && un >= n_units) ? un - n_units : un;
@@ -172,7 +198,8 @@ __global__ __launch_bounds__((NW + 1) * 64) void gemv4_kernel(const G4Params p) 
 #pragma unroll
             for (int i = 0; i < UPW; i++) {
                 if (i < i_lo || i >= i_hi) continue;
-                recs[(buf * UPB + wave * UPW + i) * 64 + lane] = g4_unit(q[i], hscr[wave] + (i * 8 + r) * G4_HX, ul + i, u, A); // (lanes u >= 4: .w is not a product, their acc_m is never read)
+                recs[(buf * UPB + wave * UPW + i) * 64 + lane] = YS ? g4_unit_y(q[i], hscr[wave] + (i * 8 + r) * G4_HX, u, Y0[yset][i], Y1[yset][i], YB[yset][i], YD[yset][i])
+                                                                    : g4_unit(q[i], hscr[wave] + (i * 8 + r) * G4_HX, ul + i, u, A); // (lanes u >= 4: .w is not a product, their acc_m is never read)
                 if (G4_PAIR == 0 || (i & 1)) __builtin_amdgcn_sched_barrier(0); // one unit (G4_PAIR: two) at a time: interleaving four of them costs registers, hides nothing
             }
         };
@@ -252,10 +279,24 @@ __global__ __launch_bounds__((NW + 1) * 64) void gemv4_kernel(const G4Params p) 
             __syncthreads();
         }
         mark(); // 2: activation in LDS
+        if (YS) { // this wave's activation operands: set k = the units of chunk k
+#pragma unroll
+            for (int k = 0; k < YN; k++) {
+                const int un = uS[k], ul = (EPI == 1 && un >= n_units) ? un - n_units : un;
+#pragma unroll
+                for (int i = 0; i < UPW; i++) {
+                    Y0[k][i] = *(const int4 *)(A.q32 + (ul + i) * 64 + u * 8);
+                    Y1[k][i] = *(const int4 *)(A.q32 + (ul + i) * 64 + u * 8 + 4);
+                    YB[k][i] = *(const int2 *)(A.bs32 + (ul + i) * 8 + 2 * (u & 3));
+                    YD[k][i] = A.d[ul + i];
+                }
+            }
+        }
         // 4. chunk it * DC + d from ring slot d
         for (int it = 0; it < n_iters; it++) {
 #pragma unroll
             for (int d = 0; d < DC; d++) {
+                yset = YS == 2 ? d : 0;
                 if constexpr (XW == 3) {
                     // split issue: the registers of a slot's first two units are free once those units are produced, so
                     // their next loads go out half a chunk earlier (more bytes in flight while this chunk is being produced,
@@ -411,43 +452,44 @@ __global__ __launch_bounds__((NW + 1) * 64) void gemv4_kernel(const G4Params p) 
     if (dbg) { dbg[31] = __builtin_amdgcn_s_memtime(); dbg[30] = __builtin_amdgcn_s_memrealtime(); }
 }
 
-template <int NW, int DC, int TPW, int XW, int EPI, int PRO>
+template <int NW, int DC, int TPW, int XW, int EPI, int PRO, int YS = 0>
 void launch_g4(hipStream_t st, int grid, const G4Params &p) {
     const size_t smem = (size_t)p.col_bytes + (size_t)2 * NW * 4 * 64 * sizeof(float4) + (size_t)3 * (p.split_q + 1) * 8 * sizeof(float);
     static unsigned long long attr = 0; // devices that have the attribute
     if (ps_first_on_device(&attr) && smem > 48 * 1024) {
-        (void)hipFuncSetAttribute((const void *)gemv4_kernel<NW, DC, TPW, XW, EPI, PRO>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        (void)hipFuncSetAttribute((const void *)gemv4_kernel<NW, DC, TPW, XW, EPI, PRO, YS>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     }
-    psk_note_kernel("gemv4_kernel<%d, %d, %d, %d, %d, %d>", NW, DC, TPW, XW, EPI, PRO);
-    hipLaunchKernelGGL((gemv4_kernel<NW, DC, TPW, XW, EPI, PRO>), dim3((unsigned)grid), dim3((NW + 1) * 64), smem, st, p);
+    if (YS) psk_note_kernel("gemv4_kernel<%d, %d, %d, %d, %d, %d, %d>", NW, DC, TPW, XW, EPI, PRO, YS);
+    else psk_note_kernel("gemv4_kernel<%d, %d, %d, %d, %d, %d>", NW, DC, TPW, XW, EPI, PRO);
+    hipLaunchKernelGGL((gemv4_kernel<NW, DC, TPW, XW, EPI, PRO, YS>), dim3((unsigned)grid), dim3((NW + 1) * 64), smem, st, p);
 }
 
 // KC: row-length class (tiles of 256 per row <= 16 << KC)
-template <int NW, int DC, int XW, int KC>
+template <int NW, int DC, int XW, int KC, int YS = 0>
 int launch_g4_ep(hipStream_t st, int grid, const G4Params &p, int epi, int pro) {
     constexpr int TPW = ((16 << KC) + NW - 1) / NW;
-    if (epi == 2) { if (pro != 1) return -1; launch_g4<NW, DC, TPW, XW, 2, 1>(st, grid, p); return 0; }
+    if (epi == 2) { if (pro != 1) return -1; launch_g4<NW, DC, TPW, XW, 2, 1, YS>(st, grid, p); return 0; }
     if (epi == 1) {
-        if (pro == 1) launch_g4<NW, DC, TPW, XW, 1, 1>(st, grid, p);
-        else if (pro == 0) launch_g4<NW, DC, TPW, XW, 1, 0>(st, grid, p);
+        if (pro == 1) launch_g4<NW, DC, TPW, XW, 1, 1, YS>(st, grid, p);
+        else if (pro == 0) launch_g4<NW, DC, TPW, XW, 1, 0, YS>(st, grid, p);
         else return -1;
         return 0;
     }
-    if (pro == 0) launch_g4<NW, DC, TPW, XW, 0, 0>(st, grid, p);
-    else if (pro == 1) launch_g4<NW, DC, TPW, XW, 0, 1>(st, grid, p);
-    else launch_g4<NW, DC, TPW, XW, 0, 2>(st, grid, p);
+    if (pro == 0) launch_g4<NW, DC, TPW, XW, 0, 0, YS>(st, grid, p);
+    else if (pro == 1) launch_g4<NW, DC, TPW, XW, 0, 1, YS>(st, grid, p);
+    else launch_g4<NW, DC, TPW, XW, 0, 2, YS>(st, grid, p);
     return 0;
 }
-template <int NW, int DC, int XW>
+template <int NW, int DC, int XW, int YS = 0>
 int launch_g4_kc(hipStream_t st, int grid, const G4Params &p, int epi, int pro) {
-    if (p.n_units <= 16) return launch_g4_ep<NW, DC, XW, 0>(st, grid, p, epi, pro);
-    if (p.n_units <= 64) return launch_g4_ep<NW, DC, XW, 2>(st, grid, p, epi, pro);
+    if (p.n_units <= 16) return launch_g4_ep<NW, DC, XW, 0, YS>(st, grid, p, epi, pro);
+    if (p.n_units <= 64) return launch_g4_ep<NW, DC, XW, 2, YS>(st, grid, p, epi, pro);
     return -1;
 }
 
 } // namespace
 
-int g_g4_cfg = 0;   // ps_hip_debug_set(1, cfg)
+int g_g4_cfg = getenv("PS_G4_CFG") ? atoi(getenv("PS_G4_CFG")) : 0; // ps_hip_debug_set(1, cfg); cfg >= 20: the LDS-DMA kernel (k_gemv7.hip), variant cfg - 20
 int g_g4_flags = 0; // ps_hip_debug_set(2, flags): reserved for what-if switches
 
 bool psk_gemv4_covers(int64_t K) { // rows end on multiples of four units
@@ -456,8 +498,13 @@ bool psk_gemv4_covers(int64_t K) { // rows end on multiples of four units
 }
 
 // Single-column Q4_K mat-vec.  Returns -1 when the launch is not covered (the caller falls back to gemv1 / gemv_kernel).
+int psk_gemv7(hipStream_t st, int n_cu, const psk_gemv_args &a, ps_act act, int64_t K, int cfg); // k_gemv7.hip
 int psk_gemv4(hipStream_t st, int n_cu, const psk_gemv_args &a, ps_act act, int64_t K) {
     if (a.n_w < 1 || a.n_w > 3 || !psk_gemv4_covers(K)) return -1;
+    if (g_g4_cfg >= 20 && g_g4_cfg < 40) {
+        const int rc = psk_gemv7(st, n_cu, a, act, K, g_g4_cfg - 20);
+        if (rc != -1) return rc;
+    }
     G4Params p{};
     int groups_total = 0;
     for (int i = 0; i < a.n_w; i++) {
@@ -483,6 +530,12 @@ int psk_gemv4(hipStream_t st, int n_cu, const psk_gemv_args &a, ps_act act, int6
     p.dbg = psk_gemv_dbg_buf(epi, a.pro);
     // wave configuration (measured, tools/g4_variants.py): rows of a multiple of 7 units take 7 (14) producers
     const bool seven = p.n_units % 7 == 0;
+    if (g_g4_cfg == 40 || g_g4_cfg == 41) { // register-resident activation operands on the register ring (41: three chunks in flight)
+        const int tot = (epi == 1 ? 2 : 1) * p.n_units, upb = (seven ? 7 : 8) * 4;
+        const int ys = upb % tot == 0 ? 1 : ((2 * upb) % tot == 0 ? 2 : 0);
+        if (ys == 1) return seven ? launch_g4_kc<7, 2, 2, 1>(st, grid, p, epi, a.pro) : launch_g4_kc<8, 2, 2, 1>(st, grid, p, epi, a.pro);
+        if (ys == 2) return seven ? launch_g4_kc<7, 2, 2, 2>(st, grid, p, epi, a.pro) : launch_g4_kc<8, 2, 2, 2>(st, grid, p, epi, a.pro);
+    }
     switch (g_g4_cfg) { // (0 is the production configuration; the others are kept for tools/g4_variants.py)
     case 1: return seven ? launch_g4_kc<7, 2, 0>(st, grid, p, epi, a.pro) : launch_g4_kc<8, 2, 0>(st, grid, p, epi, a.pro); // everything issued up front
     case 2: return seven ? launch_g4_kc<7, 3, 1>(st, grid, p, epi, a.pro) : launch_g4_kc<8, 3, 1>(st, grid, p, epi, a.pro); // three chunks in flight

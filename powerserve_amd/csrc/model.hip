@@ -70,7 +70,7 @@ struct ps_hip_model {
     size_t n_hidden = 0;
     size_t position = 0;
     int mode = 0;
-    psf16 *pf = nullptr;                // fp16 prefill perf mode (mode bit 5): rocBLAS handle, fp16 copies of the layer matrices, fp16 activation scratch
+    psf16 *pf = nullptr;                // fp16 prefill perf mode (mode bit 5): fp16 copies of the layer matrices, fp16 activation scratch
     std::vector<_Float16 *> hq, hk, hv, ho, hg, hu, hd;
     _Float16 *xh = nullptr;
     ps_step_state *state_sub = nullptr; // [64] per-chunk states of a super-chunk prefill (ps_hip_model_prefill)
@@ -195,7 +195,7 @@ static int mm(ps_hip_model *m, psk_gemv_args &g, ps_act act, int64_t K, int64_t 
 }
 
 // fp16 prefill perf mode: the first use dequantizes every layer matrix into an fp16 copy (rows through get_rows, the logits buffer as
-// fp32 scratch) and loads rocBLAS
+// fp32 scratch); the GEMMs are perf16.hip's own kernel
 static int ensure_perf16(ps_hip_model *m) {
     if (m->pf) return 0;
     ps_hip_ctx *c = m->ctx;
@@ -214,10 +214,13 @@ static int ensure_perf16(ps_hip_model *m) {
         dst.push_back(h);
         return psf16_dequantize(c, w, m->logits, m->tokens_dev, cap, h);
     };
+    // (a failed attempt leaves no half-filled lists behind: the next one starts from empty vectors; the device memory stays with the model)
+    auto fail = [&]() { for (auto *v : {&m->hq, &m->hk, &m->hv, &m->ho, &m->hg, &m->hu, &m->hd}) v->clear(); psf16_destroy(pf); return 2; };
+    for (auto *v : {&m->hq, &m->hk, &m->hv, &m->ho, &m->hg, &m->hu, &m->hd}) v->clear();
     for (uint32_t L = 0; L < f.n_layers; L++)
         if (copy(m->wq[L], m->hq) || copy(m->wk[L], m->hk) || copy(m->wv[L], m->hv) || copy(m->wo[L], m->ho) || copy(m->wg[L], m->hg) ||
-            copy(m->wu[L], m->hu) || copy(m->wd[L], m->hd)) { psf16_destroy(pf); return 2; }
-    if (dmalloc(m, (void **)&m->xh, (size_t)m->max_batch * kmax * 2)) { psf16_destroy(pf); return 2; }
+            copy(m->wu[L], m->hu) || copy(m->wd[L], m->hd)) return fail();
+    if (!m->xh && dmalloc(m, (void **)&m->xh, (size_t)m->max_batch * kmax * 2)) return fail();
     PS_CHECK(c, hipStreamSynchronize(c->stream));
     m->pf = pf;
     return 0;
@@ -280,8 +283,12 @@ static int enqueue_forward(ps_hip_model *m, int bs, bool lm_head, bool use_tree,
         if ((fuse_rope || fuse_rope_b) && !f16) g.rope = &rk;
         if (f16) {
             psf16_rmsnorm_to_h(st, m->x, m->attn_norm[L], f.norm_eps, dim, bs, m->xh);
-            if (psf16_gemm(c, m->pf, m->hq[L], dim, dim, m->xh, bs, m->q, dim, 0.f) || psf16_gemm(c, m->pf, m->hk[L], kvd, dim, m->xh, bs, m->k, kvd, 0.f) ||
-                psf16_gemm(c, m->pf, m->hv[L], kvd, dim, m->xh, bs, m->v, kvd, 0.f)) return 2;
+            {
+                const _Float16 *W3[3] = {m->hq[L], m->hk[L], m->hv[L]};
+                float *o3[3] = {m->q, m->k, m->v};
+                const int64_t n3[3] = {dim, kvd, kvd};
+                if (psf16_gemm_n(c, m->pf, 3, W3, n3, dim, m->xh, bs, o3, n3, 0.f)) return 2; // Q, K, V: one launch
+            }
             if (m->qwen2) { psf16_add_bias(st, m->q, m->bq[L], dim, bs); psf16_add_bias(st, m->k, m->bk[L], kvd, bs); psf16_add_bias(st, m->v, m->bv[L], kvd, bs); }
         } else if (mm(m, g, a1, dim, bs)) return 2;
 
@@ -339,7 +346,12 @@ static int enqueue_forward(ps_hip_model *m, int bs, bool lm_head, bool use_tree,
             psf16_to_h(st, m->att, (int64_t)bs * dim, m->xh);
             if (psf16_gemm(c, m->pf, m->ho[L], dim, dim, m->xh, bs, m->x, dim, 1.f)) return 2;
             psf16_rmsnorm_to_h(st, m->x, m->ffn_norm[L], f.norm_eps, dim, bs, m->xh);
-            if (psf16_gemm(c, m->pf, m->hg[L], hid, dim, m->xh, bs, m->g1, hid, 0.f) || psf16_gemm(c, m->pf, m->hu[L], hid, dim, m->xh, bs, m->u1, hid, 0.f)) return 2;
+            {
+                const _Float16 *W2[2] = {m->hg[L], m->hu[L]};
+                float *o2[2] = {m->g1, m->u1};
+                const int64_t n2[2] = {hid, hid};
+                if (psf16_gemm_n(c, m->pf, 2, W2, n2, dim, m->xh, bs, o2, n2, 0.f)) return 2; // gate, up: one launch
+            }
             psf16_silu_mul_to_h(st, m->g1, m->u1, (int64_t)bs * hid, m->xh);
             if (psf16_gemm(c, m->pf, m->hd[L], dim, hid, m->xh, bs, m->x, dim, 1.f)) return 2;
             continue;

@@ -1,30 +1,17 @@
 // fp16 prefill "perf mode" (second half; precedent: the reference's QNN graphs run fp16 activations,
 // src/backend/qnn/causal_models.hpp:59-75) -- NOT bit-exact, opt-in (ps_hip_model_set_mode bit 5), never part of the headline.
 // The quantized weights stay the source of truth (every parity path and every single-token step reads them); this mode adds a
-// dequantized fp16 copy of the layer matrices and runs the mat-muls of a prefill chunk as plain dense GEMMs, fp16 x fp16 with fp32
+// dequantized fp16 copy of the layer matrices and runs the mat-muls of a prefill chunk as dense GEMMs, fp16 x fp16 with fp32
 // accumulation and fp32 output: no Q8_0 / Q8_K activation quantizer, no per-block fp32 chains -- the two things the reference's
-// arithmetic costs on the matrix cores.  A dense GEMM is library work (rocBLAS, loaded with dlopen when the mode is first used: the
-// backend has no link-time dependency on it, and without the library the mode reports an error instead of falling back); everything
-// around it -- RMSNorm into fp16, SiLU(gate) * up into fp16, the conversions -- is the small kernels below, and RoPE, the KV append
-// and the attention are the parity path's own kernels on the FP32 cache.
-#include <dlfcn.h>
-#include <rocblas/rocblas.h>
-#undef rocblas_gemm_ex // (the header may alias it to the 64-bit entry; the symbol looked up below is the 32-bit one)
-
+// arithmetic costs on the matrix cores.  The GEMM is this file's own kernel (f16_gemm_kernel: v_mfma_f32_32x32x16_f16, 128 tokens x
+// 128 / 64 weight rows per workgroup, K in blocks of 64 through a double-buffered, conflict-free LDS image; round 3 handed it to
+// rocBLAS through dlopen); everything around it -- RMSNorm into fp16, SiLU(gate) * up into fp16, the conversions -- is the small
+// kernels below, and RoPE, the KV append and the attention are the parity path's own kernels on the FP32 cache.
 #include "ps_dev.h"
 #include "ps_internal.h"
 #include "ps_ops.h"
 
-struct psf16 {
-    void *lib = nullptr;
-    rocblas_handle handle = nullptr;
-    rocblas_status (*create)(rocblas_handle *) = nullptr;
-    rocblas_status (*destroy)(rocblas_handle) = nullptr;
-    rocblas_status (*set_stream)(rocblas_handle, hipStream_t) = nullptr;
-    rocblas_status (*gemm_ex)(rocblas_handle, rocblas_operation, rocblas_operation, rocblas_int, rocblas_int, rocblas_int, const void *, const void *,
-                              rocblas_datatype, rocblas_int, const void *, rocblas_datatype, rocblas_int, const void *, const void *, rocblas_datatype,
-                              rocblas_int, void *, rocblas_datatype, rocblas_int, rocblas_datatype, rocblas_gemm_algo, int32_t, uint32_t) = nullptr;
-};
+struct psf16 { int unused = 0; }; // (the mode's handle: nothing but a marker that the fp16 copies exist)
 
 namespace {
 __global__ void f32_to_f16_kernel(const float *x, _Float16 *y, int64_t n) {
@@ -60,33 +47,116 @@ __global__ void iota_kernel(int32_t *p, int32_t first, int n) {
     if (i < n) p[i] = first + i;
 }
 unsigned grid_for(int64_t n, int per = 256) { const int64_t g = (n + per - 1) / per; return (unsigned)(g < 1 ? 1 : (g > 4096 ? 4096 : g)); }
+
+// ---------------------------------------------------------------- the GEMM
+// out[token][ldo] (fp32) = beta * out + x[token][K] (fp16) . W[row][K]^T (fp16) for up to three matrices that share x (Q / K / V, gate / up):
+// both operands are K-contiguous, so the matrix instruction's A operand (32 rows x 16 k, lane l: row l % 32, k = 8 (l / 32) .. + 7 = one
+// 16-byte piece) is a token tile and its B operand a weight-row tile; D[token][row] comes out with 32 consecutive weight rows of one token
+// across lanes 0..31: the output stores are whole 128-byte lines.
+//   * workgroup = 4 waves on 128 tokens x BN weight rows (BN 128: wave = 64 x 64 = 2 x 2 instructions' tiles; BN 64: 64 x 32), K walked in
+//     blocks of 64: global -> registers (16-byte loads, the next block in flight while this one is multiplied) -> LDS rows of 128 + 16
+//     bytes (36 dwords: the 16 rows a ds_read_b128 lane group touches land on 16 distinct bank quads) -> fragments; two LDS buffers,
+//     one barrier per block;
+//   * workgroup order: the token tiles of one weight tile sit 8 workgroups apart (same XCD, same time: the weight tile is fetched into
+//     that L2 once), eight weight tiles per round;
+//   * < 128 VGPRs, 74 KiB of LDS: two workgroups per CU.
+typedef _Float16 f16_h8 __attribute__((ext_vector_type(8)));
+typedef float f16_f16v __attribute__((ext_vector_type(16)));
+struct F16Mat { const _Float16 *W; float *out; int64_t N, ldo; int tiles; };
+struct F16Gemm { F16Mat w[3]; int n_w, bs, n_tm, tiles_total; const _Float16 *x; int64_t K; float beta; };
+constexpr int F16_BM = 128, F16_BK = 64, F16_RS = F16_BK * 2 + 16; // tokens per workgroup, k per block, LDS row stride in bytes
+
+template <int BN>
+__global__ __launch_bounds__(256, 2) void f16_gemm_kernel(const F16Gemm p) {
+    extern __shared__ __attribute__((aligned(16))) char f16_lds[];
+    constexpr int A_BYTES = F16_BM * F16_RS, B_BYTES = BN * F16_RS, STAGE = A_BYTES + B_BYTES;
+    constexpr int NB = BN / 64; // 16-byte B pieces per thread and k-block / 4;  instruction tiles per wave along the weight rows
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    // (token tile, weight tile) of this workgroup
+    const int per = 8 * p.n_tm, b_in = (int)blockIdx.x % per;
+    const int tn_all = ((int)blockIdx.x / per) * 8 + (b_in & 7), tm = b_in >> 3;
+    if (tn_all >= p.tiles_total) return;
+    int wi = 0, tn = tn_all;
+    if (p.n_w > 1 && tn >= p.w[0].tiles) { tn -= p.w[0].tiles; wi = 1; }
+    if (p.n_w > 2 && wi == 1 && tn >= p.w[1].tiles) { tn -= p.w[1].tiles; wi = 2; }
+    const _Float16 *W = wi == 0 ? p.w[0].W : (wi == 1 ? p.w[1].W : p.w[2].W);
+    float *out        = wi == 0 ? p.w[0].out : (wi == 1 ? p.w[1].out : p.w[2].out);
+    const int64_t ldo = wi == 0 ? p.w[0].ldo : (wi == 1 ? p.w[1].ldo : p.w[2].ldo);
+    const int64_t K = p.K;
+    const int t0 = tm * F16_BM, n0 = tn * BN;
+    // loader roles: thread t fetches the 16-byte piece kq = t % 8 of rows t / 8 + 32 i
+    const int lr = tid >> 3, kq = tid & 7;
+    const _Float16 *ga[4], *gb[2 * NB];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int tok = t0 + lr + 32 * i;
+        ga[i] = p.x + (int64_t)(tok < p.bs ? tok : 0) * K + kq * 8; // (tokens past the batch: row 0 once more, never stored)
+    }
+#pragma unroll
+    for (int i = 0; i < 2 * NB; i++) gb[i] = W + (int64_t)(n0 + lr + 32 * i) * K + kq * 8;
+    f16_h8 ra[4], rb[2 * NB];
+    auto fetch = [&](int kb) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) ra[i] = *(const f16_h8 *)(ga[i] + (int64_t)kb * F16_BK);
+#pragma unroll
+        for (int i = 0; i < 2 * NB; i++) rb[i] = *(const f16_h8 *)(gb[i] + (int64_t)kb * F16_BK);
+    };
+    auto park = [&](int buf) {
+        char *st = f16_lds + buf * STAGE;
+#pragma unroll
+        for (int i = 0; i < 4; i++) *(f16_h8 *)(st + (lr + 32 * i) * F16_RS + kq * 16) = ra[i];
+#pragma unroll
+        for (int i = 0; i < 2 * NB; i++) *(f16_h8 *)(st + A_BYTES + (lr + 32 * i) * F16_RS + kq * 16) = rb[i];
+    };
+    f16_f16v acc[2][NB];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < NB; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+    const int nk = (int)(K / F16_BK);
+    fetch(0);
+    park(0);
+    __syncthreads();
+    const int fr = lane & 31, fk = (lane >> 5) * 16; // fragment row and byte offset of the lane's eight k inside a 16-k step
+    for (int kb = 0; kb < nk; kb++) {
+        if (kb + 1 < nk) fetch(kb + 1);
+        const char *st = f16_lds + (kb & 1) * STAGE;
+        const char *sa = st + (wm * 64 + fr) * F16_RS + fk, *sb = st + A_BYTES + (wn * (BN / 2) + fr) * F16_RS + fk;
+#pragma unroll
+        for (int ks = 0; ks < F16_BK / 16; ks++) {
+            f16_h8 a[2], b[NB];
+#pragma unroll
+            for (int i = 0; i < 2; i++) a[i] = *(const f16_h8 *)(sa + i * 32 * F16_RS + ks * 32);
+#pragma unroll
+            for (int j = 0; j < NB; j++) b[j] = *(const f16_h8 *)(sb + j * 32 * F16_RS + ks * 32);
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int j = 0; j < NB; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (kb + 1 < nk) park((kb + 1) & 1);
+        __syncthreads();
+    }
+    // D register r of lane l: token row 8 (r / 4) + 4 (l / 32) + r % 4, weight row l % 32
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < NB; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int tok = t0 + wm * 64 + i * 32 + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
+                if (tok < p.bs) {
+                    float *o = out + (int64_t)tok * ldo + n0 + wn * (BN / 2) + j * 32 + (lane & 31);
+                    *o = p.beta != 0.f ? __fmaf_rn(p.beta, *o, acc[i][j][r]) : acc[i][j][r];
+                }
+            }
+}
 } // namespace
 
-int psf16_create(ps_hip_ctx *c, psf16 **out) {
-    psf16 *f = new psf16;
-    for (const char *name : {"librocblas.so", "librocblas.so.5", "/opt/rocm/lib/librocblas.so"}) {
-        f->lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-        if (f->lib) break;
-    }
-    if (!f->lib) { delete f; PS_FAIL(c, "fp16 perf mode: librocblas.so could not be loaded (the mode has no fallback)"); }
-    f->create     = (decltype(f->create))dlsym(f->lib, "rocblas_create_handle");
-    f->destroy    = (decltype(f->destroy))dlsym(f->lib, "rocblas_destroy_handle");
-    f->set_stream = (decltype(f->set_stream))dlsym(f->lib, "rocblas_set_stream");
-    f->gemm_ex    = (decltype(f->gemm_ex))dlsym(f->lib, "rocblas_gemm_ex");
-    if (!f->create || !f->destroy || !f->set_stream || !f->gemm_ex) { dlclose(f->lib); delete f; PS_FAIL(c, "fp16 perf mode: rocBLAS entry points missing"); }
-    if (f->create(&f->handle) != rocblas_status_success || f->set_stream(f->handle, c->stream) != rocblas_status_success) {
-        dlclose(f->lib); delete f;
-        PS_FAIL(c, "fp16 perf mode: rocblas_create_handle / rocblas_set_stream failed");
-    }
-    *out = f;
-    return 0;
-}
-void psf16_destroy(psf16 *f) {
-    if (!f) return;
-    if (f->handle) (void)f->destroy(f->handle);
-    // (the library stays mapped: unloading rocBLAS under a live HIP runtime is not worth the risk)
-    delete f;
-}
+int psf16_create(ps_hip_ctx *, psf16 **out) { *out = new psf16; return 0; }
+void psf16_destroy(psf16 *f) { delete f; }
 
 // fp16 copy [N][K] of a quantized weight: its rows through the backend's own dequantizer (get_rows, the embedding path), `rows_buf`
 // = fp32 scratch for `rows_cap` rows, `ids_buf` = int32 scratch of the same count
@@ -101,15 +171,32 @@ int psf16_dequantize(ps_hip_ctx *c, const ps_weight *w, float *rows_buf, int32_t
     return 0;
 }
 
-// out[bs][ldo] (fp32) = beta * out + x[bs][K] (fp16) . W[N][K]^T (fp16), fp32 accumulation.  Row-major operands are column-major
-// transposes: out^T (N x bs) = W_cm^T (N x K) . x_cm (K x bs)
-int psf16_gemm(ps_hip_ctx *c, psf16 *f, const _Float16 *W, int64_t N, int64_t K, const _Float16 *x, int bs, float *out, int64_t ldo, float beta) {
-    const float alpha = 1.0f;
-    const rocblas_status st = f->gemm_ex(f->handle, rocblas_operation_transpose, rocblas_operation_none, (rocblas_int)N, (rocblas_int)bs, (rocblas_int)K, &alpha, W,
-                                         rocblas_datatype_f16_r, (rocblas_int)K, x, rocblas_datatype_f16_r, (rocblas_int)K, &beta, out, rocblas_datatype_f32_r,
-                                         (rocblas_int)ldo, out, rocblas_datatype_f32_r, (rocblas_int)ldo, rocblas_datatype_f32_r, rocblas_gemm_algo_standard, 0, 0);
-    if (st != rocblas_status_success) { c->err = "fp16 perf mode: rocblas_gemm_ex failed, status " + std::to_string((int)st); return 2; }
+// out_i[bs][ldo_i] (fp32) = beta * out_i + x[bs][K] (fp16) . W_i[N_i][K]^T (fp16), fp32 accumulation, for n_w <= 3 matrices sharing x in ONE launch
+int psf16_gemm_n(ps_hip_ctx *c, psf16 *, int n_w, const _Float16 *const *W, const int64_t *N, int64_t K, const _Float16 *x, int bs, float *const *out, const int64_t *ldo, float beta) {
+    if (n_w < 1 || n_w > 3 || bs < 1 || K % F16_BK != 0) PS_FAIL(c, "fp16 perf mode: GEMM shape not covered (K must be a multiple of 64)");
+    bool wide = true;
+    for (int i = 0; i < n_w; i++) { if (N[i] % 64 != 0) PS_FAIL(c, "fp16 perf mode: GEMM shape not covered (rows must be a multiple of 64)"); wide = wide && N[i] % 128 == 0; }
+    F16Gemm p{};
+    p.n_w = n_w; p.bs = bs; p.x = x; p.K = K; p.beta = beta; p.n_tm = (bs + F16_BM - 1) / F16_BM;
+    // 128-row weight tiles when that still gives every CU two workgroups, 64-row tiles otherwise
+    int64_t rows = 0;
+    for (int i = 0; i < n_w; i++) rows += N[i];
+    const int bn = (wide && rows / 128 * p.n_tm >= 2 * c->n_cu) ? 128 : 64;
+    for (int i = 0; i < n_w; i++) { p.w[i] = F16Mat{W[i], out[i], N[i], ldo[i], (int)(N[i] / bn)}; p.tiles_total += p.w[i].tiles; }
+    const unsigned grid = (unsigned)((p.tiles_total + 7) / 8 * 8 * p.n_tm);
+    const size_t smem = (size_t)2 * (F16_BM + bn) * F16_RS;
+    static unsigned long long attr = 0; // devices that have the attribute
+    if (ps_first_on_device(&attr)) {
+        (void)hipFuncSetAttribute((const void *)f16_gemm_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (F16_BM + 128) * F16_RS);
+        (void)hipFuncSetAttribute((const void *)f16_gemm_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (F16_BM + 64) * F16_RS);
+    }
+    if (bn == 128) hipLaunchKernelGGL(f16_gemm_kernel<128>, dim3(grid), dim3(256), smem, c->stream, p);
+    else hipLaunchKernelGGL(f16_gemm_kernel<64>, dim3(grid), dim3(256), smem, c->stream, p);
+    PS_CHECK(c, hipGetLastError());
     return 0;
+}
+int psf16_gemm(ps_hip_ctx *c, psf16 *f, const _Float16 *W, int64_t N, int64_t K, const _Float16 *x, int bs, float *out, int64_t ldo, float beta) {
+    return psf16_gemm_n(c, f, 1, &W, &N, K, x, bs, &out, &ldo, beta);
 }
 
 void psf16_rmsnorm_to_h(hipStream_t st, const float *x, const float *w, float eps, int64_t K, int bs, _Float16 *y) {

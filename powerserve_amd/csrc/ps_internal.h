@@ -125,6 +125,7 @@ int psf16_create(ps_hip_ctx *c, psf16 **out); // dlopen of rocBLAS + a handle on
 void psf16_destroy(psf16 *f);
 int psf16_dequantize(ps_hip_ctx *c, const ps_weight *w, float *rows_buf, int32_t *ids_buf, int rows_cap, _Float16 *out); // out [N][K]
 int psf16_gemm(ps_hip_ctx *c, psf16 *f, const _Float16 *W, int64_t N, int64_t K, const _Float16 *x, int bs, float *out, int64_t ldo, float beta);
+int psf16_gemm_n(ps_hip_ctx *c, psf16 *f, int n_w, const _Float16 *const *W, const int64_t *N, int64_t K, const _Float16 *x, int bs, float *const *out, const int64_t *ldo, float beta); // up to three matrices sharing x, one launch
 void psf16_rmsnorm_to_h(hipStream_t st, const float *x, const float *w, float eps, int64_t K, int bs, _Float16 *y);
 void psf16_to_h(hipStream_t st, const float *x, int64_t n, _Float16 *y);
 void psf16_silu_mul_to_h(hipStream_t st, const float *g, const float *u, int64_t n, _Float16 *y);

@@ -15,7 +15,7 @@ import numpy as np
 from . import gguf
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libps_hip.so")
+LIB_PATH = os.environ.get("PS_HIP_LIB") or os.path.join(HERE, "lib", "libps_hip.so")  # PS_HIP_LIB: an A/B build (tools/ab_build.py)
 
 F32, F16, Q4_0, Q8_0, Q4_K, Q5_K, Q6_K, Q8_K, I32 = 0, 1, 2, 8, 12, 13, 14, 15, 26
 QUANT = (Q4_0, Q8_0, Q4_K, Q5_K, Q6_K)
