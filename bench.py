@@ -147,6 +147,17 @@ def cpu_reference(model_dir, cfg, passes=7):
             if i >= 2:
                 times.append(time.perf_counter() - t0)
         ref.close()
+        # ... and at the reference's DEFAULT pool size (HyperParams::n_threads = 4, src/core/config.hpp:49): one untimed + three timed passes
+        times4 = []
+        ref4 = B.Ref(n_threads=4)
+        for i in range(4):
+            t0 = time.perf_counter()
+            for t, w, K, N in mats:
+                ref4.mul_mat(t, w, K, N, xs[K])
+            if i >= 1:
+                times4.append(time.perf_counter() - t0)
+        ref4.close()
+        times4.sort()
     finally:
         if saved is not None:
             os.sched_setaffinity(0, saved)
@@ -154,6 +165,9 @@ def cpu_reference(model_dir, cfg, passes=7):
     med = times[len(times) // 2]
     return {"value": 1.0 / med, "unit": "tokens/s", "cores": nth, "kind": "reference", "statistic": f"median of {passes} passes",
             "min": 1.0 / times[-1], "max": 1.0 / times[0],
+            "bimodal": bool(times[-1] / times[0] > 2.0),  # (a shared host: passes of one run have differed 6x; the median is what `value` is)
+            "n_threads_4": {"value": 1.0 / times4[1], "unit": "tokens/s", "cores": 4, "statistic": "median of 3 passes", "min": 1.0 / times4[-1], "max": 1.0 / times4[0],
+                            "note": "the reference's default pool size (HyperParams::n_threads = 4, src/core/config.hpp:49)"},
             "pinned_to": f"{len(cpus)} logical CPUs of one socket" if cpus else "not pinned (topology unreadable)",
             "sample": f"{passes} timed warm passes (after 2 untimed) over the {len(mats)} quantized mat-muls of one decode token ({nbytes / 1e9:.2f} GB of GGUF weights, resident copies) "
                       f"through powerserve_compute_forward_mul_mat on the reference's ThreadPool ({nth} threads; attention, norms and sampling "
@@ -217,12 +231,12 @@ def prefill_wide_leg(ctx, model_dir, args, prompt):
 
 def fp16_prefill_leg(ctx, model, args, prompt, ids_parity):
     """SURVEY 8 f4 (second half), reported next to the headline and never mixed into it: the same prefill with the fp16 perf mode on
-    (ps_hip_model_set_mode bit 5: the layer mat-muls as dense fp16 GEMMs on dequantized fp16 copies of the weights, rocBLAS; RoPE, KV
-    append and attention stay the parity kernels on the FP32 cache).  NOT bit-exact: the greedy ids that follow (parity decode on the
-    perf-mode cache) are compared with the parity run's."""
+    (ps_hip_model_set_mode bit 5: the layer mat-muls as dense fp16 GEMMs on dequantized fp16 copies of the weights, csrc/perf16.hip's own
+    kernel; RoPE, KV append and attention stay the parity kernels on the FP32 cache).  NOT bit-exact: layer 0's K / V rows are compared with the
+    parity run's."""
     model.reset()
     model.set_mode((1 if args.eager else 0) | 32)
-    model.prefill(prompt[:8], args.batch)  # first use: dequantizes the weights, loads the GEMM library (not timed)
+    model.prefill(prompt[:8], args.batch)  # first use: dequantizes the weights (not timed)
     res = []
     for _ in range(2):
         ctx.sync()
@@ -231,13 +245,21 @@ def fp16_prefill_leg(ctx, model, args, prompt, ids_parity):
         model.prefill(prompt[:-1], args.batch)
         ctx.sync()
         res.append((prompt.size - 1) / (time.perf_counter() - t0))
-    ids = model.decode_greedy(int(prompt[-1]), min(16, ids_parity.size))
+    # What the mode changes is bounded where nothing has compounded yet: layer 0's K / V rows (one GEMM behind the embedding) against the parity
+    # path's.  (On random synthetic weights the ids that follow say nothing: the int8 activation rounding of 32 layers amplifies ANY perturbation
+    # into a different arg-max within a few tokens -- VERDICT round 3, weak 8.)
+    n = prompt.size - 1
+    k16, v16 = model.k_cache(0)[:n].copy(), model.v_cache(0)[:, :n].copy()
     model.set_mode(1 if args.eager else 0)
-    same = 0
-    while same < ids.size and ids[same] == ids_parity[same]:
-        same += 1
-    return {"prefill_tokens_per_s": res[0], "prefill_tokens_per_s_warm": res[1], "ids_matching_prefix_vs_parity": int(same), "ids_compared": int(ids.size),
-            "note": "layer mat-muls of the prefill as dense fp16 GEMMs (fp32 accumulation) on dequantized weights; decode stays on the parity kernels; not bit-exact by design"}
+    model.reset()
+    model.prefill(prompt[:-1], args.batch)
+    k32, v32 = model.k_cache(0)[:n], model.v_cache(0)[:, :n]
+    rel = lambda a, b: float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+    return {"prefill_tokens_per_s": res[0], "prefill_tokens_per_s_warm": res[1],
+            "layer0_k_cache_max_abs_err_over_max_abs_vs_parity": rel(k16, k32), "layer0_v_cache_max_abs_err_over_max_abs_vs_parity": rel(v16, v32),
+            "gemm": "own kernel (csrc/perf16.hip: v_mfma_f32_32x32x16_f16, LDS double-buffered); no library",
+            "note": "layer mat-muls of the prefill as dense fp16 GEMMs (fp32 accumulation) on dequantized weights; decode stays on the parity kernels; not bit-exact by design "
+                    "(the parity path itself rounds activations to int8: its layer-0 V sits 4-5e-3 from a float64 evaluation, this mode 3e-4 -- tests/test_gpu_model.py)"}
 
 
 def fp16_kv_leg(ctx, model, args, prompt, ids_parity):
@@ -252,6 +274,7 @@ def fp16_kv_leg(ctx, model, args, prompt, ids_parity):
         model.forward(prompt[done:done + bs], np.arange(done, done + bs), lm_head=False)
         done += bs
     lg16, _ = model.forward([int(prompt[-1])], [model.position], lm_head=True)
+    att16 = model.scratch(2, 1).copy()  # attention output of the LAST layer at this step (csrc/model.hip: ps_hip_model_scratch)
     model.ctx.check(model.ctx.L.ps_hip_model_kv_rollback(model.h, 1))
     cur = int(prompt[-1])
     ids_w = model.decode_greedy(cur, args.warmup) if args.warmup > 0 else np.zeros(0, np.int32)
@@ -263,7 +286,6 @@ def fp16_kv_leg(ctx, model, args, prompt, ids_parity):
     ctx.sync()
     dt = time.perf_counter() - t0
     both = np.concatenate([ids_w, ids])
-    n_same = int(np.argmax(np.append(both != ids_parity[:both.size], True)))
     # parity logits of the same step
     model.reset()
     model.set_mode(1 if args.eager else 0)
@@ -273,9 +295,14 @@ def fp16_kv_leg(ctx, model, args, prompt, ids_parity):
         model.forward(prompt[done:done + bs], np.arange(done, done + bs), lm_head=False)
         done += bs
     lg32, _ = model.forward([int(prompt[-1])], [model.position], lm_head=True)
+    att32 = model.scratch(2, 1)
     rel = float(np.abs(lg16 - lg32).max() / np.abs(lg32).max())
-    return {"decode_tokens_per_s": args.steps / dt, "ms_per_step": 1e3 * dt / args.steps, "ids_matching_prefix_vs_parity": n_same, "ids_compared": int(both.size),
-            "first_step_logits_max_abs_err_over_max_abs": rel, "first_step_argmax_equal": bool(np.argmax(lg16) == np.argmax(lg32)),
+    # the bound that means something on random weights is the attention output itself (the int8 activation quantizers behind it amplify any
+    # perturbation: ids and logits diverge within a few tokens whatever the size of the error -- VERDICT round 3, weak 8); the last layer's
+    # input already carries the fp16 error of 31 layers, so this is an upper bound of one attention's error
+    return {"decode_tokens_per_s": args.steps / dt, "ms_per_step": 1e3 * dt / args.steps,
+            "last_layer_attention_output_max_abs_err_over_max_abs": float(np.abs(att16 - att32).max() / max(np.abs(att32).max(), 1e-30)),
+            "first_step_logits_max_abs_err_over_max_abs": rel, "first_step_argmax_equal": bool(np.argmax(lg16) == np.argmax(lg32)), "ids_compared": int(both.size),
             "note": "fp16 K/V mirrors + split-KV online soft-max for single-token attention only; prefill reads the FP32 cache; not bit-exact by design"}
 
 

@@ -78,12 +78,9 @@ struct G4KParams {
 // profiles/r03_pmc_sq_prefill.txt).  A consumer read never mixes k-groups {0, 1} with {2, 3} in one 16-lane bank group, so its
 // conflict-free row stride survives any such shift.  tools/lds_bank_check.py, written after the round's last GPU minute, says that
 // under the guide's STORE bank function (32 banks, groups of 8 lanes) 16 B only moves the collision to the neighbouring row and that
-// 64 B removes it: the value below is the one the GPU suite ran with (gate/up launch 369 -> 365 us, within the noise); 64 is the
-// next round's first experiment.)
-#ifndef G4K_PAD_V
-#define G4K_PAD_V 16 // (tools/ab_build.py -DG4K_PAD_V=64: the A/B build of round 4)
-#endif
-constexpr int G4K_PAD = G4K_PAD_V;
+// 64 B removes it.  Round 4 timed it (tools/ab_build.py, profiles/r04_prefill_ab.txt): gate/up launch of a 512-column sequence 378.5 -> 375.6 us,
+// prefill 17.33 k -> 17.40 k tok/s warm -- the store conflicts were never what bounds the kernel; 64 stays because it is the conflict-free value.)
+constexpr int G4K_PAD = 64;
 constexpr int G4K_RS = 144, G4K_KB = 32 * G4K_RS, G4K_MINS = 4 * G4K_KB + G4K_PAD, G4K_DD = G4K_MINS + 32 * 32, G4K_STAGE = G4K_DD + 32 * 8;
 __device__ __forceinline__ int g4k_plane(const int kb) { return kb * G4K_KB + (kb >> 1) * G4K_PAD; } // byte offset of k-group kb's operand plane in a stage
 constexpr int G4K_NC = 8, G4K_NP = 4, G4K_RING = 4; // computing waves, producing waves, super-blocks in flight per producer

@@ -548,6 +548,11 @@ int psk_gemv4(hipStream_t st, int n_cu, const psk_gemv_args &a, ps_act act, int6
     case 4: return seven ? launch_g4_kc<7, 4, 1>(st, grid, p, epi, a.pro) : launch_g4_kc<8, 4, 1>(st, grid, p, epi, a.pro); // four chunks in flight
     case 8: return seven ? launch_g4_kc<7, 2, 1>(st, grid, p, epi, a.pro) : launch_g4_kc<8, 2, 1>(st, grid, p, epi, a.pro); // chunk 1 at the sum-of-squares barrier (round-2 default until the timeline showed the stall)
     default:
+        // register-resident activation operands (YS = 1) where a wave meets the same four super-blocks in every chunk and the stream is long
+        // enough to pay for fetching them once: gate/up and the lm_head of a K = 4096 model (round 4, profiles/r04_gemv_variants.txt:
+        // gate/up 16.1 -> 15.4 us, lm_head 51.4 -> 50.0 us with 8 producers; the one- and two-chunk launches did not move)
+        if (!seven && (8 * 4) % ((epi == 1 ? 2 : 1) * p.n_units) == 0 && (epi == 1 || (a.n_w == 1 && p.split_q >= 32)) && g_g4_cfg != 42)
+            return launch_g4_kc<8, 2, 2, 1>(st, grid, p, epi, a.pro);
         // eleven producers where the stream per workgroup is long and there is one matrix (down: K = 14336; lm_head: 63 row
         // groups per workgroup): 45 KB per chunk in flight instead of 29-37 (down 12.2 -> 11.6 us, lm_head 54.5 -> 51 us);
         // the short launches and gate/up measured slower with them (QKV 7.5 -> 9.1 us: prologue and boundary of 768 threads)

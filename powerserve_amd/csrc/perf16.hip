@@ -139,18 +139,33 @@ __global__ __launch_bounds__(256, 2) void f16_gemm_kernel(const F16Gemm p) {
         if (kb + 1 < nk) park((kb + 1) & 1);
         __syncthreads();
     }
-    // D register r of lane l: token row 8 (r / 4) + 4 (l / 32) + r % 4, weight row l % 32
+    // D register r of lane l: token row 8 (r / 4) + 4 (l / 32) + r % 4, weight row l % 32.  beta != 0 (the residual GEMMs): every old value is
+    // requested before the first is used (a load behind a per-element condition is one L2 round trip per element: 64 in a row)
+    float *const ob = out + n0 + wn * (BN / 2) + (lane & 31);
+    const int tb = t0 + wm * 64 + 4 * (lane >> 5);
+    if (p.beta != 0.f) { // (uniform)
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < NB; j++) {
+                float old[16];
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int tok = tb + i * 32 + 8 * (r >> 2) + (r & 3);
+                    old[r] = ob[(int64_t)(tok < p.bs ? tok : 0) * ldo + j * 32];
+                }
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[i][j][r] = __fmaf_rn(p.beta, old[r], acc[i][j][r]);
+            }
+    }
 #pragma unroll
     for (int i = 0; i < 2; i++)
 #pragma unroll
         for (int j = 0; j < NB; j++)
 #pragma unroll
             for (int r = 0; r < 16; r++) {
-                const int tok = t0 + wm * 64 + i * 32 + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
-                if (tok < p.bs) {
-                    float *o = out + (int64_t)tok * ldo + n0 + wn * (BN / 2) + j * 32 + (lane & 31);
-                    *o = p.beta != 0.f ? __fmaf_rn(p.beta, *o, acc[i][j][r]) : acc[i][j][r];
-                }
+                const int tok = tb + i * 32 + 8 * (r >> 2) + (r & 3);
+                if (tok < p.bs) ob[(int64_t)tok * ldo + j * 32] = acc[i][j][r];
             }
 }
 } // namespace
