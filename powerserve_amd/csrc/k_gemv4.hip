@@ -146,8 +146,20 @@ __global__ __launch_bounds__((NW + 1) * 64) void gemv4_kernel(const G4Params p) 
 
     if (wave < NW) { // ------------------------------------------------------------------ producers
         // 1. the activation row, dealt tile by tile to the producers (tile t -> wave t % NW)
-        float4 xv[TPW], wv[TPW];
-        if (PRO != 0) ps_qrow_load<(PRO == 1 ? 1 : 0), TPW>(p.x, p.nw, K, xv, wv, NW);
+        // (two tiles per wave-instruction, g4_quantize_pair: pair tp = wave + i * NW, lane l holds elements tp * 512 + 8 l .. + 7.  Measured,
+        //  decode tok/s of the 8B: one tile per instruction 520, two 535, four 524 -- four leave half the waves without a tile at K = 4096)
+        constexpr int PPW = (TPW + 1) / 2;
+        const int n_pairs = n_units / 2;
+        float4 xv[PPW][2], wv[PPW][2];
+        if (PRO != 0) {
+#pragma unroll
+            for (int i = 0; i < PPW; i++) {
+                const int tp = wave + i * NW;
+                const int64_t e = (int64_t)(tp < n_pairs ? tp : 0) * 512 + lane * 8; // (never a branch around a load: a dead slot re-reads pair 0 and stores nothing)
+                xv[i][0] = *(const float4 *)(p.x + e); xv[i][1] = *(const float4 *)(p.x + e + 4);
+                if (PRO == 1) { wv[i][0] = *(const float4 *)(p.nw + e); wv[i][1] = *(const float4 *)(p.nw + e + 4); }
+            }
+        }
         // 2. this wave's slots of chunks 0 .. DC-1: (local task, unit inside the task); a slot is four consecutive units
         //    of one row group
         const int step_t = (DC * UPB) / tot, step_u = (DC * UPB) % tot; // a slot moves DC chunks per trip
@@ -239,11 +251,16 @@ __global__ __launch_bounds__((NW + 1) * 64) void gemv4_kernel(const G4Params p) 
             if (PRO == 1) {
                 double ss = 0.0;
 #pragma unroll
-                for (int i = 0; i < TPW; i++) {
-                    ss += (double)__fmul_rn(xv[i].x, xv[i].x);
-                    ss += (double)__fmul_rn(xv[i].y, xv[i].y);
-                    ss += (double)__fmul_rn(xv[i].z, xv[i].z);
-                    ss += (double)__fmul_rn(xv[i].w, xv[i].w);
+                for (int i = 0; i < PPW; i++) {
+                    if (wave + i * NW < n_pairs) { // (wave-uniform)
+#pragma unroll
+                        for (int h = 0; h < 2; h++) {
+                            ss += (double)__fmul_rn(xv[i][h].x, xv[i][h].x);
+                            ss += (double)__fmul_rn(xv[i][h].y, xv[i][h].y);
+                            ss += (double)__fmul_rn(xv[i][h].z, xv[i][h].z);
+                            ss += (double)__fmul_rn(xv[i][h].w, xv[i][h].w);
+                        }
+                    }
                 }
                 pmark(24); // the row has arrived
                 ss = wave_sum_d_dpp(ss);
@@ -259,17 +276,16 @@ __global__ __launch_bounds__((NW + 1) * 64) void gemv4_kernel(const G4Params p) 
                 pmark(26);
             }
 #pragma unroll
-            for (int i = 0; i < TPW; i++) {
-                const int t = wave + i * NW;
-                const bool live = t < n_units; // wave-uniform (n_units tiles of 256); a dead tile runs on zeros and stores nothing
-                float v[4] = {xv[i].x, xv[i].y, xv[i].z, xv[i].w};
+            for (int i = 0; i < PPW; i++) {
+                const int tp = wave + i * NW;
+                const bool live = tp < n_pairs; // wave-uniform; a dead pair runs on pair 0's values and stores nothing
+                float v[8] = {xv[i][0].x, xv[i][0].y, xv[i][0].z, xv[i][0].w, xv[i][1].x, xv[i][1].y, xv[i][1].z, xv[i][1].w};
                 if (PRO == 1) {
-                    v[0] = __fmul_rn(v[0], __fmul_rn(wv[i].x, scale));
-                    v[1] = __fmul_rn(v[1], __fmul_rn(wv[i].y, scale));
-                    v[2] = __fmul_rn(v[2], __fmul_rn(wv[i].z, scale));
-                    v[3] = __fmul_rn(v[3], __fmul_rn(wv[i].w, scale));
+                    const float w8[8] = {wv[i][0].x, wv[i][0].y, wv[i][0].z, wv[i][0].w, wv[i][1].x, wv[i][1].y, wv[i][1].z, wv[i][1].w};
+#pragma unroll
+                    for (int k = 0; k < 8; k++) v[k] = __fmul_rn(v[k], __fmul_rn(w8[k], scale));
                 }
-                g4_quantize_tile(v, t * 256 + lane * 4, t, lq, ld, lb, live);
+                g4_quantize_pair(v, tp * 512 + lane * 8, tp, lq, ld, lb, live);
             }
             pmark(27);
             if (STAGED) {

@@ -139,4 +139,47 @@ __device__ __forceinline__ void g4_quantize_tile(const float v[4], const int e, 
     }
 }
 
+// TWO tiles per wave-instruction (round 4): lanes 0..31 hold tile 2 tp (eight consecutive elements each), lanes 32..63 tile 2 tp + 1.  The
+// prologue of the mat-vec kernels is bound by vector-instruction issue (K = 14336: 56 tiles x ~150 instructions on one CU = 3.8 us), and most of a
+// tile's instructions are the same for every lane -- the two correctly rounded divisions (-127 / max, 1 / iscale), the reduction steps, the
+// first-maximum search: with a tile per half wave each of them serves two tiles.  Same arithmetic per element as g4_quantize_tile, same LDS image.
+// (A four-tile form -- a tile per row of 16 lanes, ~50 instructions per tile -- measured slower: 524 vs 535 tok/s, profiles/r04_gemv_variants.txt.)
+// v[8]: elements e0 .. e0 + 7 of the row, e0 = tp * 512 + 8 * lane.
+__device__ __forceinline__ void g4_quantize_pair(const float v[8], const int e0, const int tp, int8_t *qs, float *d, int *bs32, const bool live) {
+    const int lane = threadIdx.x & 63;
+    const bool hi = lane >= 32;
+    float am = fmaxf(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))), fmaxf(fmaxf(fabsf(v[4]), fabsf(v[5])), fmaxf(fabsf(v[6]), fabsf(v[7]))));
+    // maximum of each half wave (max is order-independent: exact): rows of 16 lanes by DPP, the two rows of a half through scalar registers
+    const float rm = row16_max(am);
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rm), 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rm), 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rm), 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rm), 48));
+    const float amax = hi ? fmaxf(r2, r3) : fmaxf(r0, r1);
+    // the first element (index order) with the largest |x| decides the sign of iscale: the lowest lane of the half with a hit, its lowest element
+    const unsigned long long hits = __ballot(am == amax);
+    float mine = v[7];
+#pragma unroll
+    for (int i = 6; i >= 0; i--) mine = fabsf(v[i]) == amax ? v[i] : mine;
+    const unsigned lo32 = (unsigned)hits, hi32 = (unsigned)(hits >> 32);
+    const int la = lo32 ? __ffs((int)lo32) - 1 : 0, lb = hi32 ? 32 + __ffs((int)hi32) - 1 : 32; // (an all-NaN half has no hit: any lane, the result is NaN either way)
+    const float ma = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine), la)), mb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine), lb));
+    const float mx = hi ? mb : ma;
+    const bool zero = amax == 0.f; // (an all-zero tile: quants 0, d 0 -- quantize_row_q8_K's early-out)
+    const float iscale = zero ? 0.f : __fdiv_rn(-127.f, mx);
+    int q[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) q[i] = min(127, __float2int_rn(__fmul_rn(iscale, v[i])));
+    const float dd = zero ? 0.f : __fdiv_rn(1.0f, iscale);
+    int s = ((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7]));
+    s += dpp_i<0xB1>(s); s += dpp_i<0x4E>(s); // the four lanes of a 32-element group hold its sum
+    if (live) { // quad-major inside the tile: dword (e / 4) % 64 = g * 8 + u goes to u * 8 + g
+        const int t = 2 * tp + (hi ? 1 : 0), dw = (e0 >> 2) & 63, base = e0 & ~255;
+        const uint32_t p0 = (uint32_t)(q[0] & 0xff) | ((uint32_t)(q[1] & 0xff) << 8) | ((uint32_t)(q[2] & 0xff) << 16) | ((uint32_t)(q[3] & 0xff) << 24);
+        const uint32_t p1 = (uint32_t)(q[4] & 0xff) | ((uint32_t)(q[5] & 0xff) << 8) | ((uint32_t)(q[6] & 0xff) << 16) | ((uint32_t)(q[7] & 0xff) << 24);
+        *(uint32_t *)(qs + base + (((dw & 7) << 3) | (dw >> 3)) * 4) = p0;             // quad dw (even: dw & 7 in {0, 2, 4, 6})
+        *(uint32_t *)(qs + base + ((((dw + 1) & 7) << 3) | (dw >> 3)) * 4) = p1;       // quad dw + 1: the same group of eight, the next u
+        d[t] = dd;
+        bs32[e0 >> 5] = s;
+    }
+}
+
 } // namespace
