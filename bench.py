@@ -521,7 +521,7 @@ def main():
 
 
 MFMA_F16_PEAK_TFLOPS = 2500.0  # dense fp16 matrix-core peak (MI355X_MICROARCH.md): the pipe the Q4_K chunk mat-mul runs its exact-integer contractions on
-TRAFFIC_FILE = os.path.join("profiles", "r03_pmc_traffic.json")
+TRAFFIC_FILE = os.path.join("profiles", "r04_pmc_traffic.json")
 
 
 def _pmc_traffic(kernel):

@@ -319,7 +319,7 @@ __device__ __forceinline__ void attn_softmax_rows(const psl_attn_args &a, const 
                 const float4 lo = *(const float4 *)(pg + gi * 8), hi = *(const float4 *)(pg + gi * 8 + 4);
                 float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
 #pragma unroll
-                for (int l = 0; l < 8; l++) v[l] = ps_v_expf(__fsub_rn(v[l], mx));
+                for (int l = 0; l < 8; l++) v[l] = ps_v_expf(__fsub_rn(v[l], mx)); // (ps_v_expf_n here costs attn_softmax_pv_cols_kernel<2> five spilled registers)
                 *(float4 *)(pg + gi * 8)     = make_float4(v[0], v[1], v[2], v[3]);
                 *(float4 *)(pg + gi * 8 + 4) = make_float4(v[4], v[5], v[6], v[7]);
                 const float a0 = __fadd_rn(v[4], v[0]), a1 = __fadd_rn(v[5], v[1]), a2 = __fadd_rn(v[6], v[2]), a3 = __fadd_rn(v[7], v[3]);
@@ -680,8 +680,7 @@ __global__ __launch_bounds__(NT) void attn_decode2_kernel(psl_attn_args a) {
         const int j0 = (t + LPH * k) * 8;
         if (!hl) continue;
         if (j0 + 8 <= n8) {
-#pragma unroll
-            for (int i = 0; i < 8; i++) sv[k][i] = ps_v_expf(__fsub_rn(sv[k][i], mx));
+            ps_v_expf_n<8>(sv[k], mx);
             const float a0 = __fadd_rn(sv[k][4], sv[k][0]), a1 = __fadd_rn(sv[k][5], sv[k][1]), a2 = __fadd_rn(sv[k][6], sv[k][2]), a3 = __fadd_rn(sv[k][7], sv[k][3]);
             rs += (double)__fadd_rn(__fadd_rn(a0, a2), __fadd_rn(a1, a3));
             if (j0 + 8 <= np) {
@@ -932,9 +931,9 @@ __global__ __launch_bounds__(256) void attn_softmax_probs_wave_kernel(psl_attn_a
     for (int k = 0; k < SMW_MAXQ; k++) {
         if (k < nq) {
             const int j = (k * 64 + lane) * 4;
-            float4 e;
-            e.x = ps_v_expf(__fsub_rn(v[k].x, mx)); e.y = ps_v_expf(__fsub_rn(v[k].y, mx));
-            e.z = ps_v_expf(__fsub_rn(v[k].z, mx)); e.w = ps_v_expf(__fsub_rn(v[k].w, mx));
+            float e4[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+            ps_v_expf_n<4>(e4, mx);
+            const float4 e = make_float4(e4[0], e4[1], e4[2], e4[3]);
             v[k] = e;
             // the neighbour's half of the group of 8 (quad_perm [1, 0, 3, 2])
             const float a0 = __fadd_rn(dpp_f<0xB1>(e.x), e.x), a1 = __fadd_rn(dpp_f<0xB1>(e.y), e.y);

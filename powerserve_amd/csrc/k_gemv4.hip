@@ -549,6 +549,7 @@ int psk_gemv4(hipStream_t st, int n_cu, const psk_gemv_args &a, ps_act act, int6
     if (g_g4_cfg == 40 || g_g4_cfg == 41) { // register-resident activation operands on the register ring (41: three chunks in flight)
         const int tot = (epi == 1 ? 2 : 1) * p.n_units, upb = (seven ? 7 : 8) * 4;
         const int ys = upb % tot == 0 ? 1 : ((2 * upb) % tot == 0 ? 2 : 0);
+        if (ys == 1 && g_g4_cfg == 41 && !seven) return launch_g4_kc<8, 3, 2, 1>(st, grid, p, epi, a.pro);
         if (ys == 1) return seven ? launch_g4_kc<7, 2, 2, 1>(st, grid, p, epi, a.pro) : launch_g4_kc<8, 2, 2, 1>(st, grid, p, epi, a.pro);
         if (ys == 2) return seven ? launch_g4_kc<7, 2, 2, 2>(st, grid, p, epi, a.pro) : launch_g4_kc<8, 2, 2, 2>(st, grid, p, epi, a.pro);
     }

@@ -77,8 +77,21 @@ __global__ __launch_bounds__((NW + 1) * 64) void gemvk_kernel(const GKParams p) 
     const int n_iters  = (n_chunks + DC - 1) / DC;
 
     if (wave < NW) { // ------------------------------------------------------------------ producers
-        float4 xv[TPW], wv[TPW];
-        if (PRO != 0) ps_qrow_load<(PRO == 1 ? 1 : 0), TPW>(p.x, p.nw, K, xv, wv, NW);
+        // (two tiles per wave-instruction, g4_quantize_pair: pair tp = wave + i * NW, lane l holds elements tp * 512 + 8 l .. + 7; an odd row's last
+        //  pair has one tile: its upper lanes load element 0 and store nothing)
+        constexpr int PPW = (TPW + 1) / 2;
+        const int n_pairs = (n_units + 1) / 2;
+        float4 xv[PPW][2], wv[PPW][2];
+        if (PRO != 0) {
+#pragma unroll
+            for (int i = 0; i < PPW; i++) {
+                const int tp = wave + i * NW;
+                int64_t e = (int64_t)(tp < n_pairs ? tp : 0) * 512 + lane * 8;
+                e = e < K ? e : 0; // (never a branch around a load)
+                xv[i][0] = *(const float4 *)(p.x + e); xv[i][1] = *(const float4 *)(p.x + e + 4);
+                if (PRO == 1) { wv[i][0] = *(const float4 *)(p.nw + e); wv[i][1] = *(const float4 *)(p.nw + e + 4); }
+            }
+        }
         int step_t = 0, step_u = DC * UPB; // a trip moves a unit of the ring DC chunks on
         while (step_u >= tot) { step_u -= tot; step_t++; }
         int tS[DC][UPW], uS[DC][UPW];
@@ -214,11 +227,17 @@ __global__ __launch_bounds__((NW + 1) * 64) void gemvk_kernel(const GKParams p) 
             if (PRO == 1) {
                 double ss = 0.0;
 #pragma unroll
-                for (int i = 0; i < TPW; i++) {
-                    ss += (double)__fmul_rn(xv[i].x, xv[i].x);
-                    ss += (double)__fmul_rn(xv[i].y, xv[i].y);
-                    ss += (double)__fmul_rn(xv[i].z, xv[i].z);
-                    ss += (double)__fmul_rn(xv[i].w, xv[i].w);
+                for (int i = 0; i < PPW; i++) {
+                    const int tp = wave + i * NW;
+                    if (tp < n_pairs && (int64_t)tp * 512 + lane * 8 < K) { // (lanes of a tile that does not exist add nothing)
+#pragma unroll
+                        for (int h = 0; h < 2; h++) {
+                            ss += (double)__fmul_rn(xv[i][h].x, xv[i][h].x);
+                            ss += (double)__fmul_rn(xv[i][h].y, xv[i][h].y);
+                            ss += (double)__fmul_rn(xv[i][h].z, xv[i][h].z);
+                            ss += (double)__fmul_rn(xv[i][h].w, xv[i][h].w);
+                        }
+                    }
                 }
                 ss = wave_sum_d_dpp(ss);
                 if (lane == 0) red[wave] = ss;
@@ -230,17 +249,16 @@ __global__ __launch_bounds__((NW + 1) * 64) void gemvk_kernel(const GKParams p) 
                 scale            = __fdiv_rn(1.0f, sqrtf(__fadd_rn(mean, p.eps)));
             }
 #pragma unroll
-            for (int i = 0; i < TPW; i++) {
-                const int t = wave + i * NW;
-                const bool live = t < n_units; // wave-uniform (n_units tiles of 256); a dead tile runs on zeros and stores nothing
-                float v[4] = {xv[i].x, xv[i].y, xv[i].z, xv[i].w};
+            for (int i = 0; i < PPW; i++) {
+                const int tp = wave + i * NW;
+                const bool live = tp < n_pairs; // wave-uniform; a dead pair runs on pair 0's values and stores nothing
+                float v[8] = {xv[i][0].x, xv[i][0].y, xv[i][0].z, xv[i][0].w, xv[i][1].x, xv[i][1].y, xv[i][1].z, xv[i][1].w};
                 if (PRO == 1) {
-                    v[0] = __fmul_rn(v[0], __fmul_rn(wv[i].x, scale));
-                    v[1] = __fmul_rn(v[1], __fmul_rn(wv[i].y, scale));
-                    v[2] = __fmul_rn(v[2], __fmul_rn(wv[i].z, scale));
-                    v[3] = __fmul_rn(v[3], __fmul_rn(wv[i].w, scale));
+                    const float w8[8] = {wv[i][0].x, wv[i][0].y, wv[i][0].z, wv[i][0].w, wv[i][1].x, wv[i][1].y, wv[i][1].z, wv[i][1].w};
+#pragma unroll
+                    for (int k = 0; k < 8; k++) v[k] = __fmul_rn(v[k], __fmul_rn(w8[k], scale));
                 }
-                g4_quantize_tile(v, t * 256 + lane * 4, t, lq, ld, lb, live);
+                g4_quantize_pair(v, tp * 512 + lane * 8, tp, lq, ld, lb, live, n_units);
             }
 #pragma unroll
             for (int d = EARLY; d < DC; d++) issue(d);

@@ -120,7 +120,10 @@ __global__ __launch_bounds__(256) void softmax_ext_kernel(TDesc dst, TDesc src, 
     for (int64_t g = threadIdx.x; g * 8 < n8; g += 256) {
         float v[8];
 #pragma unroll
-        for (int l = 0; l < 8; l++) { v[l] = ps_v_expf(__fsub_rn(wp[g * 8 + l], mx)); wp[g * 8 + l] = v[l]; }
+        for (int l = 0; l < 8; l++) v[l] = wp[g * 8 + l];
+        ps_v_expf_n<8>(v, mx);
+#pragma unroll
+        for (int l = 0; l < 8; l++) wp[g * 8 + l] = v[l];
         const float a0 = __fadd_rn(v[4], v[0]), a1 = __fadd_rn(v[5], v[1]), a2 = __fadd_rn(v[6], v[2]), a3 = __fadd_rn(v[7], v[3]);
         sum += (double)__fadd_rn(__fadd_rn(a0, a2), __fadd_rn(a1, a3));
     }

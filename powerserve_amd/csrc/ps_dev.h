@@ -190,6 +190,44 @@ __device__ __forceinline__ float ps_v_expf(float x) {
     return __fmul_rn(__fmaf_rn(s2, j, s2), s1);
 }
 
+// N values at once, in place: x[i] = ggml_v_expf(x[i] - mx).  The same operation sequence per value as ps_v_expf; what changes is the control
+// flow.  ps_v_expf's rare |n| > 126 path (overflow / underflow scaling; x - max <= 0 gets there only below -87, i.e. masked -inf logits) is a
+// per-lane branch, and called value after value it fences each value's dependent chain of ~12 fp operations off from the next: eight exponentials
+// ran as eight latency chains in a row (the soft-max phases are bound by exactly that: profiles/r03_attention_timeline.txt "exp" 0.98 us).  Here
+// the common path of all N values is straight-line code (the chains interleave) and the fix-up sits behind ONE wave-uniform test.
+template <int N>
+__device__ __forceinline__ void ps_v_expf_n(float (&x)[N], const float mx) {
+    const float r = 0x1.8p23f;
+    float nn[N], jj[N];
+    uint32_t ee[N];
+    bool slow = false;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        const float xi = __fsub_rn(x[i], mx);
+        const float z = __fmaf_rn(xi, 0x1.715476p+0f, r);
+        const float n = __fsub_rn(z, r);
+        const float b = __fmaf_rn(-n, 0x1.7f7d1cp-20f, __fmaf_rn(-n, 0x1.62e4p-1f, xi));
+        const uint32_t e = __float_as_uint(z) << 23;
+        const float k = __uint_as_float(e + 0x3f800000u);
+        const float u = __fmul_rn(b, b);
+        const float j = __fmaf_rn(__fmaf_rn(__fmaf_rn(0x1.0e4020p-7f, b, 0x1.573e2ep-5f), u, __fmaf_rn(0x1.555e66p-3f, b, 0x1.fffdb6p-2f)), u, __fmul_rn(0x1.ffffecp-1f, b));
+        x[i] = __fmaf_rn(j, k, k);
+        nn[i] = n; jj[i] = j; ee[i] = e;
+        slow = slow || fabsf(n) > 126.0f;
+    }
+    if (__builtin_amdgcn_ballot_w64(slow) != 0) { // (wave-uniform: rarely taken)
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            const float n = nn[i];
+            const uint32_t g = (n <= 0.0f) ? 0x82000000u : 0u;
+            const float s1 = __uint_as_float(g + 0x7f000000u);
+            const float s2 = __uint_as_float(ee[i] - g);
+            const float big = __fmul_rn(s1, s1), mid = __fmul_rn(__fmaf_rn(s2, jj[i], s2), s1);
+            x[i] = fabsf(n) > 126.0f ? (fabsf(n) > 192.0f ? big : mid) : x[i];
+        }
+    }
+}
+
 // ---- get_scale_min_k4 (libs/ggml/src/ggml-quants.c:1912-1920) on the 12 scale bytes held as 3 dwords
 __device__ __forceinline__ void ps_scale_min_k4(int is, uint32_t s0, uint32_t s1, uint32_t s2, int &sc, int &m) {
     const int k = is & 3, sh = 8 * k;

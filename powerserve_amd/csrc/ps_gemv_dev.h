@@ -145,7 +145,7 @@ __device__ __forceinline__ void g4_quantize_tile(const float v[4], const int e, 
 // first-maximum search: with a tile per half wave each of them serves two tiles.  Same arithmetic per element as g4_quantize_tile, same LDS image.
 // (A four-tile form -- a tile per row of 16 lanes, ~50 instructions per tile -- measured slower: 524 vs 535 tok/s, profiles/r04_gemv_variants.txt.)
 // v[8]: elements e0 .. e0 + 7 of the row, e0 = tp * 512 + 8 * lane.
-__device__ __forceinline__ void g4_quantize_pair(const float v[8], const int e0, const int tp, int8_t *qs, float *d, int *bs32, const bool live) {
+__device__ __forceinline__ void g4_quantize_pair(const float v[8], const int e0, const int tp, int8_t *qs, float *d, int *bs32, const bool live, const int n_units = 1 << 30) {
     const int lane = threadIdx.x & 63;
     const bool hi = lane >= 32;
     float am = fmaxf(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))), fmaxf(fmaxf(fabsf(v[4]), fabsf(v[5])), fmaxf(fabsf(v[6]), fabsf(v[7]))));
@@ -171,8 +171,9 @@ __device__ __forceinline__ void g4_quantize_pair(const float v[8], const int e0,
     const float dd = zero ? 0.f : __fdiv_rn(1.0f, iscale);
     int s = ((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7]));
     s += dpp_i<0xB1>(s); s += dpp_i<0x4E>(s); // the four lanes of a 32-element group hold its sum
-    if (live) { // quad-major inside the tile: dword (e / 4) % 64 = g * 8 + u goes to u * 8 + g
-        const int t = 2 * tp + (hi ? 1 : 0), dw = (e0 >> 2) & 63, base = e0 & ~255;
+    const int t = 2 * tp + (hi ? 1 : 0);
+    if (live && t < n_units) { // quad-major inside the tile: dword (e / 4) % 64 = g * 8 + u goes to u * 8 + g  (n_units: an odd row's last pair has one tile)
+        const int dw = (e0 >> 2) & 63, base = e0 & ~255;
         const uint32_t p0 = (uint32_t)(q[0] & 0xff) | ((uint32_t)(q[1] & 0xff) << 8) | ((uint32_t)(q[2] & 0xff) << 16) | ((uint32_t)(q[3] & 0xff) << 24);
         const uint32_t p1 = (uint32_t)(q[4] & 0xff) | ((uint32_t)(q[5] & 0xff) << 8) | ((uint32_t)(q[6] & 0xff) << 16) | ((uint32_t)(q[7] & 0xff) << 24);
         *(uint32_t *)(qs + base + (((dw & 7) << 3) | (dw >> 3)) * 4) = p0;             // quad dw (even: dw & 7 in {0, 2, 4, 6})
