@@ -231,11 +231,12 @@ int ps_hip_debug_set(int key, int value);
  * tree verify keep reading the FP32 caches.  Must be switched on while the cache is empty (position 0).;
  * bit 4: 1 = single-token attention as TWO launches (scores, then soft-max + V.p) instead of the one-launch form
  * (attn_decode2_kernel: scores exchanged inside the launch; it needs every workgroup of its grid resident, its wait is bounded,
- * and a wait that gives up is reported as an error by the forward that hit it and switches this bit on).  Same results bit for
- * bit;
+ * and a wait that gives up switches this bit on: the forward that hit it runs again on the two launches -- ps_hip_model_forward,
+ * _forward_tree, _prefill and _decode_greedy do that themselves, a lowered forward reports it through ps_hip_model_sync_check /
+ * ps_hip_model_kv_advance).  Same results bit for bit;
  * bit 5: 1 = fp16 prefill perf mode — NOT bit-exact: the layer mat-muls of batches without logits (prefill chunks) run
- * as dense fp16 GEMMs (fp32 accumulation) on dequantized fp16 copies of the matrices made at first use (+2 bytes per weight), through
- * rocBLAS loaded with dlopen (an error, not a fallback, when it is missing); RoPE, KV append and attention stay the parity kernels on
+ * as dense fp16 GEMMs (fp32 accumulation) on dequantized fp16 copies of the matrices made at first use (+2 bytes per weight), the
+ * backend's own matrix-core kernel (csrc/perf16.hip; row lengths must be multiples of 64); RoPE, KV append and attention stay the parity kernels on
  * the FP32 cache, single tokens and tree forwards stay entirely on the parity path.
  * The environment variable PS_HIP_MODE_OR is OR-ed into every mode (A/B runs of unmodified drivers). */
 int ps_hip_model_set_mode(ps_hip_model *m, int mode);

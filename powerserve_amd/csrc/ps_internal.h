@@ -121,7 +121,7 @@ static inline ps_act ps_act_carve(void *base, int64_t K, int64_t rows) {
 
 // ---- fp16 prefill perf mode (perf16.hip): dense GEMMs on dequantized fp16 copies of the layer matrices, NOT bit-exact
 struct psf16;
-int psf16_create(ps_hip_ctx *c, psf16 **out); // dlopen of rocBLAS + a handle on the backend's stream
+int psf16_create(ps_hip_ctx *c, psf16 **out); // the mode's handle (the GEMM is perf16.hip's own kernel: no library)
 void psf16_destroy(psf16 *f);
 int psf16_dequantize(ps_hip_ctx *c, const ps_weight *w, float *rows_buf, int32_t *ids_buf, int rows_cap, _Float16 *out); // out [N][K]
 int psf16_gemm(ps_hip_ctx *c, psf16 *f, const _Float16 *W, int64_t N, int64_t K, const _Float16 *x, int bs, float *out, int64_t ldo, float beta);

@@ -472,7 +472,7 @@ def test_fp16_kv_decode_mode_is_close_to_parity(ctx, tmp_path, preset, wt, n_pro
 @pytest.mark.parametrize("preset,wt", [("small-llama-hs128", 12), ("small-llama-hs128", 1015), ("tiny-qwen2", 2), ("tiny-llama", 8)])
 def test_fp16_prefill_perf_mode_is_close_to_parity(ctx, oracle, tmp_path, preset, wt):
     """SURVEY 8 f4, second half: ps_hip_model_set_mode bit 5 -- the layer mat-muls of prefill batches as dense fp16 GEMMs on dequantized
-    fp16 copies of the weights (rocBLAS), fp32 accumulation; no activation quantizer, no per-block fp32 chains.  Deliberately NOT
+    fp16 copies of the weights (csrc/perf16.hip's own v_mfma_f32_32x32x16_f16 GEMM), fp32 accumulation; no activation quantizer, no per-block fp32 chains.  Deliberately NOT
     bit-exact; the tolerances are stated here:
       * layer 0's V cache against a float64 evaluation of the same model (dequantized weights, exact RMSNorm, no activation rounding at
         all) is within 2e-3 of the largest |entry| -- fp16 rounding of the operands -- where the parity path, which rounds the activations

@@ -31,8 +31,8 @@ for pad in (0, 16, 64):
     print(f"  planes of k-groups 2, 3 shifted by {pad:2d} B: consumer ds_read_b128 {rd} pass(es), producer ds_write_b128 {wr} pass(es)")
 
 print("batch attention operands (lane = (row rl = l & 15, k-group m = l >> 4), 8 reads of 16 B at 128 m + 16 q):")
-for name, fn in (("rows padded to 132 floats (today)", lambda l, q: (l & 15) * 528 + (l >> 4) * 128 + 16 * q),
-                 ("rows of 128 floats, 16-B column XOR (row & 7)", lambda l, q: (l & 15) * 512 + ((((l >> 4) * 8 + q) ^ (l & 7)) << 4))):
+for name, fn in (("rows padded to 132 floats (rounds 1-3)", lambda l, q: (l & 15) * 528 + (l >> 4) * 128 + 16 * q),
+                 ("rows of 128 floats, 16-B column XOR (row & 7) (round 4: what k_attn.hip uses)", lambda l, q: (l & 15) * 512 + ((((l >> 4) * 8 + q) ^ (l & 7)) << 4))):
     print(f"  {name}: ds_read_b128 {max(passes(lambda l, q=q: fn(l, q), RD, 64) for q in range(8))} pass(es)")
 park = lambda l, r0, swz: (r0 + (l >> 5)) * (512 if swz else 528) + ((((l & 31) ^ ((r0 + (l >> 5)) & 7)) if swz else (l & 31)) << 4)
 for swz in (False, True):
