@@ -222,7 +222,8 @@ int ps_hip_model_bench_matmul(ps_hip_model *m, int reps, int which, int bs, doub
 const char *ps_hip_last_matmul_kernel(void);
 int ps_hip_debug_timeline(ps_hip_ctx *ctx, int key, uint64_t *host_out, int n_words);
 /* Diagnostic: tunables of the library (process-wide).  key 1: wave configuration of the decode mat-vec (k_gemv4.hip,
- * tools/g4_variants.py).  Returns non-zero for an unknown key. */
+ * tools/g4_variants.py); key 3: the narrow-batch Q4_K mat-mul for few row tiles (k_gemm4k.hip: 0 = round 3's four waves walking K
+ * together, 4 / 8 = gemm4k_par_kernel with that many waves per tile, 1 = by tile count, the default).  Returns non-zero for an unknown key. */
 int ps_hip_debug_set(int key, int value);
 /* bit 0: 0 = hipGraph replay of the decode step (default), 1 = eager launches (rocprofv3 needs them);
  * bits 1, 2: unused (round 1 / 2 experiments, removed);

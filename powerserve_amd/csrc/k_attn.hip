@@ -931,9 +931,9 @@ __global__ __launch_bounds__(256) void attn_softmax_probs_wave_kernel(psl_attn_a
     for (int k = 0; k < SMW_MAXQ; k++) {
         if (k < nq) {
             const int j = (k * 64 + lane) * 4;
-            float e4[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
-            ps_v_expf_n<4>(e4, mx);
-            const float4 e = make_float4(e4[0], e4[1], e4[2], e4[3]);
+            float4 e; // (ps_v_expf_n here measured slower: 12.5 against 10.1 us per launch -- the row's registers, 136, cost a wave per SIMD)
+            e.x = ps_v_expf(__fsub_rn(v[k].x, mx)); e.y = ps_v_expf(__fsub_rn(v[k].y, mx));
+            e.z = ps_v_expf(__fsub_rn(v[k].z, mx)); e.w = ps_v_expf(__fsub_rn(v[k].w, mx));
             v[k] = e;
             // the neighbour's half of the group of 8 (quad_perm [1, 0, 3, 2])
             const float a0 = __fadd_rn(dpp_f<0xB1>(e.x), e.x), a1 = __fadd_rn(dpp_f<0xB1>(e.y), e.y);
@@ -1093,10 +1093,23 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_pv_mfma_lds_kernel(psl_attn_a
     ps_f32x4 res = (t3[0] + t3[1]) + (t3[2] + t3[3]);
     const float *pr = a.scores + ((int64_t)i * a.n_heads + (int64_t)kvh * r2 + g) * a.n_ctx;
     const float *vl = a.v_cache + ((int64_t)kvh * hs + d0 + 4 * m) * a.n_ctx;
-    for (int jj = np; jj < n_kv; jj++) { // leftovers: sumf += x[j] * y[j], in order
-        const float pj = pr[jj];
+    // leftovers: sumf += x[j] * y[j], in order.  Eight positions' operands are requested before the first one is used (clamped addresses): one at
+    // a time every leftover was a memory round trip of its own, up to 31 in a row at the end of every launch
+    for (int j0 = np; j0 < n_kv; j0 += 8) {
+        float pj[8], vv[8][4];
 #pragma unroll
-        for (int r = 0; r < 4; r++) res[r] = __fadd_rn(res[r], __fmul_rn(vl[(int64_t)r * a.n_ctx + jj], pj));
+        for (int k = 0; k < 8; k++) {
+            const int jj = j0 + k < n_kv ? j0 + k : n_kv - 1;
+            pj[k] = pr[jj];
+#pragma unroll
+            for (int r = 0; r < 4; r++) vv[k][r] = vl[(int64_t)r * a.n_ctx + jj];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            if (j0 + k < n_kv) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) res[r] = __fadd_rn(res[r], __fmul_rn(vv[k][r], pj[k]));
+            }
     }
     if ((int)blockIdx.x * 16 + rl < N)
         *(float4 *)(a.att + (int64_t)i * dim + ((int64_t)kvh * r2 + g) * hs + d0 + 4 * m) = make_float4(res[0], res[1], res[2], res[3]);
@@ -1393,7 +1406,20 @@ bool psl_attn_decode2(hipStream_t st, int n_cu, const psl_attn_args &a) {
         (void)hipFuncSetAttribute((const void *)attn_decode2_kernel<2, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
     }
     const dim3 g((unsigned)(gx * a.n_kv_heads));
-    // (512-thread workgroups — template parameter NT — measured slower: 14.05 vs 13.66 us, the soft-max numerators are issue-bound)
+    // 512-thread workgroups (template parameter NT): a kernel boundary behind them costs ~1.5 us less than behind 1024-thread ones.  Round 3 measured them
+    // slower in total (14.05 vs 13.66 us: twice the soft-max numerators per lane, issue-bound); with ps_v_expf_n they win: 8B decode 534.9 -> 542.8 tok/s
+    // (profiles/r04_gemv_variants.txt).  PS_ATTN_NT=1024 brings the round-3 geometry back for an A/B run.
+    static const int nt_env = getenv("PS_ATTN_NT") ? atoi(getenv("PS_ATTN_NT")) : 512;
+    static unsigned long long attr5 = 0;
+    if (ps_first_on_device(&attr5)) {
+        (void)hipFuncSetAttribute((const void *)attn_decode2_kernel<4, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+        (void)hipFuncSetAttribute((const void *)attn_decode2_kernel<2, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+    }
+    if (nt_env == 512) {
+        if (a.head_size == 128) hipLaunchKernelGGL((attn_decode2_kernel<4, 512>), g, dim3(512), lds, st, a);
+        else hipLaunchKernelGGL((attn_decode2_kernel<2, 512>), g, dim3(512), lds, st, a);
+        return true;
+    }
     if (a.head_size == 128) hipLaunchKernelGGL((attn_decode2_kernel<4, 1024>), g, dim3(1024), lds, st, a);
     else hipLaunchKernelGGL((attn_decode2_kernel<2, 1024>), g, dim3(1024), lds, st, a);
     return true;

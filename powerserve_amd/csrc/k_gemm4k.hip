@@ -949,6 +949,7 @@ __global__ __launch_bounds__((G4K_NC + G4K_NP) * 64) void gemm6k_kernel(const G6
 
 } // namespace
 
+int g_g4k_par = getenv("PS_GEMM4K_PAR") ? atoi(getenv("PS_GEMM4K_PAR")) : 1; // ps_hip_debug_set(3, v): the few-tile narrow-batch form (gemm4k_par_kernel)
 // grid, persistence and the wide / narrow choice for a filled-in G4KParams (tasks, pointers, wt)
 // ---- narrow batches, wave-autonomous form (round 3): at most 16 columns, Q4_K.  The producer / consumer kernels above pay a
 // fixed ~0.45 us per super-block step (barriers, LDS round trips) whatever the width, and a K walk is sequential: 12 columns cost
@@ -1303,6 +1304,232 @@ __global__ __launch_bounds__(256) void gemm4k_wav4_kernel(const G4KParams p) {
     }
 }
 
+// (a & mask) | magic as ONE instruction: two constants are two scalar operands, which a VOP3 instruction cannot read, so hipcc emits v_and + v_or;
+// with the magic in a vector register it is v_and_or_b32
+__device__ __forceinline__ uint32_t g4k_and_or(const uint32_t a, const uint32_t mask, const uint32_t magic_v) {
+    uint32_t r;
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(mask), "v"(magic_v));
+    return r;
+}
+// ---- narrow batches, few tiles, round 4: the K walk taken OFF the waves.  Both forms above walk a tile's super-blocks in order -- a
+// step is ~0.43 us of one wave's instruction issue and barriers whatever was tried, 56 of them for the down projection (31 us, 1.1 TB/s).
+// But the reference's order only binds the fp32 chains acc[u] = fma(d * yd, (float)sumi[u], acc[u]): the integer sums are exact in any
+// order.  So the NWV waves of a workgroup take the super-blocks of a ROUND (sb = round * NWV + wave) side by side -- each one wave's
+// work of gemm4k_wav_kernel for its super-block: all eight accumulator lanes and the four mins lanes through the matrix cores -- and
+// park the sums with d * yd, -dmin * yd in LDS; after one barrier every wave runs the chains IT owns over the round's super-blocks
+// in order (NWV = 8: accumulator lane u = wave and half a mins lane; NWV = 4: two lanes and a mins lane, gemm4k_wav4_kernel's split).
+// 6 / 12 chains x NWV fmas per wave and round against ~250 instructions of operand building: the walk is now parallel over waves.
+template <int NWV>
+__global__ __launch_bounds__(NWV * 64) void gemm4k_par_kernel(const G4KParams p) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t par_lds[];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int m = lane & 15, kb = lane >> 4;
+    float4 *const S = (float4 *)par_lds;  // [slot][u][lane]: (float)sumi[u] of rows 4 kb + r
+    float4 *const M = S + NWV * 8 * 64;   // [slot][v][lane]: the mins products
+    float4 *const D = M + NWV * 4 * 64;   // [slot][2][lane]: d * yd, -dmin * yd of rows 4 kb + r
+    uint32_t *const trw = (uint32_t *)(D + NWV * 2 * 64) + wave * (16 * 36); // the wave's transposition buffer (gemm4k_wav_kernel)
+    unsigned long long *const dbg = (p.dbg && blockIdx.x < 1024 && lane == 0 && wave == 0) ? p.dbg + (size_t)blockIdx.x * 64 : nullptr; // timeline (tools/par_timeline.py)
+    int dbg_n = 1;
+    auto mark = [&]() { if (dbg && dbg_n < 29) dbg[dbg_n++] = __builtin_amdgcn_s_memtime(); };
+    if (dbg) { dbg[0] = __builtin_amdgcn_s_memtime(); dbg[29] = __builtin_amdgcn_s_memrealtime(); }
+    const int nsb = p.nsb;
+    int wi, pair;
+    const G4KRows R = g4k_rows<0>(p, (int)(blockIdx.x >> 1), wi, pair);
+    const G4KMat &W = wi == 0 ? p.w[0] : (wi == 1 ? p.w[1] : p.w[2]);
+    const int tt = (int)(blockIdx.x & 1), tile = tt ? R.tile[1] : R.tile[0];
+    const size_t g8 = (size_t)2 * tile + (m >> 3);
+    const uint8_t *qb = R.qs[0] + ((size_t)2 * tile * nsb << 10) + (size_t)lane * 16;
+    const uint8_t *hb = R.aux[0] + g8 * nsb * 128 + (size_t)(m & 7) * 16;
+    const int col = m, colc = col < p.bs ? col : p.bs - 1;
+    const char *qfp = (const char *)p.qf + lane * 16;
+    const uint8_t *ydp = p.mf + colc * 4, *b16p = p.mf + 64 + colc * 32;
+
+    // The wave's super-blocks of the next RA rounds (HBM), its B fragments one round ahead and the 16-sums two (L2).  Loads retire in
+    // order: the far weight loads are the LAST thing a round issues, behind the fragment loads the next round waits for -- issued before
+    // them they put a full memory latency in front of every round (RA = 2, weights first: 2.6 us per round, down 18 us).
+    constexpr int RA = 4;
+    ps_u32x4 rq[RA][2], rh[RA], rb[8], rs[2][2];
+    float ryd[2];
+    auto clampsb = [&](const int sb) { return sb < nsb ? sb : nsb - 1; };
+    auto load_a = [&](const int s, const int sbx) {
+        const int sb = clampsb(sbx);
+        rq[s][0] = __builtin_nontemporal_load((const ps_u32x4 *)(qb + ((size_t)sb << 10)));
+        rq[s][1] = __builtin_nontemporal_load((const ps_u32x4 *)(qb + ((size_t)(nsb + sb) << 10)));
+        rh[s] = *(const ps_u32x4 *)(hb + (size_t)sb * 128);
+    };
+    auto load_m = [&](const int s, const int sbx) {
+        const int sb = clampsb(sbx);
+        ryd[s]   = *(const float *)(ydp + (size_t)sb * 576);
+        rs[s][0] = *(const ps_u32x4 *)(b16p + (size_t)sb * 576);
+        rs[s][1] = *(const ps_u32x4 *)(b16p + (size_t)sb * 576 + 16);
+    };
+#pragma unroll
+    for (int s = 0; s < RA - 1; s++) load_a(s, wave + s * NWV);
+    load_m(0, wave); load_m(1, wave + NWV);
+#pragma unroll
+    for (int u = 0; u < 8; u++) rb[u] = *(const ps_u32x4 *)(qfp + ((size_t)clampsb(wave) << 13) + u * 1024);
+    load_a(RA - 1, wave + (RA - 1) * NWV); // (as a round leaves it: the farthest weights last)
+
+    constexpr int UPW = 8 / NWV;              // accumulator lanes a wave chains
+    constexpr int MR = NWV == 8 ? 2 : 4;      // rows of its mins lane
+    const int mv = NWV == 8 ? wave >> 1 : wave, mr0 = NWV == 8 ? 2 * (wave & 1) : 0;
+    float acc[UPW][4], accm[MR];
+#pragma unroll
+    for (int j = 0; j < UPW; j++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) acc[j][r] = 0.f;
+#pragma unroll
+    for (int r = 0; r < MR; r++) accm[r] = 0.f;
+    const g4k_f4 zf = {0.f, 0.f, 0.f, 0.f};
+    const g4k_h2 k1024 = {(_Float16)1024.f, (_Float16)1024.f}, km1024 = {(_Float16)-1024.f, (_Float16)-1024.f}, k16th = {(_Float16)0.0625f, (_Float16)0.0625f};
+    uint32_t magic = 0x64006400u;
+    asm volatile("" : "+v"(magic)); // (a vector register: see g4k_and_or)
+    const uint32_t sel0 = 0x04000400u | ((uint32_t)(2 * (kb & 1)) * 0x00010001u), sel1 = sel0 + 0x00010001u;
+    uint32_t msel[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) msel[e] = kb == 0 ? 0x04000400u | (uint32_t)(e * 0x00010001u) : 0x040C040Cu;
+    const int n_rounds = (nsb + NWV - 1) / NWV;
+#pragma clang loop unroll(disable)
+    for (int rd0 = 0; rd0 < n_rounds; rd0 += RA) {
+#pragma unroll
+        for (int s = 0; s < RA; s++) {
+            const int rd = rd0 + s;
+            if (rd >= n_rounds) break; // (workgroup-uniform)
+            const int sb = rd * NWV + wave; // (past the end in a ragged last round: the wave works on the last super-block again, nobody chains its slot)
+            {
+                const float yd = ryd[s & 1];
+                const ps_u32x4 h = rh[s];
+                const uint32_t scb = (kb & 2) ? ((h.w & 0x0f0f0f0fu) | (((h.y >> 6) & 0x03030303u) << 4)) : (h.y & 0x3f3f3f3fu);
+                const uint32_t t0 = __builtin_amdgcn_perm(0x64646464u, scb, sel0), t1 = __builtin_amdgcn_perm(0x64646464u, scb, sel1);
+                g4k_h2 s0, s1;
+                __builtin_memcpy(&s0, &t0, 4); __builtin_memcpy(&s1, &t1, 4);
+                // the high nibbles stay where they are (bits 4..7 of each half: fp16 1024 + 16 n) and meet s / 16: (1024 + 16 n) s / 16 - 64 s = n s, exact
+                s0 = s0 - k1024; s1 = (s1 - k1024) * k16th;
+                const g4k_h2 n0 = s0 * km1024, n1 = s1 * km1024;
+                float dr[4], dmn[4];
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const uint32_t hx = (uint32_t)__shfl((int)h.x, 4 * kb + r, 64);
+                    dr[r]  = __fmul_rn(yd, ps_h2f((uint16_t)(hx & 0xffff)));
+                    dmn[r] = __fmul_rn(-yd, ps_h2f((uint16_t)(hx >> 16)));
+                }
+                D[(wave * 2 + 0) * 64 + lane] = make_float4(dr[0], dr[1], dr[2], dr[3]);
+                D[(wave * 2 + 1) * 64 + lane] = make_float4(dmn[0], dmn[1], dmn[2], dmn[3]);
+                mark(); // 1: weights landed, header decoded
+                *(ps_u32x4 *)(trw + (lane >> 3) * 36 + (lane & 7) * 4) = rq[s][0];
+                *(ps_u32x4 *)(trw + (8 + (lane >> 3)) * 36 + (lane & 7) * 4) = rq[s][1];
+                uint32_t wq[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) wq[u] = trw[m * 36 + u * 4 + kb];
+                if (dbg) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); mark(); } // 2: transposed
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const uint32_t w = wq[u];
+                    const uint32_t w8 = w >> 8;
+                    const uint32_t tq[4] = {g4k_and_or(w, 0x000F000Fu, magic), g4k_and_or(w8, 0x000F000Fu, magic),
+                                            g4k_and_or(w, 0x00F000F0u, magic), g4k_and_or(w8, 0x00F000F0u, magic)};
+                    uint32_t o[4];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        g4k_h2 v;
+                        __builtin_memcpy(&v, &tq[k], 4);
+                        v = __builtin_elementwise_fma(v, k < 2 ? s0 : s1, k < 2 ? n0 : n1);
+                        __builtin_memcpy(&o[k], &v, 4);
+                    }
+                    const ps_u32x4 ao = {o[0], o[1], o[2], o[3]};
+                    g4k_h8 av, bv;
+                    __builtin_memcpy(&av, &ao, 16); __builtin_memcpy(&bv, &rb[u], 16);
+                    const g4k_f4 si = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bv, zf, 0, 0, 0);
+                    rb[u] = *(const ps_u32x4 *)(qfp + ((size_t)clampsb(sb + NWV) << 13) + u * 1024);
+                    S[(wave * 8 + u) * 64 + lane] = make_float4(si[0], si[1], si[2], si[3]);
+                }
+                mark(); // 3: accumulator lanes
+                {
+                    const uint32_t mn[2] = {h.z & 0x3f3f3f3fu, ((h.w >> 4) & 0x0f0f0f0fu) | (((h.z >> 6) & 0x03030303u) << 4)};
+                    const uint32_t bw[8] = {rs[s & 1][0].x, rs[s & 1][0].y, rs[s & 1][0].z, rs[s & 1][0].w, rs[s & 1][1].x, rs[s & 1][1].y, rs[s & 1][1].z, rs[s & 1][1].w};
+#pragma unroll
+                    for (int v = 0; v < 4; v++) {
+                        // (k-groups 1..3 select the constant byte 0x00 instead of the min: fp16 1024, i.e. a zero operand, without a select)
+                        const uint32_t p0 = __builtin_amdgcn_perm(0x64646464u, mn[v >> 1], msel[(2 * v) & 3]);
+                        const uint32_t p1 = __builtin_amdgcn_perm(0x64646464u, mn[v >> 1], msel[((2 * v) & 3) + 1]);
+                        g4k_h2 h0, h1;
+                        __builtin_memcpy(&h0, &p0, 4); __builtin_memcpy(&h1, &p1, 4);
+                        h0 = h0 - k1024; h1 = h1 - k1024;
+                        const g4k_h4 am = {h0[0], h0[1], h1[0], h1[1]};
+                        g4k_h4 bm;
+                        { const ps_u32x2 b2 = {bw[2 * v], bw[2 * v + 1]}; __builtin_memcpy(&bm, &b2, 8); }
+                        const g4k_f4 pr = __builtin_amdgcn_mfma_f32_16x16x16f16(am, bm, zf, 0, 0, 0);
+                        M[(wave * 4 + v) * 64 + lane] = make_float4(pr[0], pr[1], pr[2], pr[3]);
+                    }
+                }
+                load_m(s & 1, sb + 2 * NWV);
+                // (hipcc puts s_waitcnt vmcnt(0) in front of the first round of the unrolled body: nothing far may be outstanding there, so
+                //  the last slot's next load goes out a round later, with slot 0's)
+                if (s == 0) load_a(RA - 1, sb + (RA - 1) * NWV);
+                if (s != RA - 1) load_a(s, sb + RA * NWV);
+            }
+            mark(); // 4: mins lanes
+            __syncthreads();
+            mark(); // 5: barrier
+            // ---- the chains this wave owns, over the round's super-blocks in order
+            const int cnt = nsb - rd * NWV < NWV ? nsb - rd * NWV : NWV;
+            // (requesting the operands of several super-blocks ahead of the first chain step does not help: the phase is bound by LDS bandwidth --
+            //  every wave reads d * yd again, 192 KB per round of eight -- not by round trips: 0.55 -> 0.60 us, profiles/r04_par_timeline.txt)
+#pragma unroll
+            for (int q = 0; q < NWV; q++) {
+                if (q < cnt) {
+                    const float4 d4 = D[(q * 2 + 0) * 64 + lane];
+                    const float dq[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+                    for (int j = 0; j < UPW; j++) {
+                        const float4 s4 = S[(q * 8 + wave * UPW + j) * 64 + lane];
+                        const float sq[4] = {s4.x, s4.y, s4.z, s4.w};
+#pragma unroll
+                        for (int r = 0; r < 4; r++) acc[j][r] = __fmaf_rn(dq[r], sq[r], acc[j][r]);
+                    }
+                    const float *mp = (const float *)&M[(q * 4 + mv) * 64 + lane] + mr0, *mdp = (const float *)&D[(q * 2 + 1) * 64 + lane] + mr0;
+#pragma unroll
+                    for (int r = 0; r < MR; r++) accm[r] = __fmaf_rn(mdp[r], mp[r], accm[r]);
+                }
+            }
+            mark(); // 6: chains
+            __syncthreads();
+            mark(); // 7: barrier
+        }
+    }
+    // ---- the waves meet (the slots are free behind the last barrier): waves 0 and 1 finish rows 4 kb + 2 wave, + 1 in hsum_float_8's order
+#pragma unroll
+    for (int j = 0; j < UPW; j++) S[(wave * UPW + j) * 64 + lane] = make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
+#pragma unroll
+    for (int r = 0; r < MR; r++) ((float *)&M[mv * 64 + lane])[mr0 + r] = accm[r];
+    __syncthreads();
+    if (wave < 2 && col < p.bs) {
+        float v[2];
+#pragma unroll
+        for (int rr = 0; rr < 2; rr++) {
+            const int r = 2 * wave + rr;
+            float au[8], mq[4];
+#pragma unroll
+            for (int u = 0; u < 8; u++) au[u] = ((const float *)&S[u * 64 + lane])[r];
+#pragma unroll
+            for (int q = 0; q < 4; q++) mq[q] = ((const float *)&M[q * 64 + lane])[r];
+            const float s0 = __fadd_rn(au[0], au[4]), s1 = __fadd_rn(au[1], au[5]), s2 = __fadd_rn(au[2], au[6]), s3 = __fadd_rn(au[3], au[7]);
+            const float res = __fadd_rn(__fadd_rn(s0, s2), __fadd_rn(s1, s3));
+            const float mm = __fadd_rn(__fadd_rn(mq[0], mq[2]), __fadd_rn(mq[1], mq[3]));
+            v[rr] = __fadd_rn(res, mm);
+        }
+        const int64_t row0 = (int64_t)tile * 16 + kb * 4 + 2 * wave;
+#pragma unroll
+        for (int rr = 0; rr < 2; rr++) {
+            if (W.bias) v[rr] = __fadd_rn(v[rr], W.bias[row0 + rr]);
+            if (p.residual && wi == 0) v[rr] = __fadd_rn(p.residual[(int64_t)col * W.ldo + row0 + rr], v[rr]);
+        }
+        g4k_store_pair<2>(p, wi, W, col, row0, v[0], v[1]);
+    }
+    if (dbg) { dbg[31] = __builtin_amdgcn_s_memtime(); dbg[30] = __builtin_amdgcn_s_memrealtime(); }
+}
+constexpr int g4k_par_lds(const int nwv) { return nwv * ((8 + 4 + 2) * 64 * 16 + 16 * 36 * 4); }
+
 template <int EPI, int RA, int MB>
 static void g4k_launch_wav(hipStream_t st, const G4KParams &p) {
     const unsigned grid = (unsigned)(EPI == 1 ? p.n_tasks : 2 * p.n_tasks);
@@ -1325,6 +1552,7 @@ static int g4k_launch(hipStream_t st, int n_cu, G4KParams &p, const int epi, con
     if (bs < ps_gemm4k_min_cols() || p.nsb % 4) return -1;
     static const bool no_wav = getenv("PS_NO_GEMM4K_WAV") != nullptr;                                     // (A/B switches for measurements)
     static const int wav_cfg = getenv("PS_GEMM4K_WAV_CFG") ? atoi(getenv("PS_GEMM4K_WAV_CFG")) : 0;
+    const int par_cfg = g_g4k_par; // 0: off, 4 / 8: that many waves per tile, else by tile count
     const int ctw = n_ct <= 1 ? 1 : 4; // column tiles per workgroup: the narrow kernel for at most 16 columns (its two-tile form, CT = 2, spills: 13.7 ms per 8B forward against 5.9 ms, not instantiated)
     p.n_cb = (n_ct + ctw - 1) / ctw;
     p.n_items = (p.n_tasks + 7) / 8 * 8 * p.n_cb;
@@ -1348,6 +1576,17 @@ static int g4k_launch(hipStream_t st, int n_cu, G4KParams &p, const int epi, con
         if (epi != 0) return -1;
         if (ctw == 1) { psk_note_kernel("gemm4k_narrow_kernel<0, 1, 13>"); hipLaunchKernelGGL((gemm4k_narrow_kernel<0, 1, PS_Q5_K>), grid, blkn, LDS1, st, p); }
         else { psk_note_kernel("gemm4k_kernel<0, 13>"); hipLaunchKernelGGL((gemm4k_kernel<0, PS_Q5_K>), grid, blk, G4K_LDS, st, p); }
+    } else if (ctw == 1 && n_ct == 1 && !no_wav && epi != 1 && par_cfg != 0 && !(2 * p.n_tasks >= 4 * n_cu || wav_cfg == 1)) {
+        // at most 16 columns, few row tiles (Q / K / V, O, down of a tree batch): the super-blocks of a round side by side, the chains behind them
+        // (any nsb).  8B, 12 wide, us per launch, four waves walking K -> this: see profiles/r04_tree12_kernel_stats.txt
+        static unsigned long long attrp = 0;
+        if (ps_first_on_device(&attrp)) {
+            (void)hipFuncSetAttribute((const void *)gemm4k_par_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, g4k_par_lds(8));
+            (void)hipFuncSetAttribute((const void *)gemm4k_par_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, g4k_par_lds(4));
+        }
+        const int nwv = par_cfg == 4 || par_cfg == 8 ? par_cfg : (2 * p.n_tasks > n_cu ? 4 : 8); // more tiles than CUs: two workgroups of four waves per CU
+        if (nwv == 8) { psk_note_kernel("gemm4k_par_kernel<8>"); hipLaunchKernelGGL((gemm4k_par_kernel<8>), dim3((unsigned)(2 * p.n_tasks)), dim3(512), g4k_par_lds(8), st, p); }
+        else { psk_note_kernel("gemm4k_par_kernel<4>"); hipLaunchKernelGGL((gemm4k_par_kernel<4>), dim3((unsigned)(2 * p.n_tasks)), dim3(256), g4k_par_lds(4), st, p); }
     } else if (ctw == 1 && n_ct == 1 && !no_wav && p.nsb % 8 == 0) { // at most 16 columns: the wave-autonomous form
         // 8B tree forward 12 wide, us per launch, staged narrow kernel -> these (profiles/r03_tree12_kernel_stats*.txt): gate / up 39.6 -> 23.6,
         // Q / K / V and O 13 -> 11, down 31 -> 31, lm_head 151 -> 88; the forward 4.59 -> 3.68 ms.  Measured and not kept: the accumulator
@@ -1359,7 +1598,7 @@ static int g4k_launch(hipStream_t st, int n_cu, G4KParams &p, const int epi, con
         // wave that owns the HBM stream with an eight-deep fragment ring in the others (22.9 us).
         if (epi == 1) g4k_launch_wav<1, 2, 2>(st, p);
         else if (2 * p.n_tasks >= 4 * n_cu || wav_cfg == 1) g4k_launch_wav<0, 2, 2>(st, p); // many tiles (lm_head): a wave per tile, occupancy hides the latency
-        else { // few tiles: four waves per tile
+        else { // few tiles, PS_GEMM4K_PAR=0: round 3's four waves per tile walking K together
             psk_note_kernel("gemm4k_wav4_kernel<2>");
             hipLaunchKernelGGL((gemm4k_wav4_kernel<2>), dim3((unsigned)(2 * p.n_tasks)), dim3(256), 0, st, p);
         }

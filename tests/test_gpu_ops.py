@@ -122,6 +122,33 @@ def test_mul_mat_q4k_chunk_on_matrix_cores(ctx, oracle, hip, K, N, bs):
     W.free()
 
 
+@pytest.mark.parametrize("cfg,kernel", [(8, "gemm4k_par_kernel<8>"), (4, "gemm4k_par_kernel<4>"), (0, None)])
+@pytest.mark.parametrize("K,N,bs", [(14336, 64, 12), (4096, 96, 16), (2048, 32, 3), (1024, 64, 5), (3072, 32, 9), (11264, 32, 2)])
+def test_mul_mat_q4k_narrow_batch_few_tiles(ctx, oracle, hip, K, N, bs, cfg, kernel):
+    """At most 16 columns over few row tiles (the Q / K / V, O and down launches of a tree batch): gemm4k_par_kernel takes the super-blocks of a
+    round side by side through the matrix cores and runs the reference's fp32 chains behind them, in order -- with eight or four waves per
+    tile, whole and ragged rounds (K / 256 = 56, 16, 8, 4, 12, 44), an odd number of rounds; cfg 0 is round 3's kernel for the same launch."""
+    from powerserve_amd import synth
+    rng = np.random.default_rng(K + N + bs)
+    w = q4k_extreme_blocks(rng, N, K) if K == 4096 else synth.random_blocks(rng, 12, N, K)
+    x = (rng.standard_normal((bs, K)) * rng.uniform(0.1, 30.0, (bs, 1))).astype(np.float32)
+    x[bs - 1, 256:512] = 0.0
+    want = oracle.mul_mat(12, w, K, N, x)
+    W = ctx.upload_weight(12, w, K, N)
+    dx, dy = ctx.to_device(x), ctx.empty((bs, N))
+    assert ctx.L.ps_hip_debug_set(3, cfg) == 0
+    try:
+        for _ in range(2):
+            ctx.check(ctx.L.ps_hip_mul_mat(ctx.h, C.byref(dy.tensor()), C.byref(W.tensor()), C.byref(dx.tensor())))
+            if kernel:
+                assert ctx.L.ps_hip_last_matmul_kernel().decode() == kernel
+            got = dy.numpy()
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (rel_err(got, want), np.argwhere(got != want)[:8])
+    finally:
+        ctx.L.ps_hip_debug_set(3, 1)
+    W.free()
+
+
 def q4k_extreme_blocks(rng, N, K):
     """Random Q4_K rows with the corner cases the random generator never draws (synth.random_blocks: scales 8..63, mins tied to
     the scales) planted in every row: block_q4_K = d, dmin (fp16), scales[12] (6-bit scale / min pairs), qs[128]."""
