@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--no-kv-f16", action="store_true", help="skip the fp16-KV decode mode leg")
     ap.add_argument("--no-graph-path", action="store_true", help="skip the Graph -> Executor -> HIPBackend::plan leg (libps_host.so)")
     ap.add_argument("--graph-steps", type=int, default=96)
+    ap.add_argument("--f16-super-chunk", type=int, default=2048, help="side leg (fp16 perf mode): tokens per mat-mul launch")
     ap.add_argument("--wide-chunk", type=int, default=512, help="side leg: prefill in chunks of this many tokens (0: skip)")
     ap.add_argument("--super-chunks", type=int, default=4, help="reference-sized prefill chunks (--batch tokens each) per launch sequence "
                     "(ps_hip_model_prefill: same bits as chunk-by-chunk forwards; 1: one forward per chunk)")
@@ -229,11 +230,17 @@ def prefill_wide_leg(ctx, model_dir, args, prompt):
     return {"chunk": args.wide_chunk, "prefill_tokens_per_s": res[0], "prefill_tokens_per_s_warm": res[1]}
 
 
-def fp16_prefill_leg(ctx, model, args, prompt, ids_parity):
+def fp16_prefill_leg(ctx, model, args, prompt, ids_parity, model_dir):
     """SURVEY 8 f4 (second half), reported next to the headline and never mixed into it: the same prefill with the fp16 perf mode on
     (ps_hip_model_set_mode bit 5: the layer mat-muls as dense fp16 GEMMs on dequantized fp16 copies of the weights, csrc/perf16.hip's own
     kernel; RoPE, KV append and attention stay the parity kernels on the FP32 cache).  NOT bit-exact: layer 0's K / V rows are compared with the
-    parity run's."""
+    parity run's.  The mode's mat-muls take --f16-super-chunk tokens per launch (a model of its own with that max_batch: the GEMM tiles are
+    256 tokens wide and the matrices of 4096 rows need ~2048 tokens to give every CU a workgroup); the attention inside still runs chunk by
+    chunk of --batch tokens."""
+    own = None
+    if args.f16_super_chunk > model.max_batch:
+        from powerserve_amd import hip
+        own = model = hip.Model(ctx, model_dir, max_batch=args.f16_super_chunk, n_ctx=args.n_ctx)
     model.reset()
     model.set_mode((1 if args.eager else 0) | 32)
     model.prefill(prompt[:8], args.batch)  # first use: dequantizes the weights (not timed)
@@ -255,9 +262,13 @@ def fp16_prefill_leg(ctx, model, args, prompt, ids_parity):
     model.prefill(prompt[:-1], args.batch)
     k32, v32 = model.k_cache(0)[:n], model.v_cache(0)[:, :n]
     rel = lambda a, b: float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
-    return {"prefill_tokens_per_s": res[0], "prefill_tokens_per_s_warm": res[1],
-            "layer0_k_cache_max_abs_err_over_max_abs_vs_parity": rel(k16, k32), "layer0_v_cache_max_abs_err_over_max_abs_vs_parity": rel(v16, v32),
-            "gemm": "own kernel (csrc/perf16.hip: v_mfma_f32_32x32x16_f16, LDS double-buffered); no library",
+    errs = (rel(k16, k32), rel(v16, v32))
+    tokens_per_launch = min(model.max_batch // max(args.batch, 1) * max(args.batch, 1), prompt.size - 1)
+    if own is not None:
+        own.close()
+    return {"prefill_tokens_per_s": res[0], "prefill_tokens_per_s_warm": res[1], "tokens_per_mat_mul_launch": int(tokens_per_launch),
+            "layer0_k_cache_max_abs_err_over_max_abs_vs_parity": errs[0], "layer0_v_cache_max_abs_err_over_max_abs_vs_parity": errs[1],
+            "gemm": "own kernels (csrc/perf16.hip: v_mfma_f32_32x32x16_f16; 256-token tiles on the LDS-DMA path, 128-token tiles through registers for small grids); no library",
             "note": "layer mat-muls of the prefill as dense fp16 GEMMs (fp32 accumulation) on dequantized weights; decode stays on the parity kernels; not bit-exact by design "
                     "(the parity path itself rounds activations to int8: its layer-0 V sits 4-5e-3 from a float64 evaluation, this mode 3e-4 -- tests/test_gpu_model.py)"}
 
@@ -482,7 +493,7 @@ def main():
             except Exception as e:  # noqa: BLE001 — a failing side leg must not take the headline line with it
                 out["fp16_kv_mode"] = {"error": repr(e)}
             try:
-                out["fp16_prefill_mode"] = fp16_prefill_leg(ctx, model, args, prompt, np.concatenate([ids_w, ids]))
+                out["fp16_prefill_mode"] = fp16_prefill_leg(ctx, model, args, prompt, np.concatenate([ids_w, ids]), model_dir)
             except Exception as e:  # noqa: BLE001
                 out["fp16_prefill_mode"] = {"error": repr(e)}
         if args.wide_chunk > args.batch and dist is None:

@@ -223,8 +223,13 @@ const char *ps_hip_last_matmul_kernel(void);
 int ps_hip_debug_timeline(ps_hip_ctx *ctx, int key, uint64_t *host_out, int n_words);
 /* Diagnostic: tunables of the library (process-wide).  key 1: wave configuration of the decode mat-vec (k_gemv4.hip,
  * tools/g4_variants.py); key 3: the narrow-batch Q4_K mat-mul for few row tiles (k_gemm4k.hip: 0 = round 3's four waves walking K
- * together, 4 / 8 = gemm4k_par_kernel with that many waves per tile, 1 = by tile count, the default).  Returns non-zero for an unknown key. */
+ * together, 4 / 8 = gemm4k_par_kernel with that many waves per tile, 1 = by tile count, the default); key 4: the fp16 perf mode's GEMM (perf16.hip:
+ * 0 = by shape, 1 = 128-token tiles, 2 = 256 x 256 tiles).  Returns non-zero for an unknown key. */
 int ps_hip_debug_set(int key, int value);
+/* Diagnostic: one GEMM shape of the fp16 perf mode on synthetic operands (tools/f16_gemm_bench.py): out[M][N] = x[M][K] . W[N][K]^T, timed over
+ * `reps` launches (with beta: out = beta out + ...), max |difference| to a k-ordered fp32 reference (beta != 0: of a second launch on top of
+ * the first result against (1 + beta) x the reference). */
+int ps_hip_debug_f16_gemm(ps_hip_ctx *ctx, int M, int64_t N, int64_t K, int reps, float beta, double *us_per_launch, double *max_abs_err);
 /* bit 0: 0 = hipGraph replay of the decode step (default), 1 = eager launches (rocprofv3 needs them);
  * bits 1, 2: unused (round 1 / 2 experiments, removed);
  * bit 3: 1 = fp16-KV decode mode — NOT bit-exact: K and V are mirrored in fp16 as they are appended and the

@@ -30,7 +30,7 @@ EXPORTS = [
     "ps_hip_get_embedding", "ps_hip_get_mask", "ps_hip_argmax", "ps_hip_model_create", "ps_hip_model_destroy",
     "ps_hip_model_kv_position", "ps_hip_model_max_batch", "ps_hip_model_kv_truncate", "ps_hip_model_kv_advance", "ps_hip_model_kv_rollback", "ps_hip_model_kv_move",
     "ps_hip_model_forward", "ps_hip_model_decode_greedy", "ps_hip_model_logits", "ps_hip_model_scratch", "ps_hip_model_k_cache",
-    "ps_hip_model_v_cache", "ps_hip_model_weight_bytes_per_token", "ps_hip_model_set_mode", "ps_hip_model_bench_gemv", "ps_hip_model_bench_matmul", "ps_hip_debug_timeline", "ps_hip_last_matmul_kernel", "ps_hip_debug_set", "ps_hip_model_forward_tree", "ps_hip_model_prefill", "ps_hip_model_forward_lowered", "ps_hip_model_sync_check", "ps_hip_model_kv_mask",
+    "ps_hip_model_v_cache", "ps_hip_model_weight_bytes_per_token", "ps_hip_model_set_mode", "ps_hip_model_bench_gemv", "ps_hip_model_bench_matmul", "ps_hip_debug_timeline", "ps_hip_last_matmul_kernel", "ps_hip_debug_set", "ps_hip_debug_f16_gemm", "ps_hip_model_forward_tree", "ps_hip_model_prefill", "ps_hip_model_forward_lowered", "ps_hip_model_sync_check", "ps_hip_model_kv_mask",
 ]
 
 
@@ -118,6 +118,7 @@ def lib() -> C.CDLL:
         "ps_hip_debug_timeline": (i32, [vp, i32, vp, i32]),
         "ps_hip_last_matmul_kernel": (C.c_char_p, []),
         "ps_hip_debug_set": (i32, [i32, i32]),
+        "ps_hip_debug_f16_gemm": (i32, [vp, i32, C.c_int64, C.c_int64, i32, C.c_float, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)

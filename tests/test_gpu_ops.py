@@ -383,3 +383,18 @@ def test_errors_are_reported_not_thrown(ctx, hip):
     bad = a.tensor(ne=[32, 4, 1, 1])
     rc = ctx.L.ps_hip_mul_mat(ctx.h, C.byref(t), C.byref(t), C.byref(bad))
     assert rc != 0 and b"mul_mat" in ctx.L.ps_hip_last_error(ctx.h)
+
+
+@pytest.mark.parametrize("variant", [1, 2, 3])
+@pytest.mark.parametrize("M,N,K,beta", [(300, 512, 256, 0.0), (256, 768, 1024, 1.0), (1, 256, 64, 0.0), (700, 256, 4096, 1.0)])
+def test_f16_perf_gemm_variants(ctx, hip, variant, M, N, K, beta):
+    """The fp16 perf mode's GEMMs (csrc/perf16.hip; NOT part of the parity path): 128-token tiles through registers (1), 256 tokens x 256 / 128 weight
+    rows on the LDS-DMA path (2 / 3) against a k-ordered fp32 reference on synthetic operands in [-1, 1): a ragged last token tile, a single token,
+    one k block, the residual form (beta = 1).  The tolerance is the fp32 summation-order difference over K products of magnitude <= 1."""
+    assert ctx.L.ps_hip_debug_set(4, variant) == 0
+    try:
+        us, err = C.c_double(), C.c_double()
+        ctx.check(ctx.L.ps_hip_debug_f16_gemm(ctx.h, M, N, K, 1, beta, C.byref(us), C.byref(err)))
+        assert err.value <= 2e-6 * K * (1.0 + beta) + 1e-5, (variant, M, N, K, beta, err.value)
+    finally:
+        ctx.L.ps_hip_debug_set(4, 0)
