@@ -26,10 +26,14 @@ namespace {
 __device__ __forceinline__ float coh_load_f(const float *p) { return __uint_as_float(__hip_atomic_load((const uint32_t *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
 __device__ __forceinline__ void coh_store_f(float *p, float v) { __hip_atomic_store((uint32_t *)p, __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+// (pos0, bs) of the forward: from the launch arguments when the host knew them at enqueue time (eager batches), else from the device-resident state
+__device__ __forceinline__ int att_pos0(const psl_attn_args &a) { return a.bs_host > 0 ? a.n_kv_host - a.bs_host : a.state->pos0; }
+__device__ __forceinline__ int att_bs(const psl_attn_args &a) { return a.bs_host > 0 ? a.bs_host : a.state->bs; }
+
 // ---------------------------------------------------------------- rope + KV append
 __global__ void rope_append_kernel(psl_attn_args a, int bs) {
     const int hs = a.head_size, dim = a.n_heads * hs, kvd = a.n_kv_heads * hs, half = a.n_dims / 2;
-    const int pos0 = a.state->pos0;
+    const int pos0 = att_pos0(a);
     const int64_t nq = (int64_t)bs * a.n_heads * (hs / 2), nk = (int64_t)bs * a.n_kv_heads * (hs / 2), nv = (int64_t)bs * kvd;
     for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < nq + nk + nv; o += (int64_t)gridDim.x * blockDim.x) {
         if (o < nq + nk) {
@@ -71,7 +75,7 @@ __global__ __launch_bounds__(256) void attn_scores_kernel(psl_attn_args a) {
     const int hs = NV * 32, dim = a.n_heads * hs, kvd = a.n_kv_heads * hs, r2 = a.n_heads / a.n_kv_heads;
     const int c = threadIdx.x & 31, hw = threadIdx.x >> 5;
     const int kvh = blockIdx.y, i = blockIdx.z;
-    const int n_kv = a.state->pos0 + a.state->bs;
+    const int n_kv = att_pos0(a) + att_bs(a);
     const int j0 = blockIdx.x * 32;
     if (j0 >= n_kv) return;
     const int wg = blockIdx.y * gridDim.x + blockIdx.x; // timeline (tools/gpu_attn_timeline.py, key 40)
@@ -136,7 +140,7 @@ __global__ __launch_bounds__(256, 2) void attn_scores_mfma_kernel(psl_attn_args 
     auto swz = [](int row, int seg) { return row * RS + ((seg ^ (row & 7)) << 2); }; // float index of 16-byte column `seg` of row `row`
     const int dim = a.n_heads * hs, kvd = a.n_kv_heads * hs, r2 = a.n_heads / a.n_kv_heads;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int kvh = blockIdx.y, bs = a.state->bs, n_kv = a.state->pos0 + bs;
+    const int kvh = blockIdx.y, bs = att_bs(a), n_kv = att_pos0(a) + bs;
     if ((int)blockIdx.x * 64 >= n_kv) return; // (the whole workgroup)
     const int j0 = ((int)blockIdx.x * 4 + wave) * 16;
     const bool live = j0 < n_kv; // (a wave past the end still helps fetching q and keeps the barriers)
@@ -352,7 +356,7 @@ __global__ __launch_bounds__(PV_NT) void attn_softmax_pv_kernel(psl_attn_args a)
     extern __shared__ __attribute__((aligned(16))) float pl[]; // [r2][n_ctx4] e_j, then [4][PV_VSTR] V tile
     const int hs = a.head_size, dim = a.n_heads * hs, r2 = a.n_heads / a.n_kv_heads;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int kvh = blockIdx.y, i = blockIdx.z, bs = a.state->bs, pos0 = a.state->pos0;
+    const int kvh = blockIdx.y, i = blockIdx.z, bs = att_bs(a), pos0 = att_pos0(a);
     const int n_kv = pos0 + bs, n8 = n_kv & ~7, np = n_kv & ~31, n_kv4 = (n_kv + 3) & ~3;
     float *vt = pl + (size_t)r2 * (((size_t)a.n_ctx + 3) & ~(size_t)3);
     __shared__ float redf[R2MAX][PV_NW];
@@ -802,7 +806,7 @@ template <int CI>
 __global__ __launch_bounds__(PV_NT) void attn_softmax_pv_cols_kernel(psl_attn_args a) {
     extern __shared__ __attribute__((aligned(16))) float pl[]; // [CI][r2][n_ctx4] e_j
     const int hs = a.head_size, dim = a.n_heads * hs, r2 = a.n_heads / a.n_kv_heads;
-    const int kvh = blockIdx.x, i0 = blockIdx.y * CI, bs = a.state->bs, pos0 = a.state->pos0;
+    const int kvh = blockIdx.x, i0 = blockIdx.y * CI, bs = att_bs(a), pos0 = att_pos0(a);
     const size_t n_kv4 = (size_t)((pos0 + bs + 3) & ~3); // row stride in LDS (attn_softmax_rows)
     __shared__ float redf[R2MAX][PV_NW];
     __shared__ double redd[R2MAX][PV_NW];
@@ -877,7 +881,7 @@ __global__ __launch_bounds__(PV_NT) void attn_softmax_pv_cols_kernel(psl_attn_ar
 //      grid (ceil(bs * r2 / 16), n_kv_heads), one wave per 16 head channels.
 __global__ __launch_bounds__(PV_NT) void attn_softmax_probs_kernel(psl_attn_args a) {
     extern __shared__ __attribute__((aligned(16))) float pl[]; // [r2][n_kv4]
-    const int r2 = a.n_heads / a.n_kv_heads, kvh = blockIdx.x, i = blockIdx.y, bs = a.state->bs, pos0 = a.state->pos0;
+    const int r2 = a.n_heads / a.n_kv_heads, kvh = blockIdx.x, i = blockIdx.y, bs = att_bs(a), pos0 = att_pos0(a);
     const int n_kv = pos0 + bs, n_kv4 = (n_kv + 3) & ~3;
     __shared__ float redf[R2MAX][PV_NW];
     __shared__ double redd[R2MAX][PV_NW];
@@ -897,7 +901,7 @@ __global__ __launch_bounds__(PV_NT) void attn_softmax_probs_kernel(psl_attn_args
 constexpr int SMW_MAXQ = 16; // float4 per lane: n_kv <= 64 * 4 * 16
 __global__ __launch_bounds__(256) void attn_softmax_probs_wave_kernel(psl_attn_args a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int bs = a.state->bs, pos0 = a.state->pos0, n_kv = pos0 + bs, n8 = n_kv & ~7;
+    const int bs = att_bs(a), pos0 = att_pos0(a), n_kv = pos0 + bs, n8 = n_kv & ~7;
     const int row = (int)blockIdx.x * 4 + wave;
     if (row >= bs * a.n_heads) return;
     const int i = row / a.n_heads;
@@ -970,7 +974,7 @@ __global__ __launch_bounds__(256) void attn_softmax_probs_wave_kernel(psl_attn_a
 __global__ __launch_bounds__(512, 1) void attn_pv_mfma_kernel(psl_attn_args a) {
     const int hs = a.head_size, dim = a.n_heads * hs, r2 = a.n_heads / a.n_kv_heads;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int kvh = blockIdx.y, bs = a.state->bs, n_kv = a.state->pos0 + bs, np = n_kv & ~31, nblk = np >> 5;
+    const int kvh = blockIdx.y, bs = att_bs(a), n_kv = att_pos0(a) + bs, np = n_kv & ~31, nblk = np >> 5;
     const int rl = lane & 15, m = lane >> 4; // A: row rl (channel), k = m;  B: k = m, column rl
     const int N = bs * r2, n = min((int)blockIdx.x * 16 + rl, N - 1), i = n / r2, g = n - i * r2;
     const int d0 = wave * 16; // (blockDim.x = hs / 16 waves)
@@ -1024,7 +1028,7 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_pv_mfma_lds_kernel(psl_attn_a
     constexpr int hs = NW * 16, NT = NW * 64, ROWS = (NW + 1) * 16, NPS = 512 / NT; // NPS: probability segments per thread
     const int dim = a.n_heads * hs, r2 = a.n_heads / a.n_kv_heads;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int kvh = blockIdx.y, bs = a.state->bs, n_kv = a.state->pos0 + bs, np = n_kv & ~31, nblk = np >> 5, n_it = (nblk + 3) >> 2;
+    const int kvh = blockIdx.y, bs = att_bs(a), n_kv = att_pos0(a) + bs, np = n_kv & ~31, nblk = np >> 5, n_it = (nblk + 3) >> 2;
     const int rl = lane & 15, m = lane >> 4;
     const int N = bs * r2, n = min((int)blockIdx.x * 16 + rl, N - 1), i = n / r2, g = n - i * r2;
     const int d0 = wave * 16;

@@ -248,6 +248,7 @@ static int enqueue_forward(ps_hip_model *m, int bs, bool lm_head, bool use_tree,
     aa.kv_vis = m->n_hidden ? m->kv_vis_dev : nullptr;
     aa.scale = 1.0f / sqrtf((float)f.head_size);
     aa.n_kv_host = m->n_kv_host;
+    aa.bs_host = m->n_kv_host > 0 ? bs : 0;
     aa.sync = m->attn_sync;
     // fp16 perf mode (NOT bit-exact, mode bit 5): the layer mat-muls of a prefill batch as dense fp16 GEMMs (perf16.hip); single tokens,
     // tree forwards and anything that produces logits stay on the parity kernels
@@ -308,6 +309,7 @@ static int enqueue_forward(ps_hip_model *m, int bs, bool lm_head, bool use_tree,
                 as.state = m->state_sub + k;
                 as.q = m->q + (int64_t)c0 * dim; as.att = m->att + (int64_t)c0 * dim;
                 as.n_kv_host = m->n_kv_host > 0 ? m->n_kv_host - (bs - c0 - nb) : 0;
+                as.bs_host = as.n_kv_host > 0 ? nb : 0;
                 as.qact = ps_act{}; as.dbg = nullptr;
                 psl_attn_scores(st, as, nb);
                 psl_attn_softmax_pv(st, as, nb);

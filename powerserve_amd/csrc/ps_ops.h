@@ -39,6 +39,7 @@ struct psl_attn_args {
     ps_act qact;             // optional (qs != null): the V.p kernel of a batch also leaves `att` quantized (Q8_K, + the fragment copies when qf is set) for the O projection
     int64_t qact_K;          // = n_heads * head_size
     int n_kv_host;           // pos0 + bs when the host knows it at enqueue time (eager forwards), 0 inside a captured graph: sizes the score grids
+    int bs_host;             // with n_kv_host: the batch size, so that the batch kernels need not wait for the device-resident state (an L2 miss at the head of every launch)
     _Float16 *k16, *v16;     // optional fp16 mirrors of the caches, both [n_ctx][kv_dim] (fp16-KV decode mode: ps_hip_model_set_mode bit 3)
     float *part;             // [n_heads][FL_SPLITS][head_size + 2] partial (o, m, l) of the split-KV decode attention
     unsigned long long *dbg; // timeline buffer of the single-token kernels (ps_hip_debug_timeline keys 40 / 41), or null
