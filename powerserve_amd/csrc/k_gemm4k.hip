@@ -441,6 +441,9 @@ __global__ __launch_bounds__((G4K_NC + G4K_NP) * 64) void gemm4k_kernel(const G4
             if (!(sb & 1)) __syncthreads(); // the producers have parked this step and the next
             mark(sb);
             g4k_superblock<WT>(T, lds + (sb & (G4K_NST - 1)) * G4K_STAGE, zero, B, qf_ct + ((size_t)nb << 13), M, m, kb, uh);
+#ifdef G4K_MARK2
+            if (dbg) { asm volatile("" : "+v"(T.acc[0][0][0]), "+v"(T.acc[1][3][1]), "+v"(T.accm[1][1][1])); mark(sb); } // (the step's chains done)
+#endif
             M = Mn;
         };
         for (int sb = 0; sb < p.nsb - 1; sb++) step(sb);
