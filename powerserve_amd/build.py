@@ -13,7 +13,10 @@ OBJDIR = os.path.join(HERE, "build")
 SOURCES = ["api.hip", "model.hip", "k_quant.hip", "k_gemv.hip", "k_gemv4.hip", "k_gemv7.hip", "k_gemvb.hip", "k_gemvk.hip", "k_gemm4k.hip", "k_gemv6.hip", "k_ops.hip", "k_attn.hip", "perf16.hip"]
 # -ffp-contract=off: the parity contract needs every fp32 op to round where the reference's C source rounds;
 # fused multiply-adds are written explicitly (__fmaf_rn) where the reference uses FMA intrinsics.
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-result",
+# -fno-slp-vectorize: hipcc's SLP vectoriser packs adjacent scalar fp32 operations into v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32.  On gfx950 a scalar
+# v_fma_f32 already runs at the packed rate (2 cycles per wave64, MI355X_MICROARCH.md) and the packed forms cost more beside matrix instructions and in
+# dependent chains (the mat-vec's chain wave): the same source without them, same bits, 8B decode 543.6 -> 552.3 tok/s (profiles/r04_prefill_ab.txt).
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize", "-Wno-unused-result",
          "-I" + os.path.join(HERE, "..", "include")]
 
 
