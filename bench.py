@@ -49,6 +49,8 @@ def parse():
     ap.add_argument("--no-kv-f16", action="store_true", help="skip the fp16-KV decode mode leg")
     ap.add_argument("--no-graph-path", action="store_true", help="skip the Graph -> Executor -> HIPBackend::plan leg (libps_host.so)")
     ap.add_argument("--graph-steps", type=int, default=96)
+    ap.add_argument("--cpu-reference-limit", type=int, default=240, help="seconds the reference CPU baseline (a child process) may take before it is killed")
+    ap.add_argument("--cpu-reference-child", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--f16-super-chunk", type=int, default=2048, help="side leg (fp16 perf mode): tokens per mat-mul launch")
     ap.add_argument("--wide-chunk", type=int, default=512, help="side leg: prefill in chunks of this many tokens (0: skip)")
     ap.add_argument("--super-chunks", type=int, default=4, help="reference-sized prefill chunks (--batch tokens each) per launch sequence "
@@ -174,6 +176,29 @@ def cpu_reference(model_dir, cfg, passes=7):
                       f"through powerserve_compute_forward_mul_mat on the reference's ThreadPool ({nth} threads; attention, norms and sampling "
                       f"not included: an upper bound of the reference's decode rate)",
             "host_cores": cores, "weight_GBps": nbytes / med / 1e9}
+
+
+def cpu_reference_guarded(model_dir, limit_s):
+    """cpu_reference in a child process under a hard time limit.  The reference's ThreadPool synchronises its workers with a spin barrier that does not
+    survive a descheduled thread: on a shared host one run of this leg did not come back within 15 minutes (round 4, the 8B Q5_K_M run) --
+    a bench line must never hang on its baseline.  Returns the child's dict, None when the library is not there, or {"error": ...} on a time-out."""
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-reference-child", model_dir], capture_output=True, text=True, timeout=limit_s)
+    except subprocess.TimeoutExpired:
+        return {"error": f"the reference's thread pool did not finish within {limit_s} s (its spin barrier on a busy host); killed"}
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{") or l == "null"]
+    if r.returncode != 0 or not lines:
+        return {"error": f"child rc {r.returncode}: {r.stderr[-300:]}"}
+    return json.loads(lines[-1])
+
+
+def _cpu_reference_child(model_dir):
+    import types
+    from powerserve_amd import synth
+    llm = synth.load_model_json(model_dir)["llm_config"]
+    cfg = types.SimpleNamespace(dim=int(llm["embed_dim"]), hidden_dim=int(llm["ffn_dim"]), n_layers=int(llm["n_layers"]))
+    print(json.dumps(cpu_reference(model_dir, cfg)), flush=True)
 
 
 def graph_path(model_dir, device, args, prompt):
@@ -370,6 +395,9 @@ def relaunch_distributed(args):
 
 def main():
     args = parse()
+    if args.cpu_reference_child:  # (the guarded baseline's child process: CPU only, one JSON line)
+        _cpu_reference_child(args.cpu_reference_child)
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         relaunch_distributed(args)  # does not return
     # the contract is ONE JSON line on stdout: libraries that chat on fd 1 (RCCL prints its library path at init) are
@@ -516,7 +544,10 @@ def main():
                                  "prompt_tokens": int(p_short.size), "steps": len(ids_cpu), "ids_equal": [int(i) for i in ids_cpu] == ids_gpu,
                                  "max_rel_logit_err": rel, "logits_bit_equal": all(np.array_equal(g.view(np.uint32), np.asarray(c, dtype=np.float32).view(np.uint32)) for g, c in zip(logits_gpu, logits_cpu))}
                 out["cpu_port"] = port
-                refb = cpu_reference(model_dir, cfg)
+                refb = cpu_reference_guarded(model_dir, args.cpu_reference_limit)
+                if refb is not None and "error" in refb:  # (timed out / failed: the port is the baseline, the reason stays on the line)
+                    port = dict(port, reference_leg=refb["error"])
+                    refb = None
                 out["cpu_baseline"] = refb if refb is not None else port
             except Exception as e:
                 out["cpu_baseline"] = {"value": None, "error": repr(e)}

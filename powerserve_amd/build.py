@@ -13,11 +13,16 @@ OBJDIR = os.path.join(HERE, "build")
 SOURCES = ["api.hip", "model.hip", "k_quant.hip", "k_gemv.hip", "k_gemv4.hip", "k_gemv7.hip", "k_gemvb.hip", "k_gemvk.hip", "k_gemm4k.hip", "k_gemv6.hip", "k_ops.hip", "k_attn.hip", "perf16.hip"]
 # -ffp-contract=off: the parity contract needs every fp32 op to round where the reference's C source rounds;
 # fused multiply-adds are written explicitly (__fmaf_rn) where the reference uses FMA intrinsics.
-# -fno-slp-vectorize: hipcc's SLP vectoriser packs adjacent scalar fp32 operations into v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32.  On gfx950 a scalar
-# v_fma_f32 already runs at the packed rate (2 cycles per wave64, MI355X_MICROARCH.md) and the packed forms cost more beside matrix instructions and in
-# dependent chains (the mat-vec's chain wave): the same source without them, same bits, 8B decode 543.6 -> 552.3 tok/s (profiles/r04_prefill_ab.txt).
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize", "-Wno-unused-result",
+# -fno-slp-vectorize (NOSLP files only): hipcc's SLP vectoriser packs adjacent scalar fp32 operations into v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32.  On
+# gfx950 a scalar v_fma_f32 already runs at the packed rate (2 cycles per wave64, MI355X_MICROARCH.md) and the packed forms cost more in dependent chains
+# (the mat-vec's chain wave) and beside matrix instructions: the same source without them, same bits, 8B decode 543.6 -> 552.3 tok/s
+# (profiles/r04_prefill_ab.txt).  Only the two files of the headline's single-token path take the flag.  (With it on every file one 8B Q5_K_M bench
+# run did not come back within 15 minutes; the likeliest culprit is that run's CPU baseline leg -- the reference's spin-barrier thread pool on a busy
+# host, now a child process under a time limit in bench.py -- but the round had no GPU time left to tell the two apart, so every other file keeps the
+# exact compile configuration that has passed the full GPU suite and all bench configurations.)
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-result",
          "-I" + os.path.join(HERE, "..", "include")]
+NOSLP = {"k_gemv4.hip", "k_attn.hip"}
 
 
 def _newer(src: str, obj: str) -> bool:
@@ -38,7 +43,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         src, obj = os.path.join(CSRC, s), os.path.join(OBJDIR, s.replace(".hip", ".o"))
         objs.append(obj)
         if force or _newer(src, obj):
-            jobs.append([hipcc, *FLAGS, "-c", src, "-o", obj])
+            jobs.append([hipcc, *FLAGS, *(["-fno-slp-vectorize"] if s in NOSLP else []), "-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:

@@ -295,25 +295,26 @@ __device__ __forceinline__ G4KMeta g4k_meta(const uint8_t *mf_ct, const int sb, 
     return M;
 }
 
-// the fp32 chains this wave keeps: for both row tiles, rows 4 kb + r, accumulator lanes 4 uh + k and mins lanes 2 uh + vv.
-// Scalars, advanced by v_fma_f32: on gfx950 that runs at the packed rate (2 cycles per wave64) and a v_pk_fma_f32 beside matrix instructions costs
-// more than the two scalar ones it replaces (MI355X_MICROARCH.md).  (Rounds 2-3 kept them as row PAIRS for v_pk_fma_f32, because the SLP vectoriser
-// paired lanes k, k + 1 of one row -- results of two different matrix instructions -- with two v_mov per packed fma; the library is now built with
-// -fno-slp-vectorize.)
+// the fp32 chains this wave keeps: for both row tiles, rows 4 kb + r, accumulator lanes 4 uh + k and mins lanes 2 uh + vv
+// (kept as PAIRS OVER ROWS: a matrix instruction returns rows 4 kb .. 4 kb + 3 of one accumulator lane in four consecutive registers,
+// so (row r, row r + 1) of lane k is a register pair as it comes and one v_pk_fma_f32 advances two chains with no copies.  As scalars
+// the compiler paired lanes k, k + 1 of one row instead -- results of two different matrix instructions -- and spent two v_mov per
+// packed fma putting them side by side: 28 of a step's 145 instructions.)
+typedef float g4k_f2 __attribute__((ext_vector_type(2)));
 struct G4KAcc {
-    float acc[2][4][4], accm[2][2][4]; // acc[t][k][r], accm[t][vv][r]
+    g4k_f2 acc[2][4][2], accm[2][2][2]; // acc[t][k][r >> 1][r & 1], accm[t][vv][r >> 1][r & 1]
     __device__ __forceinline__ void clear() {
 #pragma unroll
         for (int t = 0; t < 2; t++)
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
+            for (int h = 0; h < 2; h++) {
 #pragma unroll
-                for (int k = 0; k < 4; k++) acc[t][k][r] = 0.f;
-                accm[t][0][r] = accm[t][1][r] = 0.f;
+                for (int k = 0; k < 4; k++) acc[t][k][h] = g4k_f2{0.f, 0.f};
+                accm[t][0][h] = accm[t][1][h] = g4k_f2{0.f, 0.f};
             }
     }
-    __device__ __forceinline__ float a(int t, int r, int k) const { return acc[t][k][r]; }
-    __device__ __forceinline__ float am(int t, int r, int vv) const { return accm[t][vv][r]; }
+    __device__ __forceinline__ float a(int t, int r, int k) const { return acc[t][k][r >> 1][r & 1]; }
+    __device__ __forceinline__ float am(int t, int r, int vv) const { return accm[t][vv][r >> 1][r & 1]; }
 };
 
 // one super-block.  B[k] = this lane's B operand for accumulator lane 4 uh + k (loaded a step ago); as soon as both row
@@ -322,12 +323,12 @@ template <int WT>
 __device__ __forceinline__ void g4k_superblock(G4KAcc &T, const char *st, const char *zero, ps_u32x4 (&B)[4], const char *nq, const G4KMeta M,
                                                const int m, const int kb, const int uh) {
     const g4k_f4 zf = {0.f, 0.f, 0.f, 0.f};
-    float dr[2][4], dmin[2][4]; // [t][r]
+    g4k_f2 dr[2][2], dmin[2][2]; // [t][r >> 1] = (row r, row r + 1)
 #pragma unroll
     for (int t = 0; t < 2; t++) {
         const g4k_f4 dda = *(const g4k_f4 *)(st + G4K_DD + (16 * t + 4 * kb) * 8), ddb = *(const g4k_f4 *)(st + G4K_DD + (16 * t + 4 * kb) * 8 + 16); // (d, dmin) of rows 4 kb + r
-        dr[t][0] = __fmul_rn(M.yd, dda[0]); dr[t][1] = __fmul_rn(M.yd, dda[2]); dr[t][2] = __fmul_rn(M.yd, ddb[0]); dr[t][3] = __fmul_rn(M.yd, ddb[2]);
-        dmin[t][0] = __fmul_rn(-M.yd, dda[1]); dmin[t][1] = __fmul_rn(-M.yd, dda[3]); dmin[t][2] = __fmul_rn(-M.yd, ddb[1]); dmin[t][3] = __fmul_rn(-M.yd, ddb[3]);
+        dr[t][0] = g4k_f2{__fmul_rn(M.yd, dda[0]), __fmul_rn(M.yd, dda[2])}; dr[t][1] = g4k_f2{__fmul_rn(M.yd, ddb[0]), __fmul_rn(M.yd, ddb[2])};
+        dmin[t][0] = g4k_f2{__fmul_rn(-M.yd, dda[1]), __fmul_rn(-M.yd, dda[3])}; dmin[t][1] = g4k_f2{__fmul_rn(-M.yd, ddb[1]), __fmul_rn(-M.yd, ddb[3])};
     }
     const char *ap = st + g4k_plane(kb) + m * G4K_RS + (4 * uh) * 16;
 #pragma unroll
@@ -340,8 +341,8 @@ __device__ __forceinline__ void g4k_superblock(G4KAcc &T, const char *st, const 
             g4k_h8 av;
             __builtin_memcpy(&av, &ao, 16);
             const g4k_f4 si = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bv, zf, 0, 0, 0); // (float)sumi[4 uh + k] of rows 4 kb + r, this lane's column
-#pragma unroll
-            for (int r = 0; r < 4; r++) T.acc[t][k][r] = __fmaf_rn(dr[t][r], si[r], T.acc[t][k][r]); // acc = fma(d, (float)sumi, acc)
+            T.acc[t][k][0] = __builtin_elementwise_fma(dr[t][0], __builtin_shufflevector(si, si, 0, 1), T.acc[t][k][0]); // acc = fma(d, (float)sumi, acc), rows r, r + 1
+            T.acc[t][k][1] = __builtin_elementwise_fma(dr[t][1], __builtin_shufflevector(si, si, 2, 3), T.acc[t][k][1]);
         }
         B[k] = *(const ps_u32x4 *)(nq + k * 1024);
     }
@@ -361,8 +362,8 @@ __device__ __forceinline__ void g4k_superblock(G4KAcc &T, const char *st, const 
                 __builtin_memcpy(&a0, &ma.x, 4); __builtin_memcpy(&a1, &ma.y, 4);
                 const g4k_h4 am = {a0[0], a0[1], a1[0], a1[1]};
                 const g4k_f4 pr = __builtin_amdgcn_mfma_f32_16x16x16f16(am, bm, zf, 0, 0, 0);
-#pragma unroll
-                for (int r = 0; r < 4; r++) T.accm[t][0][r] = __fadd_rn(T.accm[t][0][r], __fmul_rn(dmin[t][r], pr[r])); // multiply, then add: two roundings
+                T.accm[t][0][0] = T.accm[t][0][0] + dmin[t][0] * __builtin_shufflevector(pr, pr, 0, 1); // multiply, then add: two roundings (-ffp-contract=off)
+                T.accm[t][0][1] = T.accm[t][0][1] + dmin[t][1] * __builtin_shufflevector(pr, pr, 2, 3);
             }
         }
         return;
@@ -379,8 +380,8 @@ __device__ __forceinline__ void g4k_superblock(G4KAcc &T, const char *st, const 
             __builtin_memcpy(&a0, &ax, 4); __builtin_memcpy(&a1, &ay, 4); __builtin_memcpy(&g0, &bx, 4); __builtin_memcpy(&g1, &by, 4);
             const g4k_h4 am = {a0[0], a0[1], a1[0], a1[1]}, bm = {g0[0], g0[1], g1[0], g1[1]};
             const g4k_f4 pr = __builtin_amdgcn_mfma_f32_16x16x16f16(am, bm, zf, 0, 0, 0);
-#pragma unroll
-            for (int r = 0; r < 4; r++) T.accm[t][vv][r] = __fmaf_rn(dmin[t][r], pr[r], T.accm[t][vv][r]);
+            T.accm[t][vv][0] = __builtin_elementwise_fma(dmin[t][0], __builtin_shufflevector(pr, pr, 0, 1), T.accm[t][vv][0]);
+            T.accm[t][vv][1] = __builtin_elementwise_fma(dmin[t][1], __builtin_shufflevector(pr, pr, 2, 3), T.accm[t][vv][1]);
         }
     }
 }
@@ -441,7 +442,7 @@ __global__ __launch_bounds__((G4K_NC + G4K_NP) * 64) void gemm4k_kernel(const G4
             mark(sb);
             g4k_superblock<WT>(T, lds + (sb & (G4K_NST - 1)) * G4K_STAGE, zero, B, qf_ct + ((size_t)nb << 13), M, m, kb, uh);
 #ifdef G4K_MARK2
-            if (dbg) { asm volatile("" : "+v"(T.acc[0][0][0]), "+v"(T.acc[1][3][3]), "+v"(T.accm[1][1][3])); mark(sb); } // (the step's chains done)
+            if (dbg) { asm volatile("" : "+v"(T.acc[0][0][0]), "+v"(T.acc[1][3][1]), "+v"(T.accm[1][1][1])); mark(sb); } // (the step's chains done)
 #endif
             M = Mn;
         };
