@@ -16,13 +16,13 @@ SOURCES = ["api.hip", "model.hip", "k_quant.hip", "k_gemv.hip", "k_gemv4.hip", "
 # -fno-slp-vectorize (NOSLP files only): hipcc's SLP vectoriser packs adjacent scalar fp32 operations into v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32.  On
 # gfx950 a scalar v_fma_f32 already runs at the packed rate (2 cycles per wave64, MI355X_MICROARCH.md) and the packed forms cost more in dependent chains
 # (the mat-vec's chain wave) and beside matrix instructions: the same source without them, same bits, 8B decode 543.6 -> 552.3 tok/s
-# (profiles/r04_prefill_ab.txt).  Only the two files of the headline's single-token path take the flag.  (With it on every file one 8B Q5_K_M bench
+# (profiles/r04_prefill_ab.txt).  Only the files of the single-token path take the flag.  (With it on every file one 8B Q5_K_M bench
 # run did not come back within 15 minutes; the likeliest culprit is that run's CPU baseline leg -- the reference's spin-barrier thread pool on a busy
 # host, now a child process under a time limit in bench.py -- but the round had no GPU time left to tell the two apart, so every other file keeps the
 # exact compile configuration that has passed the full GPU suite and all bench configurations.)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-result",
          "-I" + os.path.join(HERE, "..", "include")]
-NOSLP = {"k_gemv4.hip", "k_attn.hip"}
+NOSLP = {"k_gemv4.hip", "k_gemvb.hip", "k_attn.hip"}  # (k_gemvb.hip: the Q4_0 / Q8_0 mat-vec, Llama-3.2-1B 1494 -> 1525 tok/s)
 
 
 def _newer(src: str, obj: str) -> bool:

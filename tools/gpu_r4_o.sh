@@ -1,5 +1,5 @@
-# round 4, last GPU minutes: the default bench line and the 8B Q5_K_M line under the final build, the CPU baseline as a child process under a time limit
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out; export TMPDIR=/tmp
 O=$GRAFT_REPO_ROOT/gpurun_out
-timeout 170 python bench.py > $O/r04_bench_8b_full.json 2> $O/r04o_full.err; echo "rc $?"; cut -c1-260 $O/r04_bench_8b_full.json
-timeout 80 python bench.py --wtype Q5_K_M --no-kv-f16 --no-graph-path > $O/r04_bench_8b_q5_k_m.json 2> $O/r04o_q5km.err; echo "rc $?"; cut -c1-200 $O/r04_bench_8b_q5_k_m.json
+timeout 60 python bench.py --preset llama-3.2-1b --wtype Q4_0 --prompt-len 512 --steps 128 --no-kv-f16 --no-graph-path > $O/r04_bench_llama32_1b_q4_0.json 2> $O/r04_bench_1b.err; cut -c1-160 $O/r04_bench_llama32_1b_q4_0.json
+timeout 60 python bench.py --preset qwen2-0.5b --wtype Q8_0 --prompt-len 512 --steps 128 --no-kv-f16 --no-graph-path > $O/r04_bench_qwen2_05b_q8_0.json 2> $O/r04_bench_05b.err; cut -c1-160 $O/r04_bench_qwen2_05b_q8_0.json
+timeout 60 python -m pytest tests/test_gpu_ops.py -m gpu -q -x -k "quant and not kquant" 2>&1 | tail -1
