@@ -80,3 +80,22 @@ def test_self_launch_command_and_world_check(tmp_path):
     env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], env=env, capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and "WORLD_SIZE=2" in (r.stderr + r.stdout)
+
+
+def test_reference_baseline_runs_under_a_time_limit(tmp_path):
+    """bench.py's cpu_baseline leg calls the REAL reference's mat-muls through the reference's own ThreadPool, whose spin barrier can stall for good
+    on a busy host: the leg runs in a child process that is killed at a time limit, and the bench line then carries the port as its baseline with
+    the reason next to it -- the line itself never hangs."""
+    import pytest
+    sys.path.insert(0, ROOT)
+    import bench
+    from oracle import binding
+    from powerserve_amd import gguf, synth
+    if not binding.have_ref():
+        pytest.skip("oracle/_ref/libps_ref.so not built (needs /root/reference)")
+    d = str(tmp_path / "m")
+    synth.write_model_dir(d, "tiny-llama", gguf.NAME_TYPE["Q4_K"], n_ctx=64, seed=1)
+    ok = bench.cpu_reference_guarded(d, 120)
+    assert ok["kind"] == "reference" and ok["value"] > 0 and ok["n_threads_4"]["value"] > 0
+    late = bench.cpu_reference_guarded(d, 0.01)
+    assert set(late) == {"error"} and "did not finish" in late["error"]
