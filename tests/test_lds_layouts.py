@@ -14,3 +14,5 @@ def test_bank_model_of_the_batch_kernels():
     assert "producer ds_write_b128 2 pass" in pad[0] and "producer ds_write_b128 1 pass" in pad[64]
     att = [l for l in lines if l.startswith("rows ")]
     assert "2 pass" in att[0] and "1 pass" in att[1]  # batch attention: padded rows conflict under the real lane groups, the swizzle does not
+    f16 = [l for l in lines if l.startswith("piece ^")]
+    assert "2 pass" in f16[0] and "(f16_gemm_w8_kernel): ds_read_b128 1 pass" in f16[1]  # the fp16 GEMM's stage image: the swizzle the kernel uses is free under the real lane groups

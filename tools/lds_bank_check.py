@@ -37,3 +37,11 @@ for name, fn in (("rows padded to 132 floats (rounds 1-3)", lambda l, q: (l & 15
 park = lambda l, r0, swz: (r0 + (l >> 5)) * (512 if swz else 528) + ((((l & 31) ^ ((r0 + (l >> 5)) & 7)) if swz else (l & 31)) << 4)
 for swz in (False, True):
     print(f"  park of two rows per instruction ({'swizzled' if swz else 'padded'}): ds_write_b128 {max(passes(lambda l, r0=r0: park(l, r0, swz), WR, 32) for r0 in range(0, 16, 2))} pass(es)")
+
+print("fp16 perf-mode GEMM stage (perf16.hip: rows of 128 B = eight 16-byte pieces, fragment read: lane = (row fr = l & 31, k half fh = l >> 5), piece 2 ks + fh):")
+for name, f in (("piece ^ (row & 7) (first version: built for '8 consecutive lanes')", lambda r: r & 7),
+                ("piece ^ (row / 2 % 8) (f16_gemm_w8_kernel)", lambda r: (r >> 1) & 7)):
+    worst = max(passes(lambda l, ks=ks: (l & 31) * 128 + (((2 * ks + (l >> 5)) ^ f(l & 31)) << 4), RD, 64) for ks in range(4))
+    print(f"  {name}: ds_read_b128 {worst} pass(es)")
+print("  64-byte rows (32-k blocks: the four-wave experiment), piece ^ (row / 4 % 4): ds_read_b128 "
+      f"{max(passes(lambda l, ks=ks: (l & 31) * 64 + (((2 * ks + (l >> 5)) ^ (((l & 31) >> 2) & 3)) << 4), RD, 64) for ks in range(2))} pass(es)")
