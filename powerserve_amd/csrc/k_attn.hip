@@ -338,7 +338,7 @@ __device__ __forceinline__ void attn_softmax_rows(const psl_attn_args &a, const 
     mark(4);
     __syncthreads();
     mark(5);
-    if (threadIdx.x < r2) {
+    if ((int)threadIdx.x < r2) {
         double t = 0.0;
         for (int w = 0; w < wpr; w++) t += redd[threadIdx.x][w];
         invs[threadIdx.x] = (float)(1.0 / t);
@@ -355,9 +355,8 @@ __device__ __forceinline__ void attn_softmax_rows(const psl_attn_args &a, const 
 __global__ __launch_bounds__(PV_NT) void attn_softmax_pv_kernel(psl_attn_args a) {
     extern __shared__ __attribute__((aligned(16))) float pl[]; // [r2][n_ctx4] e_j, then [4][PV_VSTR] V tile
     const int hs = a.head_size, dim = a.n_heads * hs, r2 = a.n_heads / a.n_kv_heads;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int kvh = blockIdx.y, i = blockIdx.z, bs = att_bs(a), pos0 = att_pos0(a);
-    const int n_kv = pos0 + bs, n8 = n_kv & ~7, np = n_kv & ~31, n_kv4 = (n_kv + 3) & ~3;
+    const int n_kv = pos0 + bs, np = n_kv & ~31, n_kv4 = (n_kv + 3) & ~3;
     float *vt = pl + (size_t)r2 * (((size_t)a.n_ctx + 3) & ~(size_t)3);
     __shared__ float redf[R2MAX][PV_NW];
     __shared__ double redd[R2MAX][PV_NW];

@@ -226,16 +226,15 @@ __global__ __launch_bounds__(512) void f16_gemm_w8_kernel(const F16Gemm p) {
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
     const int nk = (int)(K / 64);
-    constexpr int R3 = NI / 3 + (NI % 3 == 2), R0 = NI / 3 + (NI % 3 == 2), R1 = NI - R3 - R0; // pieces requested in the groups 3 (of the block before), 0 and 1
-    auto request = [&](const int kb, const int first, const int cnt_lo, const int cnt_hi) { // pieces [cnt_lo, cnt_hi) of block kb (a block past the end: nothing)
-        (void)first;
+    constexpr int R3 = NI / 3 + (NI % 3 == 2), R0 = NI / 3 + (NI % 3 == 2); // pieces requested in the groups 3 (of the block before) and 0; group 1 takes the rest
+    auto request = [&](const int kb, const int cnt_lo, const int cnt_hi) { // pieces [cnt_lo, cnt_hi) of block kb (a block past the end: nothing)
         if (kb >= nk) return;
 #pragma unroll
         for (int d = 0; d < NI; d++)
             if (d >= cnt_lo && d < cnt_hi) f16_dma1(src[d] + (int64_t)kb * 128, lds0 + (unsigned)((kb & 1) * STAGE) + my_dst + (unsigned)(d * 1024));
     };
-    request(0, 0, 0, NI);
-    request(1, 0, 0, R3);
+    request(0, 0, NI);
+    request(1, 0, R3);
     if (nk > 1) { if constexpr (R3 == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -259,12 +258,12 @@ __global__ __launch_bounds__(512) void f16_gemm_w8_kernel(const F16Gemm p) {
     for (int kb = 0; kb < nk; kb++) {
         const char *st = f16_lds + (kb & 1) * STAGE, *stn = f16_lds + ((kb + 1) & 1) * STAGE;
         frags(st, 1, fa[1], fb[1]);
-        request(kb + 1, 0, R3, R3 + R0);
+        request(kb + 1, R3, R3 + R0);
         __builtin_amdgcn_sched_barrier(0);
         mults(0);
         __builtin_amdgcn_sched_barrier(0);
         frags(st, 2, fa[0], fb[0]);
-        request(kb + 1, 0, R3 + R0, NI);
+        request(kb + 1, R3 + R0, NI);
         __builtin_amdgcn_sched_barrier(0);
         mults(1);
         __builtin_amdgcn_sched_barrier(0);
@@ -275,7 +274,7 @@ __global__ __launch_bounds__(512) void f16_gemm_w8_kernel(const F16Gemm p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // block kb + 1 has landed (this wave's share)
         __syncthreads();
         if (kb + 1 < nk) frags(stn, 0, fa[0], fb[0]);
-        request(kb + 2, 0, 0, R3); // (stage kb & 1 is free behind the barrier)
+        request(kb + 2, 0, R3); // (stage kb & 1 is free behind the barrier)
         __builtin_amdgcn_sched_barrier(0);
         mults(1);
         __builtin_amdgcn_sched_barrier(0);
