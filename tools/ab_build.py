@@ -13,7 +13,7 @@ for s in B.SOURCES:
     obj = os.path.join(B.OBJDIR, s.replace(".hip", ".o"))
     if s in files:
         obj = os.path.join(B.OBJDIR, s.replace(".hip", f"_{name}.o"))
-        subprocess.run([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), *B.FLAGS, *defs, "-c", os.path.join(B.CSRC, s), "-o", obj], check=True)
+        subprocess.run([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), *B.FLAGS, *(["-fno-slp-vectorize"] if s in B.NOSLP else []), *defs, "-c", os.path.join(B.CSRC, s), "-o", obj], check=True)
     objs.append(obj)
 so = os.path.join(B.LIBDIR, f"libps_hip_{name}.so")
 subprocess.run([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", so, *objs], check=True)
