@@ -11,6 +11,7 @@
  *   powerserve_compute_forward_rope     (ggml.h:795)      ps_hip_rope
  *   powerserve_compute_forward_dup      (ggml.h:804)      ps_hip_dup
  *   powerserve_compute_forward_softmax_ext (ggml.h:810)   ps_hip_softmax_ext
+ *   powerserve_compute_forward_soft_max (ggml.h:781)      ps_hip_soft_max
  *   powerserve_get_vec_dot_type         (ggml.h:765)      ps_hip_vec_dot_type
  *   GGMLBackend::silu_hadamard (backend/ggml/ggml.cpp:115)        ps_hip_silu_hadamard
  *   GGMLBackend::get_embedding (backend/ggml/ggml_wrapper.cpp:181) ps_hip_get_embedding
@@ -38,7 +39,9 @@
 extern "C" {
 #endif
 
-#define PS_HIP_ABI_VERSION 1
+#define PS_HIP_ABI_VERSION 2
+/* return codes: 0 ok; 1 a HIP runtime error; 2 a refused call (bad argument, unsupported shape ...); 3 see ps_hip_model_sync_check */
+#define PS_HIP_ATTN_TIMEOUT 3
 
 /* ggml_type values (libs/ggml/include/ggml.h:361-398); Q4_K/Q5_K/Q6_K extend PowerServe's DataType enum
  * (core/data_type.hpp:24-35) which stops at Q8_0. */
@@ -125,6 +128,9 @@ int ps_hip_rope(ps_hip_ctx *ctx, const ps_tensor *dst, const ps_tensor *src, con
                 const ps_rope_params *rp);
 int ps_hip_softmax_ext(ps_hip_ctx *ctx, const ps_tensor *dst, const ps_tensor *src, const ps_tensor *mask,
                        float scale, float max_bias);
+/* GGMLBackend::softmax (backend/ggml/ggml_wrapper.cpp:57-69) -> powerserve_compute_forward_soft_max (ggml.c:15060-15089): the same
+ * row soft-max with scale 1, no mask, max_bias 0 (it sets exactly those op_params and calls ggml_compute_forward_soft_max_f32). */
+int ps_hip_soft_max(ps_hip_ctx *ctx, const ps_tensor *dst, const ps_tensor *src);
 int ps_hip_add(ps_hip_ctx *ctx, const ps_tensor *dst, const ps_tensor *a, const ps_tensor *b);
 int ps_hip_dup(ps_hip_ctx *ctx, const ps_tensor *dst, const ps_tensor *src); /* COPY and CONT */
 int ps_hip_silu_hadamard(ps_hip_ctx *ctx, const ps_tensor *dst, const ps_tensor *gate, const ps_tensor *up);
@@ -164,6 +170,19 @@ int ps_hip_model_kv_truncate(ps_hip_model *m, size_t n_tokens);
 int ps_hip_model_kv_advance(ps_hip_model *m, size_t n_tokens); /* after an op-by-op forward through the ps_hip_* operators */
 int ps_hip_model_kv_rollback(ps_hip_model *m, size_t n_tokens);
 int ps_hip_model_kv_move(ps_hip_model *m, size_t dst_index, size_t src_index);
+/* The rest of KVCacheInterface (core/kv_cache.hpp:120-162).  The reference keeps a forward's K / V rows in a per-batch staging area
+ * (GGMLKV::chunk.current_k / current_v) and copies them into the cache afterwards; here every forward writes its rows straight into
+ * the cache slots kv_position + i (norm_attention.cpp:82-104 does the same through VIEW + COPY on the ggml path), so "token i of the
+ * last batch" IS cache slot kv_position + i:
+ *   copy(dst_cache_index, src_token_index)  = move(dst_cache_index, kv_position + src_token_index)
+ *   save_tokens(n)                          = nothing left to copy (checks kv_position + n <= n_ctx like the reference's assert)
+ *   unmask_tokens(n)                        = slots kv_position .. kv_position + n - 1 visible again; the position is not modified
+ *   append_tokens(n)                        = save_tokens + unmask_tokens + advance_tokens; returns 0 and the OLD position in *old_position
+ *                                             (may be NULL) */
+int ps_hip_model_kv_copy(ps_hip_model *m, size_t dst_cache_index, size_t src_token_index);
+int ps_hip_model_kv_save_tokens(ps_hip_model *m, size_t n_tokens);
+int ps_hip_model_kv_unmask_tokens(ps_hip_model *m, size_t n_tokens);
+int ps_hip_model_kv_append_tokens(ps_hip_model *m, size_t n_tokens, size_t *old_position);
 /* One Model::forward (model/llama/llama_model.cpp:52-117).  tokens/pos: HOST arrays of n entries,
  * positions consecutive from pos[0].  tree (may be NULL): bs x bs attention mask among the batch tokens
  * (speculative tree verify).  lm_head != 0: logits for all n tokens are left in the model's device buffer
@@ -177,8 +196,11 @@ int ps_hip_model_forward(ps_hip_model *m, const int32_t *tokens, int n, const in
  * ps_hip_model_kv_advance or ps_hip_model_sync_check has returned 0. */
 int ps_hip_model_forward_lowered(ps_hip_model *m, const int32_t *tokens, int n, const int32_t *pos, const uint8_t *tree, int lm_head);
 /* Waits for a pending ps_hip_model_forward_lowered and looks at the one-launch attention's time-out flag (k_attn.hip: its
- * workgroups wait for each other inside the launch, bounded).  0: the result is valid.  2: it is not -- the model has switched to
- * the two-launch attention and the caller runs the forward again (nothing was advanced).  ps_hip_model_kv_advance calls it. */
+ * workgroups wait for each other inside the launch, bounded).  0: the result is valid.  PS_HIP_ATTN_TIMEOUT: it is not -- the model
+ * has switched to the two-launch attention (sticky, see ps_hip_model_set_mode) and the caller runs the forward again, once (nothing
+ * was advanced; behind the switch a forward cannot time out).  1: a HIP error -- not a time-out, do not retry.
+ * ps_hip_model_kv_advance calls it, and so does every other model entry point before it enqueues anything, so an unconsumed lowered
+ * forward's time-out is reported to the caller that still holds its inputs instead of being pinned on the next forward. */
 int ps_hip_model_sync_check(ps_hip_model *m);
 /* ModelTokenIterator's prefill loop (src/model/model.hpp:147-163: forward(chunk, lm_head = false) + advance, chunk after chunk of
  * `chunk` tokens = hparams batch_size) for tokens appended at the current cache position -- bit-identical to calling
@@ -224,7 +246,9 @@ int ps_hip_debug_timeline(ps_hip_ctx *ctx, int key, uint64_t *host_out, int n_wo
 /* Diagnostic: tunables of the library (process-wide).  key 1: wave configuration of the decode mat-vec (k_gemv4.hip,
  * tools/g4_variants.py); key 3: the narrow-batch Q4_K mat-mul for few row tiles (k_gemm4k.hip: 0 = round 3's four waves walking K
  * together, 4 / 8 = gemm4k_par_kernel with that many waves per tile, 1 = by tile count, the default); key 4: the fp16 perf mode's GEMM (perf16.hip:
- * 0 = by shape, 1 = 128-token tiles, 2 = 256 x 256 tiles).  Returns non-zero for an unknown key. */
+ * 0 = by shape, 1 = 128-token tiles, 2 = 256 x 256 tiles); key 5: the next `value` single-token forwards on the one-launch attention
+ * report a time-out of its score exchange (tests of the retry paths: forward, forward_tree, prefill tail, decode_greedy, lowered forward +
+ * kv_advance).  Returns non-zero for an unknown key. */
 int ps_hip_debug_set(int key, int value);
 /* Diagnostic: one GEMM shape of the fp16 perf mode on synthetic operands (tools/f16_gemm_bench.py): out[M][N] = x[M][K] . W[N][K]^T, timed over
  * `reps` launches (with beta: out = beta out + ...), max |difference| to a k-ordered fp32 reference (beta != 0: of a second launch on top of
@@ -239,7 +263,8 @@ int ps_hip_debug_f16_gemm(ps_hip_ctx *ctx, int M, int64_t N, int64_t K, int reps
  * (attn_decode2_kernel: scores exchanged inside the launch; it needs every workgroup of its grid resident, its wait is bounded,
  * and a wait that gives up switches this bit on: the forward that hit it runs again on the two launches -- ps_hip_model_forward,
  * _forward_tree, _prefill and _decode_greedy do that themselves, a lowered forward reports it through ps_hip_model_sync_check /
- * ps_hip_model_kv_advance).  Same results bit for bit;
+ * ps_hip_model_kv_advance).  Same results bit for bit.  Sticky after a time-out: a later set_mode without bit 4 keeps the two launches;
+ * bit 6 (write-only): re-arm the one-launch attention after a time-out (clears the sticky state, then the other bits apply);
  * bit 5: 1 = fp16 prefill perf mode — NOT bit-exact: the layer mat-muls of batches without logits (prefill chunks) run
  * as dense fp16 GEMMs (fp32 accumulation) on dequantized fp16 copies of the matrices made at first use (+2 bytes per weight), the
  * backend's own matrix-core kernel (csrc/perf16.hip; row lengths must be multiples of 64); RoPE, KV append and attention stay the parity kernels on

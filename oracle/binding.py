@@ -17,6 +17,8 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 ORACLE_SO = os.path.join(HERE, "libps_oracle.so")
 REF_SO = os.path.join(HERE, "_ref", "libps_ref.so")
+# the same sources compiled WITHOUT -ffp-contract=off: what the reference's own CMake produces on an FMA machine (oracle/Makefile, CONTRACT=fast)
+REF_FAST_SO = os.path.join(HERE, "_ref", "libps_ref_fast.so")
 
 # ggml_type values (libs/ggml/include/ggml.h:361-398)
 F32, F16, Q4_0, Q8_0, Q4_K, Q5_K, Q6_K, Q8_K, I32 = 0, 1, 2, 8, 12, 13, 14, 15, 26
@@ -28,10 +30,15 @@ def build(ref: bool = True) -> None:
     subprocess.run(["make", "-s", "-C", HERE, "oracle"], check=True)
     if ref and os.path.isdir("/root/reference/libs/ggml/src"):
         subprocess.run(["make", "-s", "-j8", "-C", HERE, "ref"], check=True)
+        subprocess.run(["make", "-s", "-j8", "-C", HERE, "ref_fast"], check=True)
 
 
 def have_ref() -> bool:
     return os.path.exists(REF_SO)
+
+
+def have_ref_fast() -> bool:
+    return os.path.exists(REF_FAST_SO)
 
 
 class RopeParams(C.Structure):
@@ -300,10 +307,11 @@ def ref_tensor(arr, t, ne, nb=None, type_size=None, blck=1):
 
 
 class Ref:
-    def __init__(self, n_threads=1):
-        if not have_ref():
-            raise FileNotFoundError(REF_SO + " (build it in the dev container: make -C oracle ref)")
-        L = self.L = C.CDLL(REF_SO)
+    def __init__(self, n_threads=1, so=None):
+        so = so or REF_SO
+        if not os.path.exists(so):
+            raise FileNotFoundError(so + " (build it in the dev container: make -C oracle ref ref_fast)")
+        L = self.L = C.CDLL(so)
         L.ref_row_size.restype = C.c_size_t
         L.ref_row_size.argtypes = [C.c_int, C.c_int64]
         L.ref_type_size.restype = C.c_size_t

@@ -329,6 +329,8 @@ int ps_hip_rope(ps_hip_ctx *c, const ps_tensor *dst, const ps_tensor *src, const
     return 0;
 }
 
+int ps_hip_soft_max(ps_hip_ctx *c, const ps_tensor *dst, const ps_tensor *src) { return ps_hip_softmax_ext(c, dst, src, nullptr, 1.0f, 0.0f); } // ggml.c:15071-15076
+
 int ps_hip_softmax_ext(ps_hip_ctx *c, const ps_tensor *dst, const ps_tensor *src, const ps_tensor *mask, float scale, float max_bias) {
     if (max_bias != 0.0f) PS_FAIL(c, "softmax_ext: ALiBi (max_bias != 0) is not on PowerServe's path");
     if (src->ne[0] * 4 > 150 * 1024) PS_FAIL(c, "softmax_ext: row too long for the LDS-resident kernel");
@@ -413,11 +415,13 @@ int ps_hip_debug_timeline(ps_hip_ctx *ctx, int key, uint64_t *host_out, int n_wo
 }
 
 int ps_hip_debug_set(int key, int value) {
-    extern int g_g4_cfg, g_g4_flags, g_g4k_par, g_f16_variant;
+    extern int g_g4_cfg, g_g4_flags, g_g4k_par, g_f16_variant, g_force_attn_timeout, g_g4k_cbx;
     if (key == 1) { g_g4_cfg = value; return 0; }
     if (key == 2) { g_g4_flags = value; return 0; }
     if (key == 3) { g_g4k_par = value; return 0; }
     if (key == 4) { g_f16_variant = value; return 0; }
+    if (key == 5) { g_force_attn_timeout = value; return 0; }
+    if (key == 6) { g_g4k_cbx = value; return 0; }
     return 1;
 }
 

@@ -68,6 +68,8 @@ auto Graph::rope(TensorNode *src, const std::vector<int> &pos, const ModelConfig
     return emit(OpType::ROPE, {src}, dup_tensor(src), RopeParams{pos, params});
 }
 
+auto Graph::softmax(TensorNode *x) -> TensorNode * { return emit(OpType::SOFTMAX, {x}, dup_tensor(x)); }
+
 auto Graph::softmax_ext(TensorNode *x, TensorNode *mask, float scale, float max_bias) -> TensorNode * {
     return emit(OpType::SOFTMAX_EXT, {x, mask}, dup_tensor(x), SoftmaxExtParams{scale, max_bias});
 }

@@ -86,6 +86,7 @@ struct Graph {
     auto silu_hadamard(TensorNode *gate, TensorNode *up) -> TensorNode *;
     void copy(TensorNode *dst, TensorNode *src);
     auto rope(TensorNode *src, const std::vector<int> &pos, const ModelConfig::LLMConfig::RopeConfig &params) -> TensorNode *;
+    auto softmax(TensorNode *x) -> TensorNode *; // src/graph/graph.cpp:118-125
     auto softmax_ext(TensorNode *x, TensorNode *mask, float scale, float max_bias) -> TensorNode *;
     auto permute(TensorNode *x, Shape axes) -> TensorViewNode *;
     auto cont(TensorNode *x, Shape shape) -> TensorNode *;

@@ -25,6 +25,17 @@ void HIPKV::rollback(size_t n) {
     POWERSERVE_ASSERT(position() >= n);
     ps_hip_model_kv_rollback(m_model, n);
 }
+void HIPKV::copy(size_t dst, size_t src_token) { POWERSERVE_ASSERT(ps_hip_model_kv_copy(m_model, dst, src_token) == 0, "kv copy: index out of range"); }
+void HIPKV::move(size_t dst, size_t src) { POWERSERVE_ASSERT(ps_hip_model_kv_move(m_model, dst, src) == 0, "kv move: index out of range"); }
+void HIPKV::mask(size_t i) { POWERSERVE_ASSERT(i < position()); ps_hip_model_kv_mask(m_model, i, 0); }     // kv_cache.hpp:211-214
+void HIPKV::unmask(size_t i) { POWERSERVE_ASSERT(i < position()); ps_hip_model_kv_mask(m_model, i, 1); }   // kv_cache.hpp:216-219
+void HIPKV::save_tokens(size_t n) { POWERSERVE_ASSERT(ps_hip_model_kv_save_tokens(m_model, n) == 0, "the length of kvcache is up to the preset threshold"); }
+void HIPKV::unmask_tokens(size_t n) { POWERSERVE_ASSERT(ps_hip_model_kv_unmask_tokens(m_model, n) == 0, "the length of kvcache is up to the preset threshold"); }
+size_t HIPKV::append_tokens(size_t n) {
+    size_t old = 0;
+    POWERSERVE_ASSERT(ps_hip_model_kv_append_tokens(m_model, n, &old) == 0, "kv append refused");
+    return old;
+}
 
 // ---------------------------------------------------------------- backend
 HIPBackend::HIPBackend(const ModelConfig::LLMConfig &config, const HyperParams &, int device) : m_config(config), m_device(device) {
@@ -81,9 +92,23 @@ void HIPBackend::rmsnorm(const Tensor *out, const Tensor *x, const Tensor *weigh
     auto d = to_ps(out), a = to_ps(x), w = to_ps(weight);
     check(ps_hip_rms_norm(m_ctx, &d, &a, &w, eps), "rmsnorm");
 }
+int HIPBackend::get_n_tasks(std::shared_ptr<OpNode>) { return 1; }
+
+void HIPBackend::add_cache(const Tensor *k, const Tensor *v, size_t L, const std::vector<int> &pos, size_t) {
+    const size_t bs = pos.size(), kvd = m_kv->m_kv_dim, cur = m_kv->position();
+    POWERSERVE_ASSERT(bs == m_kv->m_batch_size && L < m_kv->m_n_layers && cur + bs <= m_kv->m_n_ctx);
+    auto [kc, vc] = m_kv->get_cache(L);
+    // K rows are contiguous behind the position; V is kept transposed ([kv_dim][n_ctx]): a strided view of the cache as the destination
+    Tensor kd(DataType::FP32, {kvd, bs, 1, 1}), vd(DataType::FP32, {kvd, bs, 1, 1});
+    kd.m_data = std::make_shared<HIPBuffer>(Stride{4, 4 * kvd, 4 * kvd * bs, 4 * kvd * bs}, (char *)kc.get<HIPBuffer>().m_data + cur * kvd * 4);
+    vd.m_data = std::make_shared<HIPBuffer>(Stride{4 * m_kv->m_n_ctx, 4, 4 * kvd * m_kv->m_n_ctx, 4 * kvd * m_kv->m_n_ctx}, (char *)vc.get<HIPBuffer>().m_data + cur * 4);
+    copy(&kd, k);
+    copy(&vd, v);
+}
+
 void HIPBackend::softmax(const Tensor *out, const Tensor *x) const {
     auto d = to_ps(out), a = to_ps(x);
-    check(ps_hip_softmax_ext(m_ctx, &d, &a, nullptr, 1.0f, 0.0f), "softmax");
+    check(ps_hip_soft_max(m_ctx, &d, &a), "softmax");
 }
 void HIPBackend::rope(Tensor *out, const Tensor *src, const std::vector<int> &pos, const ModelConfig::LLMConfig::RopeConfig &c) const {
     auto d = to_ps(out), a = to_ps(src);

@@ -27,6 +27,20 @@ struct HIPKV {
     void reset_kv_cache() { ps_hip_model_kv_truncate(m_model, kv_size); }
     void advance(int n);
     void rollback(size_t n);
+    // the rest of KVCacheInterface (src/core/kv_cache.hpp:120-162) on the device cache.  A forward writes its K / V rows straight into the
+    // slots position() + i (there is no per-batch staging area to copy out of), hence: copy = move from slot position() + token index,
+    // save_tokens = bounds check only, unmask_tokens = un-hide the slots behind the position, append_tokens = the three in the reference's order.
+    void copy(size_t dst_cache_index, size_t src_token_index);
+    void move(size_t dst_cache_index, size_t src_cache_index);
+    void mask(size_t cache_index);
+    void unmask(size_t cache_index);
+    void save_tokens(size_t n_tokens);
+    void save_kv(int size) { save_tokens((size_t)size); } // GGMLKV::save_kv (ggml_kv_cache.hpp:148-150)
+    void unmask_tokens(size_t n_tokens);
+    size_t advance_tokens(size_t n_tokens) { const size_t old = position(); advance((int)n_tokens); return old; }
+    size_t rollback_tokens(size_t n_tokens) { const size_t old = position(); rollback(n_tokens); return old; }
+    size_t truncate_tokens(size_t n_tokens) { const size_t old = position(); ps_hip_model_kv_truncate(m_model, n_tokens); return old; }
+    size_t append_tokens(size_t n_tokens);
     auto get_cache(size_t L) -> std::pair<Tensor &, Tensor &> { return {key_tensors[L], value_tensors[L]}; }
 };
 
@@ -62,11 +76,18 @@ struct HIPBackend {
     void cont(const Tensor *out, const Tensor *x) const;
     void softmax_ext(const Tensor *out, const Tensor *x, const Tensor *mask, float scale, float max_bias) const;
     bool is_contiguous(const Tensor *tensor, int n) const;
+    // ggml_wrapper.cpp:225-270: how many threads the CPU pool gives an op -- what GGMLBackend::plan sizes its work buffer with.  A launch covers
+    // an op whole, so every op is ONE task here; kept so that code written against the reference's backend compiles and sizes nothing.
+    int get_n_tasks(std::shared_ptr<OpNode> op);
     int get_vec_dot_type(const Tensor *tensor) const;
     void silu_hadamard(const Tensor *out, const Tensor *hb, const Tensor *hb2) const;
     void copy(const Tensor *dst, const Tensor *src) const;
     void print(const Tensor *x, size_t size) const;
     void reset_kv_batch_size(size_t batch_size) const { m_kv->reset_batch_size(batch_size); }
+    // ggml.cpp:153-168, deprecated there ("This function is deprecated!", no caller: the graphs append through VIEW + COPY): k, v are the
+    // batch's rows (kv_dim, batch_size) on the device; they are copied behind the cache position of layer L like the reference's memcpy pair
+    // (V into the transposed cache this backend's attention reads).  The position is not moved.
+    void add_cache(const Tensor *k, const Tensor *v, size_t L, const std::vector<int> &pos, size_t head_id);
     void transpose(const Tensor *out, const Tensor *x) const;
     void get_mask(const Tensor *out, const std::vector<int> &pos, const CausalAttentionMask &mask) const; // executor.cpp:210-224
     // The reference hands the whole op vector to the backend before running it (executor.cpp:47-49,79).  Here that is the

@@ -194,8 +194,9 @@ auto Model::forward_graph(const std::vector<int> &tokens, const std::vector<int>
         executor.run();
         // a lowered single-token forward is only enqueued: its one-launch attention may have given up at its exchange (bounded wait); the
         // device model has then switched to the two launches and the same graph runs once more before anything counts
-        if (ps_hip_model_sync_check(be.m_model) == 0) break;
-        if (attempt > 0) POWERSERVE_ABORT(std::string("lowered forward: ") + ps_hip_last_error(be.m_ctx));
+        const int rc = ps_hip_model_sync_check(be.m_model);
+        if (rc == 0) break;
+        if (rc != PS_HIP_ATTN_TIMEOUT || attempt > 0) POWERSERVE_ABORT(std::string("lowered forward: ") + ps_hip_last_error(be.m_ctx)); // a HIP error is not retried; a time-out once
     }
     be.m_kv->advance((int)bs);
     if (!lm_head) { be.sync(); return LogitsVector(); }
@@ -308,6 +309,85 @@ int psh_model_forward(void *h, const int32_t *tokens, int n, const int32_t *pos,
             for (int i = 0; i < n; i++) memcpy(logits_out + (size_t)i * r.logits_vector[i].size(), r.logits_vector[i].data(), r.logits_vector[i].size() * 4);
         return 0;
     } catch (const std::exception &e) { g_err = e.what(); return 1; }
+}
+// ---- boundary members no model graph uses (tests call each of them once: Graph::softmax through the executor, get_n_tasks, add_cache,
+// and the KVCacheInterface members of src/core/kv_cache.hpp:120-162 on the device cache)
+int psh_graph_softmax(void *h, const float *x_host, int64_t n, int64_t rows, float *out_host) { // SOFTMAX op: Graph::softmax -> Executor -> HIPBackend::softmax -> ps_hip_soft_max
+    try {
+        auto m = (psh_model *)h;
+        auto &be = m->model->backend();
+        Graph g(m->model->m_config->model_id);
+        auto x = g.new_tensor(DataType::FP32, {(size_t)n, (size_t)rows, 1, 1});
+        auto y = g.softmax(x);
+        Executor ex(*m->platform, g);
+        ex.plan();
+        POWERSERVE_ASSERT(!ex.lowered());
+        ex.allocate_buffers();
+        if (ps_hip_memcpy_h2d(be.m_ctx, x->get<HIPBuffer>().m_data, x_host, (size_t)n * rows * 4)) POWERSERVE_ABORT(ps_hip_last_error(be.m_ctx));
+        ex.run();
+        be.sync();
+        if (ps_hip_memcpy_d2h(be.m_ctx, out_host, y->get<HIPBuffer>().m_data, (size_t)n * rows * 4)) POWERSERVE_ABORT(ps_hip_last_error(be.m_ctx));
+        return 0;
+    } catch (const std::exception &e) { g_err = e.what(); return 1; }
+}
+int psh_backend_get_n_tasks(void *h) {
+    auto op = std::make_shared<OpNode>(OpType::MAT_MUL);
+    return ((psh_model *)h)->model->backend().get_n_tasks(op);
+}
+int psh_backend_add_cache(void *h, int L, const float *k_host, const float *v_host, int bs) { // k, v: [bs][kv_dim] rows of the batch
+    try {
+        auto m = (psh_model *)h;
+        auto &be = m->model->backend();
+        const size_t kvd = be.m_kv->m_kv_dim, bytes = kvd * (size_t)bs * 4;
+        be.reset_kv_batch_size((size_t)bs);
+        be.arena_reset();
+        be.arena_reserve(2 * bytes + 4096);
+        Tensor k(DataType::FP32, {kvd, (size_t)bs, 1, 1}), v(DataType::FP32, {kvd, (size_t)bs, 1, 1});
+        const Stride st{4, 4 * kvd, bytes, bytes};
+        k.m_data = std::make_shared<HIPBuffer>(st, be.arena_alloc(bytes));
+        v.m_data = std::make_shared<HIPBuffer>(st, be.arena_alloc(bytes));
+        if (ps_hip_memcpy_h2d(be.m_ctx, k.get<HIPBuffer>().m_data, k_host, bytes) || ps_hip_memcpy_h2d(be.m_ctx, v.get<HIPBuffer>().m_data, v_host, bytes))
+            POWERSERVE_ABORT(ps_hip_last_error(be.m_ctx));
+        std::vector<int> pos(bs);
+        std::iota(pos.begin(), pos.end(), (int)be.m_kv->position());
+        be.add_cache(&k, &v, (size_t)L, pos, 0);
+        be.sync();
+        return 0;
+    } catch (const std::exception &e) { g_err = e.what(); return 1; }
+}
+int psh_model_kv_read(void *h, int L, int64_t slot, float *k_out, float *v_out) { // cache slot `slot` of layer L: its K row and its V column, kv_dim floats each
+    try {
+        auto &be = ((psh_model *)h)->model->backend();
+        const size_t kvd = be.m_kv->m_kv_dim, n_ctx = be.m_kv->m_n_ctx;
+        be.sync();
+        std::vector<float> vt(kvd * n_ctx);
+        if (ps_hip_memcpy_d2h(be.m_ctx, k_out, ps_hip_model_k_cache(be.m_model, L) + (size_t)slot * kvd, kvd * 4) ||
+            ps_hip_memcpy_d2h(be.m_ctx, vt.data(), ps_hip_model_v_cache(be.m_model, L), vt.size() * 4))
+            POWERSERVE_ABORT(ps_hip_last_error(be.m_ctx));
+        for (size_t d = 0; d < kvd; d++) v_out[d] = vt[d * n_ctx + (size_t)slot];
+        return 0;
+    } catch (const std::exception &e) { g_err = e.what(); return 1; }
+}
+// op: 0 copy(a, b) 1 move(a, b) 2 mask(a) 3 unmask(a) 4 save_tokens(a) 5 unmask_tokens(a) 6 advance_tokens(a) 7 rollback_tokens(a) 8 truncate_tokens(a) 9 append_tokens(a);
+// returns what the member returns (the old position for 6..9, else 0), -1 on failure
+int64_t psh_kv_op(void *h, int op, int64_t a, int64_t b) {
+    try {
+        auto &kv = *((psh_model *)h)->model->backend().m_kv;
+        switch (op) {
+        case 0: kv.copy((size_t)a, (size_t)b); return 0;
+        case 1: kv.move((size_t)a, (size_t)b); return 0;
+        case 2: kv.mask((size_t)a); return 0;
+        case 3: kv.unmask((size_t)a); return 0;
+        case 4: kv.save_tokens((size_t)a); return 0;
+        case 5: kv.unmask_tokens((size_t)a); return 0;
+        case 6: return (int64_t)kv.advance_tokens((size_t)a);
+        case 7: return (int64_t)kv.rollback_tokens((size_t)a);
+        case 8: return (int64_t)kv.truncate_tokens((size_t)a);
+        case 9: return (int64_t)kv.append_tokens((size_t)a);
+        }
+        g_err = "psh_kv_op: unknown op";
+        return -1;
+    } catch (const std::exception &e) { g_err = e.what(); return -1; }
 }
 // sampler chain alone (tests against the reference's samplers) and sampled generation
 struct psh_sampler_cfg { // plain-C view of SamplerConfig + the two vocabulary ids the chain needs

@@ -58,6 +58,7 @@ struct G4KParams {
     G4KMat w[3];
     int wt;                  // PS_Q4_K or PS_Q5_K (one producer each; the consumers are the same)
     int n_w, nsb, bs, n_tasks, n_cb, n_items; // n_cb: 64-column blocks; items = (task, column block), tasks padded to a multiple of 8
+    int cbx;                 // > 0: column blocks per XCD of the XCD-aware item order (g4k_item); 0: the round-2 order
     const float *residual;
     const _Float16 *qf; // fragment-major fp16 quants
     const uint8_t *mf;  // tile-major column metadata (ps_act::mf)
@@ -187,9 +188,23 @@ __device__ __forceinline__ void g4k_store_pair(const G4KParams &p, const int wi,
     }
 }
 
-// item i -> (task, column block): 16 consecutive items are 8 tasks x 2 column blocks (for n_cb = 2), the two blocks of a task
-// 8 apart -- the same XCD at the same time, so the second one finds the weights in that L2
+// item i -> (task, column block).
+// cbx == 0 (round 2): 16 consecutive items are 8 tasks x 2 column blocks (for n_cb = 2), the two blocks of a task 8 apart -- the same XCD
+// at the same time, so the second one finds the weights in that L2.  With n_cb = 8 (a 512-column sequence) that puts ALL eight column blocks
+// on every XCD: their fragment-major activations are 4.4 MB at K = 4096, more than the XCD's 4 MB L2, cycled once per item -- the L2 thrashes
+// and the launch fetches 16 x its weights from the fabric (profiles/r04_pmc_traffic.json: 1070 MB for 66 MB).
+// cbx > 0 (round 5; needs gridDim.x == 256, n_items % 256 == 0, n_cb a power of two, cbx | n_cb): workgroup b sits on XCD b % 8 (slot b / 8
+// of its 32).  The n_cb / cbx groups of cbx column blocks are dealt over the XCDs; the 8 cbx / n_cb XCDs that share a group split the tasks
+// between them.  An XCD then cycles only cbx x 0.55 MB of activations and streams 1 / (8 cbx / n_cb) of the weights, each weight tile met by
+// cbx workgroups of that XCD at the same time.
 __device__ __forceinline__ void g4k_item(const G4KParams &p, const int i, int &task, int &cb) {
+    if (p.cbx) {
+        const int b = i & 255, k = i >> 8, xcd = b & 7, slot = b >> 3;
+        const int G = p.n_cb / p.cbx, TC = 8 / G, NT = 32 / p.cbx;
+        cb = (xcd % G) * p.cbx + slot % p.cbx;
+        task = (k * NT + slot / p.cbx) * TC + xcd / G;
+        return;
+    }
     cb = (i >> 3) % p.n_cb;
     task = (i / (8 * p.n_cb)) * 8 + (i & 7);
 }
@@ -952,6 +967,7 @@ __global__ __launch_bounds__((G4K_NC + G4K_NP) * 64) void gemm6k_kernel(const G6
 
 } // namespace
 
+int g_g4k_cbx = getenv("PS_G4K_CBX") ? atoi(getenv("PS_G4K_CBX")) : 0; // ps_hip_debug_set(6, v): column blocks per XCD of the wide Q4_K / Q5_K mat-mul's item order (0: round 2's)
 int g_g4k_par = getenv("PS_GEMM4K_PAR") ? atoi(getenv("PS_GEMM4K_PAR")) : 1; // ps_hip_debug_set(3, v): the few-tile narrow-batch form (gemm4k_par_kernel)
 // grid, persistence and the wide / narrow choice for a filled-in G4KParams (tasks, pointers, wt)
 // ---- narrow batches, wave-autonomous form (round 3): at most 16 columns, Q4_K.  The producer / consumer kernels above pay a
@@ -1563,6 +1579,13 @@ static int g4k_launch(hipStream_t st, int n_cu, G4KParams &p, const int epi, con
     // (the consumers prefetch the next item's first fragments with this item's column pointers)
     int n_wg = p.n_items;
     if (n_cu > 0 && n_wg > n_cu && n_cu % (8 * p.n_cb) == 0) n_wg = n_cu;
+    // the XCD-aware item order (g4k_item): column blocks per XCD; only where its arithmetic holds, else the round-2 order
+    p.cbx = 0;
+    if (g_g4k_cbx > 0 && n_wg == 256 && p.n_items % 256 == 0 && (p.n_cb & (p.n_cb - 1)) == 0 && p.n_cb <= 8) {
+        int cbx = g_g4k_cbx < p.n_cb ? g_g4k_cbx : p.n_cb;
+        while (cbx & (cbx - 1)) cbx &= cbx - 1; // a power of two
+        if (cbx < p.n_cb) p.cbx = cbx;          // (cbx == n_cb IS the round-2 order)
+    }
     const dim3 grid((unsigned)n_wg), blk((G4K_NC + G4K_NP) * 64), blkn((G4K_NC + G4K_NPN) * 64);
     static_assert(G4K_RING == 4, "nsb % 4 == 0 is what the producers' ring is unrolled for");
     constexpr int LDS1 = G4K_XCH + 8 * 64 * 8 * 2 * 4 + PS_EXP2F_N * 8;

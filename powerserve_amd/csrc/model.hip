@@ -49,6 +49,7 @@ struct ps_hip_model {
     unsigned *attn_sync = nullptr; // [2048] words: [31] the one-launch attention's rendezvous-timeout flag
     unsigned *attn_flag_host = nullptr; // pinned: [31] travels here behind every single-token forward (async copy on the stream)
     bool attn_unchecked = false;        // such a forward was enqueued and its flag has not been looked at yet
+    bool attn1_disabled = false;        // the one-launch attention timed out once on this device: mode bit 4 is sticky (set_mode ORs it back in; bit 6 re-arms)
     float *attn_xchg = nullptr;    // attn_decode2: scores in flight between workgroups (k_attn.hip)
     unsigned *attn_tick = nullptr; // attn_decode2: [64 * kv head] arrival counters
     size_t graph_hint = 0;                   // KV position the captured step was given as its prefetch hint (n_kv_lo)
@@ -521,9 +522,30 @@ int ps_hip_model_kv_move(ps_hip_model *m, size_t dst, size_t src) {
                            m->v_cache[L], m->k16.empty() ? nullptr : m->k16[L], m->v16.empty() ? nullptr : m->v16[L], (int)m->cfg.kv_dim, (int)m->cfg.seq_len, (int)dst, (int)src);
     return 0;
 }
+// ---- the rest of KVCacheInterface (core/kv_cache.hpp:120-162; see include/ps_hip.h for why they reduce to these)
+int ps_hip_model_kv_copy(ps_hip_model *m, size_t dst_cache_index, size_t src_token_index) {
+    return ps_hip_model_kv_move(m, dst_cache_index, m->position + src_token_index);
+}
+int ps_hip_model_kv_save_tokens(ps_hip_model *m, size_t n) {
+    if (m->position + n > m->cfg.seq_len) { m->ctx->err = "kv_save_tokens: the length of kvcache is up to the preset threshold (n_ctx)"; return 2; }
+    return 0;
+}
+int ps_hip_model_kv_unmask_tokens(ps_hip_model *m, size_t n) {
+    if (m->position + n > m->cfg.seq_len) { m->ctx->err = "kv_unmask_tokens: the length of kvcache is up to the preset threshold (n_ctx)"; return 2; }
+    unmask_range(m, m->position, n);
+    return 0;
+}
+int ps_hip_model_kv_append_tokens(ps_hip_model *m, size_t n, size_t *old_position) {
+    const size_t old = m->position;
+    if (int rc = ps_hip_model_kv_save_tokens(m, n)) return rc;
+    if (int rc = ps_hip_model_kv_unmask_tokens(m, n)) return rc;
+    if (int rc = ps_hip_model_kv_advance(m, n)) return rc;
+    if (old_position) *old_position = old;
+    return 0;
+}
 
 static int model_forward_impl(ps_hip_model *m, const int32_t *tokens, int n, const int32_t *pos, const uint8_t *tree, int lm_head,
-                              int32_t *argmax_host, bool advance);
+                              int32_t *argmax_host, bool advance, bool retried = false);
 // The one-launch attentions wait for each other's workgroups inside the launch (bounded); a wait that gave up raises
 // attn_sync[31].  Read it behind every synchronised single-token forward, clear it, and fall back to the two launches
 // from here on (mode bit 4): the forward that timed out has no valid result.  Expects the stream to be idle.
@@ -533,25 +555,36 @@ static void drop_graphs(ps_hip_model *m) { // every captured launch plan (they b
 }
 // Every single-token forward that may have used the one-launch attention is followed, on the stream, by a 4-byte copy of the flag into pinned
 // host memory (note_single_token): looking at it costs no round trip once the stream is idle.
+int g_force_attn_timeout = 0; // ps_hip_debug_set(5, n): the next n single-token forwards on the one-launch attention report a time-out (tests of the retry paths)
 static void note_single_token(ps_hip_model *m) {
     if (m->mode & 16) return; // the one-launch form is not in use
+    if (g_force_attn_timeout > 0) { g_force_attn_timeout--; (void)hipMemsetAsync(m->attn_sync + 31, 1, 1, m->ctx->stream); } // (word = 1, behind the forward's launches)
     (void)hipMemcpyAsync(m->attn_flag_host, m->attn_sync + 31, 4, hipMemcpyDeviceToHost, m->ctx->stream);
     m->attn_unchecked = true;
 }
-// 0: nothing pending or the flag is clear.  2: the forward(s) since the last check have no valid result; the model has switched to the
-// two-launch attention (mode bit 4, graphs dropped) and c->err says so -- the callers that still know their inputs run them again.
+// 0: nothing pending or the flag is clear.  PS_HIP_ATTN_TIMEOUT (3): the forward(s) since the last check have no valid result; the model has
+// switched to the two-launch attention (mode bit 4, sticky; graphs dropped) and c->err says so -- the callers that still know their inputs run
+// them again, ONCE (behind the switch no forward can time out: note_single_token arms nothing under mode bit 4).  1: a HIP error (c->err),
+// never retried.  The switch happens before anything that can fail, so a failing memset cannot leave the one-launch form armed with its flag up.
 static int check_attn_timeout(ps_hip_model *m, const char *who) {
     ps_hip_ctx *c = m->ctx;
     if (!m->attn_unchecked) return 0;
     m->attn_unchecked = false;
     if (!*(volatile unsigned *)m->attn_flag_host) return 0;
     *(volatile unsigned *)m->attn_flag_host = 0;
-    PS_CHECK(c, hipMemset(m->attn_sync + 31, 0, 4));
-    drop_graphs(m);
     m->mode |= 16;
+    m->attn1_disabled = true;
+    drop_graphs(m);
+    PS_CHECK(c, hipMemset(m->attn_sync + 31, 0, 4));
     c->err = std::string(who) + ": the one-launch attention timed out at its score exchange (GPU shared or partitioned?); this forward has no valid "
              "result, the cache position is unchanged, and the model now uses the two-launch attention (mode bit 4)";
-    return 2;
+    return PS_HIP_ATTN_TIMEOUT;
+}
+// A lowered forward that nobody has consumed yet (no kv_advance / sync_check since) must not leave its flag to the next, unrelated forward:
+// every entry point settles it first and hands a time-out back to the caller, who still owns that forward's inputs.
+static int settle_pending(ps_hip_model *m) {
+    if (!m->attn_unchecked) return 0;
+    return ps_hip_model_sync_check(m);
 }
 // The lowered op-API path (ps_hip_model_forward_lowered) returns before its launches have run: whoever consumes its result next -- the
 // cache advance (LlamaModel::forward advances right behind Executor::run, llama_model.cpp:109) or a logits read -- looks at the flag.
@@ -569,8 +602,9 @@ int ps_hip_model_forward_lowered(ps_hip_model *m, const int32_t *tokens, int n, 
     return model_forward_impl(m, tokens, n, pos, tree, lm_head, nullptr, false);
 }
 static int model_forward_impl(ps_hip_model *m, const int32_t *tokens, int n, const int32_t *pos, const uint8_t *tree, int lm_head,
-                              int32_t *argmax_host, bool advance) {
+                              int32_t *argmax_host, bool advance, bool retried) {
     ps_hip_ctx *c = m->ctx;
+    if (int rc = settle_pending(m)) return rc;
     if (n <= 0 || n > m->max_batch) PS_FAIL(c, "model_forward: batch size out of range");
     for (int i = 1; i < n; i++)
         if (pos[i] != pos[0] + i) PS_FAIL(c, "model_forward: positions must be consecutive (KV append is one contiguous copy, norm_attention.cpp:82-91)");
@@ -613,9 +647,10 @@ static int model_forward_impl(ps_hip_model *m, const int32_t *tokens, int n, con
     if (lm_head && argmax_host) PS_CHECK(c, hipMemcpyAsync(argmax_host, m->argmax_dev, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
     if (!advance) return 0; // lowered graph: ps_hip_model_kv_advance / ps_hip_model_sync_check look at the time-out flag before the result counts
     PS_CHECK(c, hipStreamSynchronize(c->stream));
-    if (check_attn_timeout(m, "model_forward")) { // the model is on the two-launch attention now: the same forward once more (inputs are the caller's)
+    if (const int rc = check_attn_timeout(m, "model_forward")) { // a time-out: the model is on the two-launch attention now, the same forward once more (inputs are the caller's)
+        if (rc != PS_HIP_ATTN_TIMEOUT || retried) return rc;
         c->err.clear();
-        return model_forward_impl(m, tokens, n, pos, tree, lm_head, argmax_host, advance);
+        return model_forward_impl(m, tokens, n, pos, tree, lm_head, argmax_host, advance, true);
     }
     unmask_range(m, (size_t)pos[0], (size_t)n);
     m->position = (size_t)pos[0] + (size_t)n; // m_kv->advance (llama_model.cpp:109)
@@ -629,6 +664,7 @@ static int model_forward_impl(ps_hip_model *m, const int32_t *tokens, int n, con
 int ps_hip_model_prefill(ps_hip_model *m, const int32_t *tokens, int n, int chunk) {
     ps_hip_ctx *c = m->ctx;
     if (n <= 0) return 0;
+    if (int rc = settle_pending(m)) return rc;
     if (chunk <= 0 || chunk > m->max_batch) PS_FAIL(c, "model_prefill: chunk size out of range");
     if (m->position + (size_t)n > m->cfg.seq_len) PS_FAIL(c, "model_prefill: KV cache is full (n_ctx)");
     for (int i = 0; i < n; i++)
@@ -637,6 +673,7 @@ int ps_hip_model_prefill(ps_hip_model *m, const int32_t *tokens, int n, int chun
     int per = m->max_batch / chunk; // reference chunks per super-chunk
     if (per > 64) per = 64;
     if (per < 1) per = 1;
+    bool retried = false;
     for (int done = 0; done < n;) {
         const int ns = n - done < per * chunk ? n - done : per * chunk;
         PS_CHECK(c, hipMemcpyAsync(m->tokens_dev, tokens + done, (size_t)ns * 4, hipMemcpyHostToDevice, c->stream));
@@ -649,7 +686,10 @@ int ps_hip_model_prefill(ps_hip_model *m, const int32_t *tokens, int n, int chun
         if (rc) return rc;
         if (ns == 1) note_single_token(m);
         PS_CHECK(c, hipStreamSynchronize(c->stream));
-        if (check_attn_timeout(m, "model_prefill")) { c->err.clear(); continue; } // a one-token tail: once more, with the two launches
+        if (const int rc = check_attn_timeout(m, "model_prefill")) { // a one-token tail: once more, with the two launches
+            if (rc != PS_HIP_ATTN_TIMEOUT || retried) return rc;
+            retried = true; c->err.clear(); continue;
+        }
         unmask_range(m, m->position, (size_t)ns);
         m->position += (size_t)ns;
         done += ns;
@@ -657,9 +697,16 @@ int ps_hip_model_prefill(ps_hip_model *m, const int32_t *tokens, int n, int chun
     return 0;
 }
 
+static int forward_tree_impl(ps_hip_model *m, const int32_t *tokens, int n, const int32_t *rope_pos, const uint8_t *tree, int lm_head,
+                             int32_t *argmax_host, int advance, bool retried);
 int ps_hip_model_forward_tree(ps_hip_model *m, const int32_t *tokens, int n, const int32_t *rope_pos, const uint8_t *tree, int lm_head,
                               int32_t *argmax_host, int advance) {
+    return forward_tree_impl(m, tokens, n, rope_pos, tree, lm_head, argmax_host, advance, false);
+}
+static int forward_tree_impl(ps_hip_model *m, const int32_t *tokens, int n, const int32_t *rope_pos, const uint8_t *tree, int lm_head,
+                             int32_t *argmax_host, int advance, bool retried) {
     ps_hip_ctx *c = m->ctx;
+    if (int rc = settle_pending(m)) return rc;
     if (n <= 0 || n > m->max_batch) PS_FAIL(c, "model_forward_tree: batch size out of range");
     if (m->position + (size_t)n > m->cfg.seq_len) PS_FAIL(c, "model_forward_tree: KV cache is full (n_ctx)");
     for (int i = 0; i < n; i++) {
@@ -679,7 +726,11 @@ int ps_hip_model_forward_tree(ps_hip_model *m, const int32_t *tokens, int n, con
     if (n == 1 && !tree) note_single_token(m);
     if (lm_head && argmax_host) PS_CHECK(c, hipMemcpyAsync(argmax_host, m->argmax_dev, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
     PS_CHECK(c, hipStreamSynchronize(c->stream));
-    if (check_attn_timeout(m, "model_forward_tree")) { c->err.clear(); return ps_hip_model_forward_tree(m, tokens, n, rope_pos, tree, lm_head, argmax_host, advance); }
+    if (const int rc = check_attn_timeout(m, "model_forward_tree")) {
+        if (rc != PS_HIP_ATTN_TIMEOUT || retried) return rc;
+        c->err.clear();
+        return forward_tree_impl(m, tokens, n, rope_pos, tree, lm_head, argmax_host, advance, true);
+    }
     if (advance) { unmask_range(m, m->position, (size_t)n); m->position += (size_t)n; }
     return 0;
 }
@@ -695,9 +746,12 @@ int ps_hip_model_kv_mask(ps_hip_model *m, size_t index, int visible) {
     return 0;
 }
 
-int ps_hip_model_decode_greedy(ps_hip_model *m, int32_t token, int steps, int32_t *out_ids) {
+static int decode_greedy_impl(ps_hip_model *m, int32_t token, int steps, int32_t *out_ids, bool retried);
+int ps_hip_model_decode_greedy(ps_hip_model *m, int32_t token, int steps, int32_t *out_ids) { return decode_greedy_impl(m, token, steps, out_ids, false); }
+static int decode_greedy_impl(ps_hip_model *m, int32_t token, int steps, int32_t *out_ids, bool retried) {
     ps_hip_ctx *c = m->ctx;
     if (steps <= 0) return 0;
+    if (int rc = settle_pending(m)) return rc;
     if (m->n_hidden) PS_FAIL(c, "decode_greedy: hidden KV slots (kv_mask) are not part of the captured step; unmask first");
     if (m->position + (size_t)steps > m->cfg.seq_len) PS_FAIL(c, "decode_greedy: KV cache would overflow n_ctx");
     if (token < 0 || (uint32_t)token >= m->cfg.vocab_size) PS_FAIL(c, "decode_greedy: token id out of range");
@@ -736,7 +790,11 @@ int ps_hip_model_decode_greedy(ps_hip_model *m, int32_t token, int steps, int32_
     PS_CHECK(c, hipStreamSynchronize(c->stream));
     // a time-out anywhere in the run: the position has not moved and the first token is the caller's -- the whole run once more on the
     // two-launch attention (every cache row it wrote is written again with the same values)
-    if (check_attn_timeout(m, "decode_greedy")) { c->err.clear(); return ps_hip_model_decode_greedy(m, token, steps, out_ids); }
+    if (const int rc = check_attn_timeout(m, "decode_greedy")) {
+        if (rc != PS_HIP_ATTN_TIMEOUT || retried) return rc;
+        c->err.clear();
+        return decode_greedy_impl(m, token, steps, out_ids, true);
+    }
     m->position += (size_t)steps;
     return 0;
 }
@@ -844,6 +902,8 @@ static int mode_env_or() {
 }
 int ps_hip_model_set_mode(ps_hip_model *m, int mode) {
     mode |= mode_env_or();
+    if (mode & 64) { m->attn1_disabled = false; mode &= ~64; } // explicit re-arm of the one-launch attention after a time-out
+    if (m->attn1_disabled) mode |= 16;                         // sticky: a later set_mode without bit 4 does not bring the form that timed out back
     if ((mode & 8) && m->k16.empty()) { // fp16 mirrors of the caches: filled from now on, so the cache must be empty
         if (m->position != 0) { m->ctx->err = "set_mode: the fp16-KV decode mode must be switched on while the cache is empty"; return 2; }
         const size_t n = (size_t)m->cfg.seq_len * m->cfg.kv_dim * 2;

@@ -18,6 +18,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PS_HIP_LIB") or os.path.join(HERE, "lib", "libps_hip.so")  # PS_HIP_LIB: an A/B build (tools/ab_build.py)
 
 F32, F16, Q4_0, Q8_0, Q4_K, Q5_K, Q6_K, Q8_K, I32 = 0, 1, 2, 8, 12, 13, 14, 15, 26
+ATTN_TIMEOUT = 3  # PS_HIP_ATTN_TIMEOUT (include/ps_hip.h)
 QUANT = (Q4_0, Q8_0, Q4_K, Q5_K, Q6_K)
 
 EXPORTS = [
@@ -31,6 +32,7 @@ EXPORTS = [
     "ps_hip_model_kv_position", "ps_hip_model_max_batch", "ps_hip_model_kv_truncate", "ps_hip_model_kv_advance", "ps_hip_model_kv_rollback", "ps_hip_model_kv_move",
     "ps_hip_model_forward", "ps_hip_model_decode_greedy", "ps_hip_model_logits", "ps_hip_model_scratch", "ps_hip_model_k_cache",
     "ps_hip_model_v_cache", "ps_hip_model_weight_bytes_per_token", "ps_hip_model_set_mode", "ps_hip_model_bench_gemv", "ps_hip_model_bench_matmul", "ps_hip_debug_timeline", "ps_hip_last_matmul_kernel", "ps_hip_debug_set", "ps_hip_debug_f16_gemm", "ps_hip_model_forward_tree", "ps_hip_model_prefill", "ps_hip_model_forward_lowered", "ps_hip_model_sync_check", "ps_hip_model_kv_mask",
+    "ps_hip_soft_max", "ps_hip_model_kv_copy", "ps_hip_model_kv_save_tokens", "ps_hip_model_kv_unmask_tokens", "ps_hip_model_kv_append_tokens",
 ]
 
 
@@ -115,6 +117,9 @@ def lib() -> C.CDLL:
         "ps_hip_model_decode_greedy": (i32, [vp, i32, i32, vp]), "ps_hip_model_logits": (vp, [vp]), "ps_hip_model_scratch": (vp, [vp, i32]),
         "ps_hip_model_k_cache": (vp, [vp, i32]), "ps_hip_model_v_cache": (vp, [vp, i32]),
         "ps_hip_model_weight_bytes_per_token": (C.c_uint64, [vp]), "ps_hip_model_set_mode": (i32, [vp, i32]),
+        "ps_hip_model_sync_check": (i32, [vp]), "ps_hip_soft_max": (i32, [vp, T, T]),
+        "ps_hip_model_kv_copy": (i32, [vp, sz, sz]), "ps_hip_model_kv_save_tokens": (i32, [vp, sz]), "ps_hip_model_kv_unmask_tokens": (i32, [vp, sz]),
+        "ps_hip_model_kv_append_tokens": (i32, [vp, sz, C.POINTER(sz)]),
         "ps_hip_debug_timeline": (i32, [vp, i32, vp, i32]),
         "ps_hip_last_matmul_kernel": (C.c_char_p, []),
         "ps_hip_debug_set": (i32, [i32, i32]),
@@ -378,6 +383,36 @@ class Model:
 
     def kv_rollback(self, n: int):
         self.ctx.check(self.ctx.L.ps_hip_model_kv_rollback(self.h, int(n)))
+
+    # the rest of KVCacheInterface (core/kv_cache.hpp:120-162)
+    def kv_copy(self, dst_cache_index: int, src_token_index: int):
+        self.ctx.check(self.ctx.L.ps_hip_model_kv_copy(self.h, int(dst_cache_index), int(src_token_index)))
+
+    def kv_save_tokens(self, n: int):
+        self.ctx.check(self.ctx.L.ps_hip_model_kv_save_tokens(self.h, int(n)))
+
+    def kv_unmask_tokens(self, n: int):
+        self.ctx.check(self.ctx.L.ps_hip_model_kv_unmask_tokens(self.h, int(n)))
+
+    def kv_append_tokens(self, n: int) -> int:
+        old = C.c_size_t()
+        self.ctx.check(self.ctx.L.ps_hip_model_kv_append_tokens(self.h, int(n), C.byref(old)))
+        return old.value
+
+    def forward_lowered(self, tokens, pos, lm_head=True):
+        """Enqueue only (what HIPBackend::run_lowered issues); the result counts after sync_check() / kv_advance()."""
+        tokens = np.ascontiguousarray(tokens, dtype=np.int32)
+        pos = np.ascontiguousarray(pos, dtype=np.int32)
+        self.ctx.check(self.ctx.L.ps_hip_model_forward_lowered(self.h, _ptr(tokens), tokens.size, _ptr(pos), None, int(lm_head)))
+
+    def sync_check(self) -> int:
+        """0, or ATTN_TIMEOUT (the pending lowered forward has no valid result: run it again)."""
+        return self.ctx.L.ps_hip_model_sync_check(self.h)
+
+    def logits(self, n: int = 1) -> np.ndarray:
+        out = np.empty((n, self.cfg.vocab_size), dtype=np.float32)
+        self.ctx.check(self.ctx.L.ps_hip_memcpy_d2h(self.ctx.h, _ptr(out), self.ctx.L.ps_hip_model_logits(self.h), out.nbytes))
+        return out
 
     def decode_greedy(self, token: int, steps: int) -> np.ndarray:
         out = np.empty(steps, dtype=np.int32)

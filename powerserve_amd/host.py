@@ -11,7 +11,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libps_host.so")
 EXPORTS = ["psh_last_error", "psh_model_load", "psh_model_free", "psh_model_set_fused", "psh_model_plan_stats", "psh_model_kv_position", "psh_model_reset",
            "psh_model_vocab", "psh_model_forward", "psh_model_generate", "psh_spec_generate", "psh_spec_generate_sampled", "psh_draft_sample", "psh_sampler_create", "psh_sampler_free", "psh_sampler_sample",
-           "psh_model_generate_sampled", "psh_token_tree_run", "psh_gguf_summary", "psh_config_summary"]
+           "psh_model_generate_sampled", "psh_token_tree_run", "psh_gguf_summary", "psh_config_summary",
+           "psh_graph_softmax", "psh_backend_get_n_tasks", "psh_backend_add_cache", "psh_model_kv_read", "psh_kv_op"]
 _LIB = None
 
 
@@ -44,6 +45,12 @@ def lib() -> C.CDLL:
         L.psh_sampler_sample.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.psh_model_generate_sampled.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.psh_token_tree_run.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int] + [C.c_void_p] * 5
+        L.psh_graph_softmax.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
+        L.psh_backend_get_n_tasks.argtypes = [C.c_void_p]
+        L.psh_backend_add_cache.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        L.psh_model_kv_read.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p]
+        L.psh_kv_op.restype = C.c_int64
+        L.psh_kv_op.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_int64]
         L.psh_config_summary.restype = C.c_int64
         L.psh_config_summary.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t]
         L.psh_gguf_summary.restype = C.c_int64
@@ -111,6 +118,41 @@ class HostModel:
         if rc:
             raise HostError(self.L.psh_last_error().decode())
         return out
+
+    # ---- boundary members no model graph uses (src/graph/graph.cpp:118, ggml.hpp:227,233, core/kv_cache.hpp:120-162)
+    def graph_softmax(self, x):
+        """Graph::softmax(x) through Executor::run (the SOFTMAX op -> HIPBackend::softmax -> ps_hip_soft_max); x [rows, n]."""
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        out = np.empty_like(x)
+        if self.L.psh_graph_softmax(self.h, x.ctypes.data, x.shape[1], x.shape[0], out.ctypes.data):
+            raise HostError(self.L.psh_last_error().decode())
+        return out
+
+    def get_n_tasks(self) -> int:
+        return self.L.psh_backend_get_n_tasks(self.h)
+
+    def add_cache(self, layer: int, k, v):
+        """GGMLBackend::add_cache (deprecated in the reference): the batch's K / V rows [bs, kv_dim] behind the cache position."""
+        k = np.ascontiguousarray(k, dtype=np.float32)
+        v = np.ascontiguousarray(v, dtype=np.float32)
+        if self.L.psh_backend_add_cache(self.h, layer, k.ctypes.data, v.ctypes.data, k.shape[0]):
+            raise HostError(self.L.psh_last_error().decode())
+
+    def kv_read(self, layer: int, slot: int, kv_dim: int):
+        k, v = np.empty(kv_dim, np.float32), np.empty(kv_dim, np.float32)
+        if self.L.psh_model_kv_read(self.h, layer, slot, k.ctypes.data, v.ctypes.data):
+            raise HostError(self.L.psh_last_error().decode())
+        return k, v
+
+    KV_OPS = {"copy": 0, "move": 1, "mask": 2, "unmask": 3, "save_tokens": 4, "unmask_tokens": 5, "advance_tokens": 6, "rollback_tokens": 7,
+              "truncate_tokens": 8, "append_tokens": 9}
+
+    def kv(self, op: str, a: int = 0, b: int = 0) -> int:
+        """One KVCacheInterface member on the device cache; returns what the member returns (old position for the *_tokens movers)."""
+        r = self.L.psh_kv_op(self.h, self.KV_OPS[op], int(a), int(b))
+        if r < 0:
+            raise HostError(self.L.psh_last_error().decode())
+        return int(r)
 
     def generate(self, prompt, batch_size: int, steps: int):
         p = np.ascontiguousarray(prompt, dtype=np.int32)

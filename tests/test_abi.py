@@ -22,7 +22,7 @@ def test_header_symbols_exported():
     missing = [n for n in names if not hasattr(L, n)]
     assert not missing, missing
     assert sorted(hip.EXPORTS) == names, set(hip.EXPORTS) ^ set(names)
-    assert L.ps_hip_abi_version() == 1
+    assert L.ps_hip_abi_version() == 2  # round 5: + ps_hip_soft_max, the KVCacheInterface leftovers, PS_HIP_ATTN_TIMEOUT
 
 
 def test_type_helpers_match_ggml():
