@@ -86,6 +86,13 @@ typedef struct {
 
 /* ------------------------------------------------------------------ context, memory, timing */
 int ps_hip_abi_version(void);
+/* Which build of the reference this library's fp32 arithmetic follows bit for bit.  0 (lib/libps_hip.so, the default and what every "bit-exact"
+ * in this repository refers to): the reference compiled with -ffp-contract=off -- each operation rounds where the C source rounds.  1
+ * (lib/libps_hip_contract.so, built with -DPS_CONTRACT by powerserve_amd/build.py): the reference as its own CMake compiles it on an FMA machine
+ * (no contraction flag: GCC's default -ffp-contract=fast; CMakeLists.txt:24-33, libs/ggml/src/CMakeLists.txt:1173), which fuses the RoPE rotation
+ * (ggml.c:15455-15475) and the n % 32 leftovers of ggml_vec_dot_f32 (ggml.c:2123-2125); Q5_K (a third fused site, ggml-quants.c:8411) is
+ * refused by that build. */
+int ps_hip_build_contract(void);
 int ps_hip_device_count(void);
 int ps_hip_create(int device, ps_hip_ctx **out);
 void ps_hip_destroy(ps_hip_ctx *ctx);

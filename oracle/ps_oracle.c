@@ -30,6 +30,19 @@
 #define QK 32
 #define QK_K 256
 
+/* ------------------------------------------------------------------ the reference's SECOND build (round 5)
+ * The reference's own CMake sets no floating-point contraction flag (CMakeLists.txt:24-33, libs/ggml/src/CMakeLists.txt:1173), so a
+ * stock build on an FMA machine is GCC's default -ffp-contract=fast.  Of everything on the hot path exactly THREE places come out
+ * different (every function of both builds compared by FMA-instruction count, then op by op: tests/test_ref_fast.py): the RoPE rotation
+ * (ggml.c:15455-15456, :15474-15475), the scalar leftovers of ggml_vec_dot_f32 (ggml.c:2123-2125: V.p with n_kv % 32 != 0) and Q5_K's
+ * `summs += dmin * hsum` (ggml-quants.c:8411).  pso_set_contract(1) makes this file follow THAT build (GCC 11.4 -O3 -mavx2 -mfma, the
+ * dev container's compiler: which operand pair is fused, and that the leftover loop is vectorised by 8 and by 4 WITHOUT fusing and only
+ * its last n % 4 steps are scalar fmas, is that compiler's choice) -- pinned bit for bit against oracle/_ref/libps_ref_fast.so.
+ * Default 0 = oracle/_ref/libps_ref.so (-ffp-contract=off): what the golden vectors, the HIP library and "bit-exact" refer to. */
+static int g_contract = 0;
+void pso_set_contract(int on) { g_contract = on; }
+int pso_get_contract(void) { return g_contract; }
+
 /* ------------------------------------------------------------------ block layouts
  * libs/ggml/src/ggml-common.h:158-162 (q4_0), :200-204 (q8_0), :296-310 (q4_K), :317-328 (q5_K), :335-340 (q6_K),
  * :344-348 (q8_K). */
@@ -312,7 +325,7 @@ static float dot_q5_K_q8_K(int64_t n, const void *vx, const void *vy) {
         for (int j = 0; j < 8; j++) get_scale_min_k4(j, x[i].scales, &sc[j], &mn[j]);
         int hsum = 0; /* madd of the mins with the pairwise sums of bsums, then both hadds: one int32 */
         for (int t = 0; t < 8; t++) hsum += mn[t] * (int16_t)(y[i].bsums[2 * t] + y[i].bsums[2 * t + 1]);
-        summs += dmin * (float)hsum;
+        summs = g_contract ? fmaf(dmin, (float)hsum, summs) : summs + dmin * (float)hsum;
         int sumi[8] = {0};
         const uint8_t *q5 = x[i].qs, *qh = x[i].qh; const int8_t *q8 = y[i].qs;
         for (int j = 0; j < QK_K / 64; ++j) {
@@ -370,7 +383,11 @@ float pso_vec_dot_f32(int64_t n, const float *x, const float *y) {
     for (int l = 0; l < 8; l++) sum[0][l] += sum[1][l];
     float t0[4]; for (int l = 0; l < 4; l++) t0[l] = sum[0][l] + sum[0][l + 4];
     float sumf = (t0[0] + t0[1]) + (t0[2] + t0[3]);
-    for (int64_t i = np; i < n; ++i) sumf += x[i] * y[i];
+    /* contracted build: GCC vectorises this loop (8 products at a time, then 4: vmulps + in-order vaddss, NOT fused) and fuses only the
+     * last (n - np) % 4 scalar steps (vfmadd231ss) */
+    const int64_t nf = g_contract ? np + ((n - np) & ~(int64_t)3) : n;
+    for (int64_t i = np; i < nf; ++i) sumf += x[i] * y[i];
+    for (int64_t i = nf; i < n; ++i) sumf = fmaf(x[i], y[i], sumf);
     return sumf;
 }
 
@@ -462,6 +479,10 @@ void pso_rope_cache(int32_t p, int64_t ne0, const pso_rope_params *rp, float *ca
         theta *= theta_scale;
     }
 }
+/* x0 * c - x1 * sn and x0 * sn + x1 * c as the contracted build evaluates them: GCC fuses the FIRST product of each expression with the
+ * add / subtract and leaves the second one a rounded multiply (vfmsub / vfmadd; the other three pairings were tried against libps_ref_fast.so and
+ * differ in 15-31 % of the outputs) */
+#define ROPE_CONTRACTED(out0, out1) do { (out0) = fmaf(x0, c, -(x1 * sn)); (out1) = fmaf(x0, sn, x1 * c); } while (0)
 void pso_rope(const float *src, float *dst, int64_t ne0, int64_t ne1, int64_t ne2, const int32_t *pos,
               const pso_rope_params *rp) {
     float *cache = malloc(sizeof(float) * (size_t)ne0);
@@ -473,12 +494,14 @@ void pso_rope(const float *src, float *dst, int64_t ne0, int64_t ne1, int64_t ne
             if (!is_neox) {
                 for (int64_t i0 = 0; i0 < n_dims; i0 += 2) {
                     const float c = cache[i0], sn = cache[i0 + 1], x0 = s[i0], x1 = s[i0 + 1];
+                    if (g_contract) { ROPE_CONTRACTED(d[i0], d[i0 + 1]); continue; }
                     d[i0] = x0 * c - x1 * sn; d[i0 + 1] = x0 * sn + x1 * c;
                 }
             } else {
                 for (int64_t i0 = 0; i0 < n_dims; i0 += 2) {
                     const int64_t ic = i0 / 2; const float c = cache[i0], sn = cache[i0 + 1];
                     const float x0 = s[ic], x1 = s[ic + n_dims / 2];
+                    if (g_contract) { ROPE_CONTRACTED(d[ic], d[ic + n_dims / 2]); continue; }
                     d[ic] = x0 * c - x1 * sn; d[ic + n_dims / 2] = x0 * sn + x1 * c;
                 }
             }

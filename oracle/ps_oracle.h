@@ -57,6 +57,10 @@ void pso_dequantize_row(int type, const void *x, float *y, int64_t k);
 
 /* ---- dot products: weight row (type) x quantized activation row (vec_dot_type(type)) */
 float pso_vec_dot(int type, int64_t n, const void *vx, const void *vy);
+/* 0 (default): follow the reference built with -ffp-contract=off (oracle/_ref/libps_ref.so); 1: follow its stock build, GCC's default
+ * -ffp-contract=fast (oracle/_ref/libps_ref_fast.so) -- see ps_oracle.c */
+void pso_set_contract(int on);
+int pso_get_contract(void);
 float pso_vec_dot_f32(int64_t n, const float *x, const float *y);
 
 /* ---- ops (contiguous layouts unless stated) */

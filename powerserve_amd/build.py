@@ -25,6 +25,14 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 NOSLP = {"k_gemv4.hip", "k_gemvb.hip", "k_attn.hip"}  # (k_gemvb.hip: the Q4_0 / Q8_0 mat-vec, Llama-3.2-1B 1494 -> 1525 tok/s)
 
 
+def _cmd_changed(obj: str, cmd: list) -> bool:
+    """the exact compile command is kept next to the object: an edited flag list rebuilds it (mtimes alone let stale objects survive)"""
+    try:
+        return open(obj + ".cmd").read() != " ".join(cmd)
+    except OSError:
+        return True
+
+
 def _newer(src: str, obj: str) -> bool:
     if not os.path.exists(obj):
         return True
@@ -34,27 +42,46 @@ def _newer(src: str, obj: str) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
+# The files that hold one of the reference's fp-contraction sites (ps_dev.h: ps_rope_pair / ps_rope_one / ps_dot_left, and the Q5_K refusal): only they are
+# compiled a second time for lib/libps_hip_contract.so (-DPS_CONTRACT: the reference's stock -ffp-contract=fast build, include/ps_hip.h ps_hip_build_contract);
+# every other object is shared with the default library.
+CONTRACT_SOURCES = {"api.hip", "k_ops.hip", "k_attn.hip", "k_gemm4k.hip", "k_gemv4.hip", "k_gemvb.hip", "k_gemvk.hip"}
+
+
+def build(force: bool = False, verbose: bool = True, contract: bool = True) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
     os.makedirs(OBJDIR, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    objs, jobs = [], []
+    objs, cobjs, jobs = [], [], []
     for s in SOURCES:
         src, obj = os.path.join(CSRC, s), os.path.join(OBJDIR, s.replace(".hip", ".o"))
         objs.append(obj)
-        if force or _newer(src, obj):
-            jobs.append([hipcc, *FLAGS, *(["-fno-slp-vectorize"] if s in NOSLP else []), "-c", src, "-o", obj])
+        cmd = [hipcc, *FLAGS, *(["-fno-slp-vectorize"] if s in NOSLP else []), "-c", src, "-o", obj]
+        if force or _newer(src, obj) or _cmd_changed(obj, cmd):
+            jobs.append(cmd)
+        if contract and s in CONTRACT_SOURCES:
+            cobj = os.path.join(OBJDIR, s.replace(".hip", ".contract.o"))
+            ccmd = [hipcc, *FLAGS, *(["-fno-slp-vectorize"] if s in NOSLP else []), "-DPS_CONTRACT=1", "-c", src, "-o", cobj]
+            if force or _newer(src, cobj) or _cmd_changed(cobj, ccmd):
+                jobs.append(ccmd)
+            cobjs.append(cobj)
+        else:
+            cobjs.append(obj)
 
     def run(cmd):
         if verbose:
-            print("[build]", os.path.basename(cmd[-3]), flush=True)
+            print("[build]", os.path.basename(cmd[-1]), flush=True)
         subprocess.run(cmd, check=True)
+        open(cmd[-1] + ".cmd", "w").write(" ".join(cmd))
 
     with ThreadPoolExecutor(max_workers=8) as ex:
         list(ex.map(run, jobs))
     so = os.path.join(LIBDIR, "libps_hip.so")
     if jobs or not os.path.exists(so):
         subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", so, *objs], check=True)
+    cso = os.path.join(LIBDIR, "libps_hip_contract.so")
+    if contract and (jobs or not os.path.exists(cso)):
+        subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", cso, *cobjs], check=True)
     build_host(force or bool(jobs), verbose)
     return so
 

@@ -3,6 +3,7 @@
 // C-ABI (include/ps_hip.h): context, memory, weights and the reference-shaped operator entry points.
 #include "ps_internal.h"
 #include "ps_ops.h"
+#include "ps_dev.h" // PS_CONTRACT_ON
 
 #include <cmath>
 #include <cstdio>
@@ -49,6 +50,7 @@ static inline bool is_row_wave(int t) { return t == PS_Q5_K || t == PS_Q6_K; } /
 extern "C" {
 
 int ps_hip_abi_version(void) { return PS_HIP_ABI_VERSION; }
+int ps_hip_build_contract(void) { return PS_CONTRACT_ON ? 1 : 0; }
 
 int ps_hip_device_count(void) {
     int n = 0;
@@ -170,6 +172,7 @@ int ps_hip_weight_upload(ps_hip_ctx *c, int dtype, const void *host, int64_t K, 
     if (!(is_quant(dtype) || dtype == PS_F32)) PS_FAIL(c, "weight_upload: unsupported dtype");
     const int64_t blk = (dtype == PS_Q4_K || dtype == PS_Q5_K || dtype == PS_Q6_K) ? 256 : (dtype == PS_F32 ? 1 : 32);
     if (K % blk) PS_FAIL(c, "weight_upload: K is not a multiple of the block size");
+    if (PS_CONTRACT_ON && dtype == PS_Q5_K) PS_FAIL(c, "weight_upload: this is the PS_CONTRACT build (the reference's stock -ffp-contract=fast build); Q5_K's fused summs is not implemented in it");
     PS_CHECK(c, hipSetDevice(c->device));
     auto w        = new ps_weight();
     w->dtype      = dtype;

@@ -54,7 +54,8 @@ __global__ void rope_append_kernel(psl_attn_args a, int bs) {
             const float c = a.rope_table[(int64_t)rp * hs + i0], s = a.rope_table[(int64_t)rp * hs + i0 + 1];
             const int ia = a.neox ? pi : i0, ib = a.neox ? pi + half : i0 + 1;
             const float x0 = src[ia], x1 = src[ib];
-            const float ra = __fsub_rn(__fmul_rn(x0, c), __fmul_rn(x1, s)), rb = __fadd_rn(__fmul_rn(x0, s), __fmul_rn(x1, c));
+            float ra, rb;
+            ps_rope_pair(x0, x1, c, s, ra, rb);
             dst[ia] = ra;
             dst[ib] = rb;
             if (!isq && a.k16) { a.k16[(int64_t)p * kvd + h * hs + ia] = (_Float16)ra; a.k16[(int64_t)p * kvd + h * hs + ib] = (_Float16)rb; }
@@ -421,7 +422,7 @@ __global__ __launch_bounds__(PV_NT) void attn_softmax_pv_kernel(psl_attn_args a)
             for (; j < tn; j += 32) acc = __fmaf_rn(vr[j], __fmul_rn(pg[t0 + j], inv), acc);
             if (t0 + PV_TILE >= n_kv) { // last tile: reduce the 32 chains, then the n%32 leftovers in order
                 float sres = reduce_f32x8x4(acc);
-                for (int jj = np; jj < n_kv; jj++) sres = __fadd_rn(sres, __fmul_rn(vr[jj - t0], __fmul_rn(pg[jj], inv)));
+                for (int jj = np; jj < n_kv; jj++) sres = ps_dot_left(sres, vr[jj - t0], __fmul_rn(pg[jj], inv), jj - np, n_kv - np);
                 out = sres;
             }
         }
@@ -792,7 +793,7 @@ __global__ __launch_bounds__(NT) void attn_decode2_kernel(psl_attn_args a) {
         float res = __fadd_rn(__fadd_rn(t3[0], t3[1]), __fadd_rn(t3[2], t3[3]));
 #pragma unroll
         for (int jj = 0; jj < 32; jj++)
-            if (jj < nleft) res = __fadd_rn(res, __fmul_rn(lv[jj], lp[jj])); // leftovers, in order (uniform bound)
+            if (jj < nleft) res = ps_dot_left(res, lv[jj], lp[jj], jj, nleft); // leftovers, in order (uniform bound)
         if (h < r2) a.att[((int64_t)kvh * r2 + h) * hs + bx * 4 + ch] = res;
     }
     if (dbg) { dbg[10] = __builtin_amdgcn_s_memtime(); dbg[30] = __builtin_amdgcn_s_memrealtime(); }
@@ -862,7 +863,7 @@ __global__ __launch_bounds__(PV_NT) void attn_softmax_pv_cols_kernel(psl_attn_ar
                 if (g < r2) {
                     float sres = reduce_f32x8x4(acc[ci][g]);
                     for (int jj = np; jj < n_kv; jj++)
-                        sres = __fadd_rn(sres, __fmul_rn(__shfl(vleft, jj - np, 32), __fmul_rn(pl[(size_t)(ci * r2 + g) * n_kv4 + jj], inv[ci][g])));
+                        sres = ps_dot_left(sres, __shfl(vleft, jj - np, 32), __fmul_rn(pl[(size_t)(ci * r2 + g) * n_kv4 + jj], inv[ci][g]), jj - np, n_kv - np);
                     if (c == 0 && i0 + ci < bs) a.att[(int64_t)(i0 + ci) * dim + ((int64_t)kvh * r2 + g) * hs + d] = sres;
                 }
             }
@@ -1006,7 +1007,7 @@ __global__ __launch_bounds__(512, 1) void attn_pv_mfma_kernel(psl_attn_args a) {
     for (int jj = np; jj < n_kv; jj++) {
         const float pj = pr[jj];
 #pragma unroll
-        for (int r = 0; r < 4; r++) res[r] = __fadd_rn(res[r], __fmul_rn(vl[(int64_t)r * a.n_ctx + jj], pj));
+        for (int r = 0; r < 4; r++) res[r] = ps_dot_left(res[r], vl[(int64_t)r * a.n_ctx + jj], pj, jj - np, n_kv - np);
     }
     if ((int)blockIdx.x * 16 + rl < N)
         *(float4 *)(a.att + (int64_t)i * dim + ((int64_t)kvh * r2 + g) * hs + d0 + 4 * m) = make_float4(res[0], res[1], res[2], res[3]);
@@ -1111,7 +1112,7 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_pv_mfma_lds_kernel(psl_attn_a
         for (int k = 0; k < 8; k++)
             if (j0 + k < n_kv) {
 #pragma unroll
-                for (int r = 0; r < 4; r++) res[r] = __fadd_rn(res[r], __fmul_rn(vv[k][r], pj[k]));
+                for (int r = 0; r < 4; r++) res[r] = ps_dot_left(res[r], vv[k][r], pj[k], j0 + k - np, n_kv - np);
             }
     }
     if ((int)blockIdx.x * 16 + rl < N)

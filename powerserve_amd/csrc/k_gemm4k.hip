@@ -178,8 +178,7 @@ __device__ __forceinline__ void g4k_store_pair(const G4KParams &p, const int wi,
     float ra = x0, rb = x1;
     if (i0 < R.n_dims) {
         const float2 cs = *(const float2 *)(R.rope_table + (int64_t)rp * R.head_size + i0);
-        ra = __fsub_rn(__fmul_rn(x0, cs.x), __fmul_rn(x1, cs.y));
-        rb = __fadd_rn(__fmul_rn(x0, cs.y), __fmul_rn(x1, cs.x));
+        ps_rope_pair(x0, x1, cs.x, cs.y, ra, rb);
     }
     if (wi == 0) *(float2 *)(W.out + (int64_t)col * W.ldo + row0) = make_float2(ra, rb);
     else {

@@ -410,7 +410,7 @@ __global__ __launch_bounds__((NW + 1) * 64) void gemv4_kernel(const G4Params p) 
                         if (e < R.n_dims) {
                             const float c = ea, sn = eb;
                             const float x0 = (e & 1) ? vp : v, x1 = (e & 1) ? v : vp;
-                            res = (e & 1) ? __fadd_rn(__fmul_rn(x0, sn), __fmul_rn(x1, c)) : __fsub_rn(__fmul_rn(x0, c), __fmul_rn(x1, sn));
+                            res = ps_rope_one(x0, x1, c, sn, (e & 1) != 0);
                         }
                         if (role == 0) o[row] = res; else { R.k_cache[(int64_t)kv_pos * R.kv_dim + row] = res; if (R.k16) R.k16[(int64_t)kv_pos * R.kv_dim + row] = (_Float16)res; }
                     }

@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void mul_mat_f32_kernel(TDesc dst, TDesc a, TD
         float s = 0.f;
         for (int64_t k = c; k < np; k += 32) s = __fmaf_rn(x[k], y[k], s);
         s = reduce_f32x8x4(s);
-        for (int64_t k = np; k < n; k++) s = __fadd_rn(s, __fmul_rn(x[k], y[k]));
+        for (int64_t k = np; k < n; k++) s = ps_dot_left(s, x[k], y[k], (int)(k - np), (int)(n - np));
         if (live && c == 0) *(float *)(dst.data + i0 * dst.nb[0] + i1 * dst.nb[1] + i2 * dst.nb[2] + i3 * dst.nb[3]) = s;
     }
 }
@@ -88,8 +88,10 @@ __global__ void rope_kernel(TDesc dst, TDesc src, const float *cache, int n_dims
         const float c = cache[i2 * src.ne[0] + i0], s = cache[i2 * src.ne[0] + i0 + 1];
         const int64_t ia = neox ? pi : i0, ib = neox ? pi + half : i0 + 1;
         const float x0 = *(const float *)(sb + ia * 4), x1 = *(const float *)(sb + ib * 4);
-        *(float *)(db + ia * 4) = __fsub_rn(__fmul_rn(x0, c), __fmul_rn(x1, s));
-        *(float *)(db + ib * 4) = __fadd_rn(__fmul_rn(x0, s), __fmul_rn(x1, c));
+        float ra, rb;
+        ps_rope_pair(x0, x1, c, s, ra, rb);
+        *(float *)(db + ia * 4) = ra;
+        *(float *)(db + ib * 4) = rb;
     }
 }
 

@@ -15,6 +15,32 @@ __device__ __forceinline__ uint16_t ps_f2h(float f) {
 }
 
 // ---- wave-level reductions (all 64 lanes end up with the result)
+// ---- the reference's second build (-DPS_CONTRACT; powerserve_amd/build.py build(contract=True) -> lib/libps_hip_contract.so).
+// The reference's own CMake sets no fp-contraction flag, so a stock build is GCC's default -ffp-contract=fast: of everything on the hot path
+// three scalar places come out different (oracle/ps_oracle.c, pso_set_contract): the RoPE rotation, the n % 32 leftovers of ggml_vec_dot_f32,
+// and Q5_K's summs (not implemented under PS_CONTRACT: ps_hip_weight_upload refuses Q5_K there).  Default: every operation rounds where the C
+// source rounds (the -ffp-contract=off build the oracle, the golden vectors and "bit-exact" refer to).
+#ifdef PS_CONTRACT
+constexpr bool PS_CONTRACT_ON = true;
+#else
+constexpr bool PS_CONTRACT_ON = false;
+#endif
+// x0 * c - x1 * s, x0 * s + x1 * c (ggml.c:15455-15456, :15474-15475); contracted: GCC fuses the first product of each with the add
+__device__ __forceinline__ void ps_rope_pair(const float x0, const float x1, const float c, const float s, float &ra, float &rb) {
+    if (PS_CONTRACT_ON) { ra = __fmaf_rn(x0, c, -__fmul_rn(x1, s)); rb = __fmaf_rn(x0, s, __fmul_rn(x1, c)); }
+    else { ra = __fsub_rn(__fmul_rn(x0, c), __fmul_rn(x1, s)); rb = __fadd_rn(__fmul_rn(x0, s), __fmul_rn(x1, c)); }
+}
+// one output of the pair (odd: the second), for epilogues whose lane finishes a single element
+__device__ __forceinline__ float ps_rope_one(const float x0, const float x1, const float c, const float s, const bool odd) {
+    if (PS_CONTRACT_ON) return odd ? __fmaf_rn(x0, s, __fmul_rn(x1, c)) : __fmaf_rn(x0, c, -__fmul_rn(x1, s));
+    return odd ? __fadd_rn(__fmul_rn(x0, s), __fmul_rn(x1, c)) : __fsub_rn(__fmul_rn(x0, c), __fmul_rn(x1, s));
+}
+// leftover j (0-based) of the nleft = n % 32 scalar steps `sumf += x[i] * y[i]` (ggml.c:2123-2125); contracted: GCC vectorises the loop by 8
+// and by 4 without fusing and fuses only the last nleft % 4 steps
+__device__ __forceinline__ float ps_dot_left(const float sum, const float x, const float y, const int j, const int nleft) {
+    if (PS_CONTRACT_ON && j >= (nleft & ~3)) return __fmaf_rn(x, y, sum);
+    return __fadd_rn(sum, __fmul_rn(x, y));
+}
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -22,7 +22,7 @@ ATTN_TIMEOUT = 3  # PS_HIP_ATTN_TIMEOUT (include/ps_hip.h)
 QUANT = (Q4_0, Q8_0, Q4_K, Q5_K, Q6_K)
 
 EXPORTS = [
-    "ps_hip_abi_version", "ps_hip_device_count", "ps_hip_create", "ps_hip_destroy", "ps_hip_last_error",
+    "ps_hip_abi_version", "ps_hip_build_contract", "ps_hip_device_count", "ps_hip_create", "ps_hip_destroy", "ps_hip_last_error",
     "ps_hip_device_name", "ps_hip_malloc", "ps_hip_free", "ps_hip_memcpy_h2d", "ps_hip_memcpy_d2h", "ps_hip_memset",
     "ps_hip_sync", "ps_hip_stream", "ps_hip_event_create", "ps_hip_event_record", "ps_hip_event_elapsed_ms",
     "ps_hip_event_destroy", "ps_hip_weight_upload", "ps_hip_weight_free", "ps_hip_weight_gguf_bytes",

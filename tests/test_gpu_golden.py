@@ -79,3 +79,56 @@ def test_e2e_golden(ctx, tmp_path, preset, tn):
     lg, _ = m.forward(prompt[:9], np.arange(9), lm_head=True)
     assert np.array_equal(lg.view(np.uint32), g["batch_logits"].view(np.uint32))
     m.close()
+
+
+def _run_builds_fixture(ctx, tmp_path, preset, tn):
+    """the e2e_builds fixture through the HIP library loaded in THIS process: (ids, per-step logits)"""
+    from powerserve_amd import hip, synth
+    g = np.load(os.path.join(GOLD, f"e2e_builds_{preset}_{tn}.npz"))
+    d = str(tmp_path / "m")
+    synth.write_model_dir(d, preset, T[tn], n_ctx=int(g["n_ctx"]), seed=int(g["seed"]))
+    assert _sha(os.path.join(d, "ggml", "weights.gguf")) == str(g["gguf_sha256"])
+    m = hip.Model(ctx, d, max_batch=16)
+    prompt, bs, steps = g["prompt"], int(g["batch"]), len(g["ids_off"])
+    ids = m.generate(prompt, bs, steps)
+    m.reset()
+    for lo in range(0, len(prompt) - 1, bs):
+        hi = min(lo + bs, len(prompt) - 1)
+        m.forward(prompt[lo:hi], np.arange(lo, hi), lm_head=False)
+    cur, logits = int(prompt[-1]), []
+    for s in range(steps):
+        lg, _ = m.forward([cur], [m.position], lm_head=True)
+        logits.append(lg[0].copy())
+        cur = int(ids[s])
+    m.close()
+    return g, ids, np.stack(logits)
+
+
+@pytest.mark.parametrize("preset,tn", [("tiny-llama", "Q4_0"), ("tiny-llama", "Q8_0"), ("tiny-qwen2", "Q8_0"), ("tiny-qwen2", "Q4_0")])
+def test_e2e_against_both_reference_builds(ctx, tmp_path, preset, tn):
+    """tests/golden/e2e_builds_*.npz: the real reference built with -ffp-contract=off ("off") and as its own CMake builds it, GCC's default
+    -ffp-contract=fast ("fast").  The default library is the first build bit for bit; against the second it is as far away as the two builds
+    are from each other (ids equal; 2.8e-3 of the largest logit on tiny-llama Q4_0, zero on the other three) -- reported, and bounded."""
+    assert ctx.L.ps_hip_build_contract() == 0
+    g, ids, logits = _run_builds_fixture(ctx, tmp_path, preset, tn)
+    assert np.array_equal(ids, g["ids_off"]) and np.array_equal(logits.view(np.uint32), g["logits_off"].view(np.uint32))
+    dev = float(np.abs(logits - g["logits_fast"]).max() / np.abs(g["logits_fast"]).max())
+    print(f"[builds] {preset} {tn}: HIP (default) vs -ffp-contract=off: bit-exact; vs the stock -ffp-contract=fast build: ids equal "
+          f"{np.array_equal(ids, g['ids_fast'])}, max logit deviation {dev:.3e} of the largest logit")
+    assert np.array_equal(ids, g["ids_fast"]) and dev < 1e-2
+
+
+def test_contract_build_is_the_stock_reference_build(tmp_path):
+    """lib/libps_hip_contract.so (-DPS_CONTRACT: fused RoPE rotation and fused last n % 4 dot-product leftovers, powerserve_amd/build.py) in a process
+    of its own (PS_HIP_LIB): every logit of every fixture model equals the stock -ffp-contract=fast build of the reference, bit for bit; the op level
+    (RoPE modes 0 / 2, V.p behind 1..31 leftovers) against the oracle's contract mode; Q5_K is refused."""
+    import subprocess
+    import sys
+    from powerserve_amd import hip
+    lib = os.path.join(os.path.dirname(hip.LIB_PATH), "libps_hip_contract.so")
+    assert os.path.exists(lib), "run __graft_entry__.build()"
+    env = dict(os.environ, PS_HIP_LIB=lib, PS_CONTRACT_TMP=str(tmp_path))
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "contract_check.py")], env=env, capture_output=True, text=True, timeout=600)
+    print(r.stdout[-3000:])
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "contract build: all checks passed" in r.stdout

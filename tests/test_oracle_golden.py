@@ -83,6 +83,35 @@ def test_e2e_bit_exact(oracle, tmp_path, preset, tn):
     m.close()
 
 
+@pytest.mark.parametrize("preset,tn", [("tiny-llama", "Q4_0"), ("tiny-llama", "Q8_0"), ("tiny-qwen2", "Q8_0"), ("tiny-qwen2", "Q4_0")])
+def test_e2e_both_reference_builds(oracle, tmp_path, preset, tn):
+    """tests/golden/e2e_builds_*.npz (oracle/gen_golden_fast.py): the real forward of the reference built with -ffp-contract=off AND as its own CMake
+    builds it (GCC's default -ffp-contract=fast).  The oracle's default mode is the first, pso_set_contract(1) the second -- every logit, bit for bit;
+    and the distance between the two builds is what the fixture says (2.8e-3 of the largest logit on tiny-llama Q4_0, nothing on the other three)."""
+    from oracle import binding as B
+    from powerserve_amd import gguf, synth
+    g = np.load(os.path.join(GOLD, f"e2e_builds_{preset}_{tn}.npz"))
+    d = str(tmp_path / "m")
+    mj = synth.write_model_dir(d, preset, T[tn], n_ctx=int(g["n_ctx"]), seed=int(g["seed"]))
+    path = os.path.join(d, "ggml", "weights.gguf")
+    assert _sha(path) == str(g["gguf_sha256"]), "synthetic model generator drifted: regenerate tests/golden (oracle/gen_golden_fast.py)"
+    rd = gguf.GGUFReader(path)
+    tensors = {n: (ti.type, np.array(rd.data(n)), ti.ne[0], (list(ti.ne) + [1])[1]) for n, ti in rd.tensors.items()}
+    try:
+        for mode, name in ((0, "off"), (1, "fast")):
+            oracle.L.pso_set_contract(mode)
+            m = oracle.model(B.make_config(mj["llm_config"]), mj["model_arch"], tensors, n_threads=4)
+            ids, logits, *_ = m.generate(g["prompt"], int(g["batch"]), len(g["ids_" + name]), want_logits=True)
+            m.close()
+            assert np.array_equal(ids, g["ids_" + name]), name
+            assert np.array_equal(bits(logits), bits(g["logits_" + name])), name
+    finally:
+        oracle.L.pso_set_contract(0)
+    dev = float(np.abs(g["logits_fast"] - g["logits_off"]).max() / np.abs(g["logits_off"]).max())
+    assert np.array_equal(g["ids_off"], g["ids_fast"])
+    assert (dev > 1e-3) == (preset == "tiny-llama" and tn == "Q4_0") and dev < 1e-2, dev
+
+
 @pytest.mark.parametrize("ci", [0, 1, 2, 3])
 def test_tree_forward_golden(oracle, tmp_path, ci):
     """Token-tree forward of the restatement == the reference's own operators given the tree mask
