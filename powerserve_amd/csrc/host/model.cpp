@@ -169,7 +169,8 @@ auto Model::forward(const std::vector<int> &tokens, const std::vector<int> &pos,
 
 // LlamaModel::forward (src/model/llama/llama_model.cpp:52-117): build the graph, allocate, run -- Executor::run hands the op
 // vector to HIPBackend::plan first, which lowers the canonical sequence to the fused launches.
-auto Model::forward_graph(const std::vector<int> &tokens, const std::vector<int> &pos, const CausalAttentionMask &mask, bool lm_head) -> LogitsVector {
+auto Model::forward_graph(const std::vector<int> &tokens, const std::vector<int> &pos, const CausalAttentionMask &mask, bool lm_head,
+                          std::vector<Token> *ids, bool plan_only) -> LogitsVector {
     auto &be = backend();
     auto &llm = m_config->llm;
     const size_t bs = tokens.size();
@@ -190,6 +191,8 @@ auto Model::forward_graph(const std::vector<int> &tokens, const std::vector<int>
     for (int attempt = 0;; attempt++) {
         Executor executor(*m_platform, g);
         executor.plan();
+        m_last_lowered = executor.lowered();
+        if (plan_only) return LogitsVector(); // (Model::prefill asks whether this chunk shape lowers; nothing has run)
         if (!executor.lowered()) executor.allocate_buffers(); // a lowered graph runs in the device model's own arena
         executor.run();
         // a lowered single-token forward is only enqueued: its one-launch attention may have given up at its exchange (bounded wait); the
@@ -200,6 +203,12 @@ auto Model::forward_graph(const std::vector<int> &tokens, const std::vector<int>
     }
     be.m_kv->advance((int)bs);
     if (!lm_head) { be.sync(); return LogitsVector(); }
+    if (ids && m_last_lowered) { // greedy caller, lowered graph: the arg-max kernel behind the lm_head has the answer, 4 bytes per token
+        std::vector<int32_t> am(bs);
+        if (ps_hip_model_argmax(be.m_model, (int)bs, am.data())) POWERSERVE_ABORT(std::string("arg-max copy: ") + ps_hip_last_error(be.m_ctx));
+        ids->assign(am.begin(), am.end());
+        return LogitsVector();
+    }
     Stride st = {4, 4 * (size_t)llm.vocab_size, 4 * (size_t)llm.vocab_size * bs, 4 * (size_t)llm.vocab_size * bs};
     auto host = std::make_shared<CPUBuffer>(st, (size_t)llm.vocab_size * bs * 4);
     be.sync();
@@ -210,10 +219,42 @@ auto Model::forward_graph(const std::vector<int> &tokens, const std::vector<int>
 
 auto Model::decode(const std::vector<Token> &tokens, const std::vector<int> &pos, bool lm_head) -> std::vector<Token> {
     std::vector<int> t(tokens.begin(), tokens.end());
-    auto ret = forward(t, pos, CausalAttentionMask(tokens.size()), lm_head);
+    POWERSERVE_ASSERT(tokens.size() == pos.size() && !tokens.empty());
+    backend().m_fused = m_use_fused;
     std::vector<Token> out;
-    for (auto lg : ret.logits_vector) out.push_back((Token)(std::max_element(lg.begin(), lg.end()) - lg.begin())); // greedy_sample
+    auto ret = forward_graph(t, pos, CausalAttentionMask(tokens.size()), lm_head, &out);
+    if (out.empty())
+        for (auto lg : ret.logits_vector) out.push_back((Token)(std::max_element(lg.begin(), lg.end()) - lg.begin())); // greedy_sample
     return out;
+}
+
+void Model::prefill(const std::vector<Token> &tokens, size_t batch_size) {
+    if (tokens.empty()) return;
+    POWERSERVE_ASSERT(batch_size > 0);
+    auto &be = backend();
+    auto &id = m_config->model_id;
+    be.m_fused = m_use_fused;
+    const size_t first = std::min(batch_size, tokens.size());
+    bool lowered = false;
+    if (m_use_fused && batch_size <= (size_t)ps_hip_model_max_batch(be.m_model)) { // does a chunk of this model's canonical graph lower?  (plan only: nothing runs)
+        std::vector<int> t(tokens.begin(), tokens.begin() + first), pos(first);
+        std::iota(pos.begin(), pos.end(), (int)m_platform->get_kv_position(id));
+        forward_graph(t, pos, CausalAttentionMask(first), false, nullptr, true);
+        lowered = m_last_lowered;
+    }
+    if (lowered) {
+        std::vector<int32_t> t(tokens.begin(), tokens.end());
+        if (ps_hip_model_prefill(be.m_model, t.data(), (int)t.size(), (int)batch_size)) POWERSERVE_ABORT(std::string("prefill: ") + ps_hip_last_error(be.m_ctx));
+        return;
+    }
+    for (size_t done = 0; done < tokens.size();) {
+        const size_t bs = std::min(batch_size, tokens.size() - done);
+        std::vector<Token> toks(tokens.begin() + done, tokens.begin() + done + bs);
+        std::vector<int> pos(bs);
+        std::iota(pos.begin(), pos.end(), (int)m_platform->get_kv_position(id));
+        decode(toks, pos, false);
+        done += bs;
+    }
 }
 
 auto Model::generate(const std::vector<Token> &prompt, int steps, size_t batch_size) -> std::vector<Token> {
@@ -222,15 +263,7 @@ auto Model::generate(const std::vector<Token> &prompt, int steps, size_t batch_s
     auto &id = m_config->model_id;
     m_platform->reset_kv_position(id);
     backend().setup_threadpool();
-    size_t n_prefilled = 0;
-    while (n_prefilled < prompt.size() - 1) {
-        const size_t bs = std::min(batch_size, prompt.size() - n_prefilled - 1);
-        std::vector<Token> toks(prompt.begin() + n_prefilled, prompt.begin() + n_prefilled + bs);
-        std::vector<int> pos(bs);
-        std::iota(pos.begin(), pos.end(), (int)m_platform->get_kv_position(id));
-        decode(toks, pos, false);
-        n_prefilled += bs;
-    }
+    prefill(std::vector<Token>(prompt.begin(), prompt.end() - 1), batch_size); // the last prompt token is the first decode input (model.hpp:147-163)
     if (m_use_fused) { // device-side greedy loop: hipGraph replay, ids stay on the GPU until the end
         out.resize(steps);
         if (ps_hip_model_decode_greedy(backend().m_model, prompt.back(), steps, out.data()))
@@ -252,15 +285,7 @@ auto Model::generate(const std::vector<Token> &prompt, int steps, size_t batch_s
     if (steps <= 0 || prompt.empty()) return out;
     auto &id = m_config->model_id;
     m_platform->reset_kv_position(id);
-    size_t n_prefilled = 0;
-    while (n_prefilled < prompt.size() - 1) {
-        const size_t bs = std::min(batch_size, prompt.size() - n_prefilled - 1);
-        std::vector<Token> toks(prompt.begin() + n_prefilled, prompt.begin() + n_prefilled + bs);
-        std::vector<int> pos(bs);
-        std::iota(pos.begin(), pos.end(), (int)m_platform->get_kv_position(id));
-        decode(toks, pos, false);
-        n_prefilled += bs;
-    }
+    prefill(std::vector<Token>(prompt.begin(), prompt.end() - 1), batch_size); // the last prompt token is the first decode input (model.hpp:147-163)
     Token cur = prompt.back();
     for (int s = 0; s < steps; s++) {
         auto ret = forward({cur}, {(int)m_platform->get_kv_position(id)}, CausalAttentionMask(1), true);
@@ -307,6 +332,23 @@ int psh_model_forward(void *h, const int32_t *tokens, int n, const int32_t *pos,
         auto r = m->model->forward(t, p, CausalAttentionMask(n), lm_head != 0);
         if (lm_head && logits_out)
             for (int i = 0; i < n; i++) memcpy(logits_out + (size_t)i * r.logits_vector[i].size(), r.logits_vector[i].data(), r.logits_vector[i].size() * 4);
+        return 0;
+    } catch (const std::exception &e) { g_err = e.what(); return 1; }
+}
+int psh_model_decode(void *h, const int32_t *tokens, int n, const int32_t *pos, int32_t *ids_out) { // Model::decode, greedy: ids only
+    try {
+        auto m = (psh_model *)h;
+        std::vector<Token> t(tokens, tokens + n);
+        std::vector<int> p(pos, pos + n);
+        auto r = m->model->decode(t, p, true);
+        for (int i = 0; i < n; i++) ids_out[i] = r[i];
+        return 0;
+    } catch (const std::exception &e) { g_err = e.what(); return 1; }
+}
+int psh_model_prefill(void *h, const int32_t *tokens, int n, int batch_size) { // ModelTokenIterator's prefill loop
+    try {
+        auto m = (psh_model *)h;
+        m->model->prefill(std::vector<Token>(tokens, tokens + n), (size_t)batch_size);
         return 0;
     } catch (const std::exception &e) { g_err = e.what(); return 1; }
 }

@@ -63,8 +63,13 @@ struct Model {
 
     // one forward over `tokens` at consecutive positions `pos`; lm_head: logits for every token
     auto forward(const std::vector<int> &tokens, const std::vector<int> &pos, const CausalAttentionMask &mask, bool lm_head = true) -> LogitsVector;
-    // greedy (top_k = 1 == arg-max, src/sampler/prob_array.cpp:65-67)
+    // greedy (top_k = 1 == arg-max, src/sampler/prob_array.cpp:65-67).  A lowered graph returns the device arg-max (4 bytes per token come to the host,
+    // the logits stay on the GPU: SURVEY a21); an op-by-op graph copies the logits and takes the first maximum on the host like the reference.
     auto decode(const std::vector<Token> &tokens, const std::vector<int> &pos, bool lm_head) -> std::vector<Token>;
+    // ModelTokenIterator's prefill loop (src/model/model.hpp:147-163): forward(chunk of batch_size tokens, lm_head = false) + advance, chunk after chunk, for
+    // tokens appended at the cache position.  The first chunk's graph goes through Executor::plan like any forward; when the backend lowers it, the LOOP is
+    // lowered too (ps_hip_model_prefill: the same bits, several reference chunks per launch sequence), else every chunk runs through forward().
+    void prefill(const std::vector<Token> &tokens, size_t batch_size);
     // ModelTokenIterator: prefill all but the last prompt token in chunks of batch_size (no lm_head), then `steps`
     // single-token greedy steps
     auto generate(const std::vector<Token> &prompt, int steps, size_t batch_size) -> std::vector<Token>;
@@ -77,7 +82,10 @@ private:
     std::unique_ptr<GGUFFile> m_gguf;
     std::vector<ps_weight *> m_dev_weights;
     std::vector<void *> m_dev_f32;
-    auto forward_graph(const std::vector<int> &tokens, const std::vector<int> &pos, const CausalAttentionMask &mask, bool lm_head) -> LogitsVector;
+    // ids != nullptr (greedy callers): a lowered graph fills it from the device arg-max and returns no logits
+    auto forward_graph(const std::vector<int> &tokens, const std::vector<int> &pos, const CausalAttentionMask &mask, bool lm_head,
+                       std::vector<Token> *ids = nullptr, bool plan_only = false) -> LogitsVector;
+    bool m_last_lowered = false; // the most recent forward_graph was lowered by HIPBackend::plan
 };
 using LlamaModel = Model;
 using Qwen2Model = Model;

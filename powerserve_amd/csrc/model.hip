@@ -800,6 +800,14 @@ static int decode_greedy_impl(ps_hip_model *m, int32_t token, int steps, int32_t
 }
 
 const float *ps_hip_model_logits(const ps_hip_model *m) { return m->logits; }
+int ps_hip_model_argmax(ps_hip_model *m, int n, int32_t *ids_host) {
+    ps_hip_ctx *c = m->ctx;
+    if (n <= 0 || n > m->max_batch) PS_FAIL(c, "model_argmax: batch size out of range");
+    if (int rc = settle_pending(m)) return rc;
+    PS_CHECK(c, hipMemcpyAsync(ids_host, m->argmax_dev, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    PS_CHECK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
 const float *ps_hip_model_scratch(const ps_hip_model *m, int which) {
     switch (which) {
     case 0: return m->x;      // [max_batch][dim]     residual stream after the last layer

@@ -17,7 +17,7 @@ __device__ __forceinline__ uint16_t ps_f2h(float f) {
 // ---- wave-level reductions (all 64 lanes end up with the result)
 // ---- the reference's second build (-DPS_CONTRACT; powerserve_amd/build.py build(contract=True) -> lib/libps_hip_contract.so).
 // The reference's own CMake sets no fp-contraction flag, so a stock build is GCC's default -ffp-contract=fast: of everything on the hot path
-// three scalar places come out different (oracle/ps_oracle.c, pso_set_contract): the RoPE rotation, the n % 32 leftovers of ggml_vec_dot_f32,
+// three scalar places come out different (tests/test_ref_fast.py): the RoPE rotation, the n % 32 leftovers of ggml_vec_dot_f32,
 // and Q5_K's summs (not implemented under PS_CONTRACT: ps_hip_weight_upload refuses Q5_K there).  Default: every operation rounds where the C
 // source rounds (the -ffp-contract=off build the oracle, the golden vectors and "bit-exact" refer to).
 #ifdef PS_CONTRACT

@@ -32,7 +32,7 @@ EXPORTS = [
     "ps_hip_model_kv_position", "ps_hip_model_max_batch", "ps_hip_model_kv_truncate", "ps_hip_model_kv_advance", "ps_hip_model_kv_rollback", "ps_hip_model_kv_move",
     "ps_hip_model_forward", "ps_hip_model_decode_greedy", "ps_hip_model_logits", "ps_hip_model_scratch", "ps_hip_model_k_cache",
     "ps_hip_model_v_cache", "ps_hip_model_weight_bytes_per_token", "ps_hip_model_set_mode", "ps_hip_model_bench_gemv", "ps_hip_model_bench_matmul", "ps_hip_debug_timeline", "ps_hip_last_matmul_kernel", "ps_hip_debug_set", "ps_hip_debug_f16_gemm", "ps_hip_model_forward_tree", "ps_hip_model_prefill", "ps_hip_model_forward_lowered", "ps_hip_model_sync_check", "ps_hip_model_kv_mask",
-    "ps_hip_soft_max", "ps_hip_model_kv_copy", "ps_hip_model_kv_save_tokens", "ps_hip_model_kv_unmask_tokens", "ps_hip_model_kv_append_tokens",
+    "ps_hip_soft_max", "ps_hip_model_kv_copy", "ps_hip_model_kv_save_tokens", "ps_hip_model_kv_unmask_tokens", "ps_hip_model_kv_append_tokens", "ps_hip_model_argmax",
 ]
 
 
@@ -119,7 +119,7 @@ def lib() -> C.CDLL:
         "ps_hip_model_weight_bytes_per_token": (C.c_uint64, [vp]), "ps_hip_model_set_mode": (i32, [vp, i32]),
         "ps_hip_model_sync_check": (i32, [vp]), "ps_hip_soft_max": (i32, [vp, T, T]),
         "ps_hip_model_kv_copy": (i32, [vp, sz, sz]), "ps_hip_model_kv_save_tokens": (i32, [vp, sz]), "ps_hip_model_kv_unmask_tokens": (i32, [vp, sz]),
-        "ps_hip_model_kv_append_tokens": (i32, [vp, sz, C.POINTER(sz)]),
+        "ps_hip_model_kv_append_tokens": (i32, [vp, sz, C.POINTER(sz)]), "ps_hip_model_argmax": (i32, [vp, i32, vp]),
         "ps_hip_debug_timeline": (i32, [vp, i32, vp, i32]),
         "ps_hip_last_matmul_kernel": (C.c_char_p, []),
         "ps_hip_debug_set": (i32, [i32, i32]),

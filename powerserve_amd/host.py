@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(HERE, "lib", "libps_host.so")
 EXPORTS = ["psh_last_error", "psh_model_load", "psh_model_free", "psh_model_set_fused", "psh_model_plan_stats", "psh_model_kv_position", "psh_model_reset",
            "psh_model_vocab", "psh_model_forward", "psh_model_generate", "psh_spec_generate", "psh_spec_generate_sampled", "psh_draft_sample", "psh_sampler_create", "psh_sampler_free", "psh_sampler_sample",
            "psh_model_generate_sampled", "psh_token_tree_run", "psh_gguf_summary", "psh_config_summary",
-           "psh_graph_softmax", "psh_backend_get_n_tasks", "psh_backend_add_cache", "psh_model_kv_read", "psh_kv_op"]
+           "psh_model_decode", "psh_model_prefill", "psh_graph_softmax", "psh_backend_get_n_tasks", "psh_backend_add_cache", "psh_model_kv_read", "psh_kv_op"]
 _LIB = None
 
 
@@ -45,6 +45,8 @@ def lib() -> C.CDLL:
         L.psh_sampler_sample.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.psh_model_generate_sampled.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.psh_token_tree_run.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int] + [C.c_void_p] * 5
+        L.psh_model_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.psh_model_prefill.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         L.psh_graph_softmax.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
         L.psh_backend_get_n_tasks.argtypes = [C.c_void_p]
         L.psh_backend_add_cache.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
@@ -118,6 +120,21 @@ class HostModel:
         if rc:
             raise HostError(self.L.psh_last_error().decode())
         return out
+
+    def decode(self, tokens, pos):
+        """Model::decode (greedy): ids only -- a lowered graph hands back the device arg-max, 4 bytes per token."""
+        t = np.ascontiguousarray(tokens, dtype=np.int32)
+        p = np.ascontiguousarray(pos, dtype=np.int32)
+        out = np.empty(t.size, dtype=np.int32)
+        if self.L.psh_model_decode(self.h, t.ctypes.data, t.size, p.ctypes.data, out.ctypes.data):
+            raise HostError(self.L.psh_last_error().decode())
+        return out
+
+    def prefill(self, tokens, batch_size: int):
+        """ModelTokenIterator's prefill loop (chunks of batch_size, no logits) for tokens appended at the cache position."""
+        t = np.ascontiguousarray(tokens, dtype=np.int32)
+        if self.L.psh_model_prefill(self.h, t.ctypes.data, t.size, int(batch_size)):
+            raise HostError(self.L.psh_last_error().decode())
 
     # ---- boundary members no model graph uses (src/graph/graph.cpp:118, ggml.hpp:227,233, core/kv_cache.hpp:120-162)
     def graph_softmax(self, x):
