@@ -22,7 +22,7 @@ SOURCES = ["api.hip", "model.hip", "k_quant.hip", "k_gemv.hip", "k_gemv4.hip", "
 # exact compile configuration that has passed the full GPU suite and all bench configurations.)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-result",
          "-I" + os.path.join(HERE, "..", "include")]
-NOSLP = {"k_gemv4.hip", "k_gemvb.hip", "k_attn.hip", "k_gemm4k.hip"}  # k_gemm4k.hip (round 5): gemm4k2_kernel's 96 chains per lane as plain v_fma_f32 -- SLP-packed they need ~60 v_mov per step and 4 registers more than there are (a spill INSIDE the step loop)  # (k_gemvb.hip: the Q4_0 / Q8_0 mat-vec, Llama-3.2-1B 1494 -> 1525 tok/s)
+NOSLP = {"k_gemv4.hip", "k_gemvb.hip", "k_attn.hip", "k_gemm4k.hip"}  # k_gemm4k.hip (round 5): gate/up chunk launch of a 512-column sequence 384.2 -> 369-371 us, same bits (profiles/r05_g4k2_variants.txt, the "v2 0" lines vs profiles/r05_g4k_item_order.txt)  # (k_gemvb.hip: the Q4_0 / Q8_0 mat-vec, Llama-3.2-1B 1494 -> 1525 tok/s)
 
 
 def _cmd_changed(obj: str, cmd: list) -> bool:

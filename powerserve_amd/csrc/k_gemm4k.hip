@@ -544,194 +544,6 @@ __global__ __launch_bounds__((G4K_NC + G4K_NP) * 64) void gemm4k_kernel(const G4
     if (dbg) { dbg[31] = __builtin_amdgcn_s_memtime(); dbg[30] = __builtin_amdgcn_s_memrealtime(); }
 }
 
-// ---- round 5: the wide kernel on v_mfma_f32_32x32x16_f16, eight waves at 256 registers.
-// What bounds gemm4k_kernel (rounds 3-4: r04_g4k_marks.txt, the stage-image / priority / nibble experiments, and round 5's item order, which took the
-// launch's fabric fetch down without moving its time) is the consumer wave's own step: a dependent chain -- operand reads from LDS, a matrix instruction,
-// the fp32 chains on its result -- that the 168 registers of a twelve-wave workgroup leave no room to software-pipeline, and that the second consumer
-// wave of the SIMD does not hide (2 x ~2000 cycles per super-block step and SIMD for ~110 instructions each).  Here a workgroup is FOUR consumers + four
-// producers, one of each per SIMD, 256 registers per wave: a consumer owns a 32-row x 32-column tile (both row tiles of the task x two column tiles) for
-// one accumulator half -- 4 lanes u + 2 mins lanes v = 96 fp32 chains per lane -- so every A operand read from LDS and every B fragment from L2 meets twice
-// the columns / rows per matrix instruction, and a step is 8 + 2 matrix instructions whose 16-register results feed 96 independent fmas: enough
-// independent work inside ONE wave to keep issuing while operands are in flight.  Same producers, same LDS stages, same items, same barriers, same
-// arithmetic per (row, column, lane): the exact integers come out of v_mfma_f32_32x32x16_f16 (two K = 16 halves chained: still exact) and
-// v_mfma_f32_32x32x8_f16 (the mins: k-half 0 carries the four (min, 16-sum) pairs, k-half 1 zeros).
-// Lane roles: D register r of lane l is weight row 8 (r / 4) + 4 (l / 32) + r % 4 of the task's 32 rows (row tile r / 8) and column l % 32 of the wave's
-// 32; the A operand of lane l is row l % 32, k-group 2 i + l / 32 of instruction i; the B operand column l % 32, the same k-group.
-constexpr int G4K2_NC = 4, G4K2_NP = 4;
-typedef float g4k_f16v __attribute__((ext_vector_type(16)));
-template <int EPI>
-__global__ __launch_bounds__((G4K2_NC + G4K2_NP) * 64) void gemm4k2_kernel(const G4KParams p) {
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
-    const int c32 = lane & 31, kh = lane >> 5;
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-    if (threadIdx.x < 8) ((uint32_t *)(lds + G4K_NST * G4K_STAGE))[threadIdx.x] = 0u; // the zero operands (visible after the first barrier)
-    if (EPI == 1 && threadIdx.x >= 64 && threadIdx.x < 64 + PS_EXP2F_N) ((uint64_t *)(lds + G4K_TAB))[threadIdx.x - 64] = ps_exp2f_tab[threadIdx.x - 64];
-    int item = (int)blockIdx.x;
-    {
-        int t, c;
-        g4k_item(p, item, t, c);
-        if (t >= p.n_tasks) item = g4k_next_item(p, item);
-    }
-    if (item >= p.n_items) return; // (the whole workgroup)
-    if (wave >= G4K2_NC) {
-        g4k_producer_wave<EPI, G4K2_NP, G4K_RING, PS_Q4_K>(p, item, lds, wave - G4K2_NC, nullptr);
-        return;
-    }
-    const int cp = wave & 1, uh = wave >> 1; // column-tile pair of the 64-column block, accumulator half
-    int task, cb;
-    g4k_item(p, item, task, cb);
-    const int ct = cb * 4 + 2 * cp + (c32 >> 4); // the lane's column tile
-    const int col = ct * 16 + (c32 & 15), colc = col < p.bs ? col : p.bs - 1;
-    const int ctc = ct * 16 < p.bs ? ct : (p.bs - 1) / 16;
-    // B operand (4 uh + k, instruction i) of super-block sb: qf_l + (sb << 13) + k * 1024 + i * 512
-    const char *qf_l = (const char *)p.qf + ((size_t)ctc * p.nsb << 13) + (size_t)(4 * uh) * 1024 + (size_t)(kh * 16 + (c32 & 15)) * 16;
-    const uint8_t *mf_ct = p.mf + (size_t)ctc * p.nsb * 576;
-    const int mc = colc & 15;
-    const char *zero = lds + G4K_NST * G4K_STAGE;
-    float *xch = (float *)(lds + G4K_XCH);
-    const g4k_f16v zf = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    ps_u32x4 B[4][2];
-#pragma unroll
-    for (int k = 0; k < 4; k++)
-#pragma unroll
-        for (int i = 0; i < 2; i++) B[k][i] = *(const ps_u32x4 *)(qf_l + k * 1024 + i * 512);
-    G4KMeta M = g4k_meta(mf_ct, 0, mc, uh * 16);
-    while (item < p.n_items) {
-        g4k_item(p, item, task, cb);
-        int wi, pair;
-        (void)g4k_rows<EPI>(p, task, wi, pair);
-        const G4KMat &W = wi == 0 ? p.w[0] : (wi == 1 ? p.w[1] : p.w[2]);
-        float acc[4][16], accm[2][16];
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-#pragma unroll
-            for (int k = 0; k < 4; k++) acc[k][r] = 0.f;
-            accm[0][r] = accm[1][r] = 0.f;
-        }
-        float4 rsd[2], bia[2];
-        for (int sb = 0; sb < p.nsb; sb++) {
-            const int nb = sb + 1 == p.nsb ? 0 : sb + 1; // (the next item meets the same columns from super-block 0)
-            const G4KMeta Mn = g4k_meta(mf_ct, nb, mc, uh * 16); // a step ahead, like B
-            if (!(sb & 1)) __syncthreads(); // the producers have parked this step and the next
-            const char *st = lds + (sb & (G4K_NST - 1)) * G4K_STAGE;
-            const char *nq = qf_l + ((size_t)nb << 13);
-            // d * y_d of the lane's sixteen rows 8 j + 4 kh + q (-dmin * y_d is formed behind the chains, in the same registers: (d, dmin) read again)
-            float dyd[16];
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const g4k_f4 dda = *(const g4k_f4 *)(st + G4K_DD + (8 * j + 4 * kh) * 8), ddb = *(const g4k_f4 *)(st + G4K_DD + (8 * j + 4 * kh) * 8 + 16);
-                dyd[4 * j + 0] = __fmul_rn(M.yd, dda[0]); dyd[4 * j + 1] = __fmul_rn(M.yd, dda[2]); dyd[4 * j + 2] = __fmul_rn(M.yd, ddb[0]); dyd[4 * j + 3] = __fmul_rn(M.yd, ddb[2]);
-            }
-            const char *ap = st + g4k_plane(kh) + c32 * G4K_RS + (4 * uh) * 16; // instruction 0: k-group kh; instruction 1: k-group 2 + kh
-            const int ap1 = g4k_plane(2) - g4k_plane(0);                        // (plane(2 + kh) - plane(kh), the same for kh = 0, 1)
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const ps_u32x4 a0 = *(const ps_u32x4 *)(ap + k * 16), a1 = *(const ps_u32x4 *)(ap + ap1 + k * 16);
-                g4k_h8 av0, av1, bv0, bv1;
-                __builtin_memcpy(&av0, &a0, 16); __builtin_memcpy(&av1, &a1, 16);
-                __builtin_memcpy(&bv0, &B[k][0], 16); __builtin_memcpy(&bv1, &B[k][1], 16);
-                g4k_f16v si = __builtin_amdgcn_mfma_f32_32x32x16_f16(av0, bv0, zf, 0, 0, 0);
-                si = __builtin_amdgcn_mfma_f32_32x32x16_f16(av1, bv1, si, 0, 0, 0); // (float)sumi[4 uh + k] of the lane's 16 rows, its column
-                B[k][0] = *(const ps_u32x4 *)(nq + k * 1024);
-                B[k][1] = *(const ps_u32x4 *)(nq + k * 1024 + 512);
-#pragma unroll
-                for (int r = 0; r < 16; r++) acc[k][r] = __fmaf_rn(dyd[r], si[r], acc[k][r]); // acc = fma(d, (float)sumi, acc)
-            }
-            { // acc_m lanes 2 uh, 2 uh + 1: k-half 0 supplies the row's mins operands and the column's fp16 16-sums, k-half 1 zeros
-                const uint4 ma = *(const uint4 *)(kh == 0 ? st + G4K_MINS + c32 * 32 + uh * 16 : zero);
-                float dmy[16];
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const g4k_f4 dda = *(const g4k_f4 *)(st + G4K_DD + (8 * j + 4 * kh) * 8), ddb = *(const g4k_f4 *)(st + G4K_DD + (8 * j + 4 * kh) * 8 + 16);
-                    dmy[4 * j + 0] = __fmul_rn(-M.yd, dda[1]); dmy[4 * j + 1] = __fmul_rn(-M.yd, dda[3]); dmy[4 * j + 2] = __fmul_rn(-M.yd, ddb[1]); dmy[4 * j + 3] = __fmul_rn(-M.yd, ddb[3]);
-                }
-#pragma unroll
-                for (int vv = 0; vv < 2; vv++) {
-                    const uint32_t ax = vv ? ma.z : ma.x, ay = vv ? ma.w : ma.y, bx = vv ? M.b16.z : M.b16.x, by = vv ? M.b16.w : M.b16.y;
-                    g4k_h2 a0, a1, g0, g1;
-                    __builtin_memcpy(&a0, &ax, 4); __builtin_memcpy(&a1, &ay, 4); __builtin_memcpy(&g0, &bx, 4); __builtin_memcpy(&g1, &by, 4);
-                    const g4k_h4 am = {a0[0], a0[1], a1[0], a1[1]}, bm = {g0[0], g0[1], g1[0], g1[1]};
-                    const g4k_f16v pr = __builtin_amdgcn_mfma_f32_32x32x8f16(am, bm, zf, 0, 0, 0);
-#pragma unroll
-                    for (int r = 0; r < 16; r++) accm[vv][r] = __fmaf_rn(dmy[r], pr[r], accm[vv][r]);
-                }
-            }
-            M = Mn;
-        }
-        if (EPI != 1) { // what the epilogue adds: requested here, met behind the exchange barrier (clamped addresses, never a branch around a load)
-            const int cole = col < p.bs ? col : 0;
-#pragma unroll
-            for (int t = 0; t < 2; t++) {
-                const int64_t row0 = (int64_t)(2 * pair + t) * 16 + 8 * uh + 4 * kh;
-                rsd[t] = *(const float4 *)((p.residual && wi == 0 ? p.residual : W.out) + (int64_t)cole * W.ldo + row0);
-                bia[t] = *(const float4 *)((W.bias ? W.bias : W.out) + row0);
-            }
-        }
-        // ---- the two accumulator halves of a tile meet (hsum_float_8, ggml-quants.c:62-68, adds lane u to lane u + 4 first: exactly the two
-        // halves): half uh finishes the register groups j = uh, uh + 2 (rows 8 uh + 4 kh + q of row tile 0 and of row tile 1) and hands the other
-        // half the chains of the groups j = 1 - uh, 3 - uh
-        {
-            float *mine = xch + ((size_t)(cp * 2 + uh) * 64 + lane) * 48;
-#pragma unroll
-            for (int jj = 0; jj < 2; jj++)
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-#define G4K2_OTHER(arr, k) (uh ? arr[k][8 * jj + q] : arr[k][8 * jj + 4 + q]) /* j = (1 - uh) + 2 jj (selects, not a runtime index) */
-                    *(float4 *)(mine + (jj * 4 + q) * 6) = make_float4(G4K2_OTHER(acc, 0), G4K2_OTHER(acc, 1), G4K2_OTHER(acc, 2), G4K2_OTHER(acc, 3));
-                    *(float2 *)(mine + (jj * 4 + q) * 6 + 4) = make_float2(G4K2_OTHER(accm, 0), G4K2_OTHER(accm, 1));
-#undef G4K2_OTHER
-                }
-        }
-        __syncthreads(); // X: (a whole item of barriers lies between this exchange and the next one's stores)
-        {
-            const float *theirs = xch + ((size_t)(cp * 2 + 1 - uh) * 64 + lane) * 48;
-            float y[2][4];
-#pragma unroll
-            for (int jj = 0; jj < 2; jj++)
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-#define G4K2_OWN(arr, k) (uh ? arr[k][8 * jj + 4 + q] : arr[k][8 * jj + q]) /* j = uh + 2 jj */
-                    const float4 o4 = *(const float4 *)(theirs + (jj * 4 + q) * 6);
-                    const float2 o2 = *(const float2 *)(theirs + (jj * 4 + q) * 6 + 4);
-                    // lanes u < 4 (and mins lanes 0, 1) are half 0's, lanes u + 4 (mins 2, 3) half 1's
-                    const float s0 = __fadd_rn(G4K2_OWN(acc, 0), o4.x), s1 = __fadd_rn(G4K2_OWN(acc, 1), o4.y), s2 = __fadd_rn(G4K2_OWN(acc, 2), o4.z), s3 = __fadd_rn(G4K2_OWN(acc, 3), o4.w);
-                    const float res = __fadd_rn(__fadd_rn(s0, s2), __fadd_rn(s1, s3));
-                    const float w0 = G4K2_OWN(accm, 0), w1 = G4K2_OWN(accm, 1);
-#undef G4K2_OWN
-                    const float ma = uh ? o2.x : w0, mb = uh ? o2.y : w1;   // acc_m lanes 0, 1
-                    const float mc2 = uh ? w0 : o2.x, md = uh ? w1 : o2.y;  // acc_m lanes 2, 3
-                    y[jj][q] = __fadd_rn(res, __fadd_rn(__fadd_rn(ma, mc2), __fadd_rn(mb, md)));
-                }
-            if (col < p.bs) {
-                if (EPI == 1) {
-                    const int64_t row0 = (int64_t)task * 16 + 8 * uh + 4 * kh;
-                    const uint64_t *tab = (const uint64_t *)(lds + G4K_TAB);
-                    float o[4];
-#pragma unroll
-                    for (int q = 0; q < 4; q++) // ps_silu_mul with the table in LDS
-                        o[q] = __fmul_rn(__fmul_rn(y[0][q], __fdiv_rn(1.0f, __fadd_rn(1.0f, ps_expf_glibc(-y[0][q], tab)))), y[1][q]);
-                    *(float4 *)(W.out + (int64_t)col * W.ldo + row0) = make_float4(o[0], o[1], o[2], o[3]);
-                } else {
-#pragma unroll
-                    for (int t = 0; t < 2; t++) {
-                        const int64_t row0 = (int64_t)(2 * pair + t) * 16 + 8 * uh + 4 * kh;
-                        const float bv[4] = {bia[t].x, bia[t].y, bia[t].z, bia[t].w}, rv[4] = {rsd[t].x, rsd[t].y, rsd[t].z, rsd[t].w};
-                        float v[4];
-#pragma unroll
-                        for (int q = 0; q < 4; q++) {
-                            v[q] = y[t][q];
-                            if (W.bias) v[q] = __fadd_rn(v[q], bv[q]);
-                            if (p.residual && wi == 0) v[q] = __fadd_rn(rv[q], v[q]);
-                        }
-                        *(float4 *)(W.out + (int64_t)col * W.ldo + row0) = make_float4(v[0], v[1], v[2], v[3]);
-                    }
-                }
-            }
-        }
-        item = g4k_next_item(p, item);
-    }
-}
-
 // ---- narrow batches (at most 32 columns: tree verify, prompt tails).  With one or two live column tiles the wide mapping
 // leaves most consumers walking dead columns, and a consumer's step is a chain of LDS and L2 round trips (0.83 us) that does
 // not get shorter when others idle.  Here the eight consumers split ONE tile's work eight ways (CT = 1: wave = accumulator
@@ -1154,8 +966,7 @@ __global__ __launch_bounds__((G4K_NC + G4K_NP) * 64) void gemm6k_kernel(const G6
 
 } // namespace
 
-int g_g4k_cbx = getenv("PS_G4K_CBX") ? atoi(getenv("PS_G4K_CBX")) : 0; // ps_hip_debug_set(6, v): column blocks per XCD of the wide Q4_K / Q5_K mat-mul's item order (0: round 2's)
-int g_g4k_v2 = getenv("PS_G4K_V2") ? atoi(getenv("PS_G4K_V2")) : 0;    // ps_hip_debug_set(7, v): the wide Q4_K mat-mul on gemm4k2_kernel (32 x 32 consumer tiles, eight waves)
+int g_g4k_cbx = getenv("PS_G4K_CBX") ? atoi(getenv("PS_G4K_CBX")) : 4; // ps_hip_debug_set(6, v): column blocks per XCD of the wide Q4_K / Q5_K mat-mul's item order (0: round 2's; default 4: profiles/r05_g4k_item_order.txt)
 int g_g4k_par = getenv("PS_GEMM4K_PAR") ? atoi(getenv("PS_GEMM4K_PAR")) : 1; // ps_hip_debug_set(3, v): the few-tile narrow-batch form (gemm4k_par_kernel)
 // grid, persistence and the wide / narrow choice for a filled-in G4KParams (tasks, pointers, wt)
 // ---- narrow batches, wave-autonomous form (round 3): at most 16 columns, Q4_K.  The producer / consumer kernels above pay a
@@ -1782,8 +1593,6 @@ static int g4k_launch(hipStream_t st, int n_cu, G4KParams &p, const int epi, con
         (void)hipFuncSetAttribute((const void *)gemm4k_kernel<0, PS_Q4_K>, hipFuncAttributeMaxDynamicSharedMemorySize, G4K_LDS);
         (void)hipFuncSetAttribute((const void *)gemm4k_kernel<1, PS_Q4_K>, hipFuncAttributeMaxDynamicSharedMemorySize, G4K_LDS);
         (void)hipFuncSetAttribute((const void *)gemm4k_kernel<0, PS_Q5_K>, hipFuncAttributeMaxDynamicSharedMemorySize, G4K_LDS);
-        (void)hipFuncSetAttribute((const void *)gemm4k2_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, G4K_LDS);
-        (void)hipFuncSetAttribute((const void *)gemm4k2_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, G4K_LDS);
         (void)hipFuncSetAttribute((const void *)gemm4k_narrow_kernel<0, 1, PS_Q4_K>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS1);
         (void)hipFuncSetAttribute((const void *)gemm4k_narrow_kernel<1, 1, PS_Q4_K>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS1);
         (void)hipFuncSetAttribute((const void *)gemm4k_narrow_kernel<0, 1, PS_Q5_K>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS1);
@@ -1821,10 +1630,6 @@ static int g4k_launch(hipStream_t st, int n_cu, G4KParams &p, const int epi, con
     } else if (ctw == 1) {
         if (epi == 1) { psk_note_kernel("gemm4k_narrow_kernel<1, 1, 12>"); hipLaunchKernelGGL((gemm4k_narrow_kernel<1, 1, PS_Q4_K>), grid, blkn, LDS1, st, p); }
         else { psk_note_kernel("gemm4k_narrow_kernel<0, 1, 12>"); hipLaunchKernelGGL((gemm4k_narrow_kernel<0, 1, PS_Q4_K>), grid, blkn, LDS1, st, p); }
-    } else if (g_g4k_v2 && ctw == 4) { // round 5: four consumers on 32 x 32 tiles + four producers, 256 registers per wave
-        const dim3 blk2((G4K2_NC + G4K2_NP) * 64);
-        if (epi == 1) { psk_note_kernel("gemm4k2_kernel<1>"); hipLaunchKernelGGL((gemm4k2_kernel<1>), grid, blk2, G4K_LDS, st, p); }
-        else { psk_note_kernel("gemm4k2_kernel<0>"); hipLaunchKernelGGL((gemm4k2_kernel<0>), grid, blk2, G4K_LDS, st, p); }
     } else if (epi == 1) { psk_note_kernel("gemm4k_kernel<1, 12>"); hipLaunchKernelGGL((gemm4k_kernel<1, PS_Q4_K>), grid, blk, G4K_LDS, st, p); }
     else { psk_note_kernel("gemm4k_kernel<0, 12>"); hipLaunchKernelGGL((gemm4k_kernel<0, PS_Q4_K>), grid, blk, G4K_LDS, st, p); }
     return 0;

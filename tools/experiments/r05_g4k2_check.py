@@ -10,6 +10,7 @@ ctx = hip.Ctx(0)
 L = ctx.L
 L.ps_hip_last_matmul_kernel.restype = C.c_char_p
 bad = 0
+V2 = int(os.environ.get("G4K2_V", "1"))  # 1 / 8 / 16: the producers' ring depth
 def mm(W, x, N):
     dx, dy = ctx.to_device(x), ctx.empty((x.shape[0], N))
     ctx.check(L.ps_hip_mul_mat(ctx.h, C.byref(dy.tensor()), C.byref(W.tensor()), C.byref(dx.tensor())))
@@ -21,7 +22,7 @@ for (K, N, bs) in [(4096, 512, 128), (1024, 96, 120), (14336, 64, 113), (2048, 2
     x[min(3, bs - 1), 256:512] = 0.0
     W = ctx.upload_weight(12, w, K, N)
     L.ps_hip_debug_set(7, 0); y1, k1 = mm(W, x, N)
-    L.ps_hip_debug_set(7, 1); y2, k2 = mm(W, x, N)
+    L.ps_hip_debug_set(7, V2); y2, k2 = mm(W, x, N)
     ok = np.array_equal(y1.view(np.uint32), y2.view(np.uint32))
     bad += not ok
     print(f"K {K} N {N} bs {bs}: {k1} vs {k2}: {'bit-equal' if ok else 'DIFFERENT ' + str(np.argwhere(y1 != y2)[:6].tolist())}", flush=True)
@@ -36,7 +37,7 @@ with tempfile.TemporaryDirectory() as d:
     synth.write_model_dir(d, "small-llama-hs128", 12, n_ctx=512, seed=3)
     prompt = np.random.default_rng(1).integers(0, 1024, 301)
     res = []
-    for v in (0, 1):
+    for v in (0, V2):
         L.ps_hip_debug_set(7, v)
         m = hip.Model(ctx, d, max_batch=128, n_ctx=512)
         m.prefill(prompt[:300], 64)
