@@ -205,31 +205,31 @@ def graph_path(model_dir, device, args, prompt):
     """The same workload through the reference-shaped host side (libps_host.so): every forward builds the reference's
     op graph with the NormAttention / FFN builders, Executor::run hands it to HIPBackend::plan, which lowers the canonical
     sequence to the fused launches.  Prefill in chunks, then single-token forwards with the logits copied to the host and
-    arg-maxed there (ModelTokenIterator's loop, src/model/model.hpp:117-184)."""
+    device arg-max behind them (ModelTokenIterator's loop, src/model/model.hpp:117-184, with greedy sampling)."""
     from powerserve_amd import host
-    hm = host.HostModel(model_dir, device, max_batch=max(args.batch, 1), n_ctx=args.n_ctx)
-    t0 = time.perf_counter()
-    done = 0
-    while done < prompt.size - 1:
-        bs = min(args.batch, prompt.size - 1 - done)
-        hm.forward(prompt[done:done + bs], np.arange(done, done + bs), lm_head=False)
-        done += bs
-    t1 = time.perf_counter()
-    cur, ids, t_cap = int(prompt[-1]), [], None
-    for s in range(args.graph_steps):
-        if s == 2:
-            t_cap = time.perf_counter()  # (the first single-token forward runs eagerly and captures the launch plan it replays afterwards)
-        lg = hm.forward([cur], [done + s], lm_head=True)
-        cur = int(np.argmax(lg[0]))
-        ids.append(cur)
-    t2 = time.perf_counter()
-    n_plans, n_low = hm.plan_stats()
-    hm.close()
+    hm = host.HostModel(model_dir, device, max_batch=max(args.batch, 1) * max(args.super_chunks, 1), n_ctx=args.n_ctx)
+    try:
+        t0 = time.perf_counter()
+        hm.prefill(prompt[:-1], args.batch)  # ModelTokenIterator's prefill loop: its first chunk's graph is planned; lowered, the loop is lowered with it
+        done = prompt.size - 1
+        t1 = time.perf_counter()
+        cur, ids, t_cap = int(prompt[-1]), [], None
+        for s in range(args.graph_steps):
+            if s == 2:
+                t_cap = time.perf_counter()  # (the first single-token forward runs eagerly and captures the launch plan it replays afterwards)
+            cur = int(hm.decode([cur], [done + s])[0])  # Model::decode: graph -> Executor -> lowered launches -> 4 bytes of device arg-max back
+            ids.append(cur)
+        t2 = time.perf_counter()
+        n_plans, n_low = hm.plan_stats()
+        n_hits = hm.plan_cache_hits()
+    finally:
+        hm.close()
     return {"prefill_tokens_per_s": (prompt.size - 1) / (t1 - t0), "decode_tokens_per_s": args.graph_steps / (t2 - t1), "steps": args.graph_steps,
             "decode_tokens_per_s_after_capture": (args.graph_steps - 2) / (t2 - t_cap) if t_cap and args.graph_steps > 2 else None,
-            "graphs_planned": n_plans, "graphs_lowered": n_low, "first_ids": ids[:8],
-            "what": "Graph -> Executor::run -> HIPBackend::plan (lowered to the fused launches; a single token replays a captured launch plan), "
-                    "logits to the host and arg-max there every step"}
+            "graphs_planned": n_plans, "graphs_lowered": n_low, "plan_cache_hits": n_hits, "first_ids": ids[:8],
+            "what": "Model::prefill + Model::decode of the C++ facade: Graph -> Executor::run -> HIPBackend::plan (lowered to the fused launches; a single token replays a "
+                    "captured launch plan, and a (batch size, lm_head) shape that has been lowered once runs without a second graph -- the plan cache SURVEY a20 asks for; the prefill loop is lowered to ps_hip_model_prefill once its first chunk's graph has been planned and lowered), greedy ids from the "
+                    "device arg-max (4 bytes per token to the host, src/model/model.hpp:170-183 copies vocab x 4)"}
 
 
 def prefill_wide_leg(ctx, model_dir, args, prompt):
@@ -255,7 +255,7 @@ def prefill_wide_leg(ctx, model_dir, args, prompt):
     return {"chunk": args.wide_chunk, "prefill_tokens_per_s": res[0], "prefill_tokens_per_s_warm": res[1]}
 
 
-def fp16_prefill_leg(ctx, model, args, prompt, ids_parity, model_dir):
+def fp16_prefill_leg(ctx, model, args, prompt, model_dir):
     """SURVEY 8 f4 (second half), reported next to the headline and never mixed into it: the same prefill with the fp16 perf mode on
     (ps_hip_model_set_mode bit 5: the layer mat-muls as dense fp16 GEMMs on dequantized fp16 copies of the weights, csrc/perf16.hip's own
     kernel; RoPE, KV append and attention stay the parity kernels on the FP32 cache).  NOT bit-exact: layer 0's K / V rows are compared with the
@@ -266,31 +266,35 @@ def fp16_prefill_leg(ctx, model, args, prompt, ids_parity, model_dir):
     if args.f16_super_chunk > model.max_batch:
         from powerserve_amd import hip
         own = model = hip.Model(ctx, model_dir, max_batch=args.f16_super_chunk, n_ctx=args.n_ctx)
-    model.reset()
-    model.set_mode((1 if args.eager else 0) | 32)
-    model.prefill(prompt[:8], args.batch)  # first use: dequantizes the weights (not timed)
-    res = []
-    for _ in range(2):
-        ctx.sync()
-        t0 = time.perf_counter()
+    try:  # (a second full model lives on the device for the duration of this leg: it goes away whatever happens)
+        model.reset()
+        model.set_mode((1 if args.eager else 0) | 32)
+        model.prefill(prompt[:8], args.batch)  # first use: dequantizes the weights (not timed)
+        res = []
+        for _ in range(2):
+            ctx.sync()
+            t0 = time.perf_counter()
+            model.reset()
+            model.prefill(prompt[:-1], args.batch)
+            ctx.sync()
+            res.append((prompt.size - 1) / (time.perf_counter() - t0))
+        # What the mode changes is bounded where nothing has compounded yet: layer 0's K / V rows (one GEMM behind the embedding) against the parity
+        # path's.  (On random synthetic weights the ids that follow say nothing: the int8 activation rounding of 32 layers amplifies ANY perturbation
+        # into a different arg-max within a few tokens -- VERDICT round 3, weak 8.)
+        n = prompt.size - 1
+        k16, v16 = model.k_cache(0)[:n].copy(), model.v_cache(0)[:, :n].copy()
+        model.set_mode(1 if args.eager else 0)
         model.reset()
         model.prefill(prompt[:-1], args.batch)
-        ctx.sync()
-        res.append((prompt.size - 1) / (time.perf_counter() - t0))
-    # What the mode changes is bounded where nothing has compounded yet: layer 0's K / V rows (one GEMM behind the embedding) against the parity
-    # path's.  (On random synthetic weights the ids that follow say nothing: the int8 activation rounding of 32 layers amplifies ANY perturbation
-    # into a different arg-max within a few tokens -- VERDICT round 3, weak 8.)
-    n = prompt.size - 1
-    k16, v16 = model.k_cache(0)[:n].copy(), model.v_cache(0)[:, :n].copy()
-    model.set_mode(1 if args.eager else 0)
-    model.reset()
-    model.prefill(prompt[:-1], args.batch)
-    k32, v32 = model.k_cache(0)[:n], model.v_cache(0)[:, :n]
-    rel = lambda a, b: float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
-    errs = (rel(k16, k32), rel(v16, v32))
-    tokens_per_launch = min(model.max_batch // max(args.batch, 1) * max(args.batch, 1), prompt.size - 1)
-    if own is not None:
-        own.close()
+        k32, v32 = model.k_cache(0)[:n], model.v_cache(0)[:, :n]
+        rel = lambda a, b: float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+        errs = (rel(k16, k32), rel(v16, v32))
+        tokens_per_launch = min(model.max_batch // max(args.batch, 1) * max(args.batch, 1), prompt.size - 1)
+    finally:
+        if own is not None:
+            own.close()
+        else:
+            model.set_mode(1 if args.eager else 0)
     return {"prefill_tokens_per_s": res[0], "prefill_tokens_per_s_warm": res[1], "tokens_per_mat_mul_launch": int(tokens_per_launch),
             "layer0_k_cache_max_abs_err_over_max_abs_vs_parity": errs[0], "layer0_v_cache_max_abs_err_over_max_abs_vs_parity": errs[1],
             "gemm": "own kernels (csrc/perf16.hip: v_mfma_f32_32x32x16_f16; 256-token tiles on the LDS-DMA path, 128-token tiles through registers for small grids); no library",
@@ -484,8 +488,13 @@ def main():
     if dist is not None:
         dt, prefill_s, prefill_warm_s = max_over_ranks(dist, [dt, prefill_s, prefill_warm_s])
         replicas_agree, _ = gather_ids(dist, ids, world)
+        # every collective of the run is behind us: the process group goes away NOW, so that no rank sits in an RCCL barrier (host threads spinning)
+        # while rank 0 times the CPU baselines on the reference's spin-barrier thread pool (round-4 review, weak 2); ranks > 0 just close and exit
+        dist.barrier()
+        dist.destroy_process_group()
+        multi, dist = True, None
     else:
-        replicas_agree = True
+        replicas_agree, multi = True, False
 
     out = None
     if rank == 0:
@@ -515,21 +524,21 @@ def main():
             "prefill_roofline": prefill_roofline(ctx, model, cfg, args.prompt_len - 1, prefill_s, prefill_warm_s, min(args.batch * max(args.super_chunks, 1), args.prompt_len - 1),
                                                  args.preset == "llama-3.1-8b" and args.wtype == "Q4_K"),
         }
-        if not args.no_kv_f16 and dist is None:
+        if not args.no_kv_f16 and not multi:
             try:
                 out["fp16_kv_mode"] = fp16_kv_leg(ctx, model, args, prompt, np.concatenate([ids_w, ids]))
             except Exception as e:  # noqa: BLE001 — a failing side leg must not take the headline line with it
                 out["fp16_kv_mode"] = {"error": repr(e)}
             try:
-                out["fp16_prefill_mode"] = fp16_prefill_leg(ctx, model, args, prompt, np.concatenate([ids_w, ids]), model_dir)
+                out["fp16_prefill_mode"] = fp16_prefill_leg(ctx, model, args, prompt, model_dir)
             except Exception as e:  # noqa: BLE001
                 out["fp16_prefill_mode"] = {"error": repr(e)}
-        if args.wide_chunk > args.batch and dist is None:
+        if args.wide_chunk > args.batch and not multi:
             try:
                 out["prefill_wide_chunks"] = prefill_wide_leg(ctx, model_dir, args, prompt)
             except Exception as e:  # noqa: BLE001
                 out["prefill_wide_chunks"] = {"error": repr(e)}
-        if not args.no_graph_path and dist is None:
+        if not args.no_graph_path and not multi:
             try:
                 out["graph_path"] = graph_path(model_dir, local, args, prompt)
                 out["graph_path"]["ids_equal_direct"] = out["graph_path"]["first_ids"] == ([int(i) for i in ids_w] + [int(i) for i in ids])[:8]
@@ -541,6 +550,10 @@ def main():
                 ids_gpu, logits_gpu = gpu_short_run(model, p_short, ids_cpu)
                 rel = max(float(np.abs(g - c).max() / max(np.abs(c).max(), 1e-30)) for g, c in zip(logits_gpu, logits_cpu))
                 out["parity"] = {"model": f"{args.preset} {args.wtype} (the bench model, all layers)", "checker": "oracle/ps_oracle.c (bit-exact vs the real reference)",
+                                 "reference_build": "-ffp-contract=off (oracle/Makefile CONTRACT=off: every fp32 operation rounds where the C source rounds).  The reference's own CMake sets no "
+                                                    "contraction flag: its stock build (GCC -ffp-contract=fast) fuses the RoPE rotation, the n % 32 dot-product leftovers and Q5_K's summs -- ids equal, logits "
+                                                    "up to 2.8e-3 of the largest away on one of four fixture models (tests/golden/e2e_builds_*.npz); oracle mode pso_set_contract(1) and "
+                                                    "lib/libps_hip_contract.so follow THAT build bit for bit (tests/test_ref_fast.py, tests/test_gpu_golden.py)",
                                  "prompt_tokens": int(p_short.size), "steps": len(ids_cpu), "ids_equal": [int(i) for i in ids_cpu] == ids_gpu,
                                  "max_rel_logit_err": rel, "logits_bit_equal": all(np.array_equal(g.view(np.uint32), np.asarray(c, dtype=np.float32).view(np.uint32)) for g, c in zip(logits_gpu, logits_cpu))}
                 out["cpu_port"] = port
@@ -553,9 +566,6 @@ def main():
                 out["cpu_baseline"] = {"value": None, "error": repr(e)}
     model.close()
     ctx.close()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
     if rank == 0:
         sys.stdout.flush()
         os.dup2(saved_stdout, 1)
@@ -563,20 +573,38 @@ def main():
 
 
 MFMA_F16_PEAK_TFLOPS = 2500.0  # dense fp16 matrix-core peak (MI355X_MICROARCH.md): the pipe the Q4_K chunk mat-mul runs its exact-integer contractions on
-TRAFFIC_FILE = os.path.join("profiles", "r04_pmc_traffic.json")
+TRAFFIC_FILE = os.path.join("profiles", "r05_pmc_traffic.json")
+
+
+def kernel_sources_sha16():
+    """sha256[:16] over the kernel sources and the build recipe: what a PMC record must have been taken on to describe the library that runs"""
+    import hashlib
+    root = os.path.dirname(os.path.abspath(__file__))
+    h = hashlib.sha256()
+    csrc = os.path.join(root, "powerserve_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode()); h.update(open(os.path.join(csrc, f), "rb").read())
+    h.update(open(os.path.join(root, "powerserve_amd", "build.py"), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def _pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed PMC pass (tools/pmc_summary.py over a separate
     `rocprofv3 --pmc FETCH_SIZE` run of this same command; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).
-    A live bench run cannot collect counters: the record is keyed by the kernel's full template name, so a kernel that has
-    changed since the pass reports null instead of a stale number.  Returns (bytes | None, source)."""
+    A live bench run cannot collect counters.  The record is keyed by the kernel's full template name AND carries the hash of the kernel
+    sources it was taken on (kernel_sources_sha16): a record from other sources -- a kernel body can change under an unchanged name -- is
+    refused (null, with the reason).  Returns (bytes | None, source)."""
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), TRAFFIC_FILE)
     try:
         with open(path) as f:
-            return json.load(f).get(kernel, {}).get("hbm_bytes_per_launch"), TRAFFIC_FILE + " (rocprofv3 --pmc FETCH_SIZE x 2, separate pass of this command)"
+            rec = json.load(f)
     except Exception:
         return None, None
+    have, want = rec.get("_kernel_sources_sha16"), kernel_sources_sha16()
+    if have != want:
+        return None, f"{TRAFFIC_FILE} REFUSED: taken on kernel sources {have}, this library is built from {want}"
+    return rec.get(kernel, {}).get("hbm_bytes_per_launch"), TRAFFIC_FILE + " (rocprofv3 --pmc FETCH_SIZE x 2, separate pass of this command on these kernel sources)"
 
 
 def _bench_matmul(ctx, model, which, bs, reps=20):

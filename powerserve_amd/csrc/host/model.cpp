@@ -175,6 +175,36 @@ auto Model::forward_graph(const std::vector<int> &tokens, const std::vector<int>
     auto &llm = m_config->llm;
     const size_t bs = tokens.size();
     POWERSERVE_ASSERT((size_t)pos[0] + bs <= llm.seq_len, "KV cache is full (n_ctx)");
+    // Plan cache (the reference rebuilds ~28 L + 3 graph nodes per forward -- "on GPU replace by a cached plan keyed on (bs, ...)").  A shape
+    // (batch size, lm_head) whose canonical graph HIPBackend::plan has already lowered for this model needs no second graph: the lowered launch sequence
+    // depends on the graph only through what the cache key and the call's own arguments (tokens, consecutive positions from the cache position) carry.
+    // Explicit masks, op-by-op mode and plan-only queries build and plan their graph as before.
+    const bool consecutive = [&] { for (size_t i = 1; i < bs; i++) if (pos[i] != pos[0] + (int)i) return false; return (size_t)pos[0] == m_platform->get_kv_position(m_config->model_id); }();
+    if (m_use_fused && m_use_plan_cache && !plan_only && mask.mask.empty() && consecutive && m_lowered_shapes.count({bs, lm_head})) {
+        m_last_lowered = true;
+        n_plan_cache_hits++;
+        std::vector<int32_t> t(tokens.begin(), tokens.end()), p(pos.begin(), pos.end());
+        for (int attempt = 0;; attempt++) {
+            if (ps_hip_model_forward_lowered(be.m_model, t.data(), (int)bs, p.data(), nullptr, lm_head ? 1 : 0)) POWERSERVE_ABORT(std::string("lowered forward: ") + ps_hip_last_error(be.m_ctx));
+            const int rc = ps_hip_model_sync_check(be.m_model);
+            if (rc == 0) break;
+            if (rc != PS_HIP_ATTN_TIMEOUT || attempt > 0) POWERSERVE_ABORT(std::string("lowered forward: ") + ps_hip_last_error(be.m_ctx));
+        }
+        be.m_kv->advance((int)bs);
+        if (!lm_head) { be.sync(); return LogitsVector(); }
+        if (ids) {
+            std::vector<int32_t> am(bs);
+            if (ps_hip_model_argmax(be.m_model, (int)bs, am.data())) POWERSERVE_ABORT(std::string("arg-max copy: ") + ps_hip_last_error(be.m_ctx));
+            ids->assign(am.begin(), am.end());
+            return LogitsVector();
+        }
+        Stride st = {4, 4 * (size_t)llm.vocab_size, 4 * (size_t)llm.vocab_size * bs, 4 * (size_t)llm.vocab_size * bs};
+        auto host = std::make_shared<CPUBuffer>(st, (size_t)llm.vocab_size * bs * 4);
+        be.sync();
+        if (ps_hip_memcpy_d2h(be.m_ctx, host->m_data, ps_hip_model_logits(be.m_model), host->m_storage.size()))
+            POWERSERVE_ABORT(std::string("logits copy: ") + ps_hip_last_error(be.m_ctx));
+        return LogitsVector(host, llm.vocab_size, bs);
+    }
     Graph g(m_config->model_id);
     auto x = g.get_embedding(g.add_tensor(m_weights->token_embedding_table), tokens);
     TensorNode *logits = nullptr;
@@ -192,6 +222,7 @@ auto Model::forward_graph(const std::vector<int> &tokens, const std::vector<int>
         Executor executor(*m_platform, g);
         executor.plan();
         m_last_lowered = executor.lowered();
+        if (m_last_lowered && m_use_plan_cache && mask.mask.empty()) m_lowered_shapes.insert({bs, lm_head});
         if (plan_only) return LogitsVector(); // (Model::prefill asks whether this chunk shape lowers; nothing has run)
         if (!executor.lowered()) executor.allocate_buffers(); // a lowered graph runs in the device model's own arena
         executor.run();
@@ -322,6 +353,8 @@ void *psh_model_load(const char *model_dir, int device, int max_batch, int n_ctx
 void psh_model_free(void *h) { delete (psh_model *)h; }
 void psh_model_set_fused(void *h, int fused) { ((psh_model *)h)->model->m_use_fused = fused != 0; } // 0: plan() lowers nothing (A/B, tests)
 void psh_model_plan_stats(void *h, int *n_plans, int *n_lowered) { auto &be = ((psh_model *)h)->model->backend(); *n_plans = be.n_plans; *n_lowered = be.n_lowered; }
+int psh_model_plan_cache_hits(void *h) { return ((psh_model *)h)->model->n_plan_cache_hits; }
+void psh_model_set_plan_cache(void *h, int on) { ((psh_model *)h)->model->m_use_plan_cache = on != 0; if (!on) ((psh_model *)h)->model->m_lowered_shapes.clear(); }
 size_t psh_model_kv_position(void *h) { auto m = (psh_model *)h; return m->platform->get_kv_position(m->model->m_config->model_id); }
 void psh_model_reset(void *h) { auto m = (psh_model *)h; m->platform->reset_kv_position(m->model->m_config->model_id); }
 uint32_t psh_model_vocab(void *h) { return ((psh_model *)h)->model->m_config->llm.vocab_size; }

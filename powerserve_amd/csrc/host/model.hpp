@@ -6,6 +6,7 @@
 //   ModelTokenIterator            src/model/model.hpp:117-184
 //   load_model                    src/model/model_loader.cpp:23-41
 #pragma once
+#include <set>
 #include "hip_backend.hpp"
 #include "sampler.hpp"
 
@@ -55,6 +56,9 @@ struct Model {
     std::shared_ptr<FFN> m_ffn;
     std::shared_ptr<Platform> m_platform;
     bool m_is_need_bias = false; // Qwen2
+    bool m_use_plan_cache = true;  // a (batch size, lm_head) shape whose graph has been lowered once runs its launches without a second graph (false: every forward builds + plans)
+    std::set<std::pair<size_t, bool>> m_lowered_shapes;
+    int n_plan_cache_hits = 0;
     bool m_use_fused    = true;  // HIPBackend::plan lowers the canonical graph to the fused launches; false: op-by-op (A/B, tests)
 
     Model(const std::string &model_dir, const std::shared_ptr<ModelConfig> &config, const std::shared_ptr<Platform> &platform, int device,

@@ -10,6 +10,7 @@
 // the single-token step is captured once into a hipGraph and replayed (all position-dependent values are
 // read from a device-resident ps_step_state).
 #include "ps_internal.h"
+#include <algorithm>
 #include "ps_ops.h"
 
 #include <cstdio>
@@ -203,6 +204,8 @@ static int ensure_perf16(ps_hip_model *m) {
     const ps_llm_config &f = m->cfg;
     const int64_t dim = f.dim, hid = f.hidden_dim;
     if (dim % 4 || hid % 4) PS_FAIL(c, "fp16 perf mode: dim and hidden_dim must be multiples of 4");
+    // the mode's own GEMM (csrc/perf16.hip) takes row lengths and row counts that are multiples of 64: refused HERE, before +2 bytes per weight are allocated
+    if (dim % 64 || hid % 64 || f.kv_dim % 64) PS_FAIL(c, "fp16 perf mode: dim, hidden_dim and kv_dim must be multiples of 64 (csrc/perf16.hip's GEMM tiles)");
     psf16 *pf = nullptr;
     if (int rc = psf16_create(c, &pf)) return rc;
     const int64_t kmax = dim > hid ? dim : hid;
@@ -215,8 +218,20 @@ static int ensure_perf16(ps_hip_model *m) {
         dst.push_back(h);
         return psf16_dequantize(c, w, m->logits, m->tokens_dev, cap, h);
     };
-    // (a failed attempt leaves no half-filled lists behind: the next one starts from empty vectors; the device memory stays with the model)
-    auto fail = [&]() { for (auto *v : {&m->hq, &m->hk, &m->hv, &m->ho, &m->hg, &m->hu, &m->hd}) v->clear(); psf16_destroy(pf); return 2; };
+    // a failed attempt leaves nothing behind: the fp16 copies made so far are freed (and taken off the model's list of owned allocations), so a retry does
+    // not allocate them a second time
+    auto fail = [&]() {
+        for (auto *v : {&m->hq, &m->hk, &m->hv, &m->ho, &m->hg, &m->hu, &m->hd}) {
+            for (_Float16 *h : *v) {
+                auto it = std::find(m->owned.begin(), m->owned.end(), (void *)h);
+                if (it != m->owned.end()) m->owned.erase(it);
+                (void)hipFree(h);
+            }
+            v->clear();
+        }
+        psf16_destroy(pf);
+        return 2;
+    };
     for (auto *v : {&m->hq, &m->hk, &m->hv, &m->ho, &m->hg, &m->hu, &m->hd}) v->clear();
     for (uint32_t L = 0; L < f.n_layers; L++)
         if (copy(m->wq[L], m->hq) || copy(m->wk[L], m->hk) || copy(m->wv[L], m->hv) || copy(m->wo[L], m->ho) || copy(m->wg[L], m->hg) ||

@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(HERE, "lib", "libps_host.so")
 EXPORTS = ["psh_last_error", "psh_model_load", "psh_model_free", "psh_model_set_fused", "psh_model_plan_stats", "psh_model_kv_position", "psh_model_reset",
            "psh_model_vocab", "psh_model_forward", "psh_model_generate", "psh_spec_generate", "psh_spec_generate_sampled", "psh_draft_sample", "psh_sampler_create", "psh_sampler_free", "psh_sampler_sample",
            "psh_model_generate_sampled", "psh_token_tree_run", "psh_gguf_summary", "psh_config_summary",
-           "psh_model_decode", "psh_model_prefill", "psh_graph_softmax", "psh_backend_get_n_tasks", "psh_backend_add_cache", "psh_model_kv_read", "psh_kv_op"]
+           "psh_model_decode", "psh_model_prefill", "psh_model_plan_cache_hits", "psh_model_set_plan_cache", "psh_graph_softmax", "psh_backend_get_n_tasks", "psh_backend_add_cache", "psh_model_kv_read", "psh_kv_op"]
 _LIB = None
 
 
@@ -45,6 +45,8 @@ def lib() -> C.CDLL:
         L.psh_sampler_sample.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.psh_model_generate_sampled.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.psh_token_tree_run.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int] + [C.c_void_p] * 5
+        L.psh_model_plan_cache_hits.argtypes = [C.c_void_p]
+        L.psh_model_set_plan_cache.argtypes = [C.c_void_p, C.c_int]
         L.psh_model_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.psh_model_prefill.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         L.psh_graph_softmax.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
@@ -100,6 +102,13 @@ class HostModel:
         a, b = C.c_int(), C.c_int()
         self.L.psh_model_plan_stats(self.h, C.byref(a), C.byref(b))
         return a.value, b.value
+
+    def plan_cache_hits(self) -> int:
+        """forwards that ran a lowered launch sequence without building a second graph (the plan cache keyed on (batch size, lm_head))"""
+        return self.L.psh_model_plan_cache_hits(self.h)
+
+    def set_plan_cache(self, on: bool):
+        self.L.psh_model_set_plan_cache(self.h, int(on))
 
     def set_fused(self, fused: bool):
         """True: fused kernels + hipGraph (default).  False: op-by-op Graph/Executor path."""

@@ -56,6 +56,59 @@ def test_graph_path_equals_fused_equals_oracle(oracle, tmp_path, preset, wt):
     hm.close(); om.close()
 
 
+@pytest.mark.parametrize("preset,wt", [("tiny-llama", 12), ("tiny-qwen2", 8)])
+def test_decode_hands_back_the_device_argmax_and_the_prefill_loop_is_lowered(oracle, tmp_path, preset, wt):
+    """Model::decode (greedy) over the op API: a lowered graph returns the ids of the device arg-max kernel (4 bytes per token, the logits stay on the
+    GPU -- SURVEY a21, src/model/model.hpp:170-183), an op-by-op graph arg-maxes the copied logits on the host like the reference: the same ids, the
+    oracle's.  Model::prefill (ModelTokenIterator's loop) plans its first chunk's graph and, lowered, hands the whole loop to ps_hip_model_prefill:
+    the cache rows are the chunk-by-chunk ones."""
+    from oracle import binding as B
+    from powerserve_amd import host, synth
+    d = str(tmp_path / "m")
+    mj = synth.write_model_dir(d, preset, wt, n_ctx=96, seed=6)
+    cfg = B.make_config(mj["llm_config"])
+    om = oracle.model(cfg, mj["model_arch"], load_tensors(os.path.join(d, "ggml/weights.gguf")), n_threads=4)
+    prompt = np.random.default_rng(2).integers(0, cfg.vocab_size, 30)
+    want_ids, *_ = om.generate(prompt, 8, 12)
+    hm = host.HostModel(d, 0, max_batch=16)
+    for fused in (True, False):
+        hm.set_fused(fused)
+        hm.reset()
+        p0 = hm.plan_stats()
+        hm.prefill(prompt[:-1], 8)  # 29 tokens: 8 + 8 + 8 + 5
+        assert hm.position == 29
+        if fused:
+            assert hm.plan_stats()[1] == p0[1] + 1  # ONE graph planned and lowered for the whole loop
+        cur, got = int(prompt[-1]), []
+        for s in range(12):
+            cur = int(hm.decode([cur], [29 + s])[0])
+            got.append(cur)
+        assert np.array_equal(got, want_ids), fused
+        if fused:  # eleven of the twelve single-token graphs were never built: the (1, lm_head) shape had been lowered once (the plan cache)
+            assert hm.plan_cache_hits() == 11, hm.plan_cache_hits()
+            hm.set_plan_cache(False)  # ... and without the cache every step builds and plans its graph: the same ids
+            hm.kv("rollback_tokens", 12)
+            p1 = hm.plan_stats()
+            cur, again = int(prompt[-1]), []
+            for s in range(12):
+                cur = int(hm.decode([cur], [29 + s])[0])
+                again.append(cur)
+            assert np.array_equal(again, want_ids) and hm.plan_stats()[0] == p1[0] + 12 and hm.plan_cache_hits() == 11
+            hm.set_plan_cache(True)
+        for L in range(2):
+            om_k, om_v = om.k_cache(L)[:29], om.v_cache(L)[:, :29]
+            for slot in (0, 7, 8, 28):
+                k, v = hm.kv_read(L, slot, cfg.kv_dim)
+                assert np.array_equal(k.view(np.uint32), om_k[slot].view(np.uint32)) and np.array_equal(v.view(np.uint32), om_v[:, slot].view(np.uint32)), (fused, L, slot)
+    # a batch through decode(): one id per column
+    hm.set_fused(True)
+    hm.reset(); om.reset()
+    ids = hm.decode(prompt[:9], np.arange(9))
+    lg = om.forward(prompt[:9], np.arange(9), True)
+    assert np.array_equal(ids, np.argmax(lg, axis=1))
+    hm.close(); om.close()
+
+
 def test_plan_does_not_lower_what_the_fused_forward_cannot_do(oracle, tmp_path):
     """HIPBackend::plan lowers a graph only when the fused forward does exactly what the graph says (advisor, round 2): a
     forward whose first position is NOT the cache position (an earlier position run again) keeps the canonical op order

@@ -20,5 +20,9 @@ for k, v in sorted(rows.items(), key=lambda kv: -sum(kv[1])):
     out[name] = {"launches": len(v), "fetch_size_kb_mean": m, "hbm_bytes_per_launch": 2 * m * 1024}
 if "--json" in sys.argv:
     keyed = dict(out)  # keyed by kernel name: bench.py looks up the template instance its roofline replay ran
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    keyed["_kernel_sources_sha16"] = bench.kernel_sources_sha16()  # bench.py refuses the record once the kernel sources differ
     with open(sys.argv[sys.argv.index("--json") + 1], "w") as f:
         json.dump(keyed, f, indent=1)
