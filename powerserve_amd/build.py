@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(HERE, "build")
-SOURCES = ["api.hip", "model.hip", "k_quant.hip", "k_gemv.hip", "k_gemv4.hip", "k_gemv7.hip", "k_gemvb.hip", "k_gemvk.hip", "k_gemm4k.hip", "k_gemv6.hip", "k_ops.hip", "k_attn.hip", "perf16.hip"]
+SOURCES = ["api.hip", "model.hip", "k_quant.hip", "k_gemv.hip", "k_gemv4.hip", "k_gemvb.hip", "k_gemvk.hip", "k_gemm4k.hip", "k_gemv6.hip", "k_ops.hip", "k_attn.hip", "perf16.hip"]
 # -ffp-contract=off: the parity contract needs every fp32 op to round where the reference's C source rounds;
 # fused multiply-adds are written explicitly (__fmaf_rn) where the reference uses FMA intrinsics.
 # -fno-slp-vectorize (NOSLP files only): hipcc's SLP vectoriser packs adjacent scalar fp32 operations into v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32.  On

@@ -505,7 +505,7 @@ int launch_g4_kc(hipStream_t st, int grid, const G4Params &p, int epi, int pro) 
 
 } // namespace
 
-int g_g4_cfg = getenv("PS_G4_CFG") ? atoi(getenv("PS_G4_CFG")) : 0; // ps_hip_debug_set(1, cfg); cfg >= 20: the LDS-DMA kernel (k_gemv7.hip), variant cfg - 20
+int g_g4_cfg = getenv("PS_G4_CFG") ? atoi(getenv("PS_G4_CFG")) : 0; // ps_hip_debug_set(1, cfg)  (cfg 20..23 were round 4's LDS-DMA kernel: tools/experiments/r04_k_gemv7.hip)
 int g_g4_flags = 0; // ps_hip_debug_set(2, flags): reserved for what-if switches
 
 bool psk_gemv4_covers(int64_t K) { // rows end on multiples of four units
@@ -514,13 +514,8 @@ bool psk_gemv4_covers(int64_t K) { // rows end on multiples of four units
 }
 
 // Single-column Q4_K mat-vec.  Returns -1 when the launch is not covered (the caller falls back to gemv1 / gemv_kernel).
-int psk_gemv7(hipStream_t st, int n_cu, const psk_gemv_args &a, ps_act act, int64_t K, int cfg); // k_gemv7.hip
 int psk_gemv4(hipStream_t st, int n_cu, const psk_gemv_args &a, ps_act act, int64_t K) {
     if (a.n_w < 1 || a.n_w > 3 || !psk_gemv4_covers(K)) return -1;
-    if (g_g4_cfg >= 20 && g_g4_cfg < 40) {
-        const int rc = psk_gemv7(st, n_cu, a, act, K, g_g4_cfg - 20);
-        if (rc != -1) return rc;
-    }
     G4Params p{};
     int groups_total = 0;
     for (int i = 0; i < a.n_w; i++) {
