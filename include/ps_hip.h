@@ -255,11 +255,12 @@ int ps_hip_model_bench_matmul(ps_hip_model *m, int reps, int which, int bs, doub
 const char *ps_hip_last_matmul_kernel(void);
 int ps_hip_debug_timeline(ps_hip_ctx *ctx, int key, uint64_t *host_out, int n_words);
 /* Diagnostic: tunables of the library (process-wide).  key 1: wave configuration of the decode mat-vec (k_gemv4.hip,
- * tools/g4_variants.py); key 3: the narrow-batch Q4_K mat-mul for few row tiles (k_gemm4k.hip: 0 = round 3's four waves walking K
- * together, 4 / 8 = gemm4k_par_kernel with that many waves per tile, 1 = by tile count, the default); key 4: the fp16 perf mode's GEMM (perf16.hip:
+ * tools/g4_variants.py); key 3: the narrow-batch Q4_K mat-mul for few row tiles (k_gemm4k.hip: 0 = gemm4k_par_kernel off (the wave-per-tile / staged forms take the launch: A/B only),
+ * 4 / 8 = gemm4k_par_kernel with that many waves per tile, 1 = by tile count, the default); key 4: the fp16 perf mode's GEMM (perf16.hip:
  * 0 = by shape, 1 = 128-token tiles, 2 = 256 x 256 tiles); key 5: the next `value` single-token forwards on the one-launch attention
  * report a time-out of its score exchange (tests of the retry paths: forward, forward_tree, prefill tail, decode_greedy, lowered forward +
- * kv_advance).  Returns non-zero for an unknown key. */
+ * kv_advance); key 6: column blocks per XCD of the wide Q4_K / Q5_K mat-mul's item order (k_gemm4k.hip g4k_item: 0 = round 2's order, default 4;
+ * PS_G4K_CBX).  Returns non-zero for an unknown key. */
 int ps_hip_debug_set(int key, int value);
 /* Diagnostic: one GEMM shape of the fp16 perf mode on synthetic operands (tools/f16_gemm_bench.py): out[M][N] = x[M][K] . W[N][K]^T, timed over
  * `reps` launches (with beta: out = beta out + ...), max |difference| to a k-ordered fp32 reference (beta != 0: of a second launch on top of

@@ -1148,180 +1148,6 @@ __global__ __launch_bounds__(EPI == 1 ? 128 : 64, MB) void gemm4k_wav_kernel(con
     }
 }
 
-// The same for launches with few row tiles (N = 4096: 256 tiles; Q / K / V: 384): one wave per tile would leave three SIMDs in
-// four idle and walk K at one wave's pace (24.9 us per launch against 19 for the staged kernel).  FOUR waves share a tile: wave q
-// owns the accumulator lanes 2q, 2q + 1 and the mins lane q.  The weights still arrive once: wave q fetches the whole tile
-// (2 KiB + 16 headers) of the super-blocks sb = q (mod 4), RA of its own steps ahead, and parks them in LDS stage sb % 4 two steps
-// before they are consumed; one workgroup barrier (four waves) per super-block.
-template <int RA> // RA of a wave's own super-blocks in flight
-__global__ __launch_bounds__(256) void gemm4k_wav4_kernel(const G4KParams p) {
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
-    const int m = lane & 15, kb = lane >> 4;
-    constexpr int STG = 16 * 36 + 16 * 4; // dwords of a stage: the transposition rows, then the 16 row headers
-    __shared__ __attribute__((aligned(16))) uint32_t stg[4][STG];
-    __shared__ float xall[4][64][16]; // [wave][lane][4 rows][2 accumulator chains, the mins chain, -]
-    const int nsb = p.nsb;
-    int wi, pair;
-    const G4KRows R = g4k_rows<0>(p, (int)(blockIdx.x >> 1), wi, pair);
-    const G4KMat &W = wi == 0 ? p.w[0] : (wi == 1 ? p.w[1] : p.w[2]);
-    const int tt = (int)(blockIdx.x & 1), tile = tt ? R.tile[1] : R.tile[0];
-    const uint8_t *qb = R.qs[0] + ((size_t)2 * tile * nsb << 10) + (size_t)lane * 16;
-    const uint8_t *hb = R.aux[0] + ((size_t)2 * tile + (m >> 3)) * nsb * 128 + (size_t)(m & 7) * 16; // row m's header (the four kb lanes of a row ask for the same 16 bytes)
-    const int col = m, colc = col < p.bs ? col : p.bs - 1;
-    const char *qfp = (const char *)p.qf + (size_t)(2 * wave) * 1024 + lane * 16;
-    const uint8_t *ydp = p.mf + colc * 4, *b16p = p.mf + 64 + colc * 32 + wave * 8;
-
-    ps_u32x4 rq[RA][2], rh[RA]; // this wave's own super-blocks wave, wave + 4, ...: RA of them in flight
-    auto load_a = [&](const int s, const int sbx) {
-        const int sb = sbx < nsb ? sbx : nsb - 1;
-        rq[s][0] = __builtin_nontemporal_load((const ps_u32x4 *)(qb + ((size_t)sb << 10)));
-        rq[s][1] = __builtin_nontemporal_load((const ps_u32x4 *)(qb + ((size_t)(nsb + sb) << 10)));
-        rh[s] = *(const ps_u32x4 *)(hb + (size_t)sb * 128);
-    };
-    auto park = [&](const int s, const int stage) {
-        uint32_t *st = stg[stage];
-        *(ps_u32x4 *)(st + (lane >> 3) * 36 + (lane & 7) * 4) = rq[s][0];
-        *(ps_u32x4 *)(st + (8 + (lane >> 3)) * 36 + (lane & 7) * 4) = rq[s][1];
-        if (kb == 0) *(ps_u32x4 *)(st + 16 * 36 + m * 4) = rh[s];
-    };
-#pragma unroll
-    for (int s = 0; s < RA; s++) load_a(s, wave + 4 * s);
-    ps_u32x4 rb[2][2]; // fragments, 16-sums and column scale two steps ahead
-    float ryd[2];
-    ps_u32x2 rs[2];
-    auto load_b = [&](const int s, const int sb) {
-        rb[s][0] = *(const ps_u32x4 *)(qfp + ((size_t)sb << 13));
-        rb[s][1] = *(const ps_u32x4 *)(qfp + ((size_t)sb << 13) + 1024);
-        ryd[s] = *(const float *)(ydp + (size_t)sb * 576);
-        rs[s]  = *(const ps_u32x2 *)(b16p + (size_t)sb * 576);
-    };
-    load_b(0, 0); load_b(1, 1 < nsb ? 1 : 0);
-    float acc[4][2], accm[4];
-#pragma unroll
-    for (int r = 0; r < 4; r++) { acc[r][0] = acc[r][1] = 0.f; accm[r] = 0.f; }
-    const g4k_f4 zf = {0.f, 0.f, 0.f, 0.f};
-    const g4k_h2 k1024 = {(_Float16)1024.f, (_Float16)1024.f}, km1024 = {(_Float16)-1024.f, (_Float16)-1024.f};
-    const uint32_t sel0 = 0x04000400u | ((uint32_t)(2 * (kb & 1)) * 0x00010001u), sel1 = sel0 + 0x00010001u;
-    const uint32_t msel0 = 0x04000400u | ((uint32_t)((2 * wave) & 3) * 0x00010001u), msel1 = msel0 + 0x00010001u;
-    // what a step reads from its stage: the row header, d | dmin of the four result rows, the two weight dwords.  Fetched one
-    // step AHEAD (the stage of step sb + 1 has been complete since the barrier of step sb - 1): at one wave per SIMD an LDS round
-    // trip in front of every dependent instruction chain is what a step costs
-    struct Ops { ps_u32x4 h; uint32_t hx[4], w[2]; };
-    auto fetch = [&](const int stage) {
-        const uint32_t *st = stg[stage];
-        Ops o;
-        o.h = *(const ps_u32x4 *)(st + 16 * 36 + m * 4);
-#pragma unroll
-        for (int r = 0; r < 4; r++) o.hx[r] = st[16 * 36 + (4 * kb + r) * 4];
-#pragma unroll
-        for (int j = 0; j < 2; j++) o.w[j] = st[m * 36 + (2 * wave + j) * 4 + kb];
-        return o;
-    };
-    // super-blocks 0 and 1 before the loop (waves 0 and 1 own them), then every step parks the one two ahead
-    if (wave < 2) park(0, wave);
-    int own = wave < 2 ? 1 % RA : 0; // ring slot of this wave's next super-block to park
-    if (wave < 2) load_a(0, wave + 4 * RA);
-    __syncthreads();
-    Ops cur = fetch(0);
-#pragma clang loop unroll(disable)
-    for (int sb0 = 0; sb0 < nsb; sb0 += 4) { // (nsb % 4 == 0)
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int sb = sb0 + k;
-            if (wave == ((k + 2) & 3) && sb + 2 < nsb) { // this wave's super-block sb + 2 goes to its stage; the slot takes the one RA rounds later
-#pragma unroll
-                for (int s = 0; s < RA; s++)
-                    if (s == own) {
-                        park(s, (k + 2) & 3);
-                        load_a(s, sb + 2 + 4 * RA);
-                    }
-                own = own + 1 == RA ? 0 : own + 1;
-            }
-            __syncthreads();
-            const Ops nxt = fetch((k + 1) & 3);
-            const float yd = ryd[k & 1];
-            const ps_u32x4 h = cur.h;
-            const uint32_t scb = (kb & 2) ? ((h.w & 0x0f0f0f0fu) | (((h.y >> 6) & 0x03030303u) << 4)) : (h.y & 0x3f3f3f3fu);
-            const uint32_t t0 = __builtin_amdgcn_perm(0x64646464u, scb, sel0), t1 = __builtin_amdgcn_perm(0x64646464u, scb, sel1);
-            g4k_h2 s0, s1;
-            __builtin_memcpy(&s0, &t0, 4); __builtin_memcpy(&s1, &t1, 4);
-            s0 = s0 - k1024; s1 = s1 - k1024;
-            const g4k_h2 n0 = s0 * km1024, n1 = s1 * km1024;
-            float dr[4], dmn[4];
-#pragma unroll
-            for (int r = 0; r < 4; r++) { // d | dmin of rows 4 kb + r
-                const uint32_t hx = cur.hx[r];
-                dr[r]  = __fmul_rn(yd, ps_h2f((uint16_t)(hx & 0xffff)));
-                dmn[r] = __fmul_rn(-yd, ps_h2f((uint16_t)(hx >> 16)));
-            }
-#pragma unroll
-            for (int j = 0; j < 2; j++) {
-                const uint32_t w = cur.w[j];
-                const uint32_t tq[4] = {(w & 0x000F000Fu) | 0x64006400u, ((w >> 8) & 0x000F000Fu) | 0x64006400u,
-                                        ((w >> 4) & 0x000F000Fu) | 0x64006400u, ((w >> 12) & 0x000F000Fu) | 0x64006400u};
-                uint32_t o[4];
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    g4k_h2 v;
-                    __builtin_memcpy(&v, &tq[q], 4);
-                    v = __builtin_elementwise_fma(v, q < 2 ? s0 : s1, q < 2 ? n0 : n1);
-                    __builtin_memcpy(&o[q], &v, 4);
-                }
-                const ps_u32x4 ao = {o[0], o[1], o[2], o[3]};
-                g4k_h8 av, bv;
-                __builtin_memcpy(&av, &ao, 16); __builtin_memcpy(&bv, &rb[k & 1][j], 16);
-                const g4k_f4 si = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bv, zf, 0, 0, 0);
-#pragma unroll
-                for (int r = 0; r < 4; r++) acc[r][j] = __fmaf_rn(dr[r], si[r], acc[r][j]);
-            }
-            {
-                const uint32_t mp = wave < 2 ? (h.z & 0x3f3f3f3fu) : (((h.w >> 4) & 0x0f0f0f0fu) | (((h.z >> 6) & 0x03030303u) << 4));
-                const uint32_t p0 = __builtin_amdgcn_perm(0x64646464u, mp, msel0), p1 = __builtin_amdgcn_perm(0x64646464u, mp, msel1);
-                g4k_h2 h0, h1;
-                __builtin_memcpy(&h0, &p0, 4); __builtin_memcpy(&h1, &p1, 4);
-                h0 = h0 - k1024; h1 = h1 - k1024;
-                const g4k_h2 z2 = {(_Float16)0.f, (_Float16)0.f};
-                if (kb != 0) { h0 = z2; h1 = z2; }
-                const g4k_h4 am = {h0[0], h0[1], h1[0], h1[1]};
-                g4k_h4 bm;
-                { const ps_u32x2 b2 = rs[k & 1]; __builtin_memcpy(&bm, &b2, 8); }
-                const g4k_f4 pr = __builtin_amdgcn_mfma_f32_16x16x16f16(am, bm, zf, 0, 0, 0);
-#pragma unroll
-                for (int r = 0; r < 4; r++) accm[r] = __fmaf_rn(dmn[r], pr[r], accm[r]);
-            }
-            load_b(k & 1, sb + 2 < nsb ? sb + 2 : nsb - 1);
-            cur = nxt;
-        }
-    }
-    // ---- the four waves meet: waves 0 and 1 finish rows 4 kb + 2 wave, + 1 (hsum_float_8's order)
-#pragma unroll
-    for (int r = 0; r < 4; r++) *(float4 *)(&xall[wave][lane][r * 4]) = make_float4(acc[r][0], acc[r][1], accm[r], 0.f);
-    __syncthreads();
-    if (wave < 2 && col < p.bs) {
-        float v[2];
-#pragma unroll
-        for (int rr = 0; rr < 2; rr++) {
-            const int r = 2 * wave + rr;
-            float au[8], mv[4];
-#pragma unroll
-            for (int u = 0; u < 8; u++) au[u] = xall[u >> 1][lane][r * 4 + (u & 1)];
-#pragma unroll
-            for (int q = 0; q < 4; q++) mv[q] = xall[q][lane][r * 4 + 2];
-            const float s0 = __fadd_rn(au[0], au[4]), s1 = __fadd_rn(au[1], au[5]), s2 = __fadd_rn(au[2], au[6]), s3 = __fadd_rn(au[3], au[7]);
-            const float res = __fadd_rn(__fadd_rn(s0, s2), __fadd_rn(s1, s3));
-            const float mm = __fadd_rn(__fadd_rn(mv[0], mv[2]), __fadd_rn(mv[1], mv[3]));
-            v[rr] = __fadd_rn(res, mm);
-        }
-        const int64_t row0 = (int64_t)tile * 16 + kb * 4 + 2 * wave;
-#pragma unroll
-        for (int rr = 0; rr < 2; rr++) {
-            if (W.bias) v[rr] = __fadd_rn(v[rr], W.bias[row0 + rr]);
-            if (p.residual && wi == 0) v[rr] = __fadd_rn(p.residual[(int64_t)col * W.ldo + row0 + rr], v[rr]);
-        }
-        g4k_store_pair<2>(p, wi, W, col, row0, v[0], v[1]);
-    }
-}
-
 // (a & mask) | magic as ONE instruction: two constants are two scalar operands, which a VOP3 instruction cannot read, so hipcc emits v_and + v_or;
 // with the magic in a vector register it is v_and_or_b32
 __device__ __forceinline__ uint32_t g4k_and_or(const uint32_t a, const uint32_t mask, const uint32_t magic_v) {
@@ -1335,7 +1161,7 @@ __device__ __forceinline__ uint32_t g4k_and_or(const uint32_t a, const uint32_t 
 // order.  So the NWV waves of a workgroup take the super-blocks of a ROUND (sb = round * NWV + wave) side by side -- each one wave's
 // work of gemm4k_wav_kernel for its super-block: all eight accumulator lanes and the four mins lanes through the matrix cores -- and
 // park the sums with d * yd, -dmin * yd in LDS; after one barrier every wave runs the chains IT owns over the round's super-blocks
-// in order (NWV = 8: accumulator lane u = wave and half a mins lane; NWV = 4: two lanes and a mins lane, gemm4k_wav4_kernel's split).
+// in order (NWV = 8: accumulator lane u = wave and half a mins lane; NWV = 4: two lanes and a mins lane).
 // 6 / 12 chains x NWV fmas per wave and round against ~250 instructions of operand building: the walk is now parallel over waves.
 template <int NWV>
 __global__ __launch_bounds__(NWV * 64) void gemm4k_par_kernel(const G4KParams p) {
@@ -1623,10 +1449,7 @@ static int g4k_launch(hipStream_t st, int n_cu, G4KParams &p, const int epi, con
         // wave that owns the HBM stream with an eight-deep fragment ring in the others (22.9 us).
         if (epi == 1) g4k_launch_wav<1, 2, 2>(st, p);
         else if (2 * p.n_tasks >= 4 * n_cu || wav_cfg == 1) g4k_launch_wav<0, 2, 2>(st, p); // many tiles (lm_head): a wave per tile, occupancy hides the latency
-        else { // few tiles, PS_GEMM4K_PAR=0: round 3's four waves per tile walking K together
-            psk_note_kernel("gemm4k_wav4_kernel<2>");
-            hipLaunchKernelGGL((gemm4k_wav4_kernel<2>), dim3((unsigned)(2 * p.n_tasks)), dim3(256), 0, st, p);
-        }
+        else g4k_launch_wav<0, 2, 2>(st, p); // few tiles with PS_GEMM4K_PAR=0 (A/B only; round 3's four-waves-per-tile kernel for this case was removed in round 5: gemm4k_par_kernel covers it)
     } else if (ctw == 1) {
         if (epi == 1) { psk_note_kernel("gemm4k_narrow_kernel<1, 1, 12>"); hipLaunchKernelGGL((gemm4k_narrow_kernel<1, 1, PS_Q4_K>), grid, blkn, LDS1, st, p); }
         else { psk_note_kernel("gemm4k_narrow_kernel<0, 1, 12>"); hipLaunchKernelGGL((gemm4k_narrow_kernel<0, 1, PS_Q4_K>), grid, blkn, LDS1, st, p); }
