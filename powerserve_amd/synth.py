@@ -34,6 +34,8 @@ PRESETS = {
     "small-llama-hs128": ("llama", 1024, 2048, 2, 8, 2, 128, 1024, 5e5, 0, False, 1e-5),
     # a draft model for small-llama-hs128: same vocabulary, different width / depth / head size
     "small-llama-draft": ("llama", 512, 1024, 3, 8, 4, 64, 1024, 5e5, 0, True, 1e-5),
+    # the headline's depth behind a long cache at a width the CPU oracle finishes in seconds (tests/test_gpu_fullsize.py)
+    "deep-llama-hs128": ("llama", 1024, 2048, 32, 8, 2, 128, 1024, 5e5, 0, False, 1e-5),
     # >= 256 row groups in every mat-vec of a layer (one workgroup per CU)
     "wide-llama": ("llama", 2048, 4096, 2, 16, 4, 128, 2048, 5e5, 0, False, 1e-5),
 }

@@ -186,3 +186,37 @@ def test_speculative_loop_at_real_dimensions_equals_the_oracles(ctx, oracle, tmp
         m.close()
     for m in (ot, od):
         m.close()
+
+
+def test_thirty_two_layers_behind_a_long_cache(ctx, oracle, tmp_path):
+    """The headline's DEPTH times a long cache (round-4 review, weak 3: the full-size tests above use 4- and 2-layer models, the bench's own parity object a
+    4-token prompt): 32 layers of Q4_K at a width the CPU oracle finishes in seconds (dim 1024 / hidden 2048: the mat-vec and chunk mat-mul kernels of the 8B
+    path, head size 128, 4 heads per kv head), a 700-token prompt prefilled in super-chunks of four 128-token reference chunks, then single-token steps
+    behind 700 cached positions (n_kv % 32 and % 8 leftovers), eager and through the captured greedy loop -- every logit of every step and the last layer's cache rows, bit for bit."""
+    from oracle import binding as B
+    from powerserve_amd import hip, synth
+    d = str(tmp_path / "m")
+    mj = synth.write_model_dir(d, "deep-llama-hs128", 12, n_ctx=768, seed=3)
+    cfg = B.make_config(mj["llm_config"])
+    assert cfg.n_layers == 32
+    om = oracle.model(cfg, mj["model_arch"], load_tensors(os.path.join(d, "ggml/weights.gguf")), n_threads=min(48, os.cpu_count() or 8))
+    prompt = np.random.default_rng(1).integers(0, cfg.vocab_size, 700)
+    steps = 6
+    want_ids, want_logits, *_ = om.generate(prompt, 128, steps, want_logits=True)
+    gm = hip.Model(ctx, d, max_batch=512, n_ctx=768)
+    gm.prefill(prompt[:-1], 128)
+    assert gm.position == 699
+    n = 699
+    assert np.array_equal(gm.k_cache(31)[:n].view(np.uint32), om.k_cache(31)[:n].view(np.uint32))
+    assert np.array_equal(gm.v_cache(31)[:, :n].view(np.uint32), om.v_cache(31)[:, :n].view(np.uint32))
+    cur = int(prompt[-1])
+    for s in range(steps):
+        lg, am = gm.forward([cur], [gm.position], lm_head=True)
+        assert np.array_equal(lg[0].view(np.uint32), np.asarray(want_logits[s], dtype=np.float32).view(np.uint32)), s
+        assert int(am[0]) == int(want_ids[s])
+        cur = int(want_ids[s])
+    # and the captured greedy loop from the same state
+    gm.kv_rollback(steps)
+    assert np.array_equal(gm.decode_greedy(int(prompt[-1]), steps), want_ids)
+    gm.close()
+    om.close()
