@@ -48,11 +48,15 @@ def _newer(src: str, obj: str) -> bool:
 CONTRACT_SOURCES = {"api.hip", "k_ops.hip", "k_attn.hip", "k_gemm4k.hip", "k_gemv4.hip", "k_gemvb.hip", "k_gemvk.hip"}
 
 
-def build(force: bool = False, verbose: bool = True, contract: bool = True) -> str:
+# Files with in-kernel timeline marks (ps_dev.h PS_TIMELINE): compiled a third time, on demand, for lib/libps_hip_timeline.so -- the library the timeline tools load.
+TIMELINE_SOURCES = {"api.hip", "k_gemv4.hip", "k_attn.hip", "k_gemm4k.hip"}
+
+
+def build(force: bool = False, verbose: bool = True, contract: bool = True, timeline: bool = False) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
     os.makedirs(OBJDIR, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    objs, cobjs, jobs = [], [], []
+    objs, cobjs, tobjs, jobs = [], [], [], []
     for s in SOURCES:
         src, obj = os.path.join(CSRC, s), os.path.join(OBJDIR, s.replace(".hip", ".o"))
         objs.append(obj)
@@ -67,6 +71,14 @@ def build(force: bool = False, verbose: bool = True, contract: bool = True) -> s
             cobjs.append(cobj)
         else:
             cobjs.append(obj)
+        if timeline and s in TIMELINE_SOURCES:
+            tobj = os.path.join(OBJDIR, s.replace(".hip", ".timeline.o"))
+            tcmd = [hipcc, *FLAGS, *(["-fno-slp-vectorize"] if s in NOSLP else []), "-DPS_TIMELINE=1", "-c", src, "-o", tobj]
+            if force or _newer(src, tobj) or _cmd_changed(tobj, tcmd):
+                jobs.append(tcmd)
+            tobjs.append(tobj)
+        else:
+            tobjs.append(obj)
 
     def run(cmd):
         if verbose:
@@ -82,6 +94,9 @@ def build(force: bool = False, verbose: bool = True, contract: bool = True) -> s
     cso = os.path.join(LIBDIR, "libps_hip_contract.so")
     if contract and (jobs or not os.path.exists(cso)):
         subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", cso, *cobjs], check=True)
+    tso = os.path.join(LIBDIR, "libps_hip_timeline.so")
+    if timeline and (jobs or not os.path.exists(tso)):
+        subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tso, *tobjs], check=True)
     build_host(force or bool(jobs), verbose)
     return so
 
@@ -107,4 +122,4 @@ def build_host(force: bool = False, verbose: bool = True) -> str:
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    print(build(force="--force" in sys.argv, timeline="--timeline" in sys.argv))

@@ -413,6 +413,8 @@ extern "C" {
 const char *ps_hip_last_matmul_kernel(void) { return psk_last_kernel(); }
 int ps_hip_debug_timeline(ps_hip_ctx *ctx, int key, uint64_t *host_out, int n_words) {
     if (!ctx) return 1;
+    if (!PS_TIMELINE && key >= 0) PS_FAIL(ctx, "debug_timeline: this library is built without the in-kernel timeline marks (they cost the decode path 3 %); "
+                                               "use lib/libps_hip_timeline.so (python -m powerserve_amd.build --timeline; PS_HIP_LIB)");
     if (host_out) PS_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     return psk_gemv_debug(key, host_out, n_words);
 }

@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void attn_scores_kernel(psl_attn_args a) {
     const int j0 = blockIdx.x * 32;
     if (j0 >= n_kv) return;
     const int wg = blockIdx.y * gridDim.x + blockIdx.x; // timeline (tools/gpu_attn_timeline.py, key 40)
-    unsigned long long *const dbg = (a.dbg && wg < 1024 && threadIdx.x == 0 && blockIdx.z == 0) ? a.dbg + (size_t)wg * 64 : nullptr;
+    unsigned long long *const dbg = (PS_TL(a.dbg) && wg < 1024 && threadIdx.x == 0 && blockIdx.z == 0) ? a.dbg + (size_t)wg * 64 : nullptr;
     if (dbg) { dbg[0] = __builtin_amdgcn_s_memtime(); dbg[29] = __builtin_amdgcn_s_memrealtime(); }
     const float *qb = a.q + (int64_t)i * dim + (int64_t)kvh * r2 * hs;
     float *sb       = a.scores + ((int64_t)i * a.n_heads + (int64_t)kvh * r2) * a.n_ctx;
@@ -363,7 +363,7 @@ __global__ __launch_bounds__(PV_NT) void attn_softmax_pv_kernel(psl_attn_args a)
     __shared__ double redd[R2MAX][PV_NW];
     __shared__ float invs[R2MAX];
     const int wg = blockIdx.y * gridDim.x + blockIdx.x; // timeline (tools/gpu_attn_timeline.py, key 41)
-    unsigned long long *const dbg = (a.dbg && wg < 1024 && threadIdx.x == 0 && blockIdx.z == 0) ? a.dbg + (size_t)wg * 64 : nullptr;
+    unsigned long long *const dbg = (PS_TL(a.dbg) && wg < 1024 && threadIdx.x == 0 && blockIdx.z == 0) ? a.dbg + (size_t)wg * 64 : nullptr;
     auto mark = [&](int k) { if (dbg) dbg[k] = __builtin_amdgcn_s_memtime(); };
     if (dbg) { dbg[0] = __builtin_amdgcn_s_memtime(); dbg[29] = __builtin_amdgcn_s_memrealtime(); }
 
@@ -480,7 +480,7 @@ __global__ __launch_bounds__(NT) void attn_decode2_kernel(psl_attn_args a) {
     float *const tails = redf + 16, *const qs = tails + 32, *const sst = qs + 4 * hs; // sst [RMAX][4][32]: scores staged for whole-row stores
     double *const redd = (double *)(sst + RMAX * 128);
     uint64_t *const etab = (uint64_t *)(redd + 16); // glibc's expf table (a constant-memory lookup behind the V requests costs > 1 us)
-    unsigned long long *const dbg = (a.dbg && blockIdx.x < 1024 && tid == 0) ? a.dbg + (size_t)blockIdx.x * 64 : nullptr; // timeline key 42
+    unsigned long long *const dbg = (PS_TL(a.dbg) && blockIdx.x < 1024 && tid == 0) ? a.dbg + (size_t)blockIdx.x * 64 : nullptr; // timeline key 42
     auto mark = [&](int k) { if (dbg) dbg[k] = __builtin_amdgcn_s_memtime(); };
     if (dbg) { dbg[0] = __builtin_amdgcn_s_memtime(); dbg[29] = __builtin_amdgcn_s_memrealtime(); }
 

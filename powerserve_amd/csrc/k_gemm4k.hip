@@ -417,7 +417,7 @@ __global__ __launch_bounds__((G4K_NC + G4K_NP) * 64) void gemm4k_kernel(const G4
     }
     if (item >= p.n_items) return; // (the whole workgroup)
     // timeline: consumer wave 0 -> words 0..31, producer wave 8 -> 32..63 of the workgroup's slot ([0]/[31] entry / exit clock, [29]/[30] 100 MHz)
-    unsigned long long *const dbg = (p.dbg && blockIdx.x < 1024 && lane == 0 && (wave == 0 || wave == G4K_NC)) ? p.dbg + ((size_t)blockIdx.x * 2 + (wave == G4K_NC)) * 32 : nullptr;
+    unsigned long long *const dbg = (PS_TL(p.dbg) && blockIdx.x < 1024 && lane == 0 && (wave == 0 || wave == G4K_NC)) ? p.dbg + ((size_t)blockIdx.x * 2 + (wave == G4K_NC)) * 32 : nullptr;
     if (dbg) { dbg[0] = __builtin_amdgcn_s_memtime(); dbg[29] = __builtin_amdgcn_s_memrealtime(); }
     if (wave >= G4K_NC) {
         g4k_producer_wave<EPI, G4K_NP, G4K_RING, WT>(p, item, lds, wave - G4K_NC, dbg);
@@ -570,7 +570,7 @@ __global__ __launch_bounds__((G4K_NC + G4K_NPN) * 64) void gemm4k_narrow_kernel(
         if (t >= p.n_tasks) item = g4k_next_item(p, item);
     }
     if (item >= p.n_items) return; // (the whole workgroup)
-    unsigned long long *const dbg = (p.dbg && blockIdx.x < 1024 && lane == 0 && (wave == 0 || wave == G4K_NC)) ? p.dbg + ((size_t)blockIdx.x * 2 + (wave == G4K_NC)) * 32 : nullptr;
+    unsigned long long *const dbg = (PS_TL(p.dbg) && blockIdx.x < 1024 && lane == 0 && (wave == 0 || wave == G4K_NC)) ? p.dbg + ((size_t)blockIdx.x * 2 + (wave == G4K_NC)) * 32 : nullptr;
     if (dbg) { dbg[0] = __builtin_amdgcn_s_memtime(); dbg[29] = __builtin_amdgcn_s_memrealtime(); }
     if (wave >= G4K_NC) {
         g4k_producer_wave<EPI, G4K_NPN, G4K_RINGN, WT>(p, item, lds, wave - G4K_NC, dbg);
@@ -1172,7 +1172,7 @@ __global__ __launch_bounds__(NWV * 64) void gemm4k_par_kernel(const G4KParams p)
     float4 *const M = S + NWV * 8 * 64;   // [slot][v][lane]: the mins products
     float4 *const D = M + NWV * 4 * 64;   // [slot][2][lane]: d * yd, -dmin * yd of rows 4 kb + r
     uint32_t *const trw = (uint32_t *)(D + NWV * 2 * 64) + wave * (16 * 36); // the wave's transposition buffer (gemm4k_wav_kernel)
-    unsigned long long *const dbg = (p.dbg && blockIdx.x < 1024 && lane == 0 && wave == 0) ? p.dbg + (size_t)blockIdx.x * 64 : nullptr; // timeline (tools/par_timeline.py)
+    unsigned long long *const dbg = (PS_TL(p.dbg) && blockIdx.x < 1024 && lane == 0 && wave == 0) ? p.dbg + (size_t)blockIdx.x * 64 : nullptr; // timeline (tools/par_timeline.py)
     int dbg_n = 1;
     auto mark = [&]() { if (dbg && dbg_n < 29) dbg[dbg_n++] = __builtin_amdgcn_s_memtime(); };
     if (dbg) { dbg[0] = __builtin_amdgcn_s_memtime(); dbg[29] = __builtin_amdgcn_s_memrealtime(); }

@@ -137,12 +137,13 @@ __global__ __launch_bounds__((NW + 1) * 64) void gemv4_kernel(const G4Params p) 
     const int s_end    = nt * tot;                  // stream units of this workgroup
     const int n_chunks = (s_end + UPB - 1) / UPB;
     const int n_iters  = (n_chunks + DC - 1) / DC;
-    unsigned long long *const dbg = (p.dbg && blockIdx.x < 1024 && lane == 0 && (wave == 0 || wave == NW)) ? p.dbg + ((size_t)blockIdx.x * 2 + (wave == NW)) * 32 : nullptr;
+    unsigned long long *const pdbg = PS_TL(p.dbg); // (null unless the library is built with -DPS_TIMELINE=1: ps_dev.h)
+    unsigned long long *const dbg = (pdbg && blockIdx.x < 1024 && lane == 0 && (wave == 0 || wave == NW)) ? pdbg + ((size_t)blockIdx.x * 2 + (wave == NW)) * 32 : nullptr;
     int dbg_n = 0;
     auto mark = [&]() { if (dbg && dbg_n < 28) dbg[dbg_n++] = __builtin_amdgcn_s_memtime(); };
     mark(); // 0: entry
     if (dbg) dbg[29] = __builtin_amdgcn_s_memrealtime();
-    if (p.dbg && blockIdx.x < 1024 && lane == 0 && wave < 16) p.dbg[((size_t)blockIdx.x * 2 + 1) * 32 + 12 + wave] = __builtin_amdgcn_s_memtime(); // every wave's entry
+    if (pdbg && blockIdx.x < 1024 && lane == 0 && wave < 16) pdbg[((size_t)blockIdx.x * 2 + 1) * 32 + 12 + wave] = __builtin_amdgcn_s_memtime(); // every wave's entry
 
     if (wave < NW) { // ------------------------------------------------------------------ producers
         // 1. the activation row, dealt tile by tile to the producers (tile t -> wave t % NW)

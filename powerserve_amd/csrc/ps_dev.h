@@ -20,6 +20,14 @@ __device__ __forceinline__ uint16_t ps_f2h(float f) {
 // three scalar places come out different (tests/test_ref_fast.py): the RoPE rotation, the n % 32 leftovers of ggml_vec_dot_f32,
 // and Q5_K's summs (not implemented under PS_CONTRACT: ps_hip_weight_upload refuses Q5_K there).  Default: every operation rounds where the C
 // source rounds (the -ffp-contract=off build the oracle, the golden vectors and "bit-exact" refer to).
+// ---- in-kernel timelines (s_memtime marks read back by ps_hip_debug_timeline, tools/gpu_*timeline*.py) are compiled in only with -DPS_TIMELINE=1
+// (powerserve_amd/build.py build(timeline=True) -> lib/libps_hip_timeline.so).  Round 5 measured what the dormant marks cost the library that ships: a
+// branch per mark, the timeline pointer's scalar load and wait at the head of every launch, registers -- all mat-vecs of a token 1.343 -> 1.293 ms, decode
+// 548 -> 563 tok/s without them (profiles/r05_decode_experiments.txt).
+#ifndef PS_TIMELINE
+#define PS_TIMELINE 0
+#endif
+#define PS_TL(ptr) (PS_TIMELINE ? (ptr) : nullptr)
 #ifdef PS_CONTRACT
 constexpr bool PS_CONTRACT_ON = true;
 #else

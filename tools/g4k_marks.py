@@ -1,6 +1,11 @@
 #!/usr/bin/env python3
 """Raw in-kernel marks of the wide chunk mat-mul's consumer wave 0 (library built with -DG4K_MARK2: a mark behind the barrier AND one behind the step's
 chains, steps 0..7): how much of a super-block step is the wave's own work and how much is waiting at the barrier.  usage: PS_HIP_LIB=... g4k_marks.py [key]"""
+# (the in-kernel marks live in the timeline build of the library: python -m powerserve_amd.build --timeline)
+import os as _os
+_tl = _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "powerserve_amd", "lib", "libps_hip_timeline.so")
+if "PS_HIP_LIB" not in _os.environ and _os.path.exists(_tl):
+    _os.environ["PS_HIP_LIB"] = _tl
 import ctypes as C, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

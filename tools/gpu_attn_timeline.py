@@ -1,6 +1,11 @@
 #!/usr/bin/env python3
 """In-kernel timeline of the single-token attention kernels (ps_hip_debug_timeline keys 40 = scores, 41 = soft-max + V.p)
 on the 8B layer shape with a long cache.  usage: gpu_attn_timeline.py [n_prefill=2048]"""
+# (the in-kernel marks live in the timeline build of the library: python -m powerserve_amd.build --timeline)
+import os as _os
+_tl = _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "powerserve_amd", "lib", "libps_hip_timeline.so")
+if "PS_HIP_LIB" not in _os.environ and _os.path.exists(_tl):
+    _os.environ["PS_HIP_LIB"] = _tl
 import ctypes as C, os, sys, tempfile
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

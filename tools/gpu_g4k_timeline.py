@@ -2,6 +2,11 @@
 """In-kernel timeline of the Q4_K prefill mat-mul (k_gemm4k.hip) on the bench model: consumer wave 0 and producer wave 8 of
 every workgroup mark the clock after the barrier of steps 0..7 and of every 8th step after.
 usage: gpu_g4k_timeline.py [key ...]   48 QKV, 49 O, 50 down, 52 gate/up"""
+# (the in-kernel marks live in the timeline build of the library: python -m powerserve_amd.build --timeline)
+import os as _os
+_tl = _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "powerserve_amd", "lib", "libps_hip_timeline.so")
+if "PS_HIP_LIB" not in _os.environ and _os.path.exists(_tl):
+    _os.environ["PS_HIP_LIB"] = _tl
 import ctypes as C, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

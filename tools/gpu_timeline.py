@@ -1,6 +1,11 @@
 #!/usr/bin/env python3
 """In-kernel timeline of the decode mat-vec on the bench model (ps_hip_debug_timeline).
 usage: gpu_timeline.py [key ...]   key = epilogue*4 + prologue (1 = QKV, 2 = O/down, 5 = gate/up)"""
+# (the in-kernel marks live in the timeline build of the library: python -m powerserve_amd.build --timeline)
+import os as _os
+_tl = _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "powerserve_amd", "lib", "libps_hip_timeline.so")
+if "PS_HIP_LIB" not in _os.environ and _os.path.exists(_tl):
+    _os.environ["PS_HIP_LIB"] = _tl
 import ctypes as C, os, sys, tempfile
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -2,6 +2,11 @@
 """In-kernel timeline of gemm4k_par_kernel (k_gemm4k.hip) on the 8B model, 12 columns: wave 0 of every workgroup marks the clock seven times per
 round (1 weights landed + header decoded, 2 transposed through LDS, 3 eight accumulator lanes, 4 mins lanes, 5 barrier, 6 chains, 7 barrier),
 first four rounds.  usage: par_timeline.py [key ...]   48 QKV, 49 O, 50 down"""
+# (the in-kernel marks live in the timeline build of the library: python -m powerserve_amd.build --timeline)
+import os as _os
+_tl = _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "powerserve_amd", "lib", "libps_hip_timeline.so")
+if "PS_HIP_LIB" not in _os.environ and _os.path.exists(_tl):
+    _os.environ["PS_HIP_LIB"] = _tl
 import ctypes as C, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
