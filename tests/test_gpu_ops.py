@@ -284,6 +284,9 @@ def test_mul_mat_f32_gqa_views(ctx, oracle, hip):
     ctx.check(ctx.L.ps_hip_mul_mat(ctx.h, C.byref(out.tensor()), C.byref(v_view), C.byref(dp.tensor())))
     want = np.einsum("gdj,grbj->grbd", Vc[:, :n_kv].reshape(n_kv_heads, hs, n_kv), p.reshape(n_kv_heads, r2, bs, n_kv)).reshape(n_heads, bs, hs)
     assert rel_err(out.numpy(), want) < TOL
+    Vn = np.ascontiguousarray(Vc[:, :n_kv])  # (n_kv = 33: one whole block of 32 chains' steps + one leftover position)
+    want_pv = np.stack([[[oracle.L.pso_vec_dot_f32(n_kv, Vn[(h // r2) * hs + d].ctypes.data, p[h, i].ctypes.data) for d in range(hs)] for i in range(bs)] for h in range(n_heads)]).astype(np.float32)
+    assert np.array_equal(out.numpy(), want_pv)  # the same order here
 
 
 @pytest.mark.parametrize("dim,eps", [(896, 1e-6), (2048, 1e-5), (4096, 1e-5)])
