@@ -1034,7 +1034,7 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_pv_mfma_lds_kernel(psl_attn_a
     const int d0 = wave * 16;
     // staging roles.  V: instruction k covers rows 2k, 2k + 1 of the wave's 16, 32 lanes x 16 B per row
     const int vrow = lane >> 5, seg = lane & 31;
-    const float *vg = a.v_cache + ((int64_t)kvh * hs + d0 + vrow) * a.n_ctx + seg * 4;
+    const float *vg = a.v_cache + ((int64_t)kvh * hs + d0 + vrow) * a.n_ctx; // (the row; the lane's 16-byte segment is added where it is known to exist)
     const float *pg[NPS];
     int prow[NPS];
 #pragma unroll
@@ -1042,17 +1042,18 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_pv_mfma_lds_kernel(psl_attn_a
         const int sidx = (int)threadIdx.x + k * NT; // segment sidx: row sidx >> 5, 16-B segment sidx & 31
         prow[k] = sidx >> 5;
         const int nn = min((int)blockIdx.x * 16 + prow[k], N - 1), ii = nn / r2, gg = nn - ii * r2;
-        pg[k] = a.scores + ((int64_t)ii * a.n_heads + (int64_t)kvh * r2 + gg) * a.n_ctx + (sidx & 31) * 4;
+        pg[k] = a.scores + ((int64_t)ii * a.n_heads + (int64_t)kvh * r2 + gg) * a.n_ctx;
     }
     float4 sv[8], sp[NPS];
-    auto fetch = [&](int it) { // (clamped, never branched over: positions past np are zeroed when they are parked)
-        const int p0 = it * 128, off = p0 + seg * 4 < np ? p0 : 0;
+    auto fetch = [&](int it) { // (clamped, never branched over: positions past np are zeroed when they are parked.  A segment past np re-reads the ROW's
+        // first 16 bytes: with its own column index it left the row -- and, in the last row of a context window of fewer than 128 slots, the allocation)
+        const int p0 = it * 128, off = p0 + seg * 4 < np ? p0 + seg * 4 : 0;
 #pragma unroll
         for (int k = 0; k < 8; k++) sv[k] = *(const float4 *)(vg + (int64_t)(2 * k) * a.n_ctx + off);
 #pragma unroll
         for (int k = 0; k < NPS; k++) {
             const int sg = ((int)threadIdx.x + k * NT) & 31;
-            sp[k] = *(const float4 *)(pg[k] + (p0 + sg * 4 < np ? p0 : 0));
+            sp[k] = *(const float4 *)(pg[k] + (p0 + sg * 4 < np ? p0 + sg * 4 : 0));
         }
     };
     auto park = [&](int it, float *buf) {

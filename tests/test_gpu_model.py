@@ -374,6 +374,36 @@ def test_batches_with_a_large_context_window(ctx, oracle, tmp_path, preset, n_ct
     om.close()
 
 
+@pytest.mark.parametrize("preset,wt,n_ctx", [("small-llama-hs128", 8, 96), ("small-llama-hs128", 12, 64), ("small-llama", 2, 96), ("tiny-qwen2", 8, 68)])
+def test_context_windows_shorter_than_one_attention_step(ctx, oracle, tmp_path, preset, wt, n_ctx):
+    """n_ctx below 128 slots (not a multiple of 32 either): the batch V.p kernel stages 128 positions per step, and a lane whose segment lies past the
+    row's last whole block must not compute its address from that segment (round 5: with its own column index it read up to 124 bytes past the last
+    row of a layer's V cache -- found by tools/gpu_fuzz.py as a memory fault when that allocation ended a mapping).  A chunk of 41, one of 9, then single
+    tokens up to the last slot; logits and cache rows on bits."""
+    from oracle import binding as B
+    from powerserve_amd import hip, synth
+    d = str(tmp_path / "m")
+    mj = synth.write_model_dir(d, preset, wt, n_ctx=n_ctx, seed=5)
+    cfg = B.make_config(mj["llm_config"])
+    om = oracle.model(cfg, mj["model_arch"], load_tensors(os.path.join(d, "ggml/weights.gguf")), n_threads=4)
+    gm = hip.Model(ctx, d, max_batch=41)
+    toks = np.random.default_rng(n_ctx).integers(0, cfg.vocab_size, n_ctx)
+    for lo, hi in ((0, 41), (41, 50)):
+        want = om.forward(toks[lo:hi], np.arange(lo, hi), True)
+        got, _ = gm.forward(toks[lo:hi], np.arange(lo, hi), True)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (lo, rel_err(got, want))
+    for i in range(50, n_ctx):
+        want = om.forward(toks[i:i + 1], [i], True)
+        got, _ = gm.forward(toks[i:i + 1], [i], True)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (i, rel_err(got, want))
+    L = cfg.n_layers - 1
+    assert np.array_equal(gm.k_cache(L), om.k_cache(L)) and np.array_equal(gm.v_cache(L), om.v_cache(L))
+    with pytest.raises(hip.PSHipError):
+        gm.forward([1], [n_ctx], True)  # the window is full
+    gm.close()
+    om.close()
+
+
 def test_kv_full_and_bad_tokens_fail_loudly(ctx, tmp_path):
     from powerserve_amd import hip, synth
     d = str(tmp_path / "m")

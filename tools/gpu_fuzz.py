@@ -16,17 +16,19 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from conftest import load_tensors  # noqa: E402
 from oracle import binding as B  # noqa: E402
-from powerserve_amd import hip, synth  # noqa: E402
+from powerserve_amd import hip, host, synth  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--seconds", type=float, default=240)
 ap.add_argument("--seed", type=int, default=1)
 ap.add_argument("--ops-share", type=float, default=0.3)
+ap.add_argument("--replay", default="", help="one model draw instead of the sweep: 'preset wt n_ctx P chunk max_batch steps tree seed' (values of a draw line)")
+ap.add_argument("--verbose", action="store_true", help="print every draw before it runs (the last line names a draw that killed the process)")
 args = ap.parse_args()
 
 oracle, ctx = B.Oracle(), hip.Ctx(0)
 rng = np.random.default_rng(args.seed)
-fails, n_ops, n_models, n_trees = [], 0, 0, 0
+fails, n_ops, n_models, n_trees, n_host = [], 0, 0, 0, 0
 t_end = time.time() + args.seconds
 
 
@@ -78,8 +80,13 @@ def random_tree(n):
     return vis, np.array(depth, np.int32)
 
 
+def stage(name):
+    if args.verbose:
+        print("  done:", name, flush=True)
+
+
 def model_case(tmp):
-    global n_models, n_trees
+    global n_models, n_trees, n_host
     preset, wts = MODELS[int(rng.integers(0, len(MODELS)))]
     wt = int(rng.choice(wts))
     n_ctx = int(rng.choice([64, 96, 160, 300, 520, 1100, 2100]))
@@ -92,7 +99,12 @@ def model_case(tmp):
     max_batch = int(rng.choice([chunk, max(chunk, 16), 128, 256, 512]))
     max_batch = max(max_batch, chunk, n_tree)
     seed = int(rng.integers(0, 1 << 30))
+    if args.replay:
+        f = args.replay.split()
+        preset, (wt, n_ctx, P, chunk, max_batch, steps, n_tree, seed) = f[0], [int(v) for v in f[1:9]]
     tag = f"{preset} wt={wt} n_ctx={n_ctx} P={P} chunk={chunk} max_batch={max_batch} steps={steps} tree={n_tree} seed={seed}"
+    if args.verbose:
+        print("draw", tag, flush=True)
     d = os.path.join(tmp, f"m{n_models}")
     mj = synth.write_model_dir(d, preset, wt, n_ctx=n_ctx, seed=seed)
     cfg = B.make_config(mj["llm_config"])
@@ -102,6 +114,7 @@ def model_case(tmp):
         prompt = rng.integers(0, cfg.vocab_size, P)
         want_ids, want_lg, *_ = om.generate(prompt, chunk, steps, want_logits=True)
         got_ids = gm.generate(prompt, chunk, steps)
+        stage("generate")
         if not np.array_equal(got_ids, want_ids):
             fails.append(f"generate ids: {tag}: {got_ids.tolist()} vs {want_ids.tolist()}")
             return
@@ -111,6 +124,7 @@ def model_case(tmp):
         gm.reset()
         if P > 1:
             gm.prefill(prompt[:-1], chunk)
+        ctx.sync(); stage("prefill")
         cur = int(prompt[-1])
         for s in range(steps):
             lg, am = gm.forward([cur], [gm.position], lm_head=True)
@@ -118,6 +132,7 @@ def model_case(tmp):
                 fails.append(f"decode logits step {s}: {tag}: {int((lg[0] != want_lg[s]).sum())} logits differ")
                 return
             cur = int(want_ids[s])
+        stage("decode steps")
         n = gm.position
         for L in (0, cfg.n_layers - 1):
             if not (np.array_equal(gm.k_cache(L)[:n], om.k_cache(L)[:n]) and np.array_equal(gm.v_cache(L)[:, :n], om.v_cache(L)[:, :n])):
@@ -139,6 +154,27 @@ def model_case(tmp):
             fails.append(f"tree forward: {tag} hidden={hidden}: {int((got != want).sum())} of {got.size} logits differ")
             return
         n_trees += 1
+        stage("tree")
+        # the reference-API path (Graph builders -> Executor / HIPBackend::plan) on the same files: lowered to the fused launch plan, or op by op
+        gm.close()
+        hm = host.HostModel(d, 0, max_batch)
+        try:
+            fused = bool(rng.random() < 0.6) or P > 600  # (op by op: a launch per operator and column block; short prompts only)
+            if args.verbose:
+                print("  host fused", fused, flush=True)
+            hm.set_fused(fused)
+            ids = hm.generate(prompt, chunk, steps)
+            if not np.array_equal(ids, want_ids):
+                fails.append(f"host generate (fused={fused}): {tag}: {ids.tolist()} vs {want_ids.tolist()}")
+                return
+            lg = hm.forward([int(want_ids[-1])], [hm.position], lm_head=True)  # one more step: its logits on bits
+            want1 = om.forward([int(want_ids[-1])], [om.position], True)
+            if not bits_equal(lg[0], want1[0]):
+                fails.append(f"host logits (fused={fused}): {tag}: {int((lg[0] != want1[0]).sum())} differ")
+                return
+            n_host += 1
+        finally:
+            hm.close()
     finally:
         gm.close(); om.close()
         for f in ("ggml/weights.gguf", "model.json"):
@@ -151,13 +187,16 @@ def model_case(tmp):
 with tempfile.TemporaryDirectory() as tmp:
     while time.time() < t_end and len(fails) < 10:
         try:
+            if args.replay:
+                model_case(tmp)
+                break
             if rng.random() < args.ops_share:
                 op_case()
             else:
                 model_case(tmp)
         except Exception as e:  # a refused shape is a finding too: report the draw, keep going
             fails.append(f"exception: {type(e).__name__}: {str(e)[:300]}")
-print(f"gpu_fuzz seed {args.seed}: {n_ops} mat-muls, {n_models} models (generate + per-step logits + cache rows), {n_trees} tree forwards; {len(fails)} failures")
+print(f"gpu_fuzz seed {args.seed}: {n_ops} mat-muls, {n_models} models (generate + per-step logits + cache rows), {n_trees} tree forwards, {n_host} runs of the reference-API path; {len(fails)} failures")
 for f in fails:
     print("FAIL", f)
 sys.exit(1 if fails else 0)
