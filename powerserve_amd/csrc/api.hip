@@ -8,6 +8,8 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
+#include <unordered_map>
 
 // ------------------------------------------------------------------ host restatement of the RoPE cache
 // ggml_rope_cache_init (libs/ggml/src/ggml.c:15344-15358) + rope_yarn (:15319-15336) + corr dims
@@ -47,6 +49,57 @@ void ps_rope_table_host(const ps_rope_params *rp, int64_t ne0, const int32_t *po
 static inline bool is_quant(int t) { return t == PS_Q4_0 || t == PS_Q8_0 || t == PS_Q4_K || t == PS_Q5_K || t == PS_Q6_K; }
 static inline bool is_row_wave(int t) { return t == PS_Q5_K || t == PS_Q6_K; } // one wave per weight row (k_gemv6.hip)
 
+// ------------------------------------------------------------------ device allocations (ps_internal.h)
+namespace {
+struct GuardRec { void *va; size_t reserved, mapped; hipMemGenericAllocationHandle_t h; };
+std::mutex g_guard_mu;
+std::unordered_map<void *, GuardRec> g_guard;
+int guard_align() { static const int a = getenv("PS_HIP_GUARD") ? atoi(getenv("PS_HIP_GUARD")) : 0; return a; } // 0: off; 1: on, hipMalloc's 256-byte alignment kept; 16 / 64 / ...: that alignment
+bool guard_on() { return guard_align() != 0; }
+} // namespace
+hipError_t ps_dev_malloc(void **p, size_t bytes) {
+    if (!guard_on()) return hipMalloc(p, bytes);
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = dev;
+    size_t gran = 0;
+    if ((e = hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum)) != hipSuccess) return e;
+    const size_t al = guard_align() >= 16 ? (size_t)guard_align() : 256;
+    const size_t user = (bytes + al - 1) / al * al, mapped = (user + gran - 1) / gran * gran, reserved = mapped + gran; // (the last granule stays unmapped)
+    GuardRec r{nullptr, reserved, mapped, {}};
+    if ((e = hipMemAddressReserve(&r.va, reserved, gran, nullptr, 0)) != hipSuccess) return e;
+    if ((e = hipMemCreate(&r.h, mapped, &prop, 0)) != hipSuccess) { (void)hipMemAddressFree(r.va, reserved); return e; }
+    if ((e = hipMemMap(r.va, mapped, 0, r.h, 0)) != hipSuccess) { (void)hipMemRelease(r.h); (void)hipMemAddressFree(r.va, reserved); return e; }
+    hipMemAccessDesc acc = {};
+    acc.location = prop.location;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    if ((e = hipMemSetAccess(r.va, mapped, &acc, 1)) != hipSuccess) { (void)hipMemUnmap(r.va, mapped); (void)hipMemRelease(r.h); (void)hipMemAddressFree(r.va, reserved); return e; }
+    *p = (char *)r.va + (mapped - user);
+    std::lock_guard<std::mutex> lk(g_guard_mu);
+    g_guard[*p] = r;
+    return hipSuccess;
+}
+hipError_t ps_dev_free(void *p) {
+    if (!p) return hipSuccess;
+    if (!guard_on()) return hipFree(p);
+    GuardRec r;
+    {
+        std::lock_guard<std::mutex> lk(g_guard_mu);
+        auto it = g_guard.find(p);
+        if (it == g_guard.end()) return hipFree(p);
+        r = it->second;
+        g_guard.erase(it);
+    }
+    // the range is never handed back: with hipMemUnmap / hipMemRelease / hipMemAddressFree behind every free, later allocations of the same process read
+    // wrong data now and then (ops tests failed at random under recycling and pass without it); a debugging run can afford the memory
+    return hipSuccess;
+}
+
+
 extern "C" {
 
 int ps_hip_abi_version(void) { return PS_HIP_ABI_VERSION; }
@@ -57,6 +110,7 @@ int ps_hip_device_count(void) {
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
 }
+
 
 int ps_hip_create(int device, ps_hip_ctx **out) {
     *out = nullptr;
@@ -76,10 +130,10 @@ void ps_hip_destroy(ps_hip_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    if (c->act_buf) (void)hipFree(c->act_buf);
-    if (c->i32_buf) (void)hipFree(c->i32_buf);
-    if (c->u8_buf) (void)hipFree(c->u8_buf);
-    if (c->rope_buf) (void)hipFree(c->rope_buf);
+    if (c->act_buf) (void)ps_dev_free(c->act_buf);
+    if (c->i32_buf) (void)ps_dev_free(c->i32_buf);
+    if (c->u8_buf) (void)ps_dev_free(c->u8_buf);
+    if (c->rope_buf) (void)ps_dev_free(c->rope_buf);
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -95,12 +149,12 @@ int ps_hip_device_name(const ps_hip_ctx *c, char *buf, size_t cap) {
 
 int ps_hip_malloc(ps_hip_ctx *c, size_t bytes, void **dptr) {
     PS_CHECK(c, hipSetDevice(c->device));
-    PS_CHECK(c, hipMalloc(dptr, bytes ? bytes : 16));
+    PS_CHECK(c, ps_dev_malloc(dptr, bytes ? bytes : 16));
     return 0;
 }
 int ps_hip_free(ps_hip_ctx *c, void *dptr) {
     PS_CHECK(c, hipStreamSynchronize(c->stream));
-    PS_CHECK(c, hipFree(dptr));
+    PS_CHECK(c, ps_dev_free(dptr));
     return 0;
 }
 int ps_hip_memcpy_h2d(ps_hip_ctx *c, void *dst, const void *src, size_t bytes) {
@@ -182,14 +236,14 @@ int ps_hip_weight_upload(ps_hip_ctx *c, int dtype, const void *host, int64_t K, 
     const size_t raw = (size_t)w->gguf_bytes;
     auto fail = [&](const char *m) { ps_hip_weight_free(c, w); c->err = m; return 1; };
     if (dtype == PS_F32) {
-        if (hipMalloc((void **)&w->qs, raw) != hipSuccess) return fail("weight_upload: hipMalloc");
+        if (ps_dev_malloc((void **)&w->qs, raw) != hipSuccess) return fail("weight_upload: hipMalloc");
         if (hipMemcpyAsync(w->qs, host, raw, hipMemcpyHostToDevice, c->stream) != hipSuccess) return fail("weight_upload: copy");
         PS_CHECK(c, hipStreamSynchronize(c->stream));
         *out = w;
         return 0;
     }
     uint8_t *tmp = nullptr;
-    if (hipMalloc((void **)&tmp, raw + 64) != hipSuccess) return fail("weight_upload: hipMalloc(tmp)");
+    if (ps_dev_malloc((void **)&tmp, raw + 64) != hipSuccess) return fail("weight_upload: ps_dev_malloc(tmp)");
     size_t qs_b = 0, aux_b = 0, qh_b = 0, sc_b = 0;
     if (dtype == PS_Q4_0 || dtype == PS_Q8_0 || dtype == PS_Q4_K) { // lane-major repack: 1 KiB units per row group
         const int64_t rg = ps_w_rg(dtype), ng = (N + rg - 1) / rg, nu = (K + ps_w_unit(dtype) - 1) / ps_w_unit(dtype);
@@ -198,13 +252,13 @@ int ps_hip_weight_upload(ps_hip_ctx *c, int dtype, const void *host, int64_t K, 
     }
     if (dtype == PS_Q6_K) { qs_b = (size_t)N * K / 2; qh_b = (size_t)N * K / 4; sc_b = (size_t)N * K / 16; aux_b = (size_t)N * (K / 256) * 2; }
     if (dtype == PS_Q5_K) { qs_b = (size_t)N * K / 2; qh_b = (size_t)N * K / 8; sc_b = (size_t)N * (K / 256) * 16; aux_b = 0; }
-    bool ok = hipMalloc((void **)&w->qs, qs_b + 64) == hipSuccess && hipMalloc((void **)&w->aux, aux_b + 64) == hipSuccess;
-    if (ok && qh_b) ok = hipMalloc((void **)&w->qh, qh_b + 64) == hipSuccess && hipMalloc((void **)&w->sc, sc_b + 64) == hipSuccess;
-    if (!ok) { (void)hipFree(tmp); return fail("weight_upload: hipMalloc(planes)"); }
-    if (hipMemcpyAsync(tmp, host, raw, hipMemcpyHostToDevice, c->stream) != hipSuccess) { (void)hipFree(tmp); return fail("weight_upload: copy"); }
+    bool ok = ps_dev_malloc((void **)&w->qs, qs_b + 64) == hipSuccess && ps_dev_malloc((void **)&w->aux, aux_b + 64) == hipSuccess;
+    if (ok && qh_b) ok = ps_dev_malloc((void **)&w->qh, qh_b + 64) == hipSuccess && ps_dev_malloc((void **)&w->sc, sc_b + 64) == hipSuccess;
+    if (!ok) { (void)ps_dev_free(tmp); return fail("weight_upload: ps_dev_malloc(planes)"); }
+    if (hipMemcpyAsync(tmp, host, raw, hipMemcpyHostToDevice, c->stream) != hipSuccess) { (void)ps_dev_free(tmp); return fail("weight_upload: copy"); }
     psk_repack_weight(c->stream, dtype, tmp, K, N, w);
     hipError_t e = hipStreamSynchronize(c->stream);
-    (void)hipFree(tmp);
+    (void)ps_dev_free(tmp);
     if (e != hipSuccess) return fail("weight_upload: repack");
     *out = w;
     return 0;
@@ -213,10 +267,10 @@ int ps_hip_weight_upload(ps_hip_ctx *c, int dtype, const void *host, int64_t K, 
 void ps_hip_weight_free(ps_hip_ctx *c, ps_weight *w) {
     if (!w) return;
     (void)c;
-    if (w->qs) (void)hipFree(w->qs);
-    if (w->aux) (void)hipFree(w->aux);
-    if (w->qh) (void)hipFree(w->qh);
-    if (w->sc) (void)hipFree(w->sc);
+    if (w->qs) (void)ps_dev_free(w->qs);
+    if (w->aux) (void)ps_dev_free(w->aux);
+    if (w->qh) (void)ps_dev_free(w->qh);
+    if (w->sc) (void)ps_dev_free(w->sc);
     delete w;
 }
 uint64_t ps_hip_weight_gguf_bytes(const ps_weight *w) { return w->gguf_bytes; }
@@ -226,10 +280,10 @@ int ps_hip_weight_dtype(const ps_weight *w) { return w->dtype; }
 static int ensure(ps_hip_ctx *c, void **buf, size_t *cap, size_t need) {
     if (*cap >= need) return 0;
     PS_CHECK(c, hipStreamSynchronize(c->stream));
-    if (*buf) PS_CHECK(c, hipFree(*buf));
+    if (*buf) PS_CHECK(c, ps_dev_free(*buf));
     *buf = nullptr;
     *cap = 0;
-    PS_CHECK(c, hipMalloc(buf, need));
+    PS_CHECK(c, ps_dev_malloc(buf, need));
     *cap = need;
     return 0;
 }

@@ -88,7 +88,7 @@ static int mode_env_or();
 static void drop_graphs(ps_hip_model *m);
 static int dmalloc(ps_hip_model *m, void **p, size_t bytes) {
     ps_hip_ctx *c = m->ctx;
-    PS_CHECK(c, hipMalloc(p, bytes ? bytes : 16));
+    PS_CHECK(c, ps_dev_malloc(p, bytes ? bytes : 16));
     m->owned.push_back(*p);
     return 0;
 }
@@ -225,7 +225,7 @@ static int ensure_perf16(ps_hip_model *m) {
             for (_Float16 *h : *v) {
                 auto it = std::find(m->owned.begin(), m->owned.end(), (void *)h);
                 if (it != m->owned.end()) m->owned.erase(it);
-                (void)hipFree(h);
+                (void)ps_dev_free(h);
             }
             v->clear();
         }
@@ -489,7 +489,7 @@ void ps_hip_model_destroy(ps_hip_model *m) {
     drop_graphs(m);
     if (m->attn_flag_host) (void)hipHostFree(m->attn_flag_host);
     psf16_destroy(m->pf);
-    for (void *p : m->owned) (void)hipFree(p);
+    for (void *p : m->owned) (void)ps_dev_free(p);
     delete m;
 }
 

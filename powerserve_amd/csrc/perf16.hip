@@ -418,11 +418,11 @@ extern "C" int ps_hip_debug_f16_gemm(ps_hip_ctx *c, int M, int64_t N, int64_t K,
     PS_CHECK(c, hipSetDevice(c->device));
     _Float16 *x = nullptr, *W = nullptr;
     float *o = nullptr, *r = nullptr, *res = nullptr;
-    PS_CHECK(c, hipMalloc((void **)&x, (size_t)M * K * 2));
-    PS_CHECK(c, hipMalloc((void **)&W, (size_t)N * K * 2));
-    PS_CHECK(c, hipMalloc((void **)&o, (size_t)M * N * 4));
-    PS_CHECK(c, hipMalloc((void **)&r, (size_t)M * N * 4));
-    PS_CHECK(c, hipMalloc((void **)&res, 4));
+    PS_CHECK(c, ps_dev_malloc((void **)&x, (size_t)M * K * 2));
+    PS_CHECK(c, ps_dev_malloc((void **)&W, (size_t)N * K * 2));
+    PS_CHECK(c, ps_dev_malloc((void **)&o, (size_t)M * N * 4));
+    PS_CHECK(c, ps_dev_malloc((void **)&r, (size_t)M * N * 4));
+    PS_CHECK(c, ps_dev_malloc((void **)&res, 4));
     hipStream_t st = c->stream;
     hipLaunchKernelGGL(f16_fill_kernel, dim3(1024), dim3(256), 0, st, x, (int64_t)M * K, 17u);
     hipLaunchKernelGGL(f16_fill_kernel, dim3(1024), dim3(256), 0, st, W, (int64_t)N * K, 91u);
@@ -452,6 +452,6 @@ extern "C" int ps_hip_debug_f16_gemm(ps_hip_ctx *c, int M, int64_t N, int64_t K,
         *us_per_launch = 1e3 * ms / reps;
         (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     }
-    (void)hipFree(x); (void)hipFree(W); (void)hipFree(o); (void)hipFree(r); (void)hipFree(res);
+    (void)ps_dev_free(x); (void)ps_dev_free(W); (void)ps_dev_free(o); (void)ps_dev_free(r); (void)ps_dev_free(res);
     return rc;
 }

@@ -7,6 +7,12 @@
 #include <string>
 #include <vector>
 
+// Every device allocation of the library goes through these two.  PS_HIP_GUARD=1 (a debugging mode, tools/gpu_guard.sh): each allocation gets a
+// virtual range of its own whose last mapped byte is the allocation's last (rounded up to hipMalloc's 256-byte alignment; PS_HIP_GUARD=16: to 16 bytes) and an unmapped stretch behind it, so that a kernel
+// reading or writing past the end of a buffer faults instead of silently landing in a neighbour (the batch V.p kernel did, round 5).
+hipError_t ps_dev_malloc(void **p, size_t bytes);
+hipError_t ps_dev_free(void *p);
+
 struct ps_hip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
