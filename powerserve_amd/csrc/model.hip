@@ -50,6 +50,11 @@ struct ps_hip_model {
     unsigned *attn_sync = nullptr; // [2048] words: [31] the one-launch attention's rendezvous-timeout flag
     unsigned *attn_flag_host = nullptr; // pinned: [31] travels here behind every single-token forward (async copy on the stream)
     bool attn_unchecked = false;        // such a forward was enqueued and its flag has not been looked at yet
+    // pinned staging of the lowered single-token path (Model::decode over the op API: one stream synchronisation per token instead of three)
+    int32_t *pin_tokens = nullptr;      // [max_batch] the token behind an async upload; pin_busy: not yet known to have been read
+    int32_t *pin_argmax = nullptr;      // [max_batch] arg-max ids copied behind a lowered forward; valid for pin_argmax_n columns once pin_argmax_pending is clear
+    bool pin_busy = false, pin_argmax_pending = false;
+    int pin_argmax_n = 0;
     bool attn1_disabled = false;        // the one-launch attention timed out once on this device: mode bit 4 is sticky (set_mode ORs it back in; bit 6 re-arms)
     float *attn_xchg = nullptr;    // attn_decode2: scores in flight between workgroups (k_attn.hip)
     unsigned *attn_tick = nullptr; // attn_decode2: [64 * kv head] arrival counters
@@ -465,6 +470,8 @@ int ps_hip_model_create(ps_hip_ctx *c, const ps_model_desc *d, ps_hip_model **ou
     (void)hipMemsetAsync(m->attn_sync, 0, 2048 * 4, c->stream);
     if (hipHostMalloc((void **)&m->attn_flag_host, 64, hipHostMallocDefault) != hipSuccess) return fail();
     *m->attn_flag_host = 0;
+    if (hipHostMalloc((void **)&m->pin_tokens, (2 * mb + 16) * 4, hipHostMallocDefault) != hipSuccess) return fail();
+    m->pin_argmax = m->pin_tokens + mb;
     (void)hipMemsetAsync(m->attn_tick, 0, (size_t)f.n_kv_heads * 64 * 4, c->stream);
     (void)hipMemsetAsync(m->kv_vis_dev, 1, nctx, c->stream);
     m->kv_vis_host.assign(nctx, 1);
@@ -488,6 +495,7 @@ void ps_hip_model_destroy(ps_hip_model *m) {
     (void)hipStreamSynchronize(m->ctx->stream);
     drop_graphs(m);
     if (m->attn_flag_host) (void)hipHostFree(m->attn_flag_host);
+    if (m->pin_tokens) (void)hipHostFree(m->pin_tokens);
     psf16_destroy(m->pf);
     for (void *p : m->owned) (void)ps_dev_free(p);
     delete m;
@@ -607,6 +615,7 @@ int ps_hip_model_sync_check(ps_hip_model *m) {
     ps_hip_ctx *c = m->ctx;
     if (!m->attn_unchecked) return 0;
     PS_CHECK(c, hipStreamSynchronize(c->stream));
+    m->pin_busy = false; m->pin_argmax_pending = false; // (everything enqueued before this point has run)
     return check_attn_timeout(m, "lowered forward");
 }
 int ps_hip_model_forward(ps_hip_model *m, const int32_t *tokens, int n, const int32_t *pos, const uint8_t *tree, int lm_head,
@@ -627,10 +636,20 @@ static int model_forward_impl(ps_hip_model *m, const int32_t *tokens, int n, con
     for (int i = 0; i < n; i++)
         if (tokens[i] < 0 || (uint32_t)tokens[i] >= m->cfg.vocab_size) PS_FAIL(c, "model_forward: token id out of range");
     PS_CHECK(c, hipSetDevice(c->device));
-    PS_CHECK(c, hipMemcpyAsync(m->tokens_dev, tokens, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
-    if (tree) PS_CHECK(c, hipMemcpyAsync(m->tree_dev, tree, (size_t)n * n, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(1), 0, c->stream, m->state, pos[0], n, 0);
-    PS_CHECK(c, hipStreamSynchronize(c->stream)); // tokens/tree may be host temporaries
+    m->pin_argmax_n = 0; // (the arg-max ids on the device are about to change)
+    if (n == 1 && !tree) { // a decode step: the token travels from a pinned word, nothing to wait for before the launches go out
+        if (m->pin_busy) { PS_CHECK(c, hipStreamSynchronize(c->stream)); m->pin_busy = false; m->pin_argmax_pending = false; } // (an upload from that word may still be queued)
+        m->pin_tokens[0] = tokens[0];
+        PS_CHECK(c, hipMemcpyAsync(m->tokens_dev, m->pin_tokens, 4, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(1), 0, c->stream, m->state, pos[0], n, 0);
+        m->pin_busy = true;
+    } else {
+        PS_CHECK(c, hipMemcpyAsync(m->tokens_dev, tokens, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+        if (tree) PS_CHECK(c, hipMemcpyAsync(m->tree_dev, tree, (size_t)n * n, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(1), 0, c->stream, m->state, pos[0], n, 0);
+        PS_CHECK(c, hipStreamSynchronize(c->stream)); // tokens/tree may be host temporaries
+        m->pin_busy = false; m->pin_argmax_pending = false;
+    }
     // A single token through this entry (ModelTokenIterator::decode over the op API, HIPBackend::plan's lowered graph) replays
     // a captured launch plan like ps_hip_model_decode_greedy does: the first call at a position range runs eagerly and captures.
     const int gk = lm_head ? 1 : 0;
@@ -660,8 +679,13 @@ static int model_forward_impl(ps_hip_model *m, const int32_t *tokens, int n, con
     }
     if (n == 1 && !tree) note_single_token(m);
     if (lm_head && argmax_host) PS_CHECK(c, hipMemcpyAsync(argmax_host, m->argmax_dev, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    if (lm_head && !advance) { // lowered graph: the ids ride to pinned memory behind the launches; ps_hip_model_argmax finds them there after the cache advance's wait
+        PS_CHECK(c, hipMemcpyAsync(m->pin_argmax, m->argmax_dev, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+        m->pin_argmax_n = n; m->pin_argmax_pending = true;
+    }
     if (!advance) return 0; // lowered graph: ps_hip_model_kv_advance / ps_hip_model_sync_check look at the time-out flag before the result counts
     PS_CHECK(c, hipStreamSynchronize(c->stream));
+    m->pin_busy = false; m->pin_argmax_pending = false;
     if (const int rc = check_attn_timeout(m, "model_forward")) { // a time-out: the model is on the two-launch attention now, the same forward once more (inputs are the caller's)
         if (rc != PS_HIP_ATTN_TIMEOUT || retried) return rc;
         c->err.clear();
@@ -685,6 +709,7 @@ int ps_hip_model_prefill(ps_hip_model *m, const int32_t *tokens, int n, int chun
     for (int i = 0; i < n; i++)
         if (tokens[i] < 0 || (uint32_t)tokens[i] >= m->cfg.vocab_size) PS_FAIL(c, "model_prefill: token id out of range");
     PS_CHECK(c, hipSetDevice(c->device));
+    m->pin_argmax_n = 0;
     int per = m->max_batch / chunk; // reference chunks per super-chunk
     if (per > 64) per = 64;
     if (per < 1) per = 1;
@@ -729,6 +754,7 @@ static int forward_tree_impl(ps_hip_model *m, const int32_t *tokens, int n, cons
         if (rope_pos[i] < 0 || (uint32_t)rope_pos[i] >= m->cfg.seq_len) PS_FAIL(c, "model_forward_tree: position out of range");
     }
     PS_CHECK(c, hipSetDevice(c->device));
+    m->pin_argmax_n = 0;
     PS_CHECK(c, hipMemcpyAsync(m->tokens_dev, tokens, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
     PS_CHECK(c, hipMemcpyAsync(m->rope_pos_dev, rope_pos, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
     if (tree) PS_CHECK(c, hipMemcpyAsync(m->tree_dev, tree, (size_t)n * n, hipMemcpyHostToDevice, c->stream));
@@ -771,6 +797,7 @@ static int decode_greedy_impl(ps_hip_model *m, int32_t token, int steps, int32_t
     if (m->position + (size_t)steps > m->cfg.seq_len) PS_FAIL(c, "decode_greedy: KV cache would overflow n_ctx");
     if (token < 0 || (uint32_t)token >= m->cfg.vocab_size) PS_FAIL(c, "decode_greedy: token id out of range");
     PS_CHECK(c, hipSetDevice(c->device));
+    m->pin_argmax_n = 0;
     PS_CHECK(c, hipMemcpyAsync(m->tokens_dev, &token, 4, hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(1), 0, c->stream, m->state, (int)m->position, 1, 0);
     PS_CHECK(c, hipStreamSynchronize(c->stream));
@@ -819,8 +846,14 @@ int ps_hip_model_argmax(ps_hip_model *m, int n, int32_t *ids_host) {
     ps_hip_ctx *c = m->ctx;
     if (n <= 0 || n > m->max_batch) PS_FAIL(c, "model_argmax: batch size out of range");
     if (int rc = settle_pending(m)) return rc;
+    if (m->pin_argmax_n >= n) { // the last forward was a lowered one and left its ids in pinned memory
+        if (m->pin_argmax_pending) { PS_CHECK(c, hipStreamSynchronize(c->stream)); m->pin_busy = false; m->pin_argmax_pending = false; }
+        memcpy(ids_host, m->pin_argmax, (size_t)n * 4);
+        return 0;
+    }
     PS_CHECK(c, hipMemcpyAsync(ids_host, m->argmax_dev, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
     PS_CHECK(c, hipStreamSynchronize(c->stream));
+    m->pin_busy = false; m->pin_argmax_pending = false;
     return 0;
 }
 const float *ps_hip_model_scratch(const ps_hip_model *m, int which) {
