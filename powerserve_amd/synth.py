@@ -38,6 +38,13 @@ PRESETS = {
     "deep-llama-hs128": ("llama", 1024, 2048, 32, 8, 2, 128, 1024, 5e5, 0, False, 1e-5),
     # >= 256 row groups in every mat-vec of a layer (one workgroup per CU)
     "wide-llama": ("llama", 2048, 4096, 2, 16, 4, 128, 2048, 5e5, 0, False, 1e-5),
+    # head sizes and query-heads-per-kv-head ratios no public config of the survey has but the backend accepts (32 / 96; 1, 3, 5, 6, 8): tools/gpu_fuzz.py
+    "odd-llama-hs96": ("llama", 768, 1024, 2, 8, 2, 96, 512, 1e4, 0, False, 1e-5),
+    "odd-llama-hs32": ("llama", 256, 512, 2, 8, 8, 32, 512, 1e4, 0, True, 1e-5),
+    "odd-qwen2-r3": ("qwen2", 384, 768, 2, 6, 2, 64, 512, 1e6, 2, True, 1e-6),
+    "odd-llama-r5": ("llama", 320, 640, 2, 5, 1, 64, 512, 5e5, 0, False, 1e-5),
+    "odd-llama-r6": ("llama", 768, 1024, 2, 6, 1, 128, 512, 5e5, 0, False, 1e-5),
+    "odd-llama-r8": ("llama", 512, 1024, 2, 8, 1, 64, 512, 5e5, 0, True, 1e-5),
 }
 
 

@@ -15,7 +15,9 @@ pytestmark = pytest.mark.gpu
 CASES = [("tiny-llama", 2), ("tiny-llama", 8), ("tiny-llama", 12), ("tiny-qwen2", 8), ("tiny-qwen2", 2),
          ("small-llama", 2), ("small-llama-hs128", 12),
          ("small-llama-hs128", 14), ("small-llama-hs128", 1015), ("tiny-llama", 1015),  # 14: pure Q6_K; 1015: synth.Q4_K_M mix
-         ("small-llama-hs128", 13), ("tiny-llama", 1017)]                                # 13: pure Q5_K; 1017: synth.Q5_K_M mix
+         ("small-llama-hs128", 13), ("tiny-llama", 1017),                                # 13: pure Q5_K; 1017: synth.Q5_K_M mix
+         # head sizes 96 / 32 and 3, 5, 6, 8 (and 1) query heads per kv head: no public config of the survey has them, the backend accepts them
+         ("odd-llama-hs96", 12), ("odd-llama-hs32", 8), ("odd-qwen2-r3", 2), ("odd-llama-r5", 8), ("odd-llama-r6", 13), ("odd-llama-r8", 2)]
 
 
 @pytest.mark.parametrize("preset,wt", CASES)

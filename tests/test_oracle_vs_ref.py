@@ -146,3 +146,25 @@ def test_q4k_corner_case_blocks(oracle, ref):
         x = (rng.standard_normal((bs, K)) * rng.uniform(0.1, 30.0, (bs, 1))).astype(np.float32)
         x[0, 0:512] = np.where(rng.random(512) < 0.5, 1.0, -1.0) * 7.0
         assert np.array_equal(bits(ref.mul_mat(12, w, K, N, x)), bits(oracle.mul_mat(12, w, K, N, x)))
+
+
+@pytest.mark.parametrize("preset,t", [("odd-llama-hs96", 8), ("odd-llama-hs32", 8), ("odd-qwen2-r3", 2), ("odd-llama-r5", 8), ("odd-llama-r6", 8), ("odd-llama-r8", 2)])
+def test_whole_forwards_at_head_sizes_and_gqa_ratios_no_public_config_has(oracle, ref, tmp_path, preset, t):
+    """Head sizes 32 / 96 and 1, 3, 5, 6, 8 query heads per kv head (synth.PRESETS "odd-*"): the restatement's generate() against the real
+    LlamaModel / Qwen2Model::forward, ids and every step's logits on bits (the shapes tools/gpu_fuzz.py --odd-share draws on the GPU)."""
+    from conftest import load_tensors
+    from oracle import binding as B
+    from powerserve_amd import synth
+    d = str(tmp_path / "m")
+    mj = synth.write_model_dir(d, preset, t, n_ctx=64, seed=3)
+    cfg = B.make_config(mj["llm_config"])
+    path = os.path.join(d, "ggml/weights.gguf")
+    om = oracle.model(cfg, mj["model_arch"], load_tensors(path), n_threads=4)
+    rm = ref.model(path, mj["model_arch"], cfg, 2)
+    prompt = np.random.default_rng(1).integers(0, cfg.vocab_size, 19)
+    ids, lg, *_ = om.generate(prompt, 8, 6, want_logits=True)
+    rids, rlg, *_ = rm.generate(prompt, 8, 6, want_logits=True)
+    assert np.array_equal(ids, rids)
+    assert np.array_equal(bits(lg), bits(rlg))
+    om.close()
+    rm.close()

@@ -22,6 +22,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--seconds", type=float, default=240)
 ap.add_argument("--seed", type=int, default=1)
 ap.add_argument("--ops-share", type=float, default=0.3)
+ap.add_argument("--odd-share", type=float, default=0.0, help="share of model draws from the odd head-size / GQA-ratio presets")
 ap.add_argument("--replay", default="", help="one model draw instead of the sweep: 'preset wt n_ctx P chunk max_batch steps tree seed' (values of a draw line)")
 ap.add_argument("--verbose", action="store_true", help="print every draw before it runs (the last line names a draw that killed the process)")
 args = ap.parse_args()
@@ -64,6 +65,8 @@ def op_case():
 
 MODELS = [("tiny-llama", [2, 8, 12, 13, 14, 1015, 1017]), ("tiny-qwen2", [2, 8, 12]), ("small-llama", [2, 8, 12, 1015]),
           ("small-llama-hs128", [12, 13, 14, 1015, 1017, 2, 8]), ("small-llama-draft", [2, 12]), ("wide-llama", [12])]
+# head sizes 32 / 96 and 1, 3, 5, 6, 8 query heads per kv head (synth.PRESETS "odd-*"; 384 and 320 are not multiples of 256: Q4_0 / Q8_0 only)
+ODD = [("odd-llama-hs96", [2, 8, 12, 14]), ("odd-llama-hs32", [2, 8, 12]), ("odd-qwen2-r3", [2, 8]), ("odd-llama-r5", [2, 8]), ("odd-llama-r6", [8, 12, 13]), ("odd-llama-r8", [2, 8, 12])]
 
 
 def random_tree(n):
@@ -87,7 +90,8 @@ def stage(name):
 
 def model_case(tmp):
     global n_models, n_trees, n_host
-    preset, wts = MODELS[int(rng.integers(0, len(MODELS)))]
+    pool = ODD if rng.random() < args.odd_share else MODELS
+    preset, wts = pool[int(rng.integers(0, len(pool)))]
     wt = int(rng.choice(wts))
     n_ctx = int(rng.choice([64, 96, 160, 300, 520, 1100, 2100]))
     steps = int(rng.integers(2, 11))
