@@ -22,6 +22,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--seconds", type=float, default=240)
 ap.add_argument("--seed", type=int, default=1)
 ap.add_argument("--ops-share", type=float, default=0.3)
+ap.add_argument("--max-draws", type=int, default=0, help="stop after this many draws (0: by --seconds only): a fixed, repeatable sequence")
 ap.add_argument("--odd-share", type=float, default=0.0, help="share of model draws from the odd head-size / GQA-ratio presets")
 ap.add_argument("--replay", default="", help="one model draw instead of the sweep: 'preset wt n_ctx P chunk max_batch steps tree seed' (values of a draw line)")
 ap.add_argument("--verbose", action="store_true", help="print every draw before it runs (the last line names a draw that killed the process)")
@@ -189,7 +190,9 @@ def model_case(tmp):
 
 
 with tempfile.TemporaryDirectory() as tmp:
-    while time.time() < t_end and len(fails) < 10:
+    n_draws = 0
+    while time.time() < t_end and len(fails) < 10 and (args.max_draws <= 0 or n_draws < args.max_draws):
+        n_draws += 1
         try:
             if args.replay:
                 model_case(tmp)
