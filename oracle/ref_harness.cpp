@@ -357,6 +357,14 @@ void *ref_model_create(const char *gguf_path, const char *arch, const ref_llm_co
     m->be            = m->platform->ggml_backends[m->cfg->model_id].get();
     m->be->setup_threadpool();
     m->pool_up = true;
+    // Work data for the longest soft-max row up front.  GGMLBackend::setup_work_data (src/backend/ggml/ggml.cpp:99-109) compares the request WITHOUT its
+    // cache-line pad against the buffer WITH it, so a soft-max whose 4 * n_kv * n_threads bytes fall within the last 64 * n_threads bytes of the current
+    // buffer is not given its per-thread pad and ggml_compute_forward_soft_max_f32 (ggml.c:14905) writes past the vector: at n_kv = 77 with two threads
+    // on the 256-wide test models (AddressSanitizer: heap-buffer-overflow, 0 bytes to the right of a 672-byte region), i.e. any single-token sequence of a
+    // few dozen steps corrupts the heap (found by tools/cpu_fuzz_oracle.py; the reference's own models only get there at n_kv of a thousand and more,
+    // where the allocator's slack usually absorbs it).  Scratch only: no result depends on the buffer's size.
+    // (the same comparison bites ROPE's per-thread cache, ggml.c:15349, when the buffer is SMALLER than a mat-mul would have made it: ask for well above both)
+    m->be->setup_work_data(4 * ((size_t)l.seq_len + (size_t)l.head_size + 32) * (size_t)n_threads + 65536);
     return m;
 }
 

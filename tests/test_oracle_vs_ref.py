@@ -168,3 +168,21 @@ def test_whole_forwards_at_head_sizes_and_gqa_ratios_no_public_config_has(oracle
     assert np.array_equal(bits(lg), bits(rlg))
     om.close()
     rm.close()
+
+
+@pytest.mark.parametrize("fast", [False, True])
+def test_seeded_random_sweep_against_the_real_reference(ref, fast):
+    """A fixed stretch of tools/cpu_fuzz_oracle.py: whole-model generate() of the restatement against the real forward at random shapes, chunkings and lengths,
+    ids and logits on bits; fast: the stock-flags build against the restatement's contract mode.  One process per draw (the reference leaks a ggml context
+    and its spinning pool threads per model)."""
+    import importlib.util
+    import sys
+    from oracle import binding as B
+    if fast and not B.have_ref_fast():
+        pytest.skip("oracle/_ref/libps_ref_fast.so not built")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("cpu_fuzz_oracle", os.path.join(root, "tools", "cpu_fuzz_oracle.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    n, fails = mod.run(seconds=240, seed=21 + int(fast), max_draws=10, fast=fast)
+    assert n == 10 and not fails, fails
