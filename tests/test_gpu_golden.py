@@ -132,3 +132,30 @@ def test_contract_build_is_the_stock_reference_build(tmp_path):
     print(r.stdout[-3000:])
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "contract build: all checks passed" in r.stdout
+
+
+@pytest.mark.parametrize("preset,tn", [("tiny-llama", "Q8_0"), ("tiny-qwen2", "Q4_0")])
+@pytest.mark.parametrize("eager", [False, True])
+def test_cache_longer_than_4096_tokens_against_the_real_reference(ctx, tmp_path, preset, tn, eager):
+    """tests/golden/long_cache_*.npz (oracle/gen_golden_long.py): the REAL reference's forward of a 4 300-token prompt in chunks of 128 behind a window of
+    4 608 slots, then 6 greedy steps.  Beyond 4 096 slots the single-token attention is the two-launch form, the batch soft-max keeps its rows in LDS and V.p
+    walks more than one tile; the oracle takes minutes for such a prompt, which is why this case is a fixture.  Ids and every step's logits on bits."""
+    from powerserve_amd import hip, synth
+    g = np.load(os.path.join(GOLD, f"long_cache_{preset}_{tn}.npz"))
+    d = str(tmp_path / "m")
+    synth.write_model_dir(d, preset, T[tn], n_ctx=int(g["n_ctx"]), seed=int(g["seed"]))
+    assert _sha(os.path.join(d, "ggml", "weights.gguf")) == str(g["gguf_sha256"])
+    m = hip.Model(ctx, d, max_batch=256)
+    if eager:
+        m.set_mode(1)
+    prompt, bs, steps = g["prompt"], int(g["batch"]), len(g["ids"])
+    ids = m.generate(prompt, bs, steps)
+    assert np.array_equal(ids, g["ids"]), (ids, g["ids"])
+    m.reset()
+    m.prefill(prompt[:-1], bs)  # (two reference chunks per launch sequence)
+    cur = int(prompt[-1])
+    for s in range(steps):
+        lg, am = m.forward([cur], [m.position], lm_head=True)
+        assert np.array_equal(lg[0].view(np.uint32), g["logits"][s].view(np.uint32)), s
+        cur = int(g["ids"][s])
+    m.close()

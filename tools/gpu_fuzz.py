@@ -23,6 +23,7 @@ ap.add_argument("--seconds", type=float, default=240)
 ap.add_argument("--seed", type=int, default=1)
 ap.add_argument("--ops-share", type=float, default=0.3)
 ap.add_argument("--max-draws", type=int, default=0, help="stop after this many draws (0: by --seconds only): a fixed, repeatable sequence")
+ap.add_argument("--big-ctx", action="store_true", help="context windows of 4608 / 6144 slots with caches longer than 4096 tokens (the two-launch single-token attention, the LDS-row soft-max)")
 ap.add_argument("--odd-share", type=float, default=0.0, help="share of model draws from the odd head-size / GQA-ratio presets")
 ap.add_argument("--replay", default="", help="one model draw instead of the sweep: 'preset wt n_ctx P chunk max_batch steps tree seed' (values of a draw line)")
 ap.add_argument("--verbose", action="store_true", help="print every draw before it runs (the last line names a draw that killed the process)")
@@ -104,6 +105,13 @@ def model_case(tmp):
     max_batch = int(rng.choice([chunk, max(chunk, 16), 128, 256, 512]))
     max_batch = max(max_batch, chunk, n_tree)
     seed = int(rng.integers(0, 1 << 30))
+    if args.big_ctx:
+        preset, wts = [("tiny-llama", [8, 12]), ("tiny-qwen2", [2, 8]), ("small-llama-draft", [2, 12]), ("small-llama-hs128", [12, 8])][int(rng.integers(0, 4))]
+        wt = int(rng.choice(wts))
+        n_ctx = int(rng.choice([4608, 6144]))
+        P = int(rng.integers(4100, n_ctx - steps - n_tree - 1))
+        chunk = int(rng.choice([33, 100, 128]))
+        max_batch = int(rng.choice([128, 256, 512]))
     if args.replay:
         f = args.replay.split()
         preset, (wt, n_ctx, P, chunk, max_batch, steps, n_tree, seed) = f[0], [int(v) for v in f[1:9]]
