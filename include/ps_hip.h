@@ -230,7 +230,8 @@ int ps_hip_model_decode_greedy(ps_hip_model *m, int32_t token, int steps, int32_
 const float *ps_hip_model_logits(const ps_hip_model *m); /* device [max_batch][vocab] */
 /* Arg-max ids of the most recent forward with lm_head (first maximum per token, what greedy_sample / TopK(1) returns: src/sampler/prob_array.cpp:65-67,
  * sampler.cpp:39-56), computed on the device behind the lm_head: 4 bytes per token come to the host instead of vocab x 4 (513 KB for 128 256 logits,
- * src/model/model.hpp:170-183).  For a lowered forward call it after ps_hip_model_sync_check / ps_hip_model_kv_advance. */
+ * src/model/model.hpp:170-183).  For a lowered forward call it after ps_hip_model_sync_check / ps_hip_model_kv_advance: the ids have then already arrived
+ * in pinned memory behind the forward's launches and the call does not wait on the stream again (one wait per decode step on the op-API path). */
 int ps_hip_model_argmax(ps_hip_model *m, int n, int32_t *ids_host);
 /* diagnostics: device scratch tensors of the most recent forward, last layer (0 x, 1 q, 2 att, 3 ffn hidden, 4 scores) */
 const float *ps_hip_model_scratch(const ps_hip_model *m, int which);
