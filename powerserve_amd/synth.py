@@ -48,13 +48,19 @@ PRESETS = {
 }
 
 
-def llm_config(preset: str, n_ctx: int) -> dict:
+# (rope_freq_scale, rope_attn_factor) draws of the random sweeps (tools/cpu_fuzz_oracle.py, tools/gpu_fuzz.py): picked by the model seed, so a replayed draw gets the same pair
+ROPE_DRAWS = [(1.0, 1.0), (0.5, 1.0), (0.25, 1.25), (1.0, 0.8)]
+
+
+def llm_config(preset: str, n_ctx: int, rope_freq_scale: float = 1.0, rope_attn_factor: float = 1.0) -> dict:
+    """model.json's llm_config of a preset.  rope_freq_scale / rope_attn_factor: the two RoPE parameters the reference reads from the model file
+    (src/core/config.cpp:96,98 -> ggml_rope_cache_init, libs/ggml/src/ggml.c:15344-15358) that no public preset of the survey moves off 1.0."""
     arch, dim, hidden, L, nh, nkv, hs, vocab, base, rtype, tied, eps = PRESETS[preset]
     return {
         "embed_dim": dim, "ffn_dim": hidden, "n_layers": L, "n_attn_heads": nh, "n_attn_kv_heads": nkv,
         "n_ctx": n_ctx, "vocab_size": vocab, "kv_dim": nkv * hs, "head_size": hs, "norm_eps": eps,
-        "rope_config": {"rope_dim": hs, "n_rope_ctx_orig": n_ctx, "rope_freq_base": base, "rope_freq_scale": 1.0,
-                        "rope_attn_factor": 1.0, "rope_type": rtype},
+        "rope_config": {"rope_dim": hs, "n_rope_ctx_orig": n_ctx, "rope_freq_base": base, "rope_freq_scale": float(rope_freq_scale),
+                        "rope_attn_factor": float(rope_attn_factor), "rope_type": rtype},
     }
 
 
@@ -140,11 +146,11 @@ def tensor_plan(cfg: dict, arch: str, wtype: int, tied: bool, embd_type: int | N
 
 
 def write_model_dir(out_dir: str, preset: str, wtype: int, n_ctx: int, seed: int = 1234, std: float = 0.02,
-                    embd_type: int | None = None, model_id: str | None = None) -> dict:
+                    embd_type: int | None = None, model_id: str | None = None, rope_freq_scale: float = 1.0, rope_attn_factor: float = 1.0) -> dict:
     """Create <out_dir>/{model.json, ggml/weights.gguf}; returns the model.json dict."""
     arch, *_rest = PRESETS[preset]
     tied = PRESETS[preset][10]
-    cfg = llm_config(preset, n_ctx)
+    cfg = llm_config(preset, n_ctx, rope_freq_scale, rope_attn_factor)
     os.makedirs(os.path.join(out_dir, "ggml"), exist_ok=True)
     mj = {"version": 1, "model_arch": arch, "model_id": model_id or f"{preset}-{'Q4_K_M' if wtype == Q4_K_M else ('Q5_K_M' if wtype == Q5_K_M else gguf.TYPE_NAME[wtype])}",
           "llm_config": cfg}

@@ -159,3 +159,35 @@ def test_cache_longer_than_4096_tokens_against_the_real_reference(ctx, tmp_path,
         assert np.array_equal(lg[0].view(np.uint32), g["logits"][s].view(np.uint32)), s
         cur = int(g["ids"][s])
     m.close()
+
+
+def test_scaled_rope_golden(ctx, tmp_path):
+    """rope_freq_scale / rope_attn_factor off 1.0 (src/core/config.cpp:96,98 -> ggml.c:15344-15358): ps_hip_rope and whole-model generations against
+    what the REAL reference produced (tests/golden/rope_scaled.npz, oracle/gen_golden_rope_scaled.py), bit for bit."""
+    from powerserve_amd import hip, synth
+    ops = ((0, 64, 1e4, 0.25, 1.0), (0, 128, 5e5, 0.5, 1.25), (2, 64, 1e6, 0.5, 0.75), (0, 64, 1e4, 1.0, 1.3), (2, 128, 5e5, 0.25, 0.8660254))
+    e2e = (("tiny-llama", 8, 0.5, 1.25), ("tiny-qwen2", 2, 0.25, 0.8), ("tiny-llama", 2, 0.25, 1.0))  # (== the generator's tables: it imports the oracle binding, this test must not)
+    g = np.load(os.path.join(GOLD, "rope_scaled.npz"))
+    for i, (mode, hs, base, fs, af) in enumerate(ops):
+        x, pos = g[f"op{i}_x"], g[f"op{i}_pos"]
+        rp = hip.RopeParams(hs, 4096, base, fs, 0.0, af, 32.0, 0.0, mode)
+        dx, dy = ctx.to_device(x), ctx.empty(x.shape)
+        ctx.check(ctx.L.ps_hip_rope(ctx.h, C.byref(dy.tensor()), C.byref(dx.tensor()), pos.ctypes.data_as(C.c_void_p), pos.size, C.byref(rp)))
+        assert np.array_equal(dy.numpy().view(np.uint32), g[f"op{i}_y"].view(np.uint32)), i
+    for i, (preset, t, fs, af) in enumerate(e2e):
+        d = str(tmp_path / f"m{i}")
+        synth.write_model_dir(d, preset, t, n_ctx=128, seed=777 + i, rope_freq_scale=fs, rope_attn_factor=af)
+        assert _sha(os.path.join(d, "ggml", "weights.gguf")) == str(g[f"e{i}_gguf_sha256"])
+        m = hip.Model(ctx, d, max_batch=16)
+        prompt = g[f"e{i}_prompt"]
+        assert np.array_equal(m.generate(prompt, 8, 20), g[f"e{i}_ids"]), i
+        m.reset()
+        for lo in range(0, 22, 8):
+            hi = min(lo + 8, 22)
+            m.forward(prompt[lo:hi], np.arange(lo, hi), lm_head=False)
+        cur = int(prompt[-1])
+        for s in range(20):  # the fused single-token path (RoPE in the QKV launch's epilogue) step by step
+            lg, _ = m.forward([cur], [m.position], lm_head=True)
+            assert np.array_equal(lg[0].view(np.uint32), g[f"e{i}_logits"][s].view(np.uint32)), (i, s)
+            cur = int(g[f"e{i}_ids"][s])
+        m.close()

@@ -20,12 +20,16 @@ CASES = [("tiny-llama", 2), ("tiny-llama", 8), ("tiny-llama", 12), ("tiny-qwen2"
          ("odd-llama-hs96", 12), ("odd-llama-hs32", 8), ("odd-qwen2-r3", 2), ("odd-llama-r5", 8), ("odd-llama-r6", 13), ("odd-llama-r8", 2)]
 
 
-@pytest.mark.parametrize("preset,wt", CASES)
-def test_generate_matches_oracle(ctx, oracle, tmp_path, preset, wt):
+# rope_freq_scale / rope_attn_factor (src/core/config.cpp:96,98 -> ggml.c:15344-15358) off 1.0: Q4_K through the fused QKV epilogue, Qwen2 through the NEOX kernel
+SCALED_ROPE = [("small-llama-hs128", 12, 0.5, 1.25), ("tiny-qwen2", 8, 0.25, 0.8), ("tiny-llama", 1015, 0.25, 1.0)]
+
+
+@pytest.mark.parametrize("preset,wt,fs,af", [(p, w, 1.0, 1.0) for p, w in CASES] + SCALED_ROPE)
+def test_generate_matches_oracle(ctx, oracle, tmp_path, preset, wt, fs, af):
     from oracle import binding as B
     from powerserve_amd import hip, synth
     d = str(tmp_path / "m")
-    mj = synth.write_model_dir(d, preset, wt, n_ctx=128, seed=wt + len(preset))
+    mj = synth.write_model_dir(d, preset, wt, n_ctx=128, seed=wt + len(preset), rope_freq_scale=fs, rope_attn_factor=af)
     cfg = B.make_config(mj["llm_config"])
     om = oracle.model(cfg, mj["model_arch"], load_tensors(os.path.join(d, "ggml/weights.gguf")), n_threads=4)
     gm = hip.Model(ctx, d, max_batch=16)

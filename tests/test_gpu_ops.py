@@ -301,16 +301,17 @@ def test_rms_norm(ctx, oracle, hip, dim, eps):
     assert np.abs(got.view(np.int32).astype(np.int64) - want.view(np.int32).astype(np.int64)).max() <= 1  # <= 1 ulp
 
 
+@pytest.mark.parametrize("fs,af", [(1.0, 1.0), (0.5, 1.0), (0.25, 1.25), (1.0, 0.8)])  # rope_freq_scale, rope_attn_factor (src/core/config.cpp:96,98)
 @pytest.mark.parametrize("mode,hs,base", [(0, 64, 1e4), (2, 64, 1e6), (0, 128, 5e5)])
-def test_rope_bit_exact(ctx, oracle, hip, mode, hs, base):
+def test_rope_bit_exact(ctx, oracle, hip, mode, hs, base, fs, af):
     from oracle import binding as B
     rng = np.random.default_rng(hs + mode)
     pos = np.array([0, 1, 17, 2047, 4095], dtype=np.int32)
     x = rng.standard_normal((pos.size, 8, hs)).astype(np.float32)
-    rp = hip.RopeParams(hs, 4096, base, 1.0, 0.0, 1.0, 32.0, 0.0, mode)
+    rp = hip.RopeParams(hs, 4096, base, fs, 0.0, af, 32.0, 0.0, mode)
     dx, dy = ctx.to_device(x), ctx.empty(x.shape)
     ctx.check(ctx.L.ps_hip_rope(ctx.h, C.byref(dy.tensor()), C.byref(dx.tensor()), pos.ctypes.data_as(C.c_void_p), pos.size, C.byref(rp)))
-    want = oracle.rope(x, pos, B.RopeParams(hs, 4096, base, 1.0, 0.0, 1.0, 32.0, 0.0, mode))
+    want = oracle.rope(x, pos, B.RopeParams(hs, 4096, base, fs, 0.0, af, 32.0, 0.0, mode))
     assert np.array_equal(dy.numpy(), want)
 
 

@@ -146,3 +146,32 @@ def test_tree_forward_golden(oracle, tmp_path, ci):
     step = m.forward_tree(g[k + "next"], [P + len(acc)], None, kv_vis, True, advance=False)
     assert np.array_equal(bits(step), bits(g[k + "step_logits"]))
     m.close()
+
+
+def test_scaled_rope_golden(oracle, tmp_path):
+    """rope_freq_scale / rope_attn_factor off 1.0 (src/core/config.cpp:96,98 -> ggml.c:15344-15358; tests/golden/rope_scaled.npz made by the REAL reference,
+    oracle/gen_golden_rope_scaled.py): the operator in both rotation modes and whole-model generations, bit for bit."""
+    import importlib.util
+    from oracle import binding as B
+    from powerserve_amd import gguf, synth
+    spec = importlib.util.spec_from_file_location("gen_rs", os.path.join(os.path.dirname(GOLD), "..", "oracle", "gen_golden_rope_scaled.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    g = np.load(os.path.join(GOLD, "rope_scaled.npz"))
+    for i, (mode, hs, base, fs, af) in enumerate(gen.OPS):
+        y = oracle.rope(g[f"op{i}_x"], g[f"op{i}_pos"], B.RopeParams(hs, 4096, base, fs, 0.0, af, 32.0, 0.0, mode))
+        assert np.array_equal(bits(y), bits(g[f"op{i}_y"])), i
+        plain = oracle.rope(g[f"op{i}_x"], g[f"op{i}_pos"], B.RopeParams(hs, 4096, base, 1.0, 0.0, 1.0, 32.0, 0.0, mode))
+        assert not np.array_equal(bits(y), bits(plain))  # (the parameters do something)
+    for i, (preset, t, fs, af) in enumerate(gen.E2E):
+        d = str(tmp_path / f"m{i}")
+        mj = synth.write_model_dir(d, preset, t, n_ctx=128, seed=777 + i, rope_freq_scale=fs, rope_attn_factor=af)
+        path = os.path.join(d, "ggml", "weights.gguf")
+        assert _sha(path) == str(g[f"e{i}_gguf_sha256"]), "synthetic model generator drifted: regenerate (oracle/gen_golden_rope_scaled.py)"
+        rd = gguf.GGUFReader(path)
+        tensors = {n: (ti.type, np.array(rd.data(n)), ti.ne[0], (list(ti.ne) + [1])[1]) for n, ti in rd.tensors.items()}
+        m = oracle.model(B.make_config(mj["llm_config"]), mj["model_arch"], tensors, n_threads=4)
+        ids, logits, *_ = m.generate(g[f"e{i}_prompt"], 8, 20, want_logits=True)
+        m.close()
+        assert np.array_equal(ids, g[f"e{i}_ids"]), i
+        assert np.array_equal(bits(logits), bits(g[f"e{i}_logits"])), i

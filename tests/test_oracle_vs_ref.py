@@ -186,3 +186,32 @@ def test_seeded_random_sweep_against_the_real_reference(ref, fast):
     spec.loader.exec_module(mod)
     n, fails = mod.run(seconds=240, seed=21 + int(fast), max_draws=10, fast=fast)
     assert n == 10 and not fails, fails
+
+
+@pytest.mark.parametrize("fs,af", [(0.5, 1.0), (0.25, 1.25), (1.0, 0.8), (0.3, 0.7)])
+def test_scaled_rope_against_the_real_reference(oracle, ref, tmp_path, fs, af):
+    """rope_freq_scale / rope_attn_factor off 1.0 (src/core/config.cpp:96,98 -> rope_compute_params -> ggml_rope_cache_init, ggml.c:15344-15358): no
+    preset, fixture or fuzz draw had moved them before round 6.  The operator in both rotation modes and whole-model generations, restatement against the live reference."""
+    from conftest import load_tensors
+    from oracle import binding as B
+    from powerserve_amd import synth
+    rng = np.random.default_rng(int(fs * 100 + af * 10))
+    pos = np.array([0, 1, 17, 777, 2047, 4095], dtype=np.int32)
+    for mode, hs, base in ((0, 64, 1e4), (2, 64, 1e6), (0, 128, 5e5), (2, 128, 1e4)):
+        x = rng.standard_normal((pos.size, 3, hs)).astype(np.float32)
+        rp = B.RopeParams(hs, 4096, base, fs, 0.0, af, 32.0, 0.0, mode)
+        assert np.array_equal(bits(ref.rope(x, pos, rp)), bits(oracle.rope(x, pos, rp))), (mode, hs)
+    for preset, t in (("tiny-llama", 8), ("tiny-qwen2", 2)):
+        d = str(tmp_path / preset)
+        mj = synth.write_model_dir(d, preset, t, n_ctx=64, seed=5, rope_freq_scale=fs, rope_attn_factor=af)
+        cfg = B.make_config(mj["llm_config"])
+        path = os.path.join(d, "ggml/weights.gguf")
+        om = oracle.model(cfg, mj["model_arch"], load_tensors(path), n_threads=4)
+        rm = ref.model(path, mj["model_arch"], cfg, 2)
+        prompt = np.random.default_rng(2).integers(0, cfg.vocab_size, 19)
+        ids, lg, *_ = om.generate(prompt, 8, 8, want_logits=True)
+        rids, rlg, *_ = rm.generate(prompt, 8, 8, want_logits=True)
+        om.close()
+        rm.close()
+        assert np.array_equal(ids, rids)
+        assert np.array_equal(bits(lg), bits(rlg))

@@ -27,7 +27,8 @@ def one(preset, wt, n_ctx, P, chunk, steps, mseed, fast):
     r = B.Ref(2, so=B.REF_FAST_SO) if fast else B.Ref(2)
     o.L.pso_set_contract(1 if fast else 0)
     with tempfile.TemporaryDirectory() as d:
-        mj = synth.write_model_dir(d, preset, wt, n_ctx=n_ctx, seed=mseed)
+        fs, af = synth.ROPE_DRAWS[mseed % len(synth.ROPE_DRAWS)]  # (rope_freq_scale, rope_attn_factor: src/core/config.cpp:96,98)
+        mj = synth.write_model_dir(d, preset, wt, n_ctx=n_ctx, seed=mseed, rope_freq_scale=fs, rope_attn_factor=af)
         cfg = B.make_config(mj["llm_config"])
         path = os.path.join(d, "ggml/weights.gguf")
         om = o.model(cfg, mj["model_arch"], load_tensors(path), n_threads=4)

@@ -42,7 +42,8 @@ def main(seed, seconds):
             mseed = int(rng.integers(0, 1 << 30))
             tag = f"{preset} wt={wt} n_ctx={n_ctx} P={P} chunk={chunk} tree={n_tree} seed={mseed}"
             d = os.path.join(tmp, f"m{n}")
-            mj = synth.write_model_dir(d, preset, wt, n_ctx=n_ctx, seed=mseed)
+            fs, af = synth.ROPE_DRAWS[mseed % len(synth.ROPE_DRAWS)]
+            mj = synth.write_model_dir(d, preset, wt, n_ctx=n_ctx, seed=mseed, rope_freq_scale=fs, rope_attn_factor=af)
             cfg = B.make_config(mj["llm_config"])
             tensors = load(os.path.join(d, "ggml", "weights.gguf"))
             om = o.model(cfg, mj["model_arch"], tensors, n_threads=4)

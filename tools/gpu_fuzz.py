@@ -119,7 +119,8 @@ def model_case(tmp):
     if args.verbose:
         print("draw", tag, flush=True)
     d = os.path.join(tmp, f"m{n_models}")
-    mj = synth.write_model_dir(d, preset, wt, n_ctx=n_ctx, seed=seed)
+    fs, af = synth.ROPE_DRAWS[seed % len(synth.ROPE_DRAWS)]  # (rope_freq_scale, rope_attn_factor: src/core/config.cpp:96,98)
+    mj = synth.write_model_dir(d, preset, wt, n_ctx=n_ctx, seed=seed, rope_freq_scale=fs, rope_attn_factor=af)
     cfg = B.make_config(mj["llm_config"])
     om = oracle.model(cfg, mj["model_arch"], load_tensors(os.path.join(d, "ggml/weights.gguf")), n_threads=8)
     gm = hip.Model(ctx, d, max_batch=max_batch)
