@@ -95,6 +95,8 @@ def build(force: bool = False, verbose: bool = True, contract: bool = True, time
     if contract and (jobs or not os.path.exists(cso)):
         subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", cso, *cobjs], check=True)
     tso = os.path.join(LIBDIR, "libps_hip_timeline.so")
+    if not timeline and jobs and os.path.exists(tso):
+        os.remove(tso)  # (a kernel was rebuilt without its timeline twin: the timeline tools prefer that library when it exists and would time an OLD kernel)
     if timeline and (jobs or not os.path.exists(tso)):
         subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tso, *tobjs], check=True)
     build_host(force or bool(jobs), verbose)

@@ -179,20 +179,20 @@ auto Model::forward_graph(const std::vector<int> &tokens, const std::vector<int>
     // (batch size, lm_head) whose canonical graph HIPBackend::plan has already lowered for this model needs no second graph: the lowered launch sequence
     // depends on the graph only through what the cache key and the call's own arguments (tokens, consecutive positions from the cache position) carry.
     // Explicit masks, op-by-op mode and plan-only queries build and plan their graph as before.
-    const bool consecutive = [&] { for (size_t i = 1; i < bs; i++) if (pos[i] != pos[0] + (int)i) return false; return (size_t)pos[0] == m_platform->get_kv_position(m_config->model_id); }();
-    if (m_use_fused && m_use_plan_cache && !plan_only && mask.mask.empty() && consecutive && m_lowered_shapes.count({bs, lm_head})) {
-        m_last_lowered = true;
-        n_plan_cache_hits++;
-        std::vector<int32_t> t(tokens.begin(), tokens.end()), p(pos.begin(), pos.end());
+    // ONE copy of the protocol both branches follow (round-5 advice): enqueue -> look at the one-launch attention's time-out flag -> on a time-out (the device
+    // model has switched to the two launches) enqueue ONCE more -> advance the cache -> hand back ids (device arg-max, 4 bytes per token) or logits
+    auto run_checked = [&](auto &&enqueue) {
         for (int attempt = 0;; attempt++) {
-            if (ps_hip_model_forward_lowered(be.m_model, t.data(), (int)bs, p.data(), nullptr, lm_head ? 1 : 0)) POWERSERVE_ABORT(std::string("lowered forward: ") + ps_hip_last_error(be.m_ctx));
+            enqueue();
             const int rc = ps_hip_model_sync_check(be.m_model);
             if (rc == 0) break;
-            if (rc != PS_HIP_ATTN_TIMEOUT || attempt > 0) POWERSERVE_ABORT(std::string("lowered forward: ") + ps_hip_last_error(be.m_ctx));
+            if (rc != PS_HIP_ATTN_TIMEOUT || attempt > 0) POWERSERVE_ABORT(std::string("lowered forward: ") + ps_hip_last_error(be.m_ctx)); // a HIP error is not retried; a time-out once
         }
+    };
+    auto finish = [&](const void *logits_dev, bool lowered) -> LogitsVector {
         be.m_kv->advance((int)bs);
         if (!lm_head) { be.sync(); return LogitsVector(); }
-        if (ids) {
+        if (ids && lowered) { // greedy caller, lowered forward: the arg-max kernel behind the lm_head has the answer
             std::vector<int32_t> am(bs);
             if (ps_hip_model_argmax(be.m_model, (int)bs, am.data())) POWERSERVE_ABORT(std::string("arg-max copy: ") + ps_hip_last_error(be.m_ctx));
             ids->assign(am.begin(), am.end());
@@ -201,9 +201,18 @@ auto Model::forward_graph(const std::vector<int> &tokens, const std::vector<int>
         Stride st = {4, 4 * (size_t)llm.vocab_size, 4 * (size_t)llm.vocab_size * bs, 4 * (size_t)llm.vocab_size * bs};
         auto host = std::make_shared<CPUBuffer>(st, (size_t)llm.vocab_size * bs * 4);
         be.sync();
-        if (ps_hip_memcpy_d2h(be.m_ctx, host->m_data, ps_hip_model_logits(be.m_model), host->m_storage.size()))
-            POWERSERVE_ABORT(std::string("logits copy: ") + ps_hip_last_error(be.m_ctx));
+        if (ps_hip_memcpy_d2h(be.m_ctx, host->m_data, logits_dev, host->m_storage.size())) POWERSERVE_ABORT(std::string("logits copy: ") + ps_hip_last_error(be.m_ctx));
         return LogitsVector(host, llm.vocab_size, bs);
+    };
+    const bool consecutive = [&] { for (size_t i = 1; i < bs; i++) if (pos[i] != pos[0] + (int)i) return false; return (size_t)pos[0] == m_platform->get_kv_position(m_config->model_id); }();
+    if (m_use_fused && m_use_plan_cache && !plan_only && mask.mask.empty() && consecutive && m_lowered_shapes.count({bs, lm_head})) {
+        m_last_lowered = true;
+        n_plan_cache_hits++;
+        std::vector<int32_t> t(tokens.begin(), tokens.end()), p(pos.begin(), pos.end());
+        run_checked([&] {
+            if (ps_hip_model_forward_lowered(be.m_model, t.data(), (int)bs, p.data(), nullptr, lm_head ? 1 : 0)) POWERSERVE_ABORT(std::string("lowered forward: ") + ps_hip_last_error(be.m_ctx));
+        });
+        return finish(ps_hip_model_logits(be.m_model), true);
     }
     Graph g(m_config->model_id);
     auto x = g.get_embedding(g.add_tensor(m_weights->token_embedding_table), tokens);
@@ -218,34 +227,23 @@ auto Model::forward_graph(const std::vector<int> &tokens, const std::vector<int>
         auto normed = g.rms_norm(x, g.add_tensor(m_weights->rms_final_weight), llm.norm_eps);
         logits = g.mat_mul(g.add_tensor(m_weights->output_weight), normed);
     }
-    for (int attempt = 0;; attempt++) {
+    if (plan_only) { // (Model::prefill asks whether this chunk shape lowers; nothing runs, and the backend forgets the probe's lowering: be.lowered() describes graphs that ran)
         Executor executor(*m_platform, g);
         executor.plan();
         m_last_lowered = executor.lowered();
         if (m_last_lowered && m_use_plan_cache && mask.mask.empty()) m_lowered_shapes.insert({bs, lm_head});
-        if (plan_only) return LogitsVector(); // (Model::prefill asks whether this chunk shape lowers; nothing has run)
-        if (!executor.lowered()) executor.allocate_buffers(); // a lowered graph runs in the device model's own arena
-        executor.run();
-        // a lowered single-token forward is only enqueued: its one-launch attention may have given up at its exchange (bounded wait); the
-        // device model has then switched to the two launches and the same graph runs once more before anything counts
-        const int rc = ps_hip_model_sync_check(be.m_model);
-        if (rc == 0) break;
-        if (rc != PS_HIP_ATTN_TIMEOUT || attempt > 0) POWERSERVE_ABORT(std::string("lowered forward: ") + ps_hip_last_error(be.m_ctx)); // a HIP error is not retried; a time-out once
-    }
-    be.m_kv->advance((int)bs);
-    if (!lm_head) { be.sync(); return LogitsVector(); }
-    if (ids && m_last_lowered) { // greedy caller, lowered graph: the arg-max kernel behind the lm_head has the answer, 4 bytes per token
-        std::vector<int32_t> am(bs);
-        if (ps_hip_model_argmax(be.m_model, (int)bs, am.data())) POWERSERVE_ABORT(std::string("arg-max copy: ") + ps_hip_last_error(be.m_ctx));
-        ids->assign(am.begin(), am.end());
+        be.discard_plan();
         return LogitsVector();
     }
-    Stride st = {4, 4 * (size_t)llm.vocab_size, 4 * (size_t)llm.vocab_size * bs, 4 * (size_t)llm.vocab_size * bs};
-    auto host = std::make_shared<CPUBuffer>(st, (size_t)llm.vocab_size * bs * 4);
-    be.sync();
-    if (ps_hip_memcpy_d2h(be.m_ctx, host->m_data, logits->get<HIPBuffer>().m_data, host->m_storage.size()))
-        POWERSERVE_ABORT(std::string("logits copy: ") + ps_hip_last_error(be.m_ctx));
-    return LogitsVector(host, llm.vocab_size, bs);
+    run_checked([&] {
+        Executor executor(*m_platform, g);
+        executor.plan();
+        m_last_lowered = executor.lowered();
+        if (m_last_lowered && m_use_plan_cache && mask.mask.empty()) m_lowered_shapes.insert({bs, lm_head});
+        if (!executor.lowered()) executor.allocate_buffers(); // a lowered graph runs in the device model's own arena
+        executor.run(); // (a lowered single-token forward is only enqueued: run_checked looks at its attention's flag before anything counts)
+    });
+    return finish(logits ? logits->get<HIPBuffer>().m_data : nullptr, m_last_lowered);
 }
 
 auto Model::decode(const std::vector<Token> &tokens, const std::vector<int> &pos, bool lm_head) -> std::vector<Token> {

@@ -505,10 +505,12 @@ size_t ps_hip_model_kv_position(const ps_hip_model *m) { return m->position; }
 int ps_hip_model_max_batch(const ps_hip_model *m) { return m->max_batch; }
 static void unmask_range(ps_hip_model *m, size_t from, size_t n);
 extern "C" int ps_hip_model_sync_check(ps_hip_model *m);
+static int settle_pending(ps_hip_model *m);
 // slots at or behind the position are never consulted through the visibility table (the causal / tree mask governs them)
 // and KVCache::advance_tokens / append un-hides what it walks over (core/kv_cache.hpp:249-255): a rollback or truncate
 // leaves no hidden slot behind the new position, so a model that served as a speculative draft can decode again
 int ps_hip_model_kv_truncate(ps_hip_model *m, size_t n) {
+    if (int rc = settle_pending(m)) return rc; // (every KV entry point: an unconsumed lowered forward's time-out belongs to ITS caller, not to the next forward)
     if (n < m->position) m->position = n;
     unmask_range(m, m->position, m->cfg.seq_len - m->position);
     return 0;
@@ -532,12 +534,14 @@ int ps_hip_model_kv_advance(ps_hip_model *m, size_t n) {
     return 0;
 }
 int ps_hip_model_kv_rollback(ps_hip_model *m, size_t n) {
+    if (int rc = settle_pending(m)) return rc;
     if (n > m->position) { m->ctx->err = "kv_rollback: more tokens than cached"; return 2; }
     m->position -= n;
     unmask_range(m, m->position, m->cfg.seq_len - m->position);
     return 0;
 }
 int ps_hip_model_kv_move(ps_hip_model *m, size_t dst, size_t src) {
+    if (int rc = settle_pending(m)) return rc; // (rows of a forward whose result is invalid must not be copied)
     if (dst == src) return 0;
     if (dst >= m->cfg.seq_len || src >= m->cfg.seq_len) { m->ctx->err = "kv_move: index out of range"; return 2; }
     for (uint32_t L = 0; L < m->cfg.n_layers; L++)
@@ -550,10 +554,12 @@ int ps_hip_model_kv_copy(ps_hip_model *m, size_t dst_cache_index, size_t src_tok
     return ps_hip_model_kv_move(m, dst_cache_index, m->position + src_token_index);
 }
 int ps_hip_model_kv_save_tokens(ps_hip_model *m, size_t n) {
+    if (int rc = settle_pending(m)) return rc;
     if (m->position + n > m->cfg.seq_len) { m->ctx->err = "kv_save_tokens: the length of kvcache is up to the preset threshold (n_ctx)"; return 2; }
     return 0;
 }
 int ps_hip_model_kv_unmask_tokens(ps_hip_model *m, size_t n) {
+    if (int rc = settle_pending(m)) return rc;
     if (m->position + n > m->cfg.seq_len) { m->ctx->err = "kv_unmask_tokens: the length of kvcache is up to the preset threshold (n_ctx)"; return 2; }
     unmask_range(m, m->position, n);
     return 0;
@@ -778,6 +784,7 @@ static int forward_tree_impl(ps_hip_model *m, const int32_t *tokens, int n, cons
 
 int ps_hip_model_kv_mask(ps_hip_model *m, size_t index, int visible) {
     ps_hip_ctx *c = m->ctx;
+    if (int rc = settle_pending(m)) return rc;
     if (index >= m->cfg.seq_len) PS_FAIL(c, "kv_mask: index out of range");
     const uint8_t v = visible ? 1 : 0;
     if (m->kv_vis_host[index] == v) return 0;

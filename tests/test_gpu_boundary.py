@@ -160,6 +160,35 @@ def test_timeout_retry_host_graph_path(ctx, oracle, tmp_path):
     om.close()
 
 
+def test_timeout_retry_on_a_plan_cache_hit(ctx, oracle, tmp_path):
+    """The façade's OTHER branch (round-5 advice): once the (1 token, lm_head) shape has been lowered, Model::forward / Model::decode run the cached launch plan without
+    a graph; a time-out there is answered by the same one re-run (both branches share Model::forward_graph's run_checked / finish), the cache advances once,
+    and the device arg-max of the greedy caller is the re-run's."""
+    from oracle import binding as B
+    from powerserve_amd import host, synth
+    d = str(tmp_path / "m")
+    mj = synth.write_model_dir(d, "tiny-llama", 12, n_ctx=128, seed=5)
+    cfg = B.make_config(mj["llm_config"])
+    om = oracle.model(cfg, mj["model_arch"], load_tensors(os.path.join(d, "ggml/weights.gguf")), n_threads=4)
+    hm = host.HostModel(d, max_batch=16)
+    prompt = np.random.default_rng(3).integers(0, cfg.vocab_size, 14)
+    hm.forward(prompt[:9], np.arange(9), lm_head=False)
+    om.forward(prompt[:9], np.arange(9), False)
+    lg = hm.forward([int(prompt[9])], [9], lm_head=True)  # builds, plans and lowers the (1, lm_head) graph: the shape is cached from here on
+    assert np.array_equal(bits(lg[0]), bits(om.forward([int(prompt[9])], [9], True)[0]))
+    hits = hm.plan_cache_hits()
+    force(ctx)
+    lg = hm.forward([int(prompt[10])], [10], lm_head=True)  # cache hit + forced time-out
+    assert ctx.L.ps_hip_debug_set(5, 0) == 0
+    assert hm.plan_cache_hits() == hits + 1 and hm.position == 11
+    want = om.forward([int(prompt[10])], [10], True)[0]
+    assert np.array_equal(bits(lg[0]), bits(want))
+    ids = hm.decode([int(prompt[11])], [11])  # (the model is on the two launches now; the greedy caller's 4-byte path)
+    assert int(ids[0]) == int(np.argmax(om.forward([int(prompt[11])], [11], True)[0])) and hm.position == 12
+    hm.close()
+    om.close()
+
+
 # ---------------------------------------------------------------------------------------------- boundary leftovers
 @pytest.mark.parametrize("n", [1, 33, 300])
 def test_soft_max_entry_and_graph_softmax(ctx, oracle, tmp_path, n):
