@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(HERE, "build")
-SOURCES = ["api.hip", "model.hip", "k_quant.hip", "k_gemv.hip", "k_gemv4.hip", "k_gemvb.hip", "k_gemvk.hip", "k_gemm4k.hip", "k_gemv6.hip", "k_ops.hip", "k_attn.hip", "perf16.hip"]
+SOURCES = ["api.hip", "model.hip", "k_quant.hip", "k_gemv.hip", "k_gemv4.hip", "k_qkvattn.hip", "k_gemvb.hip", "k_gemvk.hip", "k_gemm4k.hip", "k_gemv6.hip", "k_ops.hip", "k_attn.hip", "perf16.hip"]
 # -ffp-contract=off: the parity contract needs every fp32 op to round where the reference's C source rounds;
 # fused multiply-adds are written explicitly (__fmaf_rn) where the reference uses FMA intrinsics.
 # -fno-slp-vectorize (NOSLP files only): hipcc's SLP vectoriser packs adjacent scalar fp32 operations into v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32.  On
@@ -22,7 +22,7 @@ SOURCES = ["api.hip", "model.hip", "k_quant.hip", "k_gemv.hip", "k_gemv4.hip", "
 # exact compile configuration that has passed the full GPU suite and all bench configurations.)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-result",
          "-I" + os.path.join(HERE, "..", "include")]
-NOSLP = {"k_gemv4.hip", "k_gemvb.hip", "k_attn.hip", "k_gemm4k.hip"}  # k_gemm4k.hip (round 5): gate/up chunk launch of a 512-column sequence 384.2 -> 369-371 us, same bits (profiles/r05_g4k2_variants.txt, the "v2 0" lines vs profiles/r05_g4k_item_order.txt)  # (k_gemvb.hip: the Q4_0 / Q8_0 mat-vec, Llama-3.2-1B 1494 -> 1525 tok/s)
+NOSLP = {"k_gemv4.hip", "k_qkvattn.hip", "k_gemvb.hip", "k_attn.hip", "k_gemm4k.hip"}  # k_gemm4k.hip (round 5): gate/up chunk launch of a 512-column sequence 384.2 -> 369-371 us, same bits (profiles/r05_g4k2_variants.txt, the "v2 0" lines vs profiles/r05_g4k_item_order.txt)  # (k_gemvb.hip: the Q4_0 / Q8_0 mat-vec, Llama-3.2-1B 1494 -> 1525 tok/s)
 
 
 def _cmd_changed(obj: str, cmd: list) -> bool:
@@ -45,11 +45,11 @@ def _newer(src: str, obj: str) -> bool:
 # The files that hold one of the reference's fp-contraction sites (ps_dev.h: ps_rope_pair / ps_rope_one / ps_dot_left, and the Q5_K refusal): only they are
 # compiled a second time for lib/libps_hip_contract.so (-DPS_CONTRACT: the reference's stock -ffp-contract=fast build, include/ps_hip.h ps_hip_build_contract);
 # every other object is shared with the default library.
-CONTRACT_SOURCES = {"api.hip", "k_ops.hip", "k_attn.hip", "k_gemm4k.hip", "k_gemv4.hip", "k_gemvb.hip", "k_gemvk.hip"}
+CONTRACT_SOURCES = {"api.hip", "k_ops.hip", "k_attn.hip", "k_gemm4k.hip", "k_gemv4.hip", "k_qkvattn.hip", "k_gemvb.hip", "k_gemvk.hip"}
 
 
 # Files with in-kernel timeline marks (ps_dev.h PS_TIMELINE): compiled a third time, on demand, for lib/libps_hip_timeline.so -- the library the timeline tools load.
-TIMELINE_SOURCES = {"api.hip", "k_gemv4.hip", "k_attn.hip", "k_gemm4k.hip"}
+TIMELINE_SOURCES = {"api.hip", "k_gemv4.hip", "k_qkvattn.hip", "k_attn.hip", "k_gemm4k.hip"}
 
 
 def build(force: bool = False, verbose: bool = True, contract: bool = True, timeline: bool = False) -> str:

@@ -97,11 +97,10 @@ struct HIPBackend {
     void plan(std::vector<std::shared_ptr<OpNode>> &ops);
     bool lowered() const { return m_low.ok; }
     void run_lowered();                 // Executor::run, lowered graph
-    int n_plans = 0, n_lowered = 0;     // statistics (tests, bench): graphs planned / lowered that were meant to RUN
-    int n_probes = 0;                   // plan-only queries (Model::prefill asking whether a chunk shape lowers), counted apart
-    void discard_plan() {               // a plan-only query: nothing of it is retained, lowered() is about graphs that run
-        if (m_low.ok) n_lowered--;
-        n_plans--; n_probes++;
+    int n_plans = 0, n_lowered = 0;     // statistics (tests, bench): graphs handed to plan() / lowered by it, plan-only queries included ...
+    int n_probes = 0;                   // ... which are also counted here (Model::prefill asking whether a chunk shape lowers)
+    void discard_plan() {               // a plan-only query: nothing of it is retained -- lowered() and run_lowered() are about graphs that run
+        n_probes++;
         m_low = Lowered{};
     }
     void setup_work_data(size_t) {}

@@ -303,6 +303,7 @@ static int enqueue_forward(ps_hip_model *m, int bs, bool lm_head, bool use_tree,
         // batches of Q4_K weights: the same, in the chunk mat-mul's epilogue (k_gemm4k.hip)
         const bool fuse_rope_b = bs > 1 && !aa.neox && psk_gemm4k_rope_ok(g, dim, bs);
         if ((fuse_rope || fuse_rope_b) && !f16) g.rope = &rk;
+        bool fused_qa = false;
         if (f16) {
             psf16_rmsnorm_to_h(st, m->x, m->attn_norm[L], f.norm_eps, dim, bs, m->xh);
             {
@@ -312,11 +313,17 @@ static int enqueue_forward(ps_hip_model *m, int bs, bool lm_head, bool use_tree,
                 if (psf16_gemm_n(c, m->pf, 3, W3, n3, dim, m->xh, bs, o3, n3, 0.f)) return 2; // Q, K, V: one launch
             }
             if (m->qwen2) { psf16_add_bias(st, m->q, m->bq[L], dim, bs); psf16_add_bias(st, m->k, m->bk[L], kvd, bs); psf16_add_bias(st, m->v, m->bv[L], kvd, bs); }
+        } else if (bs == 1 && !use_tree && one_launch && !kv16 && g.rope && (m->mode & 128) == 0 &&
+                   (aa.dbg = psk_gemv_dbg_buf(10, 3), psk_qkv_attn(st, c->n_cu, g, dim, aa))) { // timeline key 43
+            // the head of the layer in ONE launch: Q / K / V mat-vec + RoPE + KV append + single-token attention (k_qkvattn.hip); mode bit 7 brings the two launches back
+            aa.dbg = nullptr;
+            fused_qa = true;
         } else if (mm(m, g, a1, dim, bs)) return 2;
 
         if (f16 || (!fuse_rope && !fuse_rope_b)) psl_rope_append(st, aa, bs);
         bool att_quantized = false;
-        if (bs == 1 && !use_tree && kv16 && psl_attn_decode_f16(st, aa)) {
+        if (fused_qa) {
+        } else if (bs == 1 && !use_tree && kv16 && psl_attn_decode_f16(st, aa)) {
             // fp16-KV decode mode (not bit-exact): split-KV online soft-max over the fp16 mirrors
         } else if (bs == 1 && !use_tree && one_launch && (aa.dbg = psk_gemv_dbg_buf(10, 2), psl_attn_decode2(st, c->n_cu, aa))) { // timeline key 42
             aa.dbg = nullptr;
@@ -979,7 +986,7 @@ int ps_hip_model_set_mode(ps_hip_model *m, int mode) {
         if (dmalloc(m, (void **)&m->attn_part, (size_t)m->cfg.n_heads * 32 * (m->cfg.head_size + 2) * 4)) return 2;
     }
     if ((mode & 8) && !(m->mode & 8) && m->position != 0) { m->ctx->err = "set_mode: the fp16-KV decode mode must be switched on while the cache is empty"; return 2; }
-    if ((m->mode ^ mode) & 62) drop_graphs(m); // the captured steps bake the launch plan in
+    if ((m->mode ^ mode) & (62 | 128)) drop_graphs(m); // the captured steps bake the launch plan in
     m->mode = mode;
     return 0;
 }

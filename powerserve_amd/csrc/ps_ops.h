@@ -55,6 +55,9 @@ bool psl_attn_pv_quantizes(const psl_attn_args &a, int bs); // whether psl_attn_
 bool psl_attn_decode_f16(hipStream_t st, const psl_attn_args &a); // single token over the fp16 mirrors: split-KV online soft-max + combine (NOT bit-exact); false: not covered
 bool psl_attn_decode2(hipStream_t st, int n_cu, const psl_attn_args &a); // single token: scores + soft-max + V.p in one launch (counter exchange of the scores, V.p on the matrix cores); false: not covered
 size_t psl_attn_decode2_xchg_bytes(int n_kv_heads, int n_ctx);
+// Q / K / V mat-vec (RMSNorm + quantizer prologue, RoPE + KV append: g.rope set) AND the single-token attention in one launch (k_qkvattn.hip): four launches per decode
+// layer instead of five; false: not covered, the caller issues psk_gemv4 + psl_attn_decode2
+bool psk_qkv_attn(hipStream_t st, int n_cu, const psk_gemv_args &g, int64_t K, const psl_attn_args &a);
 size_t psl_attn_softmax_pv_lds(const psl_attn_args &a); // dynamic LDS bytes (grows with n_ctx)
 // two-stage arg-max (64 partials per row).  With state != NULL the final stage also does the greedy-decode
 // bookkeeping: token[0] = id, ids[state->n_out++] = id, state->pos0++.

@@ -97,10 +97,11 @@ def test_one_launch_attention_is_bit_identical(ctx, oracle, tmp_path):
 
 
 @pytest.mark.parametrize("preset,n_ctx,P", [("small-llama-hs128", 4096, 2090), ("small-llama-hs128", 2048, 1031), ("small-llama", 4096, 2215),
-                                            ("small-llama-hs128", 160, 97)])
+                                            ("small-llama-hs128", 160, 97), ("llama-1b-dims-2l", 1024, 515), ("small-llama-hs128", 1024, 31)])
 def test_decode_attention_long_cache_matches_oracle(ctx, oracle, tmp_path, preset, n_ctx, P):
-    """The single-token attention (attn_decode2: scores exchanged as tagged granules, soft-max in registers, V.p on the
-    matrix cores) behind a LONG cache — several position rounds per workgroup, hinted and un-hinted K rows, both gather
+    """The single-token attention (round 6: fused with the Q / K / V mat-vec into qkv_attn_kernel where the shape allows it -- head size 128 and, with
+    llama-1b-dims-2l, 64; the 31-token prompt walks the new position across a 128-byte line of the V rows and a group of 8 K rows -- otherwise attn_decode2:
+    scores exchanged through a counter rendezvous, soft-max in registers, V.p on the matrix cores) behind a LONG cache — several position rounds per workgroup, hinted and un-hinted K rows, both gather
     trips, the n_kv % 8 / n_kv % 32 leftovers walking through all their values — bit-exact against the oracle, eager and
     hipGraph replay, and identical to the two-launch kernels (mode bit 4) also with hidden cache slots (kv_mask), which the
     CPU executor cannot express."""
@@ -127,7 +128,7 @@ def test_decode_attention_long_cache_matches_oracle(ctx, oracle, tmp_path, prese
     # hidden slots: the two attention plans agree bit for bit (and differ from the unmasked logits)
     hidden = [3, 40, P // 2, P - 2]
     outs = []
-    for mode in (0, 16):
+    for mode in (0, 128, 16):  # the fused QKV + attention launch / its two launches (QKV mat-vec, attn_decode2) / scores + soft-max.V.p behind the QKV mat-vec
         gm.set_mode(mode)
         gm.kv_rollback(5)
         for h in hidden:
@@ -139,8 +140,38 @@ def test_decode_attention_long_cache_matches_oracle(ctx, oracle, tmp_path, prese
         for h in hidden:
             gm.kv_mask(h, True)
         outs.append(np.stack(res))
-    assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32))
+    assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32)) and np.array_equal(outs[0].view(np.uint32), outs[2].view(np.uint32))
     assert not np.array_equal(outs[0][0], np.asarray(want_logits[steps - 5]))                     # (unmasked, these would be step steps - 5's logits)
+    gm.close()
+    om.close()
+
+
+@pytest.mark.parametrize("preset", ["small-llama-hs128", "llama-1b-dims-2l"])
+def test_fused_qkv_attention_from_an_empty_cache(ctx, oracle, tmp_path, preset):
+    """qkv_attn_kernel (k_qkvattn.hip: the Q / K / V mat-vec and the single-token attention in ONE launch) one token at a time from position 0: no cached row at
+    all, then positions walking through the first groups of 8 K rows and across the first 128-byte lines of the V rows (32, 64) -- what it asks of the cache before
+    its rendezvous (rows below the position, whole lines below it) and what after (the new row, the line with the new column) changes at every one of them.
+    Logits on bits against the oracle, the same from the two launches it replaces (mode bit 7), and the captured step from an empty cache."""
+    from oracle import binding as B
+    from powerserve_amd import hip, synth
+    d = str(tmp_path / "m")
+    mj = synth.write_model_dir(d, preset, 12, n_ctx=256, seed=13)
+    cfg = B.make_config(mj["llm_config"])
+    om = oracle.model(cfg, mj["model_arch"], load_tensors(os.path.join(d, "ggml/weights.gguf")), n_threads=16)
+    toks = np.random.default_rng(2).integers(0, cfg.vocab_size, 70)
+    want = [om.forward([int(t)], [i], True)[0] for i, t in enumerate(toks)]
+    gm = hip.Model(ctx, d, max_batch=8, n_ctx=256)
+    for mode in (1, 129):  # eager: fused / two launches
+        gm.set_mode(mode)
+        gm.reset()
+        for i, t in enumerate(toks):
+            lg, _ = gm.forward([int(t)], [i], lm_head=True)
+            assert np.array_equal(np.asarray(lg[0]).view(np.uint32), np.asarray(want[i]).view(np.uint32)), (mode, i)
+    om.reset()
+    want_ids, *_ = om.generate(toks[:1], 8, 40)
+    gm.set_mode(0)
+    gm.reset()
+    assert np.array_equal(gm.generate(toks[:1], 8, 40), want_ids)  # hipGraph replay from position 0
     gm.close()
     om.close()
 
