@@ -261,7 +261,8 @@ int ps_hip_debug_timeline(ps_hip_ctx *ctx, int key, uint64_t *host_out, int n_wo
  * 0 = by shape, 1 = 128-token tiles, 2 = 256 x 256 tiles); key 5: the next `value` single-token forwards on the one-launch attention
  * report a time-out of its score exchange (tests of the retry paths: forward, forward_tree, prefill tail, decode_greedy, lowered forward +
  * kv_advance); key 6: column blocks per XCD of the wide Q4_K / Q5_K mat-mul's item order (k_gemm4k.hip g4k_item: 0 = round 2's order, default 4;
- * PS_G4K_CBX).  Returns non-zero for an unknown key. */
+ * PS_G4K_CBX); key 7: 1 = the fused Q / K / V + attention launch (k_qkvattn.hip) wherever it is covered -- by default only where its grid fills three quarters
+ * of the chip (head size 128 with 8 kv heads), the head-size-64 instance otherwise runs under test only.  Returns non-zero for an unknown key. */
 int ps_hip_debug_set(int key, int value);
 /* Diagnostic: one GEMM shape of the fp16 perf mode on synthetic operands (tools/f16_gemm_bench.py): out[M][N] = x[M][K] . W[N][K]^T, timed over
  * `reps` launches (with beta: out = beta out + ...), max |difference| to a k-ordered fp32 reference (beta != 0: of a second launch on top of
@@ -282,6 +283,9 @@ int ps_hip_debug_f16_gemm(ps_hip_ctx *ctx, int M, int64_t N, int64_t K, int reps
  * as dense fp16 GEMMs (fp32 accumulation) on dequantized fp16 copies of the matrices made at first use (+2 bytes per weight), the
  * backend's own matrix-core kernel (csrc/perf16.hip; row lengths must be multiples of 64); RoPE, KV append and attention stay the parity kernels on
  * the FP32 cache, single tokens and tree forwards stay entirely on the parity path.
+ * bit 7: 1 = the head of a single-token layer as TWO launches (Q / K / V mat-vec with RoPE + KV append, then the one-launch attention) instead of the fused
+ * qkv_attn_kernel (k_qkvattn.hip, round 6: four launches per decode layer where the shape is covered).  Same results bit for bit; bit 4 implies it
+ * (the fused launch contains the one-launch attention's exchange, its time-out is the same flag and the same fallback).
  * The environment variable PS_HIP_MODE_OR is OR-ed into every mode (A/B runs of unmodified drivers). */
 int ps_hip_model_set_mode(ps_hip_model *m, int mode);
 

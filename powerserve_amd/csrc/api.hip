@@ -474,13 +474,14 @@ int ps_hip_debug_timeline(ps_hip_ctx *ctx, int key, uint64_t *host_out, int n_wo
 }
 
 int ps_hip_debug_set(int key, int value) {
-    extern int g_g4_cfg, g_g4_flags, g_g4k_par, g_f16_variant, g_force_attn_timeout, g_g4k_cbx;
+    extern int g_g4_cfg, g_g4_flags, g_g4k_par, g_f16_variant, g_force_attn_timeout, g_g4k_cbx, g_qa_force;
     if (key == 1) { g_g4_cfg = value; return 0; }
     if (key == 2) { g_g4_flags = value; return 0; }
     if (key == 3) { g_g4k_par = value; return 0; }
     if (key == 4) { g_f16_variant = value; return 0; }
     if (key == 5) { g_force_attn_timeout = value; return 0; }
     if (key == 6) { g_g4k_cbx = value; return 0; }
+    if (key == 7) { g_qa_force = value; return 0; } // the fused QKV + attention launch wherever it is covered (default: only where its grid fills 3/4 of the chip)
     return 1;
 }
 

@@ -597,6 +597,8 @@ size_t qa_lds_bytes(const QAParams &p, int hs) {
 
 } // namespace
 
+int g_qa_force = 0; // ps_hip_debug_set(7, v)
+
 // Q / K / V mat-vec (RMSNorm + quantizer prologue, RoPE + KV append) + single-token attention in ONE launch.  false: not covered -- the caller issues the two launches.
 bool psk_qkv_attn(hipStream_t st, int n_cu, const psk_gemv_args &g, int64_t K, const psl_attn_args &a) {
     static const bool off = getenv("PS_NO_QKV_ATTN") != nullptr; // (A/B switch for measurements)
@@ -609,6 +611,12 @@ bool psk_qkv_attn(hipStream_t st, int n_cu, const psk_gemv_args &g, int64_t K, c
     if (!a.xchg || !a.tick || !a.sync || a.tree || a.rope_pos || a.neox || a.k16 || a.v16 || r2 > 4 || a.n_ctx > QA_MAXCTX || a.n_dims > hs) return false;
     if (g.w[0]->N != (int64_t)a.n_heads * hs || g.w[1]->N != (int64_t)a.n_kv_heads * hs || g.w[2]->N != g.w[1]->N) return false;
     if (G * a.n_kv_heads > n_cu) return false; // every workgroup resident (one per CU: the LDS)
+    // The launch has head_size / 4 workgroups per kv head: 256 for Llama-3.1-8B's shape, 128 for Llama-3.2-1B's (head size 64) -- half the chip for a mat-vec that the
+    // unfused launch spreads over every CU: measured slower there (tools/gpu_fused_stress.py, profiles/r06_fused_stress.txt: 11.9 k vs 12.4 k tok/s on the 2-layer
+    // 1B shape in Q4_K, against 4.84 k vs 4.77 k on the 4-layer 8B shape).  Taken only where its grid fills at least three quarters of the chip;
+    // ps_hip_debug_set(7, 1) takes it wherever it is covered (the tests of the head-size-64 instance).
+    extern int g_qa_force;
+    if (!g_qa_force && 4 * G * a.n_kv_heads < 3 * n_cu) return false;
     QAParams p{};
     for (int i = 0; i < 3; i++) { p.qs[i] = g.w[i]->qs; p.aux[i] = g.w[i]->aux; p.bias[i] = g.bias[i]; }
     p.n_units = (int)(K / 256); p.K = (int)K; p.col_bytes = (int)psk_gemv_lds_col_bytes(PS_Q4_K, K);

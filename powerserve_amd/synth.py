@@ -146,8 +146,12 @@ def tensor_plan(cfg: dict, arch: str, wtype: int, tied: bool, embd_type: int | N
 
 
 def write_model_dir(out_dir: str, preset: str, wtype: int, n_ctx: int, seed: int = 1234, std: float = 0.02,
-                    embd_type: int | None = None, model_id: str | None = None, rope_freq_scale: float = 1.0, rope_attn_factor: float = 1.0) -> dict:
-    """Create <out_dir>/{model.json, ggml/weights.gguf}; returns the model.json dict."""
+                    embd_type: int | None = None, model_id: str | None = None, rope_freq_scale: float = 1.0, rope_attn_factor: float = 1.0,
+                    late_layers: tuple | None = None) -> dict:
+    """Create <out_dir>/{model.json, ggml/weights.gguf}; returns the model.json dict.
+    late_layers = (first_layer, factor): the output projections (attn_output, ffn_down) of layers >= first_layer are drawn `factor` times smaller -- a target whose
+    late layers only refine what its early layers decide, so that a prefix of its own layers is a draft with measurable acceptance (tools/bench_speculative.py).
+    The random stream is the one of the plain model (only scales differ)."""
     arch, *_rest = PRESETS[preset]
     tied = PRESETS[preset][10]
     cfg = llm_config(preset, n_ctx, rope_freq_scale, rope_attn_factor)
@@ -175,9 +179,36 @@ def write_model_dir(out_dir: str, preset: str, wtype: int, n_ctx: int, seed: int
         rows = int(np.prod(ti.ne[1:]))
         # std scaled so that a K-long dot with unit-rms input stays O(1): 0.02 at K=4096
         s = std * (4096.0 / k) ** 0.5 if ti.name != "token_embd.weight" or not tied else std * (4096.0 / k) ** 0.5
+        if late_layers and ti.name.startswith("blk.") and int(ti.name.split(".")[1]) >= late_layers[0] and (ti.name.endswith("attn_output.weight") or ti.name.endswith("ffn_down.weight")):
+            s *= late_layers[1]
         return random_blocks(rng, ti.type, rows, k, s)
 
     w.write(produce)
+    return mj
+
+
+def truncate_model_dir(src_dir: str, out_dir: str, n_layers: int, model_id: str | None = None) -> dict:
+    """A model that is the first `n_layers` layers of the one in `src_dir` plus ITS output norm / lm_head / embeddings (a "truncated self-draft" for speculative
+    decoding: on synthetic weights an unrelated small model agrees with the target on nothing, a prefix of the target's own layers on a measurable share)."""
+    mj = load_model_json(src_dir)
+    L = int(mj["llm_config"]["n_layers"])
+    assert 0 < n_layers <= L
+    mj = json.loads(json.dumps(mj))
+    mj["llm_config"]["n_layers"] = int(n_layers)
+    mj["model_id"] = model_id or f"{mj['model_id']}-first{n_layers}"
+    os.makedirs(os.path.join(out_dir, "ggml"), exist_ok=True)
+    with open(os.path.join(out_dir, "model.json"), "w") as f:
+        json.dump(mj, f, indent=1)
+    rd = gguf.GGUFReader(os.path.join(src_dir, "ggml", "weights.gguf"))
+    w = gguf.GGUFWriter(os.path.join(out_dir, "ggml", "weights.gguf"))
+    w.add_kv("general.architecture", mj["model_arch"])
+    w.add_kv("general.name", mj["model_id"])
+    w.add_kv("general.alignment", gguf.ALIGNMENT)
+    for name, ti in rd.tensors.items():
+        if name.startswith("blk.") and int(name.split(".")[1]) >= n_layers:
+            continue
+        w.add_tensor(name, ti.type, ti.ne)
+    w.write(lambda ti: np.array(rd.data(ti.name)))
     return mj
 
 

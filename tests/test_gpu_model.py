@@ -114,6 +114,7 @@ def test_decode_attention_long_cache_matches_oracle(ctx, oracle, tmp_path, prese
     prompt = np.random.default_rng(17).integers(0, cfg.vocab_size, P)
     steps = 40
     want_ids, want_logits, *_ = om.generate(prompt, 128, steps, want_logits=True)
+    assert ctx.L.ps_hip_debug_set(7, 1) == 0  # (the fused QKV + attention launch wherever it is covered: also its head-size-64 instance)
     gm = hip.Model(ctx, d, max_batch=128, n_ctx=n_ctx)
     assert np.array_equal(gm.generate(prompt, 128, steps), want_ids)           # hipGraph replay
     gm.set_mode(1)
@@ -142,6 +143,7 @@ def test_decode_attention_long_cache_matches_oracle(ctx, oracle, tmp_path, prese
         outs.append(np.stack(res))
     assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32)) and np.array_equal(outs[0].view(np.uint32), outs[2].view(np.uint32))
     assert not np.array_equal(outs[0][0], np.asarray(want_logits[steps - 5]))                     # (unmasked, these would be step steps - 5's logits)
+    assert ctx.L.ps_hip_debug_set(7, 0) == 0
     gm.close()
     om.close()
 
@@ -160,6 +162,7 @@ def test_fused_qkv_attention_from_an_empty_cache(ctx, oracle, tmp_path, preset):
     om = oracle.model(cfg, mj["model_arch"], load_tensors(os.path.join(d, "ggml/weights.gguf")), n_threads=16)
     toks = np.random.default_rng(2).integers(0, cfg.vocab_size, 70)
     want = [om.forward([int(t)], [i], True)[0] for i, t in enumerate(toks)]
+    assert ctx.L.ps_hip_debug_set(7, 1) == 0  # (the head-size-64 instance fills half the chip and is not dispatched by default: taken here wherever it is covered)
     gm = hip.Model(ctx, d, max_batch=8, n_ctx=256)
     for mode in (1, 129):  # eager: fused / two launches
         gm.set_mode(mode)
@@ -172,6 +175,7 @@ def test_fused_qkv_attention_from_an_empty_cache(ctx, oracle, tmp_path, preset):
     gm.set_mode(0)
     gm.reset()
     assert np.array_equal(gm.generate(toks[:1], 8, 40), want_ids)  # hipGraph replay from position 0
+    assert ctx.L.ps_hip_debug_set(7, 0) == 0
     gm.close()
     om.close()
 
