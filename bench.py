@@ -573,7 +573,15 @@ def main():
 
 
 MFMA_F16_PEAK_TFLOPS = 2500.0  # dense fp16 matrix-core peak (MI355X_MICROARCH.md): the pipe the Q4_K chunk mat-mul runs its exact-integer contractions on
-TRAFFIC_FILE = os.path.join("profiles", "r05_pmc_traffic.json")
+def _traffic_file():
+    """the newest round's PMC record (profiles/rNN_pmc_traffic.json, written by tools/gpu_round_prof.sh)"""
+    import glob
+    root = os.path.dirname(os.path.abspath(__file__))
+    found = sorted(glob.glob(os.path.join(root, "profiles", "r[0-9][0-9]_pmc_traffic.json")))
+    return os.path.relpath(found[-1], root) if found else os.path.join("profiles", "r06_pmc_traffic.json")
+
+
+TRAFFIC_FILE = _traffic_file()
 
 
 def kernel_sources_sha16():
