@@ -2,10 +2,11 @@
 // (LlamaModel::forward, src/model/llama/llama_model.cpp:52-117; NormAttention::build,
 // src/model/module/norm_attention.cpp:26-160; FFN::build, src/model/module/ffn.cpp:22-42).
 //
-// Launch plan per layer (decode, bs <= 4):
-//   quantize_act(rmsnorm) -> gemv[Wq|Wk|Wv](+bias) -> rope_append -> attn_scores -> attn_softmax_pv
-//   -> quantize_act -> gemv[Wo]+residual -> quantize_act(rmsnorm) -> gemv[Wgate|Wup] SiLU*up
-//   -> quantize_act -> gemv[Wdown]+residual
+// Launch plan per layer (single token, Q4_K, the headline's shape):
+//   [matvec[Wq|Wk|Wv] + RMSNorm + quantizer + RoPE + KV append + attention]  (k_qkvattn.hip; elsewhere the mat-vec, then attn_decode2 or scores + soft-max.V.p)
+//   -> matvec[Wo] + quantizer + residual -> matvec[Wgate|Wup] + RMSNorm + quantizer + SiLU*up -> matvec[Wdown] + quantizer + residual
+// Batches: quantize_act(rmsnorm) -> mat-mul[Wq|Wk|Wv] -> rope_append -> attn_scores -> soft-max -> V.p (+ quantize) -> mat-mul[Wo] + residual
+//   -> quantize_act(rmsnorm) -> mat-mul[Wgate|Wup] SiLU*up -> quantize_act -> mat-mul[Wdown] + residual
 // A persistent arena replaces the reference's malloc-per-intermediate (src/executor/executor.cpp:23-45);
 // the single-token step is captured once into a hipGraph and replayed (all position-dependent values are
 // read from a device-resident ps_step_state).

@@ -25,3 +25,5 @@ timeout 600 python bench.py --preset llama-3.2-1b --wtype Q4_0 --prompt-len 512 
 timeout 600 python bench.py --preset qwen2-0.5b --wtype Q8_0 --prompt-len 512 --steps 128 --n-ctx 1024 > $O/${R}_bench_qwen2_05b_q8_0.json 2>/dev/null; cut -c1-200 $O/${R}_bench_qwen2_05b_q8_0.json
 timeout 900 python bench.py --wtype Q4_K_M --no-kv-f16 > $O/${R}_bench_8b_q4_k_m.json 2>/dev/null; cut -c1-200 $O/${R}_bench_8b_q4_k_m.json
 timeout 900 python bench.py --wtype Q5_K_M --no-kv-f16 > $O/${R}_bench_8b_q5_k_m.json 2>/dev/null; cut -c1-200 $O/${R}_bench_8b_q5_k_m.json
+python tools/bench_speculative.py --steps 96 --truncated-draft 4 --late-scale 0.03 2>&1 | tail -1 > $O/${R}_speculative_8b_late_scaled_target.json; cut -c1-400 $O/${R}_speculative_8b_late_scaled_target.json
+timeout 600 python bench.py --steps 20 --warmup 5 > $O/${R}_bench_8b_driver_line.json 2>/dev/null; cut -c1-200 $O/${R}_bench_8b_driver_line.json
