@@ -2,7 +2,7 @@
 """Kernel resource table: hipcc -Rpass-analysis=kernel-resource-usage for one csrc file, filtered by a name substring."""
 import re, subprocess, sys
 src, pat = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else "")
-out = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-Iinclude",
+out = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-Iinclude", *(["-fno-slp-vectorize"] if any(n in src for n in ("k_gemv4", "k_qkvattn", "k_gemvb", "k_attn", "k_gemm4k")) else []),
                       "-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", "/tmp/kres.o"], capture_output=True, text=True).stderr
 cur, rows = None, []
 for line in out.splitlines():
