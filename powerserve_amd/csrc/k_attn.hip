@@ -467,6 +467,18 @@ __global__ __launch_bounds__(PV_NT) void attn_softmax_pv_kernel(psl_attn_args a)
 // LDS: e [4][RS] and V [4][RS] (RS = n_ctx rounded up to 128, + 36: rows 4 banks apart), n_ctx <= 4096.
 // NT threads: 1024, or 512 (tried for its shorter kernel boundary; the per-lane work doubles and the launch measured 0.4 us slower).  LPH = NT / 4 lanes per head take groups of 8 positions: LPH x 8 x TRIPS >= n_ctx
 constexpr int D2_MAXCTX = 4096;
+// (round 6) the cached K rows and V channels of a single-token step are read ONCE per token: non-temporal loads, so that they do not displace everything else in the L2s and
+// the memory-side cache (k_qkvattn.hip QA_KV_NT: +2.1 % decode on the 8B shape, profiles/r06_kv_nt_ab.txt)
+#ifndef AD2_KV_NT
+#define AD2_KV_NT 1
+#endif
+__device__ __forceinline__ float4 ad2_ld4(const float *p) {
+    if (!AD2_KV_NT) return *(const float4 *)p;
+    const ps_u32x4 t = __builtin_nontemporal_load((const ps_u32x4 *)p);
+    float4 r;
+    __builtin_memcpy(&r, &t, 16);
+    return r;
+}
 template <int NV, int NT>
 __global__ __launch_bounds__(NT) void attn_decode2_kernel(psl_attn_args a) {
     constexpr int NW = NT / 64, SPP = NW / 4, LPH = NT / 4, WPH = LPH / 64, D2_TRIPS = D2_MAXCTX / (8 * LPH), VCH = D2_MAXCTX / (4 * NT); // SPP: slices per pass
@@ -505,7 +517,7 @@ __global__ __launch_bounds__(NT) void attn_decode2_kernel(psl_attn_args a) {
         const bool early = sl * 32 + 32 <= nlo && sl * 32 + 32 <= a.n_ctx; // (uniform)
         const float *kr = kb + (int64_t)(early ? sl * 32 + (uw & 3) * 8 + p8 : 0) * kvd; // (not hinted: row 0 once more, a cache hit)
 #pragma unroll
-        for (int m = 0; m < NV; m++) kf[ps][m] = *(const float4 *)(kr + m * 32);
+        for (int m = 0; m < NV; m++) kf[ps][m] = ad2_ld4(kr + m * 32);
     }
     mark(1);
     const int pos0 = __builtin_amdgcn_readfirstlane(st_pos0); // (uniform: everything derived from it is scalar control flow)
@@ -519,7 +531,7 @@ __global__ __launch_bounds__(NT) void attn_decode2_kernel(psl_attn_args a) {
         if (!early && sl * 32 + (uw & 3) * 8 < n_kv) {
             const float *kr = kb + (int64_t)(j < n_kv ? j : 0) * kvd;
 #pragma unroll
-            for (int m = 0; m < NV; m++) kf[ps][m] = *(const float4 *)(kr + m * 32);
+            for (int m = 0; m < NV; m++) kf[ps][m] = ad2_ld4(kr + m * 32);
         }
     }
     // ---- this workgroup's four V rows, columns below the cache length (registers; parked in LDS with the drain below).  Here,
@@ -533,7 +545,7 @@ __global__ __launch_bounds__(NT) void attn_decode2_kernel(psl_attn_args a) {
         const int col = 4 * (tid + NT * cc);
         const bool v_in = col < ((n_kv + 3) & ~3); // (n_kv rounded up to 4 <= n_ctx: in bounds)
 #pragma unroll
-        for (int k = 0; k < 4; k++) vld[cc][k] = *(const float4 *)(vbase + (v_in ? (int64_t)k * a.n_ctx + col : 0));
+        for (int k = 0; k < 4; k++) vld[cc][k] = ad2_ld4(vbase + (v_in ? (int64_t)k * a.n_ctx + col : 0));
     }
     if (tid < nq4) *(float4 *)(qs + tid * 4) = q4;
     if (tid < PS_EXP2F_N) etab[tid] = et_w;

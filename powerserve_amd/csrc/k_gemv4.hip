@@ -138,7 +138,7 @@ __global__ __launch_bounds__((NW + 1) * 64) void gemv4_kernel(const G4Params p) 
 #pragma unroll
             for (int i = 0; i < UPW; i++)
                 if (i >= i_lo && i < i_hi) q[i] = __builtin_nontemporal_load((const ps_u32x4 *)(qg + i * (1024 * st) + lo));
-            if (i_lo == 0) h = *(const ps_u32x4 *)(ag + (live ? (uint32_t)(lane & 31) * 16u : 0u));
+            if (i_lo == 0) h = G4_HDR_NT ? __builtin_nontemporal_load((const ps_u32x4 *)(ag + (live ? (uint32_t)(lane & 31) * 16u : 0u))) : *(const ps_u32x4 *)(ag + (live ? (uint32_t)(lane & 31) * 16u : 0u));
         };
         constexpr int YN = YS ? YS : 1;
         int4 Y0[YN][UPW], Y1[YN][UPW];

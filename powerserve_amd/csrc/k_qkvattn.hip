@@ -23,6 +23,11 @@
 #include "ps_expf.h"
 #include "ps_g4_dev.h"
 #include "ps_ops.h"
+#ifndef QA_KV_NT
+#define QA_KV_NT 7 // (round 6) the cached K rows (bit 0) and V channels (bit 1) are read with NON-TEMPORAL loads, and the wave that owns the new position then asks for the new
+                   // row only, not for its seven streamed neighbours again (bit 2).  They are read once per token and were displacing everything else in the L2s and the memory-side
+                   // cache: same-box A/B, 8B decode over 32 steps (profiles/r06_kv_nt_ab.txt): 577.5 tok/s with plain loads, K 584.6, V 582.6, both 587.1, all three 589.8 (+2.1 %)
+#endif
 
 namespace {
 typedef float ps_f32x4 __attribute__((ext_vector_type(4)));
@@ -141,7 +146,7 @@ __global__ __launch_bounds__(QA_THREADS) void qkv_attn_kernel(const QAParams p) 
             const uint32_t lo = live ? lane16 : 0u, st = live ? 1u : 0u;
 #pragma unroll
             for (int i = 0; i < UPW; i++) q[i] = __builtin_nontemporal_load((const ps_u32x4 *)(qg + i * (1024 * st) + lo));
-            h = *(const ps_u32x4 *)(ag + (live ? (uint32_t)(lane & 31) * 16u : 0u));
+            h = G4_HDR_NT ? __builtin_nontemporal_load((const ps_u32x4 *)(ag + (live ? (uint32_t)(lane & 31) * 16u : 0u))) : *(const ps_u32x4 *)(ag + (live ? (uint32_t)(lane & 31) * 16u : 0u));
         };
         auto produce = [&](const ps_u32x4 (&q)[UPW], const ps_u32x4 &hc, int tl, int un, int chunk) {
             if (tl >= nt) return; // wave-uniform
@@ -209,7 +214,10 @@ __global__ __launch_bounds__(QA_THREADS) void qkv_attn_kernel(const QAParams p) 
                 if (j0 < pos0) { // (uniform) at least one cached row; lanes at or past the position read row 0 again (an old row: pos0 > 0 here)
                     const float *kr = kb + (int64_t)(j < pos0 ? j : 0) * kvd;
 #pragma unroll
-                    for (int m = 0; m < NV; m++) kf[ps][m] = *(const float4 *)(kr + m * 32);
+                    for (int m = 0; m < NV; m++) {
+                        if (QA_KV_NT & 1) { const ps_u32x4 t = __builtin_nontemporal_load((const ps_u32x4 *)(kr + m * 32)); __builtin_memcpy(&kf[ps][m], &t, 16); }
+                        else kf[ps][m] = *(const float4 *)(kr + m * 32);
+                    }
                 }
             }
         };
@@ -235,7 +243,10 @@ __global__ __launch_bounds__(QA_THREADS) void qkv_attn_kernel(const QAParams p) 
             const unsigned vt0 = g4_lds_addr(vt);
             for (int pi = wave; (pi >> 2) * 256 < vlim; pi += NW) { // piece pi: row pi & 3, columns (pi >> 2) * 256 ..
                 const int row = pi & 3, c0 = (pi >> 2) * 256, col = c0 + 4 * lane;
-                if (col < vlim) g4_pull((const uint8_t *)(vbase + (int64_t)row * a.n_ctx + col), vt0 + (unsigned)(row * RS + c0) * 4u);
+                if (col < vlim) {
+                    if (QA_KV_NT & 2) g4_pull_nt((const uint8_t *)(vbase + (int64_t)row * a.n_ctx + col), vt0 + (unsigned)(row * RS + c0) * 4u);
+                    else g4_pull((const uint8_t *)(vbase + (int64_t)row * a.n_ctx + col), vt0 + (unsigned)(row * RS + c0) * 4u);
+                }
             }
         }
         mark(14); // V requested
@@ -363,8 +374,10 @@ __global__ __launch_bounds__(QA_THREADS) void qkv_attn_kernel(const QAParams p) 
             const int sl = bx + ((uw >> 2) + SPP * ps) * G, j0 = sl * 32 + (uw & 3) * 8, j = j0 + p8;
             if (j0 <= pos0 && pos0 < j0 + 8) { // (uniform)
                 const float *kr = kb + (int64_t)(j <= pos0 ? j : 0) * kvd;
+                if (!(QA_KV_NT & 4) || j == pos0 || j0 == pos0) { // (QA_KV_NT: the old rows were streamed past the caches -- only the new row, or the whole group when nobody has asked for it yet)
 #pragma unroll
-                for (int m = 0; m < NV; m++) kf[ps][m] = *(const float4 *)(kr + m * 32);
+                    for (int m = 0; m < NV; m++) kf[ps][m] = *(const float4 *)(kr + m * 32);
+                }
             }
         }
     }

@@ -66,6 +66,10 @@ __device__ __forceinline__ float4 g4_unit_y(const ps_u32x4 q, const char *hx, co
 // one wave-instruction pulls 1 KiB through the L2 into an LDS dump (global_load_lds_dwordx4: lane l lands at M0 + 16 l; no destination register, so nothing
 // to wait for and nothing the compiler could reuse too early): the chain wave's L2 prefetch below
 __device__ __forceinline__ unsigned g4_lds_addr(const void *p) { return (unsigned)(size_t)(const __attribute__((address_space(3))) char *)p; }
+__device__ __forceinline__ void g4_pull_nt(const uint8_t *q, const unsigned lds_dst) { // (the same with the non-temporal hint)
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(q), "s"(lds_dst) : "memory");
+}
 __device__ __forceinline__ void g4_pull(const uint8_t *q, const unsigned lds_dst) {
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(q), "s"(lds_dst) : "memory");

@@ -37,9 +37,10 @@ for cfg in cfgs:
         us = 1e3 * seq_ms.value / n.value
         line += f"  {names[which]} {us:6.2f} us ({mb[which] / (n.value if which == 0 else 1) / us * 1e-0:5.2f} TB/s)" if which else f"  all {seq_ms.value:6.3f} ms ({mb[0] / seq_ms.value * 1e-3:5.2f} TB/s)"
     # a real decode (graph replay): 32 tokens from the same state
-    m.set_mode(0)
+    MODE = int(os.environ.get("G4V_MODE", "0"))  # (128: the Q / K / V mat-vec and the single-token attention as two launches)
+    m.set_mode(MODE)
     ctx.check(L.ps_hip_model_kv_truncate(m.h, pos0))
-    m.set_mode(16); m.set_mode(0)  # drop the captured graph: the launch plan changed
+    m.set_mode(16 | MODE); m.set_mode(MODE)  # drop the captured graph: the launch plan changed
     m.decode_greedy(int(prompt[-1]), 4)
     ctx.check(L.ps_hip_model_kv_truncate(m.h, pos0))
     ctx.sync()
