@@ -467,19 +467,19 @@ __global__ __launch_bounds__(PV_NT) void attn_softmax_pv_kernel(psl_attn_args a)
 // LDS: e [4][RS] and V [4][RS] (RS = n_ctx rounded up to 128, + 36: rows 4 banks apart), n_ctx <= 4096.
 // NT threads: 1024, or 512 (tried for its shorter kernel boundary; the per-lane work doubles and the launch measured 0.4 us slower).  LPH = NT / 4 lanes per head take groups of 8 positions: LPH x 8 x TRIPS >= n_ctx
 constexpr int D2_MAXCTX = 4096;
-// (round 6) the cached K rows and V channels of a single-token step are read ONCE per token: non-temporal loads, so that they do not displace everything else in the L2s and
-// the memory-side cache (k_qkvattn.hip QA_KV_NT: +2.1 % decode on the 8B shape, profiles/r06_kv_nt_ab.txt)
-#ifndef AD2_KV_NT
-#define AD2_KV_NT 1
-#endif
+// (round 6) KVS = psl_attn_args::kv_stream: the cached K rows and V channels of a single-token step are read ONCE per token; when the model's whole cache is larger than the
+// memory-side cache nothing of it survives to the next token, and read with plain loads it displaces everything else there and in the L2s: non-temporal loads then
+// (8B at n_kv 2048, 537 MB of cache: +2.1 % decode in the fused launch, +0.8 % here; profiles/r06_kv_nt_ab.txt, r06_nt_more_ab.txt).  A small cache (Llama-3.2-1B at 640
+// positions: 42 MB) IS served from there token after token: plain loads (1548 against 1517 tok/s with the hint, profiles/r06_ad2_nt_small_models.txt).
+template <int KVS>
 __device__ __forceinline__ float4 ad2_ld4(const float *p) {
-    if (!AD2_KV_NT) return *(const float4 *)p;
+    if (!KVS) return *(const float4 *)p;
     const ps_u32x4 t = __builtin_nontemporal_load((const ps_u32x4 *)p);
     float4 r;
     __builtin_memcpy(&r, &t, 16);
     return r;
 }
-template <int NV, int NT>
+template <int NV, int NT, int KVS>
 __global__ __launch_bounds__(NT) void attn_decode2_kernel(psl_attn_args a) {
     constexpr int NW = NT / 64, SPP = NW / 4, LPH = NT / 4, WPH = LPH / 64, D2_TRIPS = D2_MAXCTX / (8 * LPH), VCH = D2_MAXCTX / (4 * NT); // SPP: slices per pass
     extern __shared__ __attribute__((aligned(16))) float d2s[];
@@ -517,7 +517,7 @@ __global__ __launch_bounds__(NT) void attn_decode2_kernel(psl_attn_args a) {
         const bool early = sl * 32 + 32 <= nlo && sl * 32 + 32 <= a.n_ctx; // (uniform)
         const float *kr = kb + (int64_t)(early ? sl * 32 + (uw & 3) * 8 + p8 : 0) * kvd; // (not hinted: row 0 once more, a cache hit)
 #pragma unroll
-        for (int m = 0; m < NV; m++) kf[ps][m] = ad2_ld4(kr + m * 32);
+        for (int m = 0; m < NV; m++) kf[ps][m] = ad2_ld4<KVS>(kr + m * 32);
     }
     mark(1);
     const int pos0 = __builtin_amdgcn_readfirstlane(st_pos0); // (uniform: everything derived from it is scalar control flow)
@@ -531,7 +531,7 @@ __global__ __launch_bounds__(NT) void attn_decode2_kernel(psl_attn_args a) {
         if (!early && sl * 32 + (uw & 3) * 8 < n_kv) {
             const float *kr = kb + (int64_t)(j < n_kv ? j : 0) * kvd;
 #pragma unroll
-            for (int m = 0; m < NV; m++) kf[ps][m] = ad2_ld4(kr + m * 32);
+            for (int m = 0; m < NV; m++) kf[ps][m] = ad2_ld4<KVS>(kr + m * 32);
         }
     }
     // ---- this workgroup's four V rows, columns below the cache length (registers; parked in LDS with the drain below).  Here,
@@ -545,7 +545,7 @@ __global__ __launch_bounds__(NT) void attn_decode2_kernel(psl_attn_args a) {
         const int col = 4 * (tid + NT * cc);
         const bool v_in = col < ((n_kv + 3) & ~3); // (n_kv rounded up to 4 <= n_ctx: in bounds)
 #pragma unroll
-        for (int k = 0; k < 4; k++) vld[cc][k] = ad2_ld4(vbase + (v_in ? (int64_t)k * a.n_ctx + col : 0));
+        for (int k = 0; k < 4; k++) vld[cc][k] = ad2_ld4<KVS>(vbase + (v_in ? (int64_t)k * a.n_ctx + col : 0));
     }
     if (tid < nq4) *(float4 *)(qs + tid * 4) = q4;
     if (tid < PS_EXP2F_N) etab[tid] = et_w;
@@ -1419,8 +1419,10 @@ bool psl_attn_decode2(hipStream_t st, int n_cu, const psl_attn_args &a) {
     const size_t lds = ((size_t)8 * RS + 512 + 128 + 16 + 32 + 4 * a.head_size + (16 * 32 / (a.head_size / 32)) * 4 + 32 + 64) * 4;
     static unsigned long long attr = 0; // devices that have the attribute
     if (ps_first_on_device(&attr)) {
-        (void)hipFuncSetAttribute((const void *)attn_decode2_kernel<4, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
-        (void)hipFuncSetAttribute((const void *)attn_decode2_kernel<2, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+        (void)hipFuncSetAttribute((const void *)attn_decode2_kernel<4, 1024, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+        (void)hipFuncSetAttribute((const void *)attn_decode2_kernel<4, 1024, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+        (void)hipFuncSetAttribute((const void *)attn_decode2_kernel<2, 1024, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+        (void)hipFuncSetAttribute((const void *)attn_decode2_kernel<2, 1024, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
     }
     const dim3 g((unsigned)(gx * a.n_kv_heads));
     // 512-thread workgroups (template parameter NT): a kernel boundary behind them costs ~1.5 us less than behind 1024-thread ones.  Round 3 measured them
@@ -1429,16 +1431,18 @@ bool psl_attn_decode2(hipStream_t st, int n_cu, const psl_attn_args &a) {
     static const int nt_env = getenv("PS_ATTN_NT") ? atoi(getenv("PS_ATTN_NT")) : 512;
     static unsigned long long attr5 = 0;
     if (ps_first_on_device(&attr5)) {
-        (void)hipFuncSetAttribute((const void *)attn_decode2_kernel<4, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
-        (void)hipFuncSetAttribute((const void *)attn_decode2_kernel<2, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+        (void)hipFuncSetAttribute((const void *)attn_decode2_kernel<4, 512, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+        (void)hipFuncSetAttribute((const void *)attn_decode2_kernel<4, 512, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+        (void)hipFuncSetAttribute((const void *)attn_decode2_kernel<2, 512, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+        (void)hipFuncSetAttribute((const void *)attn_decode2_kernel<2, 512, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
     }
     if (nt_env == 512) {
-        if (a.head_size == 128) hipLaunchKernelGGL((attn_decode2_kernel<4, 512>), g, dim3(512), lds, st, a);
-        else hipLaunchKernelGGL((attn_decode2_kernel<2, 512>), g, dim3(512), lds, st, a);
+        if (a.head_size == 128) { if (a.kv_stream) hipLaunchKernelGGL((attn_decode2_kernel<4, 512, 1>), g, dim3(512), lds, st, a); else hipLaunchKernelGGL((attn_decode2_kernel<4, 512, 0>), g, dim3(512), lds, st, a); }
+        else { if (a.kv_stream) hipLaunchKernelGGL((attn_decode2_kernel<2, 512, 1>), g, dim3(512), lds, st, a); else hipLaunchKernelGGL((attn_decode2_kernel<2, 512, 0>), g, dim3(512), lds, st, a); }
         return true;
     }
-    if (a.head_size == 128) hipLaunchKernelGGL((attn_decode2_kernel<4, 1024>), g, dim3(1024), lds, st, a);
-    else hipLaunchKernelGGL((attn_decode2_kernel<2, 1024>), g, dim3(1024), lds, st, a);
+    if (a.head_size == 128) { if (a.kv_stream) hipLaunchKernelGGL((attn_decode2_kernel<4, 1024, 1>), g, dim3(1024), lds, st, a); else hipLaunchKernelGGL((attn_decode2_kernel<4, 1024, 0>), g, dim3(1024), lds, st, a); }
+    else { if (a.kv_stream) hipLaunchKernelGGL((attn_decode2_kernel<2, 1024, 1>), g, dim3(1024), lds, st, a); else hipLaunchKernelGGL((attn_decode2_kernel<2, 1024, 0>), g, dim3(1024), lds, st, a); }
     return true;
 }
 

@@ -23,11 +23,10 @@
 #include "ps_expf.h"
 #include "ps_g4_dev.h"
 #include "ps_ops.h"
-#ifndef QA_KV_NT
-#define QA_KV_NT 7 // (round 6) the cached K rows (bit 0) and V channels (bit 1) are read with NON-TEMPORAL loads, and the wave that owns the new position then asks for the new
-                   // row only, not for its seven streamed neighbours again (bit 2).  They are read once per token and were displacing everything else in the L2s and the memory-side
-                   // cache: same-box A/B, 8B decode over 32 steps (profiles/r06_kv_nt_ab.txt): 577.5 tok/s with plain loads, K 584.6, V 582.6, both 587.1, all three 589.8 (+2.1 %)
-#endif
+// KVS (psl_attn_args::kv_stream, round 6): the cached K rows and V channels are read with NON-TEMPORAL loads, and the wave that owns the new position then asks for the new row
+// only, not for its seven streamed neighbours again.  They are read once per token; when the model's whole cache is larger than the memory-side cache (8B at n_kv 2048: 537 MB)
+// nothing of it survives to the next token and, read with plain loads, it displaces everything else there and in the L2s: same-box A/B, 8B decode over 32 steps
+// (profiles/r06_kv_nt_ab.txt): 577.5 tok/s plain, K 584.6, V 582.6, both 587.1, with the new-row request 589.8 (+2.1 %).  A cache that fits stays there: plain loads (k_attn.hip).
 
 namespace {
 typedef float ps_f32x4 __attribute__((ext_vector_type(4)));
@@ -60,7 +59,7 @@ __device__ __forceinline__ void qa_rendezvous(unsigned *ctr, const unsigned base
     }
 }
 
-template <int NV> // head_size / 32
+template <int NV, int KVS> // head_size / 32; the cache is streamed (non-temporal loads: see above)
 __global__ __launch_bounds__(QA_THREADS) void qkv_attn_kernel(const QAParams p) {
     constexpr int NW = 8, DC = 2, UPW = 4, UPB = NW * UPW;                                       // mat-vec geometry (gemv4_kernel<8, 2, ...>)
     constexpr int NT = 512, AW = NT / 64, SPP = AW / 4, LPH = NT / 4, WPH = LPH / 64, D2_TRIPS = QA_MAXCTX / (8 * LPH); // attention geometry (attn_decode2_kernel<NV, 512>)
@@ -215,7 +214,7 @@ __global__ __launch_bounds__(QA_THREADS) void qkv_attn_kernel(const QAParams p) 
                     const float *kr = kb + (int64_t)(j < pos0 ? j : 0) * kvd;
 #pragma unroll
                     for (int m = 0; m < NV; m++) {
-                        if (QA_KV_NT & 1) { const ps_u32x4 t = __builtin_nontemporal_load((const ps_u32x4 *)(kr + m * 32)); __builtin_memcpy(&kf[ps][m], &t, 16); }
+                        if (KVS) { const ps_u32x4 t = __builtin_nontemporal_load((const ps_u32x4 *)(kr + m * 32)); __builtin_memcpy(&kf[ps][m], &t, 16); }
                         else kf[ps][m] = *(const float4 *)(kr + m * 32);
                     }
                 }
@@ -244,7 +243,7 @@ __global__ __launch_bounds__(QA_THREADS) void qkv_attn_kernel(const QAParams p) 
             for (int pi = wave; (pi >> 2) * 256 < vlim; pi += NW) { // piece pi: row pi & 3, columns (pi >> 2) * 256 ..
                 const int row = pi & 3, c0 = (pi >> 2) * 256, col = c0 + 4 * lane;
                 if (col < vlim) {
-                    if (QA_KV_NT & 2) g4_pull_nt((const uint8_t *)(vbase + (int64_t)row * a.n_ctx + col), vt0 + (unsigned)(row * RS + c0) * 4u);
+                    if (KVS) g4_pull_nt((const uint8_t *)(vbase + (int64_t)row * a.n_ctx + col), vt0 + (unsigned)(row * RS + c0) * 4u);
                     else g4_pull((const uint8_t *)(vbase + (int64_t)row * a.n_ctx + col), vt0 + (unsigned)(row * RS + c0) * 4u);
                 }
             }
@@ -374,7 +373,7 @@ __global__ __launch_bounds__(QA_THREADS) void qkv_attn_kernel(const QAParams p) 
             const int sl = bx + ((uw >> 2) + SPP * ps) * G, j0 = sl * 32 + (uw & 3) * 8, j = j0 + p8;
             if (j0 <= pos0 && pos0 < j0 + 8) { // (uniform)
                 const float *kr = kb + (int64_t)(j <= pos0 ? j : 0) * kvd;
-                if (!(QA_KV_NT & 4) || j == pos0 || j0 == pos0) { // (QA_KV_NT: the old rows were streamed past the caches -- only the new row, or the whole group when nobody has asked for it yet)
+                if (!KVS || j == pos0 || j0 == pos0) { // (KVS: the old rows were streamed past the caches -- only the new row, or the whole group when nobody has asked for it yet)
 #pragma unroll
                     for (int m = 0; m < NV; m++) kf[ps][m] = *(const float4 *)(kr + m * 32);
                 }
@@ -645,11 +644,13 @@ bool psk_qkv_attn(hipStream_t st, int n_cu, const psk_gemv_args &g, int64_t K, c
     if (lds > 160 * 1024) return false;
     static unsigned long long attr = 0;
     if (ps_first_on_device(&attr)) {
-        (void)hipFuncSetAttribute((const void *)qkv_attn_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void *)qkv_attn_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void *)qkv_attn_kernel<4, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void *)qkv_attn_kernel<2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void *)qkv_attn_kernel<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void *)qkv_attn_kernel<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
     const dim3 grid((unsigned)(G * a.n_kv_heads));
-    if (hs == 128) hipLaunchKernelGGL((qkv_attn_kernel<4>), grid, dim3(QA_THREADS), lds, st, p);
-    else hipLaunchKernelGGL((qkv_attn_kernel<2>), grid, dim3(QA_THREADS), lds, st, p);
+    if (hs == 128) { if (a.kv_stream) hipLaunchKernelGGL((qkv_attn_kernel<4, 1>), grid, dim3(QA_THREADS), lds, st, p); else hipLaunchKernelGGL((qkv_attn_kernel<4, 0>), grid, dim3(QA_THREADS), lds, st, p); }
+    else { if (a.kv_stream) hipLaunchKernelGGL((qkv_attn_kernel<2, 1>), grid, dim3(QA_THREADS), lds, st, p); else hipLaunchKernelGGL((qkv_attn_kernel<2, 0>), grid, dim3(QA_THREADS), lds, st, p); }
     return true;
 }

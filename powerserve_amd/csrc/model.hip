@@ -278,6 +278,15 @@ static int enqueue_forward(ps_hip_model *m, int bs, bool lm_head, bool use_tree,
     if (f16) if (int rc = ensure_perf16(m)) return rc;
     const bool one_launch = (m->mode & 16) == 0; // default; mode bit 4 switches attn_decode2 off (two launches)
     aa.xchg = m->attn_xchg; aa.tick = m->attn_tick;
+    // Single-token attention: are the cached K rows / V channels read with non-temporal loads (psl_attn_args::kv_stream)?  Measured (profiles/r06_kv_stream_threshold.txt,
+    // r06_ad2_nt_small_models.txt): the fused Q / K / V + attention launch is faster with them at every cache length tried (8B: +1.0 % behind a 256-token prompt, +1.6 % behind
+    // 1024, +2.2 % behind 2048); the attention launch of its own (attn_decode2) gains where the whole cache -- every layer, K and V -- is more than the memory-side cache keeps
+    // from token to token (8B behind 2048 tokens, 537 MB: +0.8 %) and loses where it fits (Llama-3.2-1B behind 512 tokens, 42 MB: -2.2 %).  PS_KV_STREAM=0 / 1 forces both (A/B).
+    static const int kvs_force = getenv("PS_KV_STREAM") ? atoi(getenv("PS_KV_STREAM")) : -1;
+    const int64_t n_kv_now = m->n_kv_host > 0 ? m->n_kv_host : (m->n_kv_hint > 0 ? m->n_kv_hint : (int64_t)m->position);
+    const int kvs_fused = kvs_force >= 0 ? kvs_force : 1;
+    const int kvs_own = kvs_force >= 0 ? kvs_force : ((int64_t)f.n_layers * 2 * n_kv_now * kvd * 4 > ((int64_t)160 << 20) ? 1 : 0);
+    aa.kv_stream = kvs_own;
     aa.n_kv_lo = m->n_kv_host > 0 ? m->n_kv_host : (m->n_kv_hint > 0 ? m->n_kv_hint : (int)m->position); // (a hint: rows below it are requested before the device-side position has arrived)
 
     for (uint32_t L = 0; L < f.n_layers; L++) {
@@ -315,12 +324,13 @@ static int enqueue_forward(ps_hip_model *m, int bs, bool lm_head, bool use_tree,
             }
             if (m->qwen2) { psf16_add_bias(st, m->q, m->bq[L], dim, bs); psf16_add_bias(st, m->k, m->bk[L], kvd, bs); psf16_add_bias(st, m->v, m->bv[L], kvd, bs); }
         } else if (bs == 1 && !use_tree && one_launch && !kv16 && g.rope && (m->mode & 128) == 0 &&
-                   (aa.dbg = psk_gemv_dbg_buf(10, 3), psk_qkv_attn(st, c->n_cu, g, dim, aa))) { // timeline key 43
+                   (aa.dbg = psk_gemv_dbg_buf(10, 3), aa.kv_stream = kvs_fused, psk_qkv_attn(st, c->n_cu, g, dim, aa))) { // timeline key 43
             // the head of the layer in ONE launch: Q / K / V mat-vec + RoPE + KV append + single-token attention (k_qkvattn.hip); mode bit 7 brings the two launches back
-            aa.dbg = nullptr;
+            aa.dbg = nullptr; aa.kv_stream = kvs_own;
             fused_qa = true;
         } else if (mm(m, g, a1, dim, bs)) return 2;
 
+        aa.kv_stream = kvs_own; aa.dbg = nullptr; // (also when the fused launch declined the shape)
         if (f16 || (!fuse_rope && !fuse_rope_b)) psl_rope_append(st, aa, bs);
         bool att_quantized = false;
         if (fused_qa) {

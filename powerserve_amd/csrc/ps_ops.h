@@ -47,6 +47,8 @@ struct psl_attn_args {
     float *xchg;             // attn_decode2: raw scores in flight between the workgroups of a kv head, [n_kv_heads][4][n_ctx rounded up to 32]; null: not used
     unsigned *tick;          // attn_decode2: [64 * kv head] arrival counters, zeroed once (epoch = ticket / workgroups per head)
     int n_kv_lo;             // attn_decode2: a lower bound of pos0 + 1 known to the host at enqueue time (a prefetch HINT only)
+    int kv_stream;           // single-token kernels: 1 = the cached K rows / V channels are read with non-temporal loads (the model's whole cache does not fit the memory-side
+                             // cache, so nothing of it survives from token to token and it should not displace what does); 0 = plain loads (a small cache is served from there)
 };
 void psl_rope_append(hipStream_t st, const psl_attn_args &a, int bs);
 void psl_attn_scores(hipStream_t st, const psl_attn_args &a, int bs);
