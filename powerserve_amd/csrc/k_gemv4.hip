@@ -14,6 +14,11 @@
 //     28 units = half a row group).
 // Epilogues: EPI 0 bias / residual, EPI 1 SiLU(gate)*up, EPI 2 RoPE + KV-cache append (QKV).
 #include "ps_g4_dev.h"
+#ifndef G4_OUT_WT
+#define G4_OUT_WT 1 // (round 6) the result rows are stored write-through: nothing dirty is left for the end-of-kernel write-back, the next launch finds the row in memory; same-box A/B,
+                    // three rounds (profiles/r06_out_wt_ab.txt): all mat-vecs of a token 1.239 -> 1.226 ms, 8B decode 596.3 -> 599.7 tok/s
+#endif
+namespace { __device__ __forceinline__ void g4_out(float *p, const float v) { if (G4_OUT_WT) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *p = v; } }
 
 namespace {
 constexpr int G4_PAIR = 0; // units of a chunk the scheduler may interleave (0: one at a time)
@@ -138,7 +143,7 @@ __global__ __launch_bounds__((NW + 1) * 64) void gemv4_kernel(const G4Params p) 
 #pragma unroll
             for (int i = 0; i < UPW; i++)
                 if (i >= i_lo && i < i_hi) q[i] = __builtin_nontemporal_load((const ps_u32x4 *)(qg + i * (1024 * st) + lo));
-            if (i_lo == 0) h = G4_HDR_NT ? __builtin_nontemporal_load((const ps_u32x4 *)(ag + (live ? (uint32_t)(lane & 31) * 16u : 0u))) : *(const ps_u32x4 *)(ag + (live ? (uint32_t)(lane & 31) * 16u : 0u));
+            if (i_lo == 0) h = *(const ps_u32x4 *)(ag + (live ? (uint32_t)(lane & 31) * 16u : 0u)); // (plain: with the non-temporal hint the fused launch gains 0.3 us, these launches nothing -- ps_gemv_dev.h G4_HDR_NT)
         };
         constexpr int YN = YS ? YS : 1;
         int4 Y0[YN][UPW], Y1[YN][UPW];
@@ -359,12 +364,12 @@ __global__ __launch_bounds__((NW + 1) * 64) void gemv4_kernel(const G4Params p) 
                 }
             } else if (u == 0 && row < Nw) {
                 if (EPI == 1) {
-                    o[row] = g4_silu_mul(ygate, y, exp_tab);
+                    g4_out(o + row, g4_silu_mul(ygate, y, exp_tab));
                 } else {
                     float v = y;
                     if (b) v = __fadd_rn(v, ec);
                     if (p.residual && wi == 0) v = __fadd_rn(ea, v);
-                    o[row] = v;
+                    g4_out(o + row, v);
                 }
             }
             acc0 = 0.f; acc1 = 0.f; accm = 0.f;

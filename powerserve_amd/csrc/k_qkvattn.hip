@@ -594,7 +594,7 @@ __global__ __launch_bounds__(QA_THREADS) void qkv_attn_kernel(const QAParams p) 
 #pragma unroll
         for (int jj = 0; jj < 32; jj++)
             if (jj < nleft) res = ps_dot_left(res, lv[jj], lp[jj], jj, nleft);
-        if (hh < r2) a.att[((int64_t)kvh * r2 + hh) * hs + bx * 4 + ch] = res;
+        if (hh < r2) a.att[((int64_t)kvh * r2 + hh) * hs + bx * 4 + ch] = res; // (write-through like the mat-vecs' rows: no difference, profiles/r06_out_wt_ab.txt)
     }
     if (dbg) { dbg[13] = __builtin_amdgcn_s_memtime(); dbg[30] = __builtin_amdgcn_s_memrealtime(); }
 }

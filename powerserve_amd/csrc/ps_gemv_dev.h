@@ -1,11 +1,11 @@
 // Device code shared by the quantized mat-vec kernels (k_gemv.hip: gemv / gemv1 / gemm8*, k_gemv4.hip, k_gemvb.hip, k_gemvk.hip):
 // weight-type traits, the LDS image of an activation column, the per-unit integer work (unit_dot) and hsum_float_8 (row_reduce).  See k_gemv.hip's header for the numerics contract.
 #pragma once
-// (round 6) everything a decode step STREAMS -- quants, their row headers / scales, the cached K rows and V channels -- is read once per token and carries the non-temporal
-// hint, so that 4 GB of it per token do not cycle through the L2s and the memory-side cache in front of what is reused (activations, exchanges, code).  Quants had it since round 2;
-// the Q4_K row headers (gemv4, qkv_attn): 8B decode 576 -> 587 tok/s, same box (profiles/r06_nt_more_ab.txt); K / V: +2.1 % (k_qkvattn.hip QA_KV_NT, k_attn.hip AD2_KV_NT).
-// NOT the Q6_K / Q5_K scales (gemvk: the eight lanes of a row share one 16-byte piece; 8B Q4_K_M 530 -> 519 tok/s with the hint) nor the Q4_0 / Q8_0 block scales (gemvb:
-// no difference): profiles/r06_nt_other_ab.txt
+// (round 6) what a decode step STREAMS and reads once per token should not cycle through the L2s and the memory-side cache in front of what is reused (activations,
+// exchanges): the quants carry the non-temporal hint since round 2; the cached K rows / V channels since round 6 (k_qkvattn.hip KVS, k_attn.hip: +2.1 % decode on the 8B shape).
+// G4_HDR_NT: the Q4_K row headers of the FUSED Q / K / V + attention launch as well (same box, rocprofv3 per launch, profiles/r06_hdr_nt_kernel_times.txt: 20.62 -> 20.33 us;
+// the mat-vec launches of their own do not move -- 14.49 -> 14.54 us for gate / up -- and keep plain header loads).  NOT the Q6_K / Q5_K scales (gemvk: the eight lanes of a row
+// share one 16-byte piece; 8B Q4_K_M 530 -> 519 tok/s with the hint) nor the Q4_0 / Q8_0 block scales (gemvb: no difference): profiles/r06_nt_other_ab.txt
 #ifndef G4_HDR_NT
 #define G4_HDR_NT 1
 #endif
