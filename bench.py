@@ -52,6 +52,7 @@ def parse():
     ap.add_argument("--cpu-reference-limit", type=int, default=240, help="seconds the reference CPU baseline (a child process) may take before it is killed")
     ap.add_argument("--cpu-reference-child", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--f16-super-chunk", type=int, default=2048, help="side leg (fp16 perf mode): tokens per mat-mul launch")
+    ap.add_argument("--prefill-warmup-tokens", type=int, default=128, help="untimed tokens forwarded before the timed prefill (first use of the prefill kernels in the process; 0: none)")
     ap.add_argument("--wide-chunk", type=int, default=512, help="side leg: prefill in chunks of this many tokens (0: skip)")
     ap.add_argument("--super-chunks", type=int, default=4, help="reference-sized prefill chunks (--batch tokens each) per launch sequence "
                     "(ps_hip_model_prefill: same bits as chunk-by-chunk forwards; 1: one forward per chunk)")
@@ -460,11 +461,18 @@ def main():
             model.forward(prompt[done:done + bs], np.arange(done, done + bs), lm_head=False)
             done += bs
 
+    # one UNTIMED reference-sized chunk first (like the decode's W warm-up steps): the first launch of a kernel in a process loads its code object, and on a cold box that alone
+    # moved the first pass between 14.9 k and 16.8 k tok/s from run to run (profiles/r06_bench_8b_full.json).  The timed pass below still prefills the WHOLE prompt from an empty cache.
+    if args.prefill_warmup_tokens > 0:
+        model.reset()
+        n_w = min(args.prefill_warmup_tokens, prompt.size - 1)
+        model.forward(prompt[:n_w], np.arange(n_w), lm_head=False)
+        ctx.sync(); barrier()
     t0 = time.perf_counter()
     prefill()
     ctx.sync(); barrier()
     prefill_s = time.perf_counter() - t0
-    # (the pass above is the first use of every prefill kernel in this process; the same prompt once more, warm, is reported next to it)
+    # (the same prompt once more is reported next to it)
     barrier(); ctx.sync()
     t0 = time.perf_counter()
     prefill()
@@ -516,6 +524,7 @@ def main():
                        "prefill_chunk": args.batch, "prefill_chunks_per_launch_sequence": max(args.super_chunks, 1), "replicas": world, "collectives": "RCCL broadcast(prompt) + all_gather(ids)" if world > 1 else "none"},
             "prefill_tokens_per_s": world * (args.prompt_len - 1) / prefill_s, "prefill_s": prefill_s,
             "prefill_tokens_per_s_warm": world * (args.prompt_len - 1) / prefill_warm_s, "prefill_warm_s": prefill_warm_s,
+            "prefill_warmup_tokens": args.prefill_warmup_tokens,
             "decode_device_ms_per_step": dev_ms / args.steps, "model_load_s": load_s,
             "weight_bytes_per_token": wbytes, "kv_bytes_per_token_mid": kv_bytes,
             "decode_effective_GBps": (wbytes + kv_bytes) / (dt / args.steps) / 1e9,
@@ -661,7 +670,7 @@ def prefill_roofline(ctx, model, cfg, n_tok, prefill_s, prefill_warm_s, batch, i
     flops = 2.0 * n_tok * cfg.n_layers * layer_kn
     out = {"bound": "mfma", "flops": flops, "achieved": flops / prefill_s / 1e12, "achieved_warm": flops / prefill_warm_s / 1e12,
            "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flops / prefill_s / 1e12 / MFMA_F16_PEAK_TFLOPS,
-           "what": "2 * n_tok * sum(K * N) of the layer mat-muls / measured prefill time (first pass of the process; attention, quantizers, launches included)"}
+           "what": "2 * n_tok * sum(K * N) of the layer mat-muls / measured prefill time (the first whole-prompt pass of the process, behind --prefill-warmup-tokens untimed tokens; attention, quantizers, launches included)"}
     if hasattr(ctx.L, "ps_hip_model_bench_matmul") and batch <= model.max_batch:
         g_ms, _, g_n, kernel = _bench_matmul(ctx, model, 1, batch, reps=5)
         us = 1e3 * g_ms / g_n
