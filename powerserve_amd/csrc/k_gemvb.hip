@@ -315,12 +315,12 @@ __global__ __launch_bounds__((NW + 1) * 64) void gemvb_kernel(const GBParams p) 
                 }
             } else if (u == 0 && row < Nw) {
                 if (EPI == 1) {
-                    o[row] = gb_silu_mul(ygate, y, exp_tab);
+                    ps_out_wt(o + row, gb_silu_mul(ygate, y, exp_tab));
                 } else {
                     float v = y;
                     if (b) v = __fadd_rn(v, ec);
                     if (p.residual && wi == 0) v = __fadd_rn(ea, v);
-                    o[row] = v;
+                    ps_out_wt(o + row, v);
                 }
             }
             acc0 = 0.f; acc1 = 0.f;

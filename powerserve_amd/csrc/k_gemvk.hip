@@ -355,12 +355,12 @@ __global__ __launch_bounds__((NW + 1) * 64) void gemvk_kernel(const GKParams p) 
                 }
             } else if (u == 0) {
                 if (EPI == 1) {
-                    o[row] = g4_silu_mul(ygate, y, exp_tab);
+                    ps_out_wt(o + row, g4_silu_mul(ygate, y, exp_tab));
                 } else {
                     float v = y;
                     if (b) v = __fadd_rn(v, ec);
                     if (p.residual && wi == 0) v = __fadd_rn(ea, v);
-                    o[row] = v;
+                    ps_out_wt(o + row, v);
                 }
             }
             un = 0;

@@ -15,6 +15,12 @@
 #include "ps_ops.h"
 #include "ps_quant_dev.h"
 
+// the result rows of the Q4_0 / Q8_0 / Q6_K / Q5_K mat-vecs stored write-through like gemv4's (k_gemv4.hip G4_OUT_WT); A/B: -DPS_OUT_WT=0
+#ifndef PS_OUT_WT
+#define PS_OUT_WT 1
+#endif
+__device__ __forceinline__ void ps_out_wt(float *p, const float v) { if (PS_OUT_WT) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *p = v; }
+
 namespace {
 
 template <int WT> struct WTraits;
