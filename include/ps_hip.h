@@ -262,7 +262,9 @@ int ps_hip_debug_timeline(ps_hip_ctx *ctx, int key, uint64_t *host_out, int n_wo
  * report a time-out of its score exchange (tests of the retry paths: forward, forward_tree, prefill tail, decode_greedy, lowered forward +
  * kv_advance); key 6: column blocks per XCD of the wide Q4_K / Q5_K mat-mul's item order (k_gemm4k.hip g4k_item: 0 = round 2's order, default 4;
  * PS_G4K_CBX); key 7: 1 = the fused Q / K / V + attention launch (k_qkvattn.hip) wherever it is covered -- by default only where its grid fills three quarters
- * of the chip (head size 128 with 8 kv heads), the head-size-64 instance otherwise runs under test only.  Returns non-zero for an unknown key. */
+ * of the chip (head size 128 with 8 kv heads), the head-size-64 instance otherwise runs under test only; key 9: the single-token attention kernels read the cached K rows / V channels
+ * with plain (0) or non-temporal (1) loads whatever the cache's size, -1 (default): by the rule of csrc/model.hip (a cache-policy hint: no result bit depends on it; PS_KV_STREAM).
+ * Returns non-zero for an unknown key.  (A captured single-token step keeps the launch plan it was captured with: ps_hip_model_set_mode drops it.) */
 int ps_hip_debug_set(int key, int value);
 /* Diagnostic: one GEMM shape of the fp16 perf mode on synthetic operands (tools/f16_gemm_bench.py): out[M][N] = x[M][K] . W[N][K]^T, timed over
  * `reps` launches (with beta: out = beta out + ...), max |difference| to a k-ordered fp32 reference (beta != 0: of a second launch on top of

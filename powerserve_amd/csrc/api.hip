@@ -474,14 +474,15 @@ int ps_hip_debug_timeline(ps_hip_ctx *ctx, int key, uint64_t *host_out, int n_wo
 }
 
 int ps_hip_debug_set(int key, int value) {
-    extern int g_g4_cfg, g_g4_flags, g_g4k_par, g_f16_variant, g_force_attn_timeout, g_g4k_cbx, g_qa_force;
+    extern int g_g4_cfg, g_g4_flags, g_g4k_par, g_f16_variant, g_force_attn_timeout, g_g4k_cbx, g_qa_force, g_kv_stream_force;
     if (key == 1) { g_g4_cfg = value; return 0; }
     if (key == 2) { g_g4_flags = value; return 0; }
     if (key == 3) { g_g4k_par = value; return 0; }
     if (key == 4) { g_f16_variant = value; return 0; }
     if (key == 5) { g_force_attn_timeout = value; return 0; }
     if (key == 6) { g_g4k_cbx = value; return 0; }
-    if (key == 7) { g_qa_force = value; return 0; } // the fused QKV + attention launch wherever it is covered (default: only where its grid fills 3/4 of the chip)
+    if (key == 7) { g_qa_force = value; return 0; }
+    if (key == 9) { g_kv_stream_force = value; return 0; } // single-token attention: the cached K / V with plain (0) / non-temporal (1) loads whatever the cache's size; -1: by size (model.hip) // the fused QKV + attention launch wherever it is covered (default: only where its grid fills 3/4 of the chip)
     return 1;
 }
 

@@ -249,6 +249,7 @@ static int ensure_perf16(ps_hip_model *m) {
 }
 
 // enqueue one forward over `bs` tokens whose ids are in tokens_dev and whose state is in m->state
+int g_kv_stream_force = getenv("PS_KV_STREAM") ? atoi(getenv("PS_KV_STREAM")) : -1; // ps_hip_debug_set(9, v)
 static int enqueue_forward(ps_hip_model *m, int bs, bool lm_head, bool use_tree, bool advance = false, bool use_rope_pos = false) {
     ps_hip_ctx *c = m->ctx;
     hipStream_t st = c->stream;
@@ -282,7 +283,7 @@ static int enqueue_forward(ps_hip_model *m, int bs, bool lm_head, bool use_tree,
     // r06_ad2_nt_small_models.txt): the fused Q / K / V + attention launch is faster with them at every cache length tried (8B: +1.0 % behind a 256-token prompt, +1.6 % behind
     // 1024, +2.2 % behind 2048); the attention launch of its own (attn_decode2) gains where the whole cache -- every layer, K and V -- is more than the memory-side cache keeps
     // from token to token (8B behind 2048 tokens, 537 MB: +0.8 %) and loses where it fits (Llama-3.2-1B behind 512 tokens, 42 MB: -2.2 %).  PS_KV_STREAM=0 / 1 forces both (A/B).
-    static const int kvs_force = getenv("PS_KV_STREAM") ? atoi(getenv("PS_KV_STREAM")) : -1;
+    const int kvs_force = g_kv_stream_force; // (PS_KV_STREAM / ps_hip_debug_set(9, v): -1 by the rule below, 0 / 1 forced)
     const int64_t n_kv_now = m->n_kv_host > 0 ? m->n_kv_host : (m->n_kv_hint > 0 ? m->n_kv_hint : (int64_t)m->position);
     const int kvs_fused = kvs_force >= 0 ? kvs_force : 1;
     const int kvs_own = kvs_force >= 0 ? kvs_force : ((int64_t)f.n_layers * 2 * n_kv_now * kvd * 4 > ((int64_t)160 << 20) ? 1 : 0);

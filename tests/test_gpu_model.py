@@ -180,6 +180,42 @@ def test_fused_qkv_attention_from_an_empty_cache(ctx, oracle, tmp_path, preset):
     om.close()
 
 
+@pytest.mark.parametrize("preset,wt", [("small-llama-hs128", 12), ("llama-1b-dims-2l", 12), ("llama-1b-dims-2l", 2), ("tiny-qwen2", 8)])
+def test_kv_cache_policy_hint_changes_no_bit(ctx, oracle, tmp_path, preset, wt):
+    """The single-token attention reads the cached K rows / V channels with plain or with non-temporal loads (and, streaming, its new K row alone) depending on the cache's
+    size (csrc/model.hip, ps_hip_debug_set(9, v)): both forms of the fused Q / K / V + attention launch and of the attention launch of its own, forced, against the oracle --
+    a prompt whose length puts the new position at several places of its group of eight K rows, per-step logits through eager single-token forwards and greedy ids through
+    the captured step."""
+    from oracle import binding as B
+    from powerserve_amd import hip, synth
+    d = str(tmp_path / "m")
+    mj = synth.write_model_dir(d, preset, wt, n_ctx=256, seed=29)
+    cfg = B.make_config(mj["llm_config"])
+    om = oracle.model(cfg, mj["model_arch"], load_tensors(os.path.join(d, "ggml/weights.gguf")), n_threads=16)
+    prompt = np.random.default_rng(8).integers(0, cfg.vocab_size, 45)
+    steps = 21
+    want_ids, want_logits, *_ = om.generate(prompt, 32, steps, want_logits=True)
+    assert ctx.L.ps_hip_debug_set(7, 1) == 0  # (the fused launch wherever it is covered)
+    gm = hip.Model(ctx, d, max_batch=32, n_ctx=256)
+    try:
+        for force in (0, 1, -1):
+            assert ctx.L.ps_hip_debug_set(9, force) == 0
+            for mode in (0, 128):  # fused where covered / the two launches; set_mode drops the captured step, the next one is captured with this policy
+                gm.set_mode(16 | mode); gm.set_mode(mode)
+                gm.reset()
+                assert np.array_equal(gm.generate(prompt, 32, steps), want_ids), (force, mode)
+                gm.kv_rollback(steps)
+                cur = int(prompt[-1])
+                for s_ in range(steps):
+                    lg, _ = gm.forward([cur], [gm.position], lm_head=True)
+                    assert np.array_equal(np.asarray(lg[0]).view(np.uint32), np.asarray(want_logits[s_]).view(np.uint32)), (force, mode, s_)
+                    cur = int(want_ids[s_])
+    finally:
+        ctx.L.ps_hip_debug_set(9, -1); ctx.L.ps_hip_debug_set(7, 0)
+    gm.close()
+    om.close()
+
+
 @pytest.mark.parametrize("preset,wt,P", [("llama-8b-dims-4l", 12, 161), ("llama-8b-dims-4l", 1015, 140), ("llama-1b-dims-2l", 2, 300), ("qwen2-0.5b-dims-2l", 8, 300)])
 def test_real_layer_shapes_match_oracle(ctx, oracle, tmp_path, preset, wt, P):
     """The BASELINE.json configurations at their REAL layer dimensions (a few layers, a 4096-token vocabulary): Llama-3.1-8B
