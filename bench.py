@@ -108,7 +108,7 @@ def _one_socket_cpus():
         return None
 
 
-def cpu_reference(model_dir, cfg, passes=7):
+def cpu_reference(model_dir, cfg, passes=7, progress=None):
     """The REAL reference on this host: powerserve_compute_forward_mul_mat of the vendored ggml (AVX2 vec_dot_q4_K_q8_K,
     quantize_row_q8_K) compiled from /root/reference into oracle/_ref/libps_ref.so, called through the reference's own
     ThreadPool over the 7 * L + 1 mat-muls of a decode token (the op that is > 90 % of the reference's decode time,
@@ -161,22 +161,31 @@ def cpu_reference(model_dir, cfg, passes=7):
             r_.close()
             ts.sort()
             sweep[n_thr] = ts
+            if progress is not None:  # (cpu_reference_guarded: a pool size that hangs later must not take this one with it)
+                progress(_cpu_reference_line(sweep, passes, cpus, cores, len(mats), nbytes, partial=True))
     finally:
         if saved is not None:
             os.sched_setaffinity(0, saved)
+    return _cpu_reference_line(sweep, passes, cpus, cores, len(mats), nbytes)
+
+
+def _cpu_reference_line(sweep, passes, cpus, cores, n_mats, nbytes, partial=False):
     best = min(sweep, key=lambda k: sweep[k][len(sweep[k]) // 2])
     times = sweep[best]
     med = times[len(times) // 2]
-    return {"value": 1.0 / med, "unit": "tokens/s", "cores": best, "kind": "reference", "statistic": f"best median over pool sizes {sorted(sweep)}, {passes} timed passes each",
-            "min": 1.0 / times[-1], "max": 1.0 / times[0],
-            "bimodal": bool(times[-1] / times[0] > 2.0),  # (a shared host: passes of one run have differed 6x; the median is what `value` is)
-            "pool_size_sweep": {str(k): {"median": 1.0 / v[len(v) // 2], "min": 1.0 / v[-1], "max": 1.0 / v[0]} for k, v in sorted(sweep.items())},
-            "default_pool_size": 4,  # (HyperParams::n_threads, src/core/config.hpp:49)
-            "pinned_to": f"{len(cpus)} logical CPUs of one socket" if cpus else "not pinned (topology unreadable)",
-            "sample": f"{passes} timed warm passes (after 2 untimed) per pool size over the {len(mats)} quantized mat-muls of one decode token ({nbytes / 1e9:.2f} GB of GGUF weights, resident copies) "
-                      f"through powerserve_compute_forward_mul_mat on the reference's ThreadPool (attention, norms and sampling "
-                      f"not included: an upper bound of the reference's decode rate)",
-            "host_cores": cores, "weight_GBps": nbytes / med / 1e9}
+    out = {"value": 1.0 / med, "unit": "tokens/s", "cores": best, "kind": "reference", "statistic": f"best median over pool sizes {sorted(sweep)}, {passes} timed passes each",
+           "min": 1.0 / times[-1], "max": 1.0 / times[0],
+           "bimodal": bool(times[-1] / times[0] > 2.0),  # (a shared host: passes of one run have differed 6x; the median is what `value` is)
+           "pool_size_sweep": {str(k): {"median": 1.0 / v[len(v) // 2], "min": 1.0 / v[-1], "max": 1.0 / v[0]} for k, v in sorted(sweep.items())},
+           "default_pool_size": 4,  # (HyperParams::n_threads, src/core/config.hpp:49)
+           "pinned_to": f"{len(cpus)} logical CPUs of one socket" if cpus else "not pinned (topology unreadable)",
+           "sample": f"{passes} timed warm passes (after 2 untimed) per pool size over the {n_mats} quantized mat-muls of one decode token ({nbytes / 1e9:.2f} GB of GGUF weights, resident copies) "
+                     f"through powerserve_compute_forward_mul_mat on the reference's ThreadPool (attention, norms and sampling "
+                     f"not included: an upper bound of the reference's decode rate)",
+           "host_cores": cores, "weight_GBps": nbytes / med / 1e9}
+    if partial:
+        out["partial"] = True
+    return out
 
 
 def cpu_reference_guarded(model_dir, limit_s):
@@ -186,7 +195,15 @@ def cpu_reference_guarded(model_dir, limit_s):
     import subprocess
     try:
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-reference-child", model_dir], capture_output=True, text=True, timeout=limit_s)
-    except subprocess.TimeoutExpired:
+    except subprocess.TimeoutExpired as e:
+        # the child prints a line after every pool size of its sweep: what finished before the hang is the baseline (round 6: one size that hung had taken the whole sweep with it)
+        so = e.stdout.decode() if isinstance(e.stdout, bytes) else (e.stdout or "")
+        done = [l for l in so.splitlines() if l.startswith("{")]
+        if done:
+            r_ = json.loads(done[-1])
+            r_.pop("partial", None)
+            r_["sweep_cut_short"] = f"the reference's thread pool did not finish its sweep within {limit_s} s (its spin barrier on a busy host); killed -- the pool sizes above are the ones that finished"
+            return r_
         return {"error": f"the reference's thread pool did not finish within {limit_s} s (its spin barrier on a busy host); killed"}
     lines = [l for l in r.stdout.splitlines() if l.startswith("{") or l == "null"]
     if r.returncode != 0 or not lines:
@@ -199,7 +216,7 @@ def _cpu_reference_child(model_dir):
     from powerserve_amd import synth
     llm = synth.load_model_json(model_dir)["llm_config"]
     cfg = types.SimpleNamespace(dim=int(llm["embed_dim"]), hidden_dim=int(llm["ffn_dim"]), n_layers=int(llm["n_layers"]))
-    print(json.dumps(cpu_reference(model_dir, cfg)), flush=True)
+    print(json.dumps(cpu_reference(model_dir, cfg, progress=lambda d: print(json.dumps(d), flush=True))), flush=True)
 
 
 def graph_path(model_dir, device, args, prompt):
