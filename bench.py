@@ -49,7 +49,7 @@ def parse():
     ap.add_argument("--no-kv-f16", action="store_true", help="skip the fp16-KV decode mode leg")
     ap.add_argument("--no-graph-path", action="store_true", help="skip the Graph -> Executor -> HIPBackend::plan leg (libps_host.so)")
     ap.add_argument("--graph-steps", type=int, default=96)
-    ap.add_argument("--cpu-reference-limit", type=int, default=240, help="seconds the reference CPU baseline (a child process) may take before it is killed")
+    ap.add_argument("--cpu-reference-limit", type=int, default=150, help="seconds the reference CPU baseline (a child process) may take before it is killed")
     ap.add_argument("--cpu-reference-child", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--f16-super-chunk", type=int, default=2048, help="side leg (fp16 perf mode): tokens per mat-mul launch")
     ap.add_argument("--prefill-warmup-tokens", type=int, default=128, help="untimed tokens forwarded before the timed prefill (first use of the prefill kernels in the process; 0: none)")
